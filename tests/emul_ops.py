@@ -1,0 +1,312 @@
+"""Pure-torch statement of every primitive in ``svpc_amd.ops`` — TEST INFRASTRUCTURE ONLY.
+
+Two uses: (1) ``-m "not gpu"`` tests swap it in for ``svpc_amd.ops`` to check the host-side
+orchestration of the batched model against the oracle on CPU; (2) ``-m gpu`` tests use it (on cuda
+tensors) as the plain-PyTorch fp32 reference each HIP kernel is compared with, forward and backward
+(autograd differentiates these definitions).  The product never imports this file.
+
+Signatures are identical to svpc_amd/ops.py.  Dropout: ``drop=(p, rng, site)``; here the mask comes from
+``rng.mask(site, n, p, device)`` so that GPU tests can hand in the very mask the kernels generate.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from svpc_amd.ops_common import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, FIdx, Idx, SeqInfo,  # noqa: F401
+                                 as_idx)
+
+
+def _h(v):
+    """host list of an index argument (Idx / FIdx / list / tensor)."""
+    if isinstance(v, (Idx, FIdx)):
+        return v.host
+    if isinstance(v, torch.Tensor):
+        return v.tolist()
+    return list(v)
+
+
+def _apply_drop(x, drop):
+    if drop is None or drop[0] <= 0.0:
+        return x
+    p, rng, site = drop
+    m = rng.mask(site, x.numel(), p, x.device).view(x.shape)
+    return x * m * (1.0 / (1.0 - p))
+
+
+def _act(z, act):
+    if act == ACT_RELU:
+        return torch.relu(z)
+    if act == ACT_GELU:
+        return z * 0.5 * (1.0 + torch.erf(z / math.sqrt(2.0)))
+    if act == ACT_SIGMOID:
+        return torch.sigmoid(z)
+    return z
+
+
+def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None):
+    z = x @ (w if trans_w else w.t())
+    if b is not None:
+        z = z + b
+    return _apply_drop(_act(z, act), drop)
+
+
+def layernorm(x, gamma, beta, eps, residual=None, src_rows=None, pad_row=-1, pre_drop=None, post_drop=None,
+              add1=None, add1_mod=0, add2=None, add2_idx=None):
+    h = x if src_rows is None else x[src_rows.long()]
+    h = _apply_drop(h, pre_drop)
+    if residual is not None:
+        h = h + residual
+    mu = h.mean(-1, keepdim=True)
+    var = ((h - mu) ** 2).mean(-1, keepdim=True)
+    y = gamma * ((h - mu) / torch.sqrt(var + eps)) + beta
+    y = _apply_drop(y, post_drop)
+    R = y.shape[0]
+    if add1 is not None:
+        y = y + add1[torch.arange(R, device=y.device) % add1_mod]
+    if add2 is not None:
+        y = y + add2[add2_idx.long()]
+    return y
+
+
+class _ZeroPadRowGrad(torch.autograd.Function):
+    """nn.Embedding(padding_idx=k): row k of the table never receives a gradient."""
+
+    @staticmethod
+    def forward(ctx, table, row):
+        ctx.row = row
+        return table.view_as(table)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.clone()
+        g[ctx.row] = 0
+        return g, None
+
+
+def embedding_table(table, pad_row):
+    return _ZeroPadRowGrad.apply(table, pad_row) if pad_row >= 0 else table
+
+
+def attention(qt, kvt, cols, D, n_heads, seq, key_mask=None, causal=False, drop=None):
+    """qt (Rq, ≥D) holds the queries in columns [cols[0], cols[0]+D); kvt (Rk, ·) holds keys at cols[1] and
+    values at cols[2] (packed projection outputs are consumed in place; qt may be kvt)."""
+    q = qt[:, cols[0]:cols[0] + D]
+    k = kvt[:, cols[1]:cols[1] + D]
+    v = kvt[:, cols[2]:cols[2] + D]
+    dh = D // n_heads
+    out = []
+    for i in range(seq.n):
+        qo, ql, ko, kl = seq.h_q_off[i], seq.h_q_len[i], seq.h_k_off[i], seq.h_k_len[i]
+        qi = q[qo:qo + ql].reshape(ql, n_heads, dh).permute(1, 0, 2)
+        ki = k[ko:ko + kl].reshape(kl, n_heads, dh).permute(1, 0, 2)
+        vi = v[ko:ko + kl].reshape(kl, n_heads, dh).permute(1, 0, 2)
+        m = torch.ones(ql, kl, device=q.device)
+        if key_mask is not None:
+            m = m * key_mask[ko:ko + kl].unsqueeze(0)
+        if causal:
+            m = m * torch.tril(torch.ones(ql, kl, device=q.device))
+        s = qi @ ki.transpose(-1, -2) / math.sqrt(dh) + (1.0 - m) * -10000.0
+        p = torch.softmax(s, dim=-1)
+        if drop is not None and drop[0] > 0:
+            pd, rng, site = drop
+            # element index of the mask: ((seq*H + head)*max_q + i)*max_k + j
+            full = rng.mask(site, seq.n * n_heads * seq.max_q * seq.max_k, pd, q.device)
+            full = full.view(seq.n, n_heads, seq.max_q, seq.max_k)[i, :, :ql, :kl]
+            p = p * full * (1.0 / (1.0 - pd))
+        out.append((p @ vi).permute(1, 0, 2).reshape(ql, D))
+    return torch.cat(out, 0)
+
+
+def span_mean(x, starts, lens, weights=None, add=None, add_idx=None):
+    outs = []
+    starts, lens = _h(starts), _h(lens)
+    for g in range(len(starts)):
+        s, l = int(starts[g]), int(lens[g])
+        rows = x[s:s + l]
+        if weights is None:
+            outs.append(rows.mean(0))
+        else:
+            w = weights[s:s + l].unsqueeze(1)
+            outs.append((rows * w).sum(0) / w.sum())
+    out = torch.stack(outs)
+    if add is not None:
+        out = out + add[torch.as_tensor(_h(add_idx), device=out.device).long()]
+    return out
+
+
+def row_normalize(a):
+    return a / a.sum(-1, keepdim=True)
+
+
+def softmax_rows(x):
+    return torch.softmax(x, dim=-1)
+
+
+def sim_recur(q, c, w4f, E0, step_off, step_len, ent_off, ent_len, e_max):
+    """Batched recurrent part of the simulator (Eqs. (2)-(7) after the per-step projections)."""
+    T, D = q.shape
+    step_off, step_len, ent_off, ent_len = _h(step_off), _h(step_len), _h(ent_off), _h(ent_len)
+    ebar_out, eall_out = [], []
+    e_rows = []
+    for b in range(len(step_off)):
+        E = E0[ent_off[b]:ent_off[b] + ent_len[b]]
+        prev = torch.zeros(ent_len[b], device=q.device)
+        for t in range(step_len[b]):
+            j = step_off[b] + t
+            e = torch.sigmoid(E @ q[j])
+            alpha = c[j, 0] * e + c[j, 1] * prev
+            ebar = (alpha / alpha.sum()) @ E
+            k = torch.relu(w4f[j] * ebar)
+            E = alpha.unsqueeze(1) * k.unsqueeze(0) + (1 - alpha).unsqueeze(1) * E
+            prev = e
+            e_rows.append(F.pad(e, (0, e_max - ent_len[b])))
+            ebar_out.append(ebar)
+            eall_out.append(F.pad(E, (0, 0, 0, e_max - ent_len[b])))
+    return torch.stack(e_rows), torch.stack(ebar_out), torch.stack(eall_out)
+
+
+def ptr_attn(dec, proj, bank, step_ne, lt):
+    """dec (T*lt, D); proj, bank (T, Emax, D); step_ne: python list of entity counts per step."""
+    T, e_max, D = bank.shape
+    d3 = dec.view(T, lt, D)
+    score = torch.einsum("jed,jtd->jte", proj, d3)
+    valid = torch.arange(e_max, device=dec.device).unsqueeze(0) < torch.as_tensor(_h(step_ne), device=dec.device).unsqueeze(1)
+    score = score.masked_fill(~valid.unsqueeze(1), float("-inf"))
+    pi = torch.softmax(score, dim=-1)
+    att = torch.einsum("jte,jed->jtd", pi, bank)
+    return pi.reshape(T * lt, e_max), att.reshape(T * lt, D)
+
+
+def ptr_mix_loss(logits, g, pi, labels, row_c, row_vid, csr_off, csr_ent, csr_id, csr_w, c_max, smoothing,
+                 dp_ext_hook=None):
+    """Rows r: P = g*softmax(logits) over V columns, zeros up to C_r, copy mass (1-g)*pi[e]*w scattered to
+    csr_id; label-smoothed KL per row (0 for label −1).  g/pi None → plain softmax (MODEL_TYPE=v).
+    Returns (P (R, c_max), loss_rows (R,))."""
+    R, V = logits.shape
+    row_c, row_vid, csr_off, csr_ent, csr_id, csr_w = map(_h, (row_c, row_vid, csr_off, csr_ent, csr_id, csr_w))
+    sm = torch.softmax(logits, dim=-1)
+    P = torch.zeros(R, c_max, device=logits.device)
+    if g is None:
+        P = torch.cat([sm, P[:, V:]], 1)
+    else:
+        P = torch.cat([g * sm, P[:, V:]], 1)
+        add = torch.zeros_like(P)
+        for b in range(len(csr_off) - 1):
+            rows = (torch.as_tensor(row_vid, device=logits.device) == b).nonzero().view(-1)
+            for n in range(csr_off[b], csr_off[b + 1]):
+                col = torch.zeros(c_max, device=logits.device)
+                col[csr_id[n]] = 1.0
+                contrib = ((1 - g[rows, 0]) * pi[rows, csr_ent[n]] * csr_w[n]).unsqueeze(1) * col.unsqueeze(0)
+                add = add.index_add(0, rows, contrib)
+        P = P + add
+    losses = []
+    for r in range(R):
+        y = int(labels[r])
+        if y == -1:
+            losses.append(P[r].sum() * 0.0)
+            continue
+        C = int(row_c[r])
+        qv = torch.full((C,), smoothing / (C - 1), device=logits.device)
+        qv[C - 1] = 0
+        qv[y] = 1.0 - smoothing
+        logp = torch.log(P[r, :C] + 1e-12)
+        losses.append(F.kl_div(logp, qv, reduction="sum"))
+    return P, torch.stack(losses)
+
+
+def gumbel_bow(P, row_c, emb, tau, noise=None, rng=None, site=0):
+    """Straight-through Gumbel-softmax over each row's C_r columns of log(P+1e-12), sliced to V, times emb."""
+    R, c_max = P.shape
+    V = emb.shape[0]
+    assert noise is not None, "the emulation needs explicit noise"
+    cols = torch.arange(c_max, device=P.device).unsqueeze(0)
+    valid = cols < torch.as_tensor(_h(row_c), device=P.device).unsqueeze(1)
+    logits = (torch.log(P + 1e-12) + noise) / tau
+    logits = logits.masked_fill(~valid, float("-inf"))
+    y = torch.softmax(logits, dim=-1)
+    idx = y.max(-1, keepdim=True)[1]
+    hard = torch.zeros_like(y).scatter_(-1, idx, 1.0)
+    st = hard - y.detach() + y
+    return st[:, :V] @ emb
+
+
+def lstm_cell(gx, gh, c_prev, h_prev, active):
+    """gates = gx + gh (i, f, g, o); rows with active == 0 pass (h, c) through."""
+    gates = gx + gh
+    i, f, g, o = gates.chunk(4, dim=1)
+    c = torch.sigmoid(f) * c_prev + torch.sigmoid(i) * torch.tanh(g)
+    h = torch.sigmoid(o) * torch.tanh(c)
+    a = active.unsqueeze(1)
+    return a * h + (1 - a) * h_prev, a * c + (1 - a) * c_prev
+
+
+def bce_rows(p, y, widths):
+    """Per-row sum of binary cross-entropy over the first widths[r] columns (nn.BCELoss clamps log at -100)."""
+    cols = torch.arange(p.shape[1], device=p.device).unsqueeze(0)
+    valid = (cols < torch.as_tensor(_h(widths), device=p.device).unsqueeze(1)).float()
+    pp = torch.where(valid > 0, p, torch.full_like(p, 0.5))
+    l = -(y * torch.log(pp).clamp(min=-100) + (1 - y) * torch.log(1 - pp).clamp(min=-100))
+    return (l * valid).sum(1)
+
+
+def asl_rows(p, y, row_active, gamma_neg=4.0, gamma_pos=1.0, clip=0.05, eps=1e-8):
+    p_neg = (1 - p + clip).clamp(max=1)
+    loss = y * torch.log(p.clamp(min=eps)) + (1 - y) * torch.log(p_neg.clamp(min=eps))
+    pt = p * y + p_neg * (1 - y)
+    w = torch.pow(1 - pt, gamma_pos * y + gamma_neg * (1 - y))
+    return -(loss * w).sum(1) * row_active
+
+
+def sum_all(x):
+    return x.sum()
+
+
+def take_rows(x, idx):
+    return x[idx.long()]
+
+
+def add(a, b):
+    return a + b
+
+
+def clamp_labels(labels, vocab, unk):
+    return torch.where(labels >= vocab, torch.full_like(labels, unk), labels)
+
+
+def row_any_eq1(x):
+    return (x == 1).any(dim=1).float()
+
+
+def make_rng(device):
+    return EmulRng(device=device)
+
+
+_default = None
+
+
+def default_rng(device):
+    global _default
+    if _default is None:
+        _default = EmulRng()
+    return _default
+
+
+class EmulRng:
+    """CPU stand-in for svpc_amd.ops.Rng (eval-mode tests never draw from it)."""
+
+    def __init__(self, seed=0, device="cpu"):
+        self.seed = seed
+        self._site = 0
+        self.device = torch.device(device)
+
+    def begin_step(self):
+        self._site = 0
+
+    def site(self):
+        self._site += 1
+        return self._site
+
+    def mask(self, site, n, p, device):
+        g = torch.Generator().manual_seed(self.seed * 7919 + site)
+        return (torch.rand(n, generator=g) >= p).float().to(device)
