@@ -1,0 +1,139 @@
+/* svpc_hip.h — C-ABI of the MI355X (gfx950) kernel library behind svpc_amd's StateAwareRecursiveTransformer.
+ *
+ * The reference (awkrail/svpc) has no FFI / plugin layer: its hot path is eager PyTorch inside
+ * src/rtransformer/model.py.  The drop-in boundary is therefore the Python module API; this
+ * header is what sits directly beneath it.  Each entry point replaces the group of eager ops cited next to it
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions: every pointer is a device (HBM) pointer unless noted; tensors are row-major fp32 / int32;
+ * `stream` is the HIP stream to launch on (svpc_amd passes PyTorch's current stream); nothing is allocated
+ * and nothing synchronises inside (graph-capture safe); return 0 = ok, non-zero = error with a message in
+ * svpc_last_error().  Dropout / Gumbel draws are counter-based: (`seed` device word, `site`, element index).
+ */
+#ifndef SVPC_HIP_H
+#define SVPC_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* svpc_stream_t; /* == hipStream_t */
+typedef unsigned long long svpc_u64;
+
+#define SVPC_ACT_NONE 0
+#define SVPC_ACT_RELU 1
+#define SVPC_ACT_GELU 2    /* exact erf GELU, model.py:58-64 */
+#define SVPC_ACT_SIGMOID 3
+
+const char* svpc_last_error(void);
+int svpc_abi_version(void);
+
+/* ---- LayerNorm family: BertLayerNorm model.py:143-156 and its fused uses :229-233, :285-289, :493-499, :548-562,
+ *      :650, :659, :889-891.  y = post_drop(LN(pre_drop(x[src_rows[r]]) + res[r])·gamma+beta) + add1[r%mod1] + add2[idx2[r]] */
+int svpc_ln_fwd(const float* x, const int* src_rows, const float* res, const float* gamma, const float* beta, float* y,
+                float* mean, float* rstd, int R, int D, float eps, float p_pre, unsigned site_pre, float p_post,
+                unsigned site_post, const svpc_u64* seed, const float* add1, int mod1, const float* add2, const int* idx2,
+                svpc_stream_t stream);
+int svpc_ln_bwd_groups(int R); /* workspace floats needed by svpc_ln_bwd = (groups + 1) * 2 * D */
+int svpc_ln_bwd(const float* dy, const float* x, const int* src_rows, const float* res, const float* gamma,
+                const float* mean, const float* rstd, float* dh, float* dx, float* dgamma, float* dbeta, int accumulate,
+                float* workspace, int R, int D, float p_pre, unsigned site_pre, float p_post, unsigned site_post,
+                const svpc_u64* seed, svpc_stream_t stream);
+/* out[k][c] (+)= Σ_{r: idx[r]==k} x[r][c]  — bias gradients (K=1, idx NULL) and the token-type table gradient (model.py:890) */
+int svpc_colsum_chunks(int R); /* workspace floats = chunks * K * C */
+int svpc_bucket_colsum(const float* x, int ldx, const int* idx, int R, int C, int K, float* out, int accumulate,
+                       float* workspace, svpc_stream_t stream);
+
+/* ---- fp32 MFMA GEMM with fused epilogue: every nn.Linear on the path (model.py:195-197, :230, :259, :281, :496, :551,
+ *      :706, :738, :755-770, :846-850, :859-860, nn.LSTM projections :865) and their dgrad / wgrad products.
+ *      C[M,N] = epi(Σ_k A(m,k)·B(n,k)); a_kc/b_kc: 1 = k contiguous ([rows][ld]), 0 = k strided ([K][ld]). */
+int svpc_gemm_f32(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, int M, int N,
+                  int K, const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed, int accumulate,
+                  float* workspace, size_t workspace_bytes, svpc_stream_t stream);
+/* dz = dy · act'(aux) · dropout  (aux = pre-activation for GELU, activated output for ReLU / sigmoid) */
+int svpc_act_bwd(const float* dy, const float* aux, float* dz, size_t n, int act, float p, unsigned site, const svpc_u64* seed,
+                 svpc_stream_t stream);
+
+/* ---- attention core: BertSelfAttention.forward model.py:194-219 (scale, additive -10000 mask, softmax, dropout, PV).
+ *      seq = int32[4][n_seq]: q_off, q_len, k_off, k_len.  LSE: (n_seq, H, max_q). */
+int svpc_attn_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, float* LSE,
+                  const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal, float scale,
+                  float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
+int svpc_attn_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                  const float* LSE, const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
+                  float* delta, const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,
+                  float scale, float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
+
+/* ---- simulator recurrence: EntitiyReasoningNetwork.forward model.py:792-820 (Eqs. 2-7), one workgroup per video */
+int svpc_sim_recur_fwd(const float* q, const float* c, const float* w4f, const float* E0, const int* step_off, const int* step_len,
+                       const int* ent_off, const int* ent_len, int n_videos, int e_max, int D, float* e_out, float* ebar,
+                       float* eall, svpc_stream_t stream);
+int svpc_sim_recur_bwd(const float* q, const float* c, const float* w4f, const float* E0, const int* step_off, const int* step_len,
+                       const int* ent_off, const int* ent_len, int n_videos, int e_max, int D, const float* e_out,
+                       const float* ebar, const float* eall, const float* de, const float* debar, const float* deall, float* dq,
+                       float* dc, float* dw4f, float* dE0, svpc_stream_t stream);
+
+/* ---- pointer-generator + caption loss: model.py:896-923, :37-55 */
+int svpc_ptr_attn_fwd(const float* dec, const float* proj, const float* bank, const int* step_ne, float* pi, float* att, int T,
+                      int lt, int e_max, int D, svpc_stream_t stream);
+int svpc_ptr_attn_bwd(const float* dec, const float* proj, const float* bank, const int* step_ne, const float* pi, const float* dpi,
+                      const float* datt, float* ddec, float* dproj, float* dbank, int T, int lt, int e_max, int D,
+                      svpc_stream_t stream);
+int svpc_ptr_mix_loss_fwd(const float* logits, const float* g, const float* pi, const int* labels, const int* row_c,
+                          const int* row_vid, const int* csr_off, const int* csr_ent, const int* csr_id, const float* csr_w, float* P,
+                          float* loss_rows, int R, int V, int c_max, int e_max, float smoothing, svpc_stream_t stream);
+int svpc_ptr_mix_loss_bwd(const float* logits, const float* g, const float* pi, const int* labels, const int* row_c,
+                          const int* row_vid, const int* csr_off, const int* csr_ent, const int* csr_id, const float* csr_w,
+                          const float* P, const float* dP_ext, const float* dloss, float* dlogits, float* dg, float* dpi, int R, int V,
+                          int c_max, int e_max, float smoothing, svpc_stream_t stream);
+
+/* ---- Gumbel-softmax (hard) re-sampling of the caption: reconstruct model.py:1018 */
+int svpc_gumbel_noise(float* out, size_t n, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
+int svpc_gumbel_fwd(const float* P, const float* noise, const int* row_c, const float* emb, float* bow, int* idx, float* stats, int R,
+                    int c_max, int V, int W, float tau, svpc_stream_t stream);
+int svpc_gumbel_bwd(const float* P, const float* noise, const int* row_c, const float* stats, const float* dy, float* dP, int R,
+                    int c_max, int V, float tau, svpc_stream_t stream);
+int svpc_gumbel_emb_grad(const float* dbow, const int* idx, const float* stats, float* demb, int R, int V, int W,
+                         svpc_stream_t stream);
+
+/* ---- row / span / loss kernels: Eq.(1) a/Σa model.py:798; softmax(W3 ĥ) :804; ingredient pooling :125-139; [CLS]+PE :1064;
+ *      masked bag-of-words mean :1019-1021; nn.BCELoss(sum) :871; AsymmetricLoss libs/ASL/src/loss_functions/losses.py:15-50;
+ *      nn.LSTM cell :865; nn.Embedding(padding_idx=0) gradient :492,:519 */
+int svpc_rownorm_fwd(const float* a, float* y, int R, int C, int mode, svpc_stream_t stream);  /* mode 0: a/Σa, 1: softmax */
+int svpc_rownorm_bwd(const float* dy, const float* y, const float* a, float* da, int R, int C, int mode, svpc_stream_t stream);
+int svpc_span_mean_fwd(const float* x, const int* starts, const int* lens, const float* w, const float* add, const int* add_idx,
+                       float* out, int G, int D, svpc_stream_t stream);
+int svpc_span_mean_bwd(const float* dout, const int* starts, const int* lens, const float* w, float* dx, int G, int D,
+                       svpc_stream_t stream);
+int svpc_scatter_add_rows(const float* dx, const int* idx, float* dtable, int R, int D, int pad_row, svpc_stream_t stream);
+int svpc_bce_rows_fwd(const float* p, const float* y, const int* widths, float* out, int R, int C, svpc_stream_t stream);
+int svpc_bce_rows_bwd(const float* dout, const float* p, const float* y, const int* widths, float* dp, int R, int C,
+                      svpc_stream_t stream);
+int svpc_asl_rows_fwd(const float* p, const float* y, const float* active, float* out, int R, int C, float gneg, float gpos,
+                      float clip, float eps, svpc_stream_t stream);
+int svpc_asl_rows_bwd(const float* dout, const float* p, const float* y, const float* active, float* dp, int R, int C, float gneg,
+                      float gpos, float clip, float eps, svpc_stream_t stream);
+int svpc_row_any_eq1(const float* x, float* out, int R, int C, svpc_stream_t stream);
+int svpc_clamp_labels(const int* in, int* out, int n, int vocab, int unk, svpc_stream_t stream); /* model.py:1013 */
+int svpc_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, const float* h_prev, const float* active, float* h,
+                       float* c, float* gates_act, int N, int D, svpc_stream_t stream);
+int svpc_lstm_cell_bwd(const float* dh, const float* dc, const float* gates_act, const float* c_prev, const float* active,
+                       float* dgates, float* dc_prev, float* dh_prev, int N, int D, svpc_stream_t stream);
+int svpc_add(const float* a, const float* b, float* c, size_t n, svpc_stream_t stream);
+int svpc_sum_all(const float* x, size_t n, float* out, float scale, svpc_stream_t stream);
+int svpc_fill_from(float* x, size_t n, const float* v, svpc_stream_t stream);
+int svpc_dropout_mask(float* out, size_t n, float p, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
+int svpc_bump_seed(svpc_u64* seed, svpc_stream_t stream);
+
+/* ---- fused training-step tail: clip_grad_norm_ train.py:141-142, BertAdam optimization.py:284-331, EMA :196-203.
+ *      meta = device array of {float* p,g,m,v,ema; long long n; float wd; int pad}; chunk tables built by the host. */
+int svpc_opt_chunk(void);
+int svpc_opt_meta_bytes(void);
+int svpc_opt_step(const void* meta, const int* chunk_tid, const long long* chunk_start, const int* tensor_chunk_off, int n_tensors,
+                  int n_chunks, float* partial, float* norms_sq, const float* hyper, svpc_stream_t stream);
+int svpc_opt_zero_grad(const void* meta, const int* chunk_tid, const long long* chunk_start, int n_chunks, svpc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVPC_HIP_H */

@@ -1,0 +1,100 @@
+// Shared device helpers for the svpc gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SVPC_WAVE 64
+
+typedef unsigned long long u64;
+
+// ---- status plumbing for the C-ABI -------------------------------------------------------------
+extern "C" void svpc_set_error(const char* msg);
+static inline int svpc_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+        svpc_set_error(buf);
+        return (int)e;
+    }
+    return 0;
+}
+#define SVPC_REQUIRE(cond, msg)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            svpc_set_error(msg);                \
+            return -1;                          \
+        }                                       \
+    } while (0)
+
+// ---- wave / block reductions -------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum for blockDim.x == 256 (4 waves); `red` is 4 floats of LDS. Result valid in all threads.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ---- counter-based RNG (dropout masks, Gumbel noise) ---------------------------------------------
+// One 32-bit uniform per (seed, site, element index); recomputed in backward, never stored.
+__device__ __host__ __forceinline__ uint32_t svpc_hash32(u64 seed, uint32_t site, u64 idx) {
+    u64 z = seed + 0x9E3779B97F4A7C15ull * (u64)(site + 1) + idx * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+// keep-probability 1-p; returns the multiplier (0 or 1/(1-p))
+__device__ __forceinline__ float drop_scale(u64 seed, uint32_t site, u64 idx, float p, float inv_keep) {
+    uint32_t thr = (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f);
+    return svpc_hash32(seed, site, idx) >= thr ? inv_keep : 0.0f;
+}
+__device__ __forceinline__ float gumbel_noise(u64 seed, uint32_t site, u64 idx) {
+    float u = ((float)svpc_hash32(seed, site, idx) + 0.5f) * (1.0f / 4294967296.0f);
+    u = fminf(fmaxf(u, 1e-10f), 1.0f - 6e-8f);
+    return -logf(-logf(u));
+}
+
+// ---- activations -------------------------------------------------------------------------------
+#define ACT_NONE 0
+#define ACT_RELU 1
+#define ACT_GELU 2
+#define ACT_SIGMOID 3
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    // d/dx [x Φ(x)] = Φ(x) + x φ(x)
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float apply_act(float z, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(z, 0.0f);
+        case ACT_GELU: return gelu_erf(z);
+        case ACT_SIGMOID: return sigmoidf_(z);
+        default: return z;
+    }
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,396 @@
+// Row-wise / element-wise kernels of the hot path (all HBM-bound; wave64 shuffle reductions, coalesced rows):
+//   activation backward (+dropout) for the GEMM epilogues      (model.py:58-64 gelu, ReLU/sigmoid of :497,:552,:755-759)
+//   span (weighted) mean + table add                           (ingredient pooling :125-139, [CLS]+step PE :1064,
+//                                                               masked bag-of-words mean :1019-1021)
+//   row normalise a/Σa (Eq. 1, :798), 3-way softmax (Eq. 3, :804)
+//   BCE-sum (:871) and asymmetric loss rows (libs/ASL/src/loss_functions/losses.py:15-50)
+//   LSTM cell (nn.LSTM gate order i,f,g,o; :865)
+//   embedding-gradient scatter-add with padding row (nn.Embedding(padding_idx=0), :492,:519)
+#include "common.h"
+
+// ---- dz = dy * act'(.) * dropout ----------------------------------------------------------------------------
+// `aux` is the pre-activation z for GELU, the activated (pre-dropout) output y for ReLU / sigmoid.
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ aux,
+                                                      float* __restrict__ dz, size_t n, int act, float p, uint32_t site,
+                                                      const u64* __restrict__ seed_ptr) {
+    const u64 seed = p > 0.f ? seed_ptr[0] : 0ull;
+    const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float g = dy[i];
+        if (p > 0.f) g *= drop_scale(seed, site, i, p, ik);
+        const float a = aux[i];
+        if (act == ACT_RELU) g = a > 0.f ? g : 0.f;
+        else if (act == ACT_GELU) g *= gelu_erf_grad(a);
+        else if (act == ACT_SIGMOID) g *= a * (1.0f - a);
+        dz[i] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c,
+                                                  size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) c[i] = a[i] + b[i];
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, size_t n, float p, uint32_t site,
+                                                           const u64* __restrict__ seed_ptr) {
+    const u64 seed = seed_ptr[0];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = drop_scale(seed, site, i, p, 1.0f);
+}
+
+__global__ __launch_bounds__(256) void gumbel_noise_kernel(float* __restrict__ out, size_t n, uint32_t site,
+                                                           const u64* __restrict__ seed_ptr) {
+    const u64 seed = seed_ptr[0];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = gumbel_noise(seed, site, i);
+}
+
+__global__ void bump_seed_kernel(u64* seed) { seed[0] = seed[0] * 6364136223846793005ull + 1442695040888963407ull; }
+
+// ---- deterministic full reduction: out[0] = scale * sum(x) (single workgroup, fixed order) -------------------
+__global__ __launch_bounds__(256) void sum_all_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out, float scale) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ x, size_t n, const float* __restrict__ v) {
+    const float s = v[0];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] = s;
+}
+
+// ---- rows: one wave per row ------------------------------------------------------------------------------------
+// mode 0: y = a / sum(a)       mode 1: y = softmax(a)
+__global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* __restrict__ a, float* __restrict__ y, int R, int C, int mode) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* ar = a + (size_t)r * C;
+    float* yr = y + (size_t)r * C;
+    if (mode == 0) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += ar[c];
+        s = 1.0f / wave_sum(s);
+        for (int c = lane; c < C; c += 64) yr[c] = ar[c] * s;
+    } else {
+        float m = -INFINITY;
+        for (int c = lane; c < C; c += 64) m = fmaxf(m, ar[c]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += expf(ar[c] - m);
+        s = 1.0f / wave_sum(s);
+        for (int c = lane; c < C; c += 64) yr[c] = expf(ar[c] - m) * s;
+    }
+}
+// mode 0: da = (dy - sum(dy*y)) / sum(a)  [y = a/S]      mode 1: da = y (dy - sum(dy*y))
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          const float* __restrict__ a, float* __restrict__ da, int R, int C, int mode) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const size_t o = (size_t)r * C;
+    float dot = 0.f, s = 0.f;
+    for (int c = lane; c < C; c += 64) { dot += dy[o + c] * y[o + c]; if (mode == 0) s += a[o + c]; }
+    dot = wave_sum(dot);
+    if (mode == 0) {
+        s = 1.0f / wave_sum(s);
+        for (int c = lane; c < C; c += 64) da[o + c] = (dy[o + c] - dot) * s;
+    } else {
+        for (int c = lane; c < C; c += 64) da[o + c] = y[o + c] * (dy[o + c] - dot);
+    }
+}
+
+// ---- span weighted mean: out[g] = Σ_{r<len} w x / Σ w + add[add_idx[g]] ---------------------------------------
+__global__ __launch_bounds__(256) void span_mean_fwd_kernel(const float* __restrict__ x, const int* __restrict__ starts,
+                                                            const int* __restrict__ lens, const float* __restrict__ w,
+                                                            const float* __restrict__ add, const int* __restrict__ add_idx,
+                                                            float* __restrict__ out, int G, int D) {
+    const int g = blockIdx.x;
+    const int s = starts[g], l = lens[g];
+    float wsum = 0.f;
+    if (w) { for (int r = 0; r < l; ++r) wsum += w[s + r]; } else wsum = (float)l;
+    const float inv = 1.0f / wsum;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float acc = 0.f;
+        for (int r = 0; r < l; ++r) acc += (w ? w[s + r] : 1.0f) * x[(size_t)(s + r) * D + c];
+        acc *= inv;
+        if (add) acc += add[(size_t)add_idx[g] * D + c];
+        out[(size_t)g * D + c] = acc;
+    }
+}
+// dx must be zero-initialised (rows outside every span get no gradient)
+__global__ __launch_bounds__(256) void span_mean_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ starts,
+                                                            const int* __restrict__ lens, const float* __restrict__ w,
+                                                            float* __restrict__ dx, int G, int D) {
+    const int g = blockIdx.x;
+    const int s = starts[g], l = lens[g];
+    float wsum = 0.f;
+    if (w) { for (int r = 0; r < l; ++r) wsum += w[s + r]; } else wsum = (float)l;
+    const float inv = 1.0f / wsum;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float d = dout[(size_t)g * D + c] * inv;
+        for (int r = 0; r < l; ++r) dx[(size_t)(s + r) * D + c] = (w ? w[s + r] : 1.0f) * d;
+    }
+}
+
+// ---- dtable[idx[r]] += dx[r]  (fp32 atomics, skipping the padding row) --------------------------------------
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ dx, const int* __restrict__ idx,
+                                                               float* __restrict__ dtable, int R, int D, int pad_row) {
+    const int r = blockIdx.x;
+    const int t = idx[r];
+    if (t == pad_row) return;
+    for (int c = threadIdx.x; c < D; c += 256) atomicAdd(&dtable[(size_t)t * D + c], dx[(size_t)r * D + c]);
+}
+
+// ---- BCE rows (nn.BCELoss(sum): log clamped at -100) -----------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_rows_fwd_kernel(const float* __restrict__ p, const float* __restrict__ y,
+                                                           const int* __restrict__ widths, float* __restrict__ out, int R, int C) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int wdt = widths[r];
+    float s = 0.f;
+    for (int c = lane; c < wdt; c += 64) {
+        const float pp = p[(size_t)r * C + c], yy = y[(size_t)r * C + c];
+        s -= yy * fmaxf(logf(pp), -100.f) + (1.f - yy) * fmaxf(logf(1.f - pp), -100.f);
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s;
+}
+__global__ __launch_bounds__(256) void bce_rows_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ p,
+                                                           const float* __restrict__ y, const int* __restrict__ widths,
+                                                           float* __restrict__ dp, int R, int C) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int wdt = widths[r];
+    const float go = dout[r];
+    for (int c = lane; c < C; c += 64) {
+        float g = 0.f;
+        if (c < wdt) {
+            const float pp = p[(size_t)r * C + c], yy = y[(size_t)r * C + c];
+            // d/dp[-(y log p + (1-y) log(1-p))]; the -100 clamp zeroes the slope where it is active
+            const float a = logf(pp) > -100.f ? -yy / pp : 0.f;
+            const float b = logf(1.f - pp) > -100.f ? (1.f - yy) / (1.f - pp) : 0.f;
+            g = go * (a + b);
+        }
+        dp[(size_t)r * C + c] = g;
+    }
+}
+
+// ---- asymmetric loss rows (gamma- 4, gamma+ 1, clip .05, eps 1e-8; focal weights differentiated) --------------
+__device__ __forceinline__ void asl_terms(float p, float y, float gneg, float gpos, float clip, float eps, float& loss, float& dldp) {
+    const float pn_raw = 1.f - p + clip;
+    const float pn = fminf(pn_raw, 1.f);
+    const float dpn = pn_raw < 1.f ? -1.f : 0.f;               // d pn / d p
+    const float lp = logf(fmaxf(p, eps)), ln = logf(fmaxf(pn, eps));
+    const float dlp = p > eps ? 1.f / p : 0.f;
+    const float dln = pn > eps ? dpn / pn : 0.f;
+    const float ce = y * lp + (1.f - y) * ln;
+    const float dce = y * dlp + (1.f - y) * dln;
+    const float pt = p * y + pn * (1.f - y);
+    const float dpt = y + dpn * (1.f - y);
+    const float gam = gpos * y + gneg * (1.f - y);
+    const float base = 1.f - pt;
+    const float w = powf(base, gam);
+    // d/dp base^gam = -gam * base^(gam-1) * dpt   (torch.pow backward; 0 where gam == 0)
+    const float dw = gam == 0.f ? 0.f : -gam * powf(base, gam - 1.f) * dpt;
+    loss = -(ce * w);
+    dldp = -(dce * w + ce * dw);
+}
+__global__ __launch_bounds__(256) void asl_rows_fwd_kernel(const float* __restrict__ p, const float* __restrict__ y,
+                                                           const float* __restrict__ active, float* __restrict__ out, int R, int C,
+                                                           float gneg, float gpos, float clip, float eps) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    float s = 0.f;
+    if (active[r] != 0.f) {
+        for (int c = lane; c < C; c += 64) {
+            float l, d;
+            asl_terms(p[(size_t)r * C + c], y[(size_t)r * C + c], gneg, gpos, clip, eps, l, d);
+            s += l;
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s;
+}
+__global__ __launch_bounds__(256) void asl_rows_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ p,
+                                                           const float* __restrict__ y, const float* __restrict__ active,
+                                                           float* __restrict__ dp, int R, int C, float gneg, float gpos, float clip,
+                                                           float eps) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float go = active[r] != 0.f ? dout[r] : 0.f;
+    for (int c = lane; c < C; c += 64) {
+        float l, d = 0.f;
+        if (go != 0.f) asl_terms(p[(size_t)r * C + c], y[(size_t)r * C + c], gneg, gpos, clip, eps, l, d);
+        dp[(size_t)r * C + c] = go * d;
+    }
+}
+__global__ __launch_bounds__(256) void row_any_eq1_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    float f = 0.f;
+    for (int c = lane; c < C; c += 64) f = fmaxf(f, x[(size_t)r * C + c] == 1.0f ? 1.f : 0.f);
+    f = wave_max(f);
+    if (lane == 0) out[r] = f;
+}
+__global__ __launch_bounds__(256) void clamp_labels_kernel(const int* __restrict__ in, int* __restrict__ out, int n, int vocab, int unk) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i] >= vocab ? unk : in[i];
+}
+
+// ---- LSTM cell: gates = gx + gh (i, f, g, o); inactive rows pass (h, c) through ---------------------------------
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ gh,
+                                                            const float* __restrict__ c_prev, const float* __restrict__ h_prev,
+                                                            const float* __restrict__ active, float* __restrict__ h,
+                                                            float* __restrict__ c, float* __restrict__ gates_act, int N, int D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * D) return;
+    const int n = i / D, d = i - n * D;
+    const size_t g0 = (size_t)n * 4 * D + d;
+    const float gi = sigmoidf_(gx[g0] + gh[g0]);
+    const float gf = sigmoidf_(gx[g0 + D] + gh[g0 + D]);
+    const float gg = tanhf(gx[g0 + 2 * D] + gh[g0 + 2 * D]);
+    const float go = sigmoidf_(gx[g0 + 3 * D] + gh[g0 + 3 * D]);
+    gates_act[g0] = gi; gates_act[g0 + D] = gf; gates_act[g0 + 2 * D] = gg; gates_act[g0 + 3 * D] = go;
+    const float cn = gf * c_prev[i] + gi * gg;
+    const float hn = go * tanhf(cn);
+    const float a = active[n];
+    c[i] = a * cn + (1.f - a) * c_prev[i];
+    h[i] = a * hn + (1.f - a) * h_prev[i];
+}
+// dgates is the gradient of the pre-activation gate sums (shared by gx and gh)
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc,
+                                                            const float* __restrict__ gates_act, const float* __restrict__ c_prev,
+                                                            const float* __restrict__ active, float* __restrict__ dgates,
+                                                            float* __restrict__ dc_prev, float* __restrict__ dh_prev, int N, int D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * D) return;
+    const int n = i / D, d = i - n * D;
+    const size_t g0 = (size_t)n * 4 * D + d;
+    const float gi = gates_act[g0], gf = gates_act[g0 + D], gg = gates_act[g0 + 2 * D], go = gates_act[g0 + 3 * D];
+    const float a = active[n];
+    const float dhn = a * dh[i], dcn_in = a * dc[i];
+    const float cn = gf * c_prev[i] + gi * gg;
+    const float tc = tanhf(cn);
+    const float dcn = dcn_in + dhn * go * (1.f - tc * tc);
+    dgates[g0] = dcn * gg * gi * (1.f - gi);
+    dgates[g0 + D] = dcn * c_prev[i] * gf * (1.f - gf);
+    dgates[g0 + 2 * D] = dcn * gi * (1.f - gg * gg);
+    dgates[g0 + 3 * D] = dhn * tc * go * (1.f - go);
+    dc_prev[i] = dcn * gf + (1.f - a) * dc[i];
+    dh_prev[i] = (1.f - a) * dh[i];
+}
+
+static inline unsigned grid1d(size_t n) { size_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+extern "C" {
+
+int svpc_act_bwd(const float* dy, const float* aux, float* dz, size_t n, int act, float p, unsigned site, const u64* seed,
+                 hipStream_t s) {
+    if (n == 0) return 0;
+    SVPC_REQUIRE(p <= 0.f || seed != nullptr, "act_bwd: dropout needs a seed pointer");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, s, dy, aux, dz, n, act, p, site, seed);
+    return svpc_check_launch("act_bwd");
+}
+int svpc_add(const float* a, const float* b, float* c, size_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(add_kernel, dim3(grid1d(n)), dim3(256), 0, s, a, b, c, n);
+    return svpc_check_launch("add");
+}
+int svpc_dropout_mask(float* out, size_t n, float p, unsigned site, const u64* seed, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid1d(n)), dim3(256), 0, s, out, n, p, site, seed);
+    return svpc_check_launch("dropout_mask");
+}
+int svpc_gumbel_noise(float* out, size_t n, unsigned site, const u64* seed, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gumbel_noise_kernel, dim3(grid1d(n)), dim3(256), 0, s, out, n, site, seed);
+    return svpc_check_launch("gumbel_noise");
+}
+int svpc_bump_seed(u64* seed, hipStream_t s) {
+    hipLaunchKernelGGL(bump_seed_kernel, dim3(1), dim3(1), 0, s, seed);
+    return svpc_check_launch("bump_seed");
+}
+int svpc_sum_all(const float* x, size_t n, float* out, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, s, x, n, out, scale);
+    return svpc_check_launch("sum_all");
+}
+int svpc_fill_from(float* x, size_t n, const float* v, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid1d(n)), dim3(256), 0, s, x, n, v);
+    return svpc_check_launch("fill_from");
+}
+int svpc_rownorm_fwd(const float* a, float* y, int R, int C, int mode, hipStream_t s) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(rownorm_fwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, a, y, R, C, mode);
+    return svpc_check_launch("rownorm_fwd");
+}
+int svpc_rownorm_bwd(const float* dy, const float* y, const float* a, float* da, int R, int C, int mode, hipStream_t s) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, dy, y, a, da, R, C, mode);
+    return svpc_check_launch("rownorm_bwd");
+}
+int svpc_span_mean_fwd(const float* x, const int* starts, const int* lens, const float* w, const float* add, const int* add_idx,
+                       float* out, int G, int D, hipStream_t s) {
+    if (G == 0) return 0;
+    hipLaunchKernelGGL(span_mean_fwd_kernel, dim3(G), dim3(256), 0, s, x, starts, lens, w, add, add_idx, out, G, D);
+    return svpc_check_launch("span_mean_fwd");
+}
+int svpc_span_mean_bwd(const float* dout, const int* starts, const int* lens, const float* w, float* dx, int G, int D,
+                       hipStream_t s) {
+    if (G == 0) return 0;
+    hipLaunchKernelGGL(span_mean_bwd_kernel, dim3(G), dim3(256), 0, s, dout, starts, lens, w, dx, G, D);
+    return svpc_check_launch("span_mean_bwd");
+}
+int svpc_scatter_add_rows(const float* dx, const int* idx, float* dtable, int R, int D, int pad_row, hipStream_t s) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(R), dim3(256), 0, s, dx, idx, dtable, R, D, pad_row);
+    return svpc_check_launch("scatter_add_rows");
+}
+int svpc_bce_rows_fwd(const float* p, const float* y, const int* widths, float* out, int R, int C, hipStream_t s) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(bce_rows_fwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, p, y, widths, out, R, C);
+    return svpc_check_launch("bce_rows_fwd");
+}
+int svpc_bce_rows_bwd(const float* dout, const float* p, const float* y, const int* widths, float* dp, int R, int C, hipStream_t s) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(bce_rows_bwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, dout, p, y, widths, dp, R, C);
+    return svpc_check_launch("bce_rows_bwd");
+}
+int svpc_asl_rows_fwd(const float* p, const float* y, const float* active, float* out, int R, int C, float gneg, float gpos,
+                      float clip, float eps, hipStream_t s) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(asl_rows_fwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, p, y, active, out, R, C, gneg, gpos, clip, eps);
+    return svpc_check_launch("asl_rows_fwd");
+}
+int svpc_asl_rows_bwd(const float* dout, const float* p, const float* y, const float* active, float* dp, int R, int C, float gneg,
+                      float gpos, float clip, float eps, hipStream_t s) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(asl_rows_bwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, dout, p, y, active, dp, R, C, gneg, gpos, clip, eps);
+    return svpc_check_launch("asl_rows_bwd");
+}
+int svpc_row_any_eq1(const float* x, float* out, int R, int C, hipStream_t s) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(row_any_eq1_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, x, out, R, C);
+    return svpc_check_launch("row_any_eq1");
+}
+int svpc_clamp_labels(const int* in, int* out, int n, int vocab, int unk, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(clamp_labels_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, n, vocab, unk);
+    return svpc_check_launch("clamp_labels");
+}
+int svpc_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, const float* h_prev, const float* active, float* h,
+                       float* c, float* gates_act, int N, int D, hipStream_t s) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ceil_div(N * D, 256)), dim3(256), 0, s, gx, gh, c_prev, h_prev, active, h, c,
+                       gates_act, N, D);
+    return svpc_check_launch("lstm_cell_fwd");
+}
+int svpc_lstm_cell_bwd(const float* dh, const float* dc, const float* gates_act, const float* c_prev, const float* active,
+                       float* dgates, float* dc_prev, float* dh_prev, int N, int D, hipStream_t s) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ceil_div(N * D, 256)), dim3(256), 0, s, dh, dc, gates_act, c_prev, active, dgates,
+                       dc_prev, dh_prev, N, D);
+    return svpc_check_launch("lstm_cell_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,363 @@
+// LayerNorm family for the recurrent-transformer hot path (reference: src/rtransformer/model.py:143-156 and
+// the fused variants at :229-233, :285-289, :493-499, :548-562, :650, :659, :889-891).
+//
+//   h = pre_dropout(x[src_rows[r]]) + residual[r]
+//   y = post_dropout( (h - mean) / sqrt(var_biased + eps) * gamma + beta ) + add1[r % mod1] + add2[idx2[r]]
+//
+// One 64-lane wave owns one row (wave-shuffle reduce, two-pass variance in registers, eps inside the sqrt);
+// 16-byte coalesced loads when D % 4 == 0.  HBM-bound: algorithmic bytes = (reads of x, residual) + write of y.
+// Backward recomputes h and x_hat from the saved inputs + (mean, rstd); gamma/beta gradients are accumulated
+// per workgroup in registers → LDS → one partial row per workgroup, reduced by colsum_finalize (deterministic).
+#include "common.h"
+
+template <int W>
+struct VecIO;
+template <>
+struct VecIO<4> {
+    static __device__ __forceinline__ void load(const float* p, float* v) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <>
+struct VecIO<1> {
+    static __device__ __forceinline__ void load(const float* p, float* v) { v[0] = p[0]; }
+    static __device__ __forceinline__ void store(float* p, const float* v) { p[0] = v[0]; }
+};
+
+struct LnArgs {
+    const float* x; const int* src_rows; const float* res; const float* gamma; const float* beta;
+    float* y; float* mean; float* rstd; int R; int D; float eps;
+    float p_pre; uint32_t site_pre; float p_post; uint32_t site_post; const u64* seed;
+    const float* add1; int mod1; const float* add2; const int* idx2;
+};
+
+template <int NPL, int W>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.R) return;
+    const int D = a.D;
+    const size_t xrow = (size_t)(a.src_rows ? a.src_rows[r] : r) * D;
+    const size_t orow = (size_t)r * D;
+    const bool any_drop = (a.p_pre > 0.f) || (a.p_post > 0.f);
+    const u64 seed = any_drop ? a.seed[0] : 0ull;
+    const float ik_pre = a.p_pre > 0.f ? 1.0f / (1.0f - a.p_pre) : 1.0f;
+    const float ik_post = a.p_post > 0.f ? 1.0f / (1.0f - a.p_post) : 1.0f;
+
+    float v[NPL * W];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int col = (lane + 64 * i) * W;
+        if (col < D) {
+            VecIO<W>::load(a.x + xrow + col, &v[i * W]);
+            if (a.p_pre > 0.f) {
+#pragma unroll
+                for (int j = 0; j < W; ++j) v[i * W + j] *= drop_scale(seed, a.site_pre, orow + col + j, a.p_pre, ik_pre);
+            }
+            if (a.res) {
+                float t[W];
+                VecIO<W>::load(a.res + orow + col, t);
+#pragma unroll
+                for (int j = 0; j < W; ++j) v[i * W + j] += t[j];
+            }
+#pragma unroll
+            for (int j = 0; j < W; ++j) sum += v[i * W + j];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int col = (lane + 64 * i) * W;
+        if (col < D) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                float d = v[i * W + j] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float var = wave_sum(sq) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    if (lane == 0) {
+        if (a.mean) a.mean[r] = mean;
+        if (a.rstd) a.rstd[r] = rstd;
+    }
+    const size_t a1row = a.add1 ? (size_t)(r % a.mod1) * D : 0;
+    const size_t a2row = a.add2 ? (size_t)a.idx2[r] * D : 0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int col = (lane + 64 * i) * W;
+        if (col < D) {
+            float g[W], b[W], o[W];
+            VecIO<W>::load(a.gamma + col, g);
+            VecIO<W>::load(a.beta + col, b);
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                float t = (v[i * W + j] - mean) * rstd * g[j] + b[j];
+                if (a.p_post > 0.f) t *= drop_scale(seed, a.site_post, orow + col + j, a.p_post, ik_post);
+                o[j] = t;
+            }
+            if (a.add1) {
+                float t[W];
+                VecIO<W>::load(a.add1 + a1row + col, t);
+#pragma unroll
+                for (int j = 0; j < W; ++j) o[j] += t[j];
+            }
+            if (a.add2) {
+                float t[W];
+                VecIO<W>::load(a.add2 + a2row + col, t);
+#pragma unroll
+                for (int j = 0; j < W; ++j) o[j] += t[j];
+            }
+            VecIO<W>::store(a.y + orow + col, o);
+        }
+    }
+}
+
+struct LnBwdArgs {
+    const float* dy; const float* x; const int* src_rows; const float* res; const float* gamma;
+    const float* mean; const float* rstd;
+    float* dh;      // (R, D) gradient w.r.t. the pre-LN sum (= residual gradient); may be null
+    float* dx;      // (R, D) gradient w.r.t. the gathered, pre-dropout x rows; may be null or == dh
+    float* partial; // (gridDim.x, 2, D) per-workgroup [dgamma; dbeta]
+    int R; int D;
+    float p_pre; uint32_t site_pre; float p_post; uint32_t site_post; const u64* seed;
+};
+
+template <int NPL, int W>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
+    extern __shared__ float smem[];  // 2*D floats
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int D = a.D;
+    for (int c = threadIdx.x; c < 2 * D; c += 256) smem[c] = 0.f;
+    __syncthreads();
+    const bool any_drop = (a.p_pre > 0.f) || (a.p_post > 0.f);
+    const u64 seed = any_drop ? a.seed[0] : 0ull;
+    const float ik_pre = a.p_pre > 0.f ? 1.0f / (1.0f - a.p_pre) : 1.0f;
+    const float ik_post = a.p_post > 0.f ? 1.0f / (1.0f - a.p_post) : 1.0f;
+    const float invD = 1.0f / (float)D;
+
+    float g[NPL * W], accg[NPL * W], accb[NPL * W];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int col = (lane + 64 * i) * W;
+#pragma unroll
+        for (int j = 0; j < W; ++j) { accg[i * W + j] = 0.f; accb[i * W + j] = 0.f; g[i * W + j] = 0.f; }
+        if (col < D) VecIO<W>::load(a.gamma + col, &g[i * W]);
+    }
+    for (int r = blockIdx.x * 4 + wave; r < a.R; r += gridDim.x * 4) {
+        const size_t xrow = (size_t)(a.src_rows ? a.src_rows[r] : r) * D;
+        const size_t orow = (size_t)r * D;
+        const float mean = a.mean[r], rstd = a.rstd[r];
+        float xh[NPL * W], dxh[NPL * W];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int col = (lane + 64 * i) * W;
+            if (col < D) {
+                float h[W], d[W];
+                VecIO<W>::load(a.x + xrow + col, h);
+                if (a.p_pre > 0.f) {
+#pragma unroll
+                    for (int j = 0; j < W; ++j) h[j] *= drop_scale(seed, a.site_pre, orow + col + j, a.p_pre, ik_pre);
+                }
+                if (a.res) {
+                    float t[W];
+                    VecIO<W>::load(a.res + orow + col, t);
+#pragma unroll
+                    for (int j = 0; j < W; ++j) h[j] += t[j];
+                }
+                VecIO<W>::load(a.dy + orow + col, d);
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    float dy0 = d[j];
+                    if (a.p_post > 0.f) dy0 *= drop_scale(seed, a.site_post, orow + col + j, a.p_post, ik_post);
+                    const float xhat = (h[j] - mean) * rstd;
+                    accg[i * W + j] += dy0 * xhat;
+                    accb[i * W + j] += dy0;
+                    const float t = dy0 * g[i * W + j];
+                    xh[i * W + j] = xhat;
+                    dxh[i * W + j] = t;
+                    s1 += t;
+                    s2 += t * xhat;
+                }
+            }
+        }
+        if (a.dh || a.dx) {
+            s1 = wave_sum(s1) * invD;
+            s2 = wave_sum(s2) * invD;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                const int col = (lane + 64 * i) * W;
+                if (col < D) {
+                    float o[W];
+#pragma unroll
+                    for (int j = 0; j < W; ++j) o[j] = rstd * (dxh[i * W + j] - s1 - xh[i * W + j] * s2);
+                    if (a.dh) VecIO<W>::store(a.dh + orow + col, o);
+                    if (a.dx && a.dx != a.dh) {
+                        if (a.p_pre > 0.f) {
+#pragma unroll
+                            for (int j = 0; j < W; ++j) o[j] *= drop_scale(seed, a.site_pre, orow + col + j, a.p_pre, ik_pre);
+                        }
+                        VecIO<W>::store(a.dx + orow + col, o);
+                    }
+                }
+            }
+        }
+    }
+    // workgroup reduce of the gamma/beta partials through LDS (float adds on LDS)
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int col = (lane + 64 * i) * W;
+        if (col < D) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                atomicAdd(&smem[col + j], accg[i * W + j]);
+                atomicAdd(&smem[D + col + j], accb[i * W + j]);
+            }
+        }
+    }
+    __syncthreads();
+    float* out = a.partial + (size_t)blockIdx.x * 2 * D;
+    for (int c = threadIdx.x; c < 2 * D; c += 256) out[c] = smem[c];
+}
+
+// out[c] (+)= sum_g partial[g][c]
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int G, int ncols,
+                                                              float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncols) return;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += partial[(size_t)g * ncols + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// partial[chunk][k][c] = sum over rows r of the chunk with idx[r]==k (idx null → k = 0) of x[r][c]
+template <int KMAX>
+__global__ __launch_bounds__(256) void bucket_colsum_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ idx,
+                                                            int R, int C, int K, int rows_per_chunk, float* __restrict__ partial) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int chunk = blockIdx.y;
+    const int r0 = chunk * rows_per_chunk;
+    const int r1 = min(R, r0 + rows_per_chunk);
+    float acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+    if (c < C) {
+        for (int r = r0; r < r1; ++r) {
+            const float v = x[(size_t)r * ldx + c];
+            const int k = idx ? idx[r] : 0;
+#pragma unroll
+            for (int kk = 0; kk < KMAX; ++kk) acc[kk] += (kk == k) ? v : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) partial[((size_t)chunk * K + k) * C + c] = acc[k];
+    }
+}
+
+template <int NPL, int W>
+static int launch_ln_fwd(const LnArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((ln_fwd_kernel<NPL, W>), dim3(ceil_div(a.R, 4)), dim3(256), 0, s, a);
+    return svpc_check_launch("ln_fwd");
+}
+template <int NPL, int W>
+static int launch_ln_bwd(const LnBwdArgs& a, int G, hipStream_t s) {
+    hipLaunchKernelGGL((ln_bwd_kernel<NPL, W>), dim3(G), dim3(256), (size_t)2 * a.D * sizeof(float), s, a);
+    return svpc_check_launch("ln_bwd");
+}
+
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+extern "C" {
+
+int svpc_ln_fwd(const float* x, const int* src_rows, const float* res, const float* gamma, const float* beta, float* y,
+                float* mean, float* rstd, int R, int D, float eps, float p_pre, unsigned site_pre, float p_post,
+                unsigned site_post, const u64* seed, const float* add1, int mod1, const float* add2, const int* idx2,
+                hipStream_t stream) {
+    if (R == 0) return 0;
+    LnArgs a{x, src_rows, res, gamma, beta, y, mean, rstd, R, D, eps, p_pre, site_pre, p_post, site_post, seed,
+             add1, mod1, add2, idx2};
+    SVPC_REQUIRE((p_pre <= 0.f && p_post <= 0.f) || seed != nullptr, "ln_fwd: dropout needs a seed pointer");
+    const bool vec = (D % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) &&
+                     (!res || aligned16(res)) && (!add1 || aligned16(add1)) && (!add2 || aligned16(add2));
+    if (vec) {
+        if (D <= 256) return launch_ln_fwd<1, 4>(a, stream);
+        if (D <= 1024) return launch_ln_fwd<4, 4>(a, stream);
+        if (D <= 3072) return launch_ln_fwd<12, 4>(a, stream);
+        if (D <= 8192) return launch_ln_fwd<32, 4>(a, stream);
+    } else {
+        if (D <= 256) return launch_ln_fwd<4, 1>(a, stream);
+        if (D <= 1024) return launch_ln_fwd<16, 1>(a, stream);
+        if (D <= 3072) return launch_ln_fwd<48, 1>(a, stream);
+    }
+    svpc_set_error("ln_fwd: row width not supported");
+    return -1;
+}
+
+// workspace: at least svpc_ln_bwd_groups(R) * 2 * D floats
+int svpc_ln_bwd_groups(int R) { int g = ceil_div(R, 4); return g < 1 ? 1 : (g > 512 ? 512 : g); }
+
+int svpc_ln_bwd(const float* dy, const float* x, const int* src_rows, const float* res, const float* gamma,
+                const float* mean, const float* rstd, float* dh, float* dx, float* dgamma, float* dbeta,
+                int accumulate, float* workspace, int R, int D, float p_pre, unsigned site_pre, float p_post,
+                unsigned site_post, const u64* seed, hipStream_t stream) {
+    if (R == 0) return 0;
+    const int G = svpc_ln_bwd_groups(R);
+    LnBwdArgs a{dy, x, src_rows, res, gamma, mean, rstd, dh, dx, workspace, R, D, p_pre, site_pre, p_post, site_post, seed};
+    const bool vec = (D % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(gamma) && (!res || aligned16(res)) &&
+                     (!dh || aligned16(dh)) && (!dx || aligned16(dx));
+    int rc = -1;
+    if (vec) {
+        if (D <= 256) rc = launch_ln_bwd<1, 4>(a, G, stream);
+        else if (D <= 1024) rc = launch_ln_bwd<4, 4>(a, G, stream);
+        else if (D <= 3072) rc = launch_ln_bwd<12, 4>(a, G, stream);
+        else if (D <= 8192) rc = launch_ln_bwd<32, 4>(a, G, stream);
+    } else {
+        if (D <= 256) rc = launch_ln_bwd<4, 1>(a, G, stream);
+        else if (D <= 1024) rc = launch_ln_bwd<16, 1>(a, G, stream);
+        else if (D <= 3072) rc = launch_ln_bwd<48, 1>(a, G, stream);
+    }
+    if (rc != 0) { if (rc == -1) svpc_set_error("ln_bwd: row width not supported"); return rc; }
+    // partial layout per group: [dgamma(D) ; dbeta(D)] → two strided reductions
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(2 * D, 256)), dim3(256), 0, stream, workspace, G, 2 * D,
+                       workspace + (size_t)G * 2 * D, 0);
+    rc = svpc_check_launch("ln_bwd finalize");
+    if (rc) return rc;
+    // scatter the two halves (tiny): reuse finalize with G=1 to honour `accumulate`
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, stream,
+                       workspace + (size_t)G * 2 * D, 1, D, dgamma, accumulate);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, stream,
+                       workspace + (size_t)G * 2 * D + D, 1, D, dbeta, accumulate);
+    return svpc_check_launch("ln_bwd scatter");
+}
+
+// out[k][c] (+)= sum_{r : idx[r]==k} x[r][c]   (idx null → plain column sum, K must be 1).  K <= 8.
+// workspace: svpc_colsum_chunks(R) * K * C floats
+int svpc_colsum_chunks(int R) { int g = ceil_div(R, 128); return g < 1 ? 1 : (g > 128 ? 128 : g); }
+
+int svpc_bucket_colsum(const float* x, int ldx, const int* idx, int R, int C, int K, float* out, int accumulate,
+                       float* workspace, hipStream_t stream) {
+    SVPC_REQUIRE(K >= 1 && K <= 8, "bucket_colsum: K must be 1..8");
+    if (R == 0 || C == 0) return 0;
+    const int chunks = svpc_colsum_chunks(R);
+    const int rpc = ceil_div(R, chunks);
+    dim3 grid(ceil_div(C, 256), chunks);
+    if (K == 1) hipLaunchKernelGGL((bucket_colsum_kernel<1>), grid, dim3(256), 0, stream, x, ldx, idx, R, C, K, rpc, workspace);
+    else if (K <= 4) hipLaunchKernelGGL((bucket_colsum_kernel<4>), grid, dim3(256), 0, stream, x, ldx, idx, R, C, K, rpc, workspace);
+    else hipLaunchKernelGGL((bucket_colsum_kernel<8>), grid, dim3(256), 0, stream, x, ldx, idx, R, C, K, rpc, workspace);
+    int rc = svpc_check_launch("bucket_colsum");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(K * C, 256)), dim3(256), 0, stream, workspace, chunks, K * C,
+                       out, accumulate);
+    return svpc_check_launch("bucket_colsum finalize");
+}
+
+}  // extern "C"

@@ -1,0 +1,337 @@
+// Pointer-generator, caption loss and Gumbel re-sampling kernels (reference: src/rtransformer/model.py:896-923
+// pointer_generator_network, :37-55 LabelSmoothingLoss, :1018 gumbel_softmax(hard) @ word embeddings).
+//
+//  ptr_attn      per step j: score[t,e] = <Wing(B_j)[e], dec[j,t]>, pi = softmax_e, att[t] = Σ_e pi[t,e]·B_j[e]
+//                (one workgroup per step: proj/bank rows come from L2, the Lt×E score matrix lives in LDS;
+//                 backward needs no atomics because every reduction is local to the step)
+//  ptr_mix_loss  per text row: P[:V] = g·softmax(logits); P[V:C] = 0; P[id] += (1-g)·pi[e]/|I_e| for the video's
+//                (ingredient → word-id) CSR; label-smoothed KL with log(P+1e-12), last class gets no smoothing mass
+//                (one workgroup per row, the row lives in LDS; duplicate ids resolved with LDS float adds)
+//  gumbel        per text row: straight-through one-hot of argmax softmax((log(P+1e-12)+G)/tau) → embedding row gather
+// All are latency/HBM-bound (rows ≤ 4,224 × ≤ ~1,000 columns).
+#include "common.h"
+
+constexpr int PTR_EMAX = 32;
+
+// ------------------------------------------------------------------------------------------------ ptr_attn
+// grid: T steps. LDS: lt*32 floats (scores/pi).
+__global__ __launch_bounds__(256) void ptr_attn_fwd_kernel(const float* __restrict__ dec, const float* __restrict__ proj,
+                                                           const float* __restrict__ bank, const int* __restrict__ step_ne,
+                                                           float* __restrict__ pi, float* __restrict__ att, int lt, int em, int D) {
+    extern __shared__ float sc[];   // lt × PTR_EMAX
+    const int j = blockIdx.x, E = step_ne[j];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* pj = proj + (size_t)j * em * D;
+    const float* bj = bank + (size_t)j * em * D;
+    const float* dj = dec + (size_t)j * lt * D;
+    for (int pe = wave; pe < lt * E; pe += 4) {
+        const int t = pe / E, e = pe - t * E;
+        float dot = 0.f;
+        for (int d = lane; d < D; d += 64) dot += pj[(size_t)e * D + d] * dj[(size_t)t * D + d];
+        dot = wave_sum(dot);
+        if (lane == 0) sc[t * PTR_EMAX + e] = dot;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < lt; t += 256) {
+        float m = -INFINITY;
+        for (int e = 0; e < E; ++e) m = fmaxf(m, sc[t * PTR_EMAX + e]);
+        float s = 0.f;
+        for (int e = 0; e < E; ++e) { const float v = expf(sc[t * PTR_EMAX + e] - m); sc[t * PTR_EMAX + e] = v; s += v; }
+        const float inv = 1.0f / s;
+        for (int e = 0; e < em; ++e) {
+            const float v = e < E ? sc[t * PTR_EMAX + e] * inv : 0.f;
+            if (e < E) sc[t * PTR_EMAX + e] = v;
+            pi[((size_t)j * lt + t) * em + e] = v;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < lt * D; i += 256) {
+        const int t = i / D, d = i - t * D;
+        float acc = 0.f;
+        for (int e = 0; e < E; ++e) acc += sc[t * PTR_EMAX + e] * bj[(size_t)e * D + d];
+        att[((size_t)j * lt + t) * D + d] = acc;
+    }
+}
+
+// dproj/dbank are (T, em, D) and fully written (zeros for e ≥ E); ddec (T*lt, D) fully written.
+__global__ __launch_bounds__(256) void ptr_attn_bwd_kernel(const float* __restrict__ dec, const float* __restrict__ proj,
+                                                           const float* __restrict__ bank, const int* __restrict__ step_ne,
+                                                           const float* __restrict__ pi, const float* __restrict__ dpi,
+                                                           const float* __restrict__ datt, float* __restrict__ ddec,
+                                                           float* __restrict__ dproj, float* __restrict__ dbank, int lt, int em, int D) {
+    extern __shared__ float sm[];   // dsc: lt × 32, pis: lt × 32
+    float* dsc = sm;
+    float* pis = sm + lt * PTR_EMAX;
+    const int j = blockIdx.x, E = step_ne[j];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* pj = proj + (size_t)j * em * D;
+    const float* bj = bank + (size_t)j * em * D;
+    const float* dj = dec + (size_t)j * lt * D;
+    const float* daj = datt + (size_t)j * lt * D;
+    for (int pe = wave; pe < lt * E; pe += 4) {
+        const int t = pe / E, e = pe - t * E;
+        float dot = 0.f;
+        for (int d = lane; d < D; d += 64) dot += daj[(size_t)t * D + d] * bj[(size_t)e * D + d];
+        dot = wave_sum(dot);
+        if (lane == 0) {
+            const size_t o = ((size_t)j * lt + t) * em + e;
+            dsc[t * PTR_EMAX + e] = dot + (dpi ? dpi[o] : 0.f);
+            pis[t * PTR_EMAX + e] = pi[o];
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < lt; t += 256) {
+        float mix = 0.f;
+        for (int e = 0; e < E; ++e) mix += pis[t * PTR_EMAX + e] * dsc[t * PTR_EMAX + e];
+        for (int e = 0; e < E; ++e) dsc[t * PTR_EMAX + e] = pis[t * PTR_EMAX + e] * (dsc[t * PTR_EMAX + e] - mix);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < lt * D; i += 256) {
+        const int t = i / D, d = i - t * D;
+        float acc = 0.f;
+        for (int e = 0; e < E; ++e) acc += dsc[t * PTR_EMAX + e] * pj[(size_t)e * D + d];
+        ddec[((size_t)j * lt + t) * D + d] = acc;
+    }
+    for (int i = threadIdx.x; i < em * D; i += 256) {
+        const int e = i / D, d = i - e * D;
+        float ap = 0.f, ab = 0.f;
+        if (e < E) {
+            for (int t = 0; t < lt; ++t) {
+                ap += dsc[t * PTR_EMAX + e] * dj[(size_t)t * D + d];
+                ab += pis[t * PTR_EMAX + e] * daj[(size_t)t * D + d];
+            }
+        }
+        dproj[(size_t)j * em * D + i] = ap;
+        dbank[(size_t)j * em * D + i] = ab;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ptr_mix_loss
+struct MixArgs {
+    const float* logits; const float* g; const float* pi; const int* labels; const int* row_c; const int* row_vid;
+    const int* csr_off; const int* csr_ent; const int* csr_id; const float* csr_w;
+    float* P; float* loss_rows; int V; int c_max; int em; float smoothing;
+    // backward
+    const float* dP_ext; const float* dloss; float* dlogits; float* dg; float* dpi;
+};
+
+// grid: R rows. LDS: c_max floats.
+__global__ __launch_bounds__(256) void ptr_mix_loss_fwd_kernel(MixArgs a) {
+    extern __shared__ float row[];
+    __shared__ float red[4];
+    const int r = blockIdx.x, V = a.V, C = a.row_c[r];
+    const float* lg = a.logits + (size_t)r * V;
+    float m = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += 256) m = fmaxf(m, lg[v]);
+    m = block_max_256(m, red);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) { const float e = expf(lg[v] - m); row[v] = e; s += e; }
+    s = block_sum_256(s, red);
+    const float gate = a.g ? a.g[r] : 1.0f;
+    const float sc = gate / s;
+    for (int v = threadIdx.x; v < a.c_max; v += 256) row[v] = v < V ? row[v] * sc : 0.f;
+    __syncthreads();
+    if (a.g) {
+        const int b = a.row_vid[r];
+        for (int n = a.csr_off[b] + threadIdx.x; n < a.csr_off[b + 1]; n += 256)
+            atomicAdd(&row[a.csr_id[n]], (1.0f - gate) * a.pi[(size_t)r * a.em + a.csr_ent[n]] * a.csr_w[n]);
+        __syncthreads();
+    }
+    const int y = a.labels[r];
+    float loss = 0.f;
+    const float qs = a.smoothing / (float)(C - 1), conf = 1.0f - a.smoothing;
+    for (int v = threadIdx.x; v < a.c_max; v += 256) {
+        const float p = row[v];
+        a.P[(size_t)r * a.c_max + v] = p;
+        if (y >= 0 && v < C) {
+            const float qv = v == y ? conf : (v == C - 1 ? 0.f : qs);
+            if (qv > 0.f) loss += qv * (logf(qv) - logf(p + 1e-12f));
+        }
+    }
+    loss = block_sum_256(loss, red);
+    if (threadIdx.x == 0) a.loss_rows[r] = loss;
+}
+
+// LDS: 2*c_max floats (dP row, softmax row)
+__global__ __launch_bounds__(256) void ptr_mix_loss_bwd_kernel(MixArgs a) {
+    extern __shared__ float sm[];
+    __shared__ float red[4];
+    __shared__ float dpis[PTR_EMAX];
+    float* dP = sm;
+    float* smx = sm + a.c_max;
+    const int r = blockIdx.x, V = a.V, C = a.row_c[r];
+    const int y = a.labels[r];
+    const float go = a.dloss ? a.dloss[r] : 1.0f;
+    const float qs = a.smoothing / (float)(C - 1), conf = 1.0f - a.smoothing;
+    const float* lg = a.logits + (size_t)r * V;
+    float m = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += 256) m = fmaxf(m, lg[v]);
+    m = block_max_256(m, red);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) { const float e = expf(lg[v] - m); smx[v] = e; s += e; }
+    s = block_sum_256(s, red);
+    const float inv = 1.0f / s;
+    for (int v = threadIdx.x; v < a.c_max; v += 256) {
+        float d = a.dP_ext ? a.dP_ext[(size_t)r * a.c_max + v] : 0.f;
+        if (y >= 0 && v < C) {
+            const float qv = v == y ? conf : (v == C - 1 ? 0.f : qs);
+            if (qv > 0.f) d -= go * qv / (a.P[(size_t)r * a.c_max + v] + 1e-12f);
+        }
+        dP[v] = d;
+        if (v < V) smx[v] *= inv;
+    }
+    __syncthreads();
+    const float gate = a.g ? a.g[r] : 1.0f;
+    float dot = 0.f;                      // Σ_v dP_v · sm_v
+    for (int v = threadIdx.x; v < V; v += 256) dot += dP[v] * smx[v];
+    dot = block_sum_256(dot, red);
+    // d logits: sm_v · g · (dP_v - dot)
+    for (int v = threadIdx.x; v < V; v += 256) a.dlogits[(size_t)r * V + v] = smx[v] * gate * (dP[v] - dot);
+    if (a.g) {
+        const int b = a.row_vid[r];
+        if (threadIdx.x < PTR_EMAX) dpis[threadIdx.x] = 0.f;
+        __syncthreads();
+        float cp = 0.f;                   // Σ_n dP[id]·pi[e]·w
+        for (int n = a.csr_off[b] + threadIdx.x; n < a.csr_off[b + 1]; n += 256) {
+            const float t = dP[a.csr_id[n]] * a.csr_w[n];
+            cp += t * a.pi[(size_t)r * a.em + a.csr_ent[n]];
+            atomicAdd(&dpis[a.csr_ent[n]], (1.0f - gate) * t);
+        }
+        cp = block_sum_256(cp, red);
+        if (threadIdx.x == 0) a.dg[r] = dot - cp;
+        if (threadIdx.x < a.em) a.dpi[(size_t)r * a.em + threadIdx.x] = dpis[threadIdx.x];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ gumbel
+// fwd: idx[r] = argmax_j<C (log(P+eps)+G)/tau ; stats[r] = (max, sumexp) ; bow[r] = coef·emb[idx] (0 if idx ≥ V)
+__global__ __launch_bounds__(256) void gumbel_fwd_kernel(const float* __restrict__ P, const float* __restrict__ noise,
+                                                         const int* __restrict__ row_c, const float* __restrict__ emb,
+                                                         float* __restrict__ bow, int* __restrict__ idx_out,
+                                                         float* __restrict__ stats, int c_max, int V, int W, float inv_tau) {
+    __shared__ float red[4];
+    __shared__ float sval[4];
+    __shared__ int sidx[4];
+    const int r = blockIdx.x, C = row_c[r];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int v = threadIdx.x; v < C; v += 256) {
+        const float l = (logf(P[(size_t)r * c_max + v] + 1e-12f) + noise[(size_t)r * c_max + v]) * inv_tau;
+        if (l > best) { best = l; bi = v; }
+    }
+    // wave argmax (first index on ties), then across the 4 waves
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { sval[wave] = best; sidx[wave] = bi; }
+    __syncthreads();
+    best = sval[0]; bi = sidx[0];
+    for (int w = 1; w < 4; ++w)
+        if (sval[w] > best || (sval[w] == best && sidx[w] < bi)) { best = sval[w]; bi = sidx[w]; }
+    float s = 0.f;
+    for (int v = threadIdx.x; v < C; v += 256)
+        s += expf((logf(P[(size_t)r * c_max + v] + 1e-12f) + noise[(size_t)r * c_max + v]) * inv_tau - best);
+    s = block_sum_256(s, red);
+    const float ymax = 1.0f / s;                       // soft probability of the arg-max class
+    const float coef = (1.0f - ymax) + ymax;           // hard - y.detach() + y, evaluated like the reference
+    if (threadIdx.x == 0) { idx_out[r] = bi; stats[2 * r] = best; stats[2 * r + 1] = s; }
+    for (int c = threadIdx.x; c < W; c += 256) bow[(size_t)r * W + c] = bi < V ? coef * emb[(size_t)bi * W + c] : 0.f;
+}
+
+// bwd: dy (R, V) = dbow @ embᵀ comes from the GEMM; dP_j = y_j (dy_j[j<V] - Σ_k<V y_k dy_k) / tau / (P_j + eps)
+__global__ __launch_bounds__(256) void gumbel_bwd_kernel(const float* __restrict__ P, const float* __restrict__ noise,
+                                                         const int* __restrict__ row_c, const float* __restrict__ stats,
+                                                         const float* __restrict__ dy, float* __restrict__ dP, int c_max, int V,
+                                                         float inv_tau) {
+    __shared__ float red[4];
+    const int r = blockIdx.x, C = row_c[r];
+    const float mx = stats[2 * r], inv = 1.0f / stats[2 * r + 1];
+    float dot = 0.f;
+    for (int v = threadIdx.x; v < C && v < V; v += 256) {
+        const float yv = expf((logf(P[(size_t)r * c_max + v] + 1e-12f) + noise[(size_t)r * c_max + v]) * inv_tau - mx) * inv;
+        dot += yv * dy[(size_t)r * V + v];
+    }
+    dot = block_sum_256(dot, red);
+    for (int v = threadIdx.x; v < c_max; v += 256) {
+        float out = 0.f;
+        if (v < C) {
+            const float p = P[(size_t)r * c_max + v];
+            const float yv = expf((logf(p + 1e-12f) + noise[(size_t)r * c_max + v]) * inv_tau - mx) * inv;
+            const float d = v < V ? dy[(size_t)r * V + v] : 0.f;
+            out = yv * (d - dot) * inv_tau / (p + 1e-12f);
+        }
+        dP[(size_t)r * c_max + v] = out;
+    }
+}
+// demb[idx[r]] += coef·dbow[r]
+__global__ __launch_bounds__(256) void gumbel_emb_grad_kernel(const float* __restrict__ dbow, const int* __restrict__ idx,
+                                                              const float* __restrict__ stats, float* __restrict__ demb, int V, int W) {
+    const int r = blockIdx.x, t = idx[r];
+    if (t >= V) return;
+    const float ymax = 1.0f / stats[2 * r + 1];
+    const float coef = (1.0f - ymax) + ymax;
+    for (int c = threadIdx.x; c < W; c += 256) atomicAdd(&demb[(size_t)t * W + c], coef * dbow[(size_t)r * W + c]);
+}
+
+extern "C" {
+
+int svpc_ptr_attn_fwd(const float* dec, const float* proj, const float* bank, const int* step_ne, float* pi, float* att, int T,
+                      int lt, int e_max, int D, hipStream_t s) {
+    if (T == 0) return 0;
+    SVPC_REQUIRE(e_max <= PTR_EMAX, "ptr_attn: at most 32 entities");
+    hipLaunchKernelGGL(ptr_attn_fwd_kernel, dim3(T), dim3(256), (size_t)lt * PTR_EMAX * sizeof(float), s, dec, proj, bank, step_ne, pi,
+                       att, lt, e_max, D);
+    return svpc_check_launch("ptr_attn_fwd");
+}
+int svpc_ptr_attn_bwd(const float* dec, const float* proj, const float* bank, const int* step_ne, const float* pi, const float* dpi,
+                      const float* datt, float* ddec, float* dproj, float* dbank, int T, int lt, int e_max, int D, hipStream_t s) {
+    if (T == 0) return 0;
+    SVPC_REQUIRE(e_max <= PTR_EMAX, "ptr_attn: at most 32 entities");
+    hipLaunchKernelGGL(ptr_attn_bwd_kernel, dim3(T), dim3(256), (size_t)2 * lt * PTR_EMAX * sizeof(float), s, dec, proj, bank, step_ne,
+                       pi, dpi, datt, ddec, dproj, dbank, lt, e_max, D);
+    return svpc_check_launch("ptr_attn_bwd");
+}
+int svpc_ptr_mix_loss_fwd(const float* logits, const float* g, const float* pi, const int* labels, const int* row_c,
+                          const int* row_vid, const int* csr_off, const int* csr_ent, const int* csr_id, const float* csr_w, float* P,
+                          float* loss_rows, int R, int V, int c_max, int e_max, float smoothing, hipStream_t s) {
+    if (R == 0) return 0;
+    MixArgs a{};
+    a.logits = logits; a.g = g; a.pi = pi; a.labels = labels; a.row_c = row_c; a.row_vid = row_vid; a.csr_off = csr_off;
+    a.csr_ent = csr_ent; a.csr_id = csr_id; a.csr_w = csr_w; a.P = P; a.loss_rows = loss_rows; a.V = V; a.c_max = c_max;
+    a.em = e_max; a.smoothing = smoothing;
+    hipLaunchKernelGGL(ptr_mix_loss_fwd_kernel, dim3(R), dim3(256), (size_t)c_max * sizeof(float), s, a);
+    return svpc_check_launch("ptr_mix_loss_fwd");
+}
+int svpc_ptr_mix_loss_bwd(const float* logits, const float* g, const float* pi, const int* labels, const int* row_c,
+                          const int* row_vid, const int* csr_off, const int* csr_ent, const int* csr_id, const float* csr_w,
+                          const float* P, const float* dP_ext, const float* dloss, float* dlogits, float* dg, float* dpi, int R, int V,
+                          int c_max, int e_max, float smoothing, hipStream_t s) {
+    if (R == 0) return 0;
+    MixArgs a{};
+    a.logits = logits; a.g = g; a.pi = pi; a.labels = labels; a.row_c = row_c; a.row_vid = row_vid; a.csr_off = csr_off;
+    a.csr_ent = csr_ent; a.csr_id = csr_id; a.csr_w = csr_w; a.P = const_cast<float*>(P); a.V = V; a.c_max = c_max; a.em = e_max;
+    a.smoothing = smoothing; a.dP_ext = dP_ext; a.dloss = dloss; a.dlogits = dlogits; a.dg = dg; a.dpi = dpi;
+    hipLaunchKernelGGL(ptr_mix_loss_bwd_kernel, dim3(R), dim3(256), (size_t)2 * c_max * sizeof(float), s, a);
+    return svpc_check_launch("ptr_mix_loss_bwd");
+}
+int svpc_gumbel_fwd(const float* P, const float* noise, const int* row_c, const float* emb, float* bow, int* idx, float* stats, int R,
+                    int c_max, int V, int W, float tau, hipStream_t s) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(gumbel_fwd_kernel, dim3(R), dim3(256), 0, s, P, noise, row_c, emb, bow, idx, stats, c_max, V, W, 1.0f / tau);
+    return svpc_check_launch("gumbel_fwd");
+}
+int svpc_gumbel_bwd(const float* P, const float* noise, const int* row_c, const float* stats, const float* dy, float* dP, int R,
+                    int c_max, int V, float tau, hipStream_t s) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(R), dim3(256), 0, s, P, noise, row_c, stats, dy, dP, c_max, V, 1.0f / tau);
+    return svpc_check_launch("gumbel_bwd");
+}
+int svpc_gumbel_emb_grad(const float* dbow, const int* idx, const float* stats, float* demb, int R, int V, int W, hipStream_t s) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(gumbel_emb_grad_kernel, dim3(R), dim3(256), 0, s, dbow, idx, stats, demb, V, W);
+    return svpc_check_launch("gumbel_emb_grad");
+}
+
+}  // extern "C"

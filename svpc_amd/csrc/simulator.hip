@@ -1,0 +1,288 @@
+// Entity-state recurrence of the visual simulator / textual re-simulator (reference: src/rtransformer/model.py:792-820,
+// Eqs. (2)-(7)).  Everything that depends only on the step vector (action selector, verb mixture f̄, ĥ = ReLU(W1 v),
+// q = W2[ĥ;a], c = softmax(W3 ĥ), w = W4 f̄) is hoisted into batched GEMMs by the host; what is left is sequential in
+// the step index t and tiny, so ONE workgroup per video walks its S_b steps with the entity matrix E (E_b × D) resident
+// in LDS — no launches inside the recurrence:
+//     e  = sigmoid(E q_t)                     alpha = c0·e + c1·e_prev          ē = (alpha/Σalpha)ᵀ E
+//     k  = ReLU(w_t · ē)                      E ← alpha kᵀ + (1-alpha) ⊙ E      e_prev ← e
+// Backward walks t in reverse with the gradient of E carried in registers (thread-owned columns), recomputing alpha, k
+// from the saved e / ē / E_t; the 2·E_b+1 per-step scalars (dα pieces, dw) are reduced once per step through LDS.
+#include "common.h"
+
+constexpr int SIM_EMAX = 32;
+
+struct SimArgs {
+    const float* q; const float* c; const float* w4f; const float* E0;
+    const int* step_off; const int* step_len; const int* ent_off; const int* ent_len;
+    float* e_out; float* ebar; float* eall; int e_max; int D;
+    // backward
+    const float* de; const float* debar; const float* deall;
+    float* dq; float* dc; float* dw4f; float* dE0;
+};
+
+__global__ __launch_bounds__(256) void sim_recur_fwd_kernel(SimArgs a) {
+    extern __shared__ float smem[];
+    const int b = blockIdx.x, D = a.D, em = a.e_max;
+    const int s0 = a.step_off[b], S = a.step_len[b], e0 = a.ent_off[b], E = a.ent_len[b];
+    float* Es = smem;                 // em × D
+    float* ev = Es + (size_t)em * D;  // 32
+    float* prev = ev + SIM_EMAX;      // 32
+    float* al = prev + SIM_EMAX;      // 32
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < E * D; i += 256) Es[i] = a.E0[(size_t)e0 * D + i];
+    if (threadIdx.x < SIM_EMAX) prev[threadIdx.x] = 0.f;
+    __syncthreads();
+    for (int t = 0; t < S; ++t) {
+        const int j = s0 + t;
+        const float* qj = a.q + (size_t)j * D;
+        for (int e = wave; e < E; e += 4) {
+            float dot = 0.f;
+            for (int d = lane; d < D; d += 64) dot += Es[(size_t)e * D + d] * qj[d];
+            dot = wave_sum(dot);
+            if (lane == 0) ev[e] = sigmoidf_(dot);
+        }
+        __syncthreads();
+        const float c0 = a.c[(size_t)j * 3], c1 = a.c[(size_t)j * 3 + 1];
+        if (threadIdx.x < SIM_EMAX) {
+            const int e = threadIdx.x;
+            al[e] = e < E ? c0 * ev[e] + c1 * prev[e] : 0.f;
+            if (e < em) a.e_out[(size_t)j * em + e] = e < E ? ev[e] : 0.f;
+        }
+        __syncthreads();
+        float Z = 0.f;
+        for (int e = 0; e < E; ++e) Z += al[e];
+        const float invZ = 1.0f / Z;
+        const float w = a.w4f[j];
+        for (int d = threadIdx.x; d < D; d += 256) {
+            float eb = 0.f;
+            for (int e = 0; e < E; ++e) eb += al[e] * Es[(size_t)e * D + d];
+            eb *= invZ;
+            a.ebar[(size_t)j * D + d] = eb;
+            const float k = fmaxf(w * eb, 0.f);
+            for (int e = 0; e < em; ++e) {
+                float v = 0.f;
+                if (e < E) {
+                    v = al[e] * k + (1.f - al[e]) * Es[(size_t)e * D + d];
+                    Es[(size_t)e * D + d] = v;
+                }
+                a.eall[((size_t)j * em + e) * D + d] = v;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < SIM_EMAX) prev[threadIdx.x] = threadIdx.x < E ? ev[threadIdx.x] : 0.f;
+        __syncthreads();
+    }
+}
+
+// CPT = columns per thread (D <= 256*CPT)
+template <int CPT>
+__global__ __launch_bounds__(256) void sim_recur_bwd_kernel(SimArgs a) {
+    extern __shared__ float smem[];
+    const int b = blockIdx.x, D = a.D, em = a.e_max;
+    const int s0 = a.step_off[b], S = a.step_len[b], e0 = a.ent_off[b], E = a.ent_len[b];
+    float* Es = smem;                              // em × D : state BEFORE step t
+    float* red = Es + (size_t)em * D;              // (2*32+1) × 4 wave partials
+    float* sc = red + (2 * SIM_EMAX + 1) * 4;      // scalars: ds[32]
+    float* dprev = sc + SIM_EMAX;                  // 32: gradient flowing into e_{t-1} through "prev"
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    float dE[SIM_EMAX][CPT];
+#pragma unroll
+    for (int e = 0; e < SIM_EMAX; ++e)
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) dE[e][u] = 0.f;
+    if (threadIdx.x < SIM_EMAX) dprev[threadIdx.x] = 0.f;
+
+    for (int t = S - 1; t >= 0; --t) {
+        const int j = s0 + t;
+        __syncthreads();
+        // state before step t
+        const float* Eprev = t == 0 ? a.E0 + (size_t)e0 * D : nullptr;
+        for (int i = threadIdx.x; i < E * D; i += 256) {
+            const int e = i / D, d = i - e * D;
+            Es[i] = t == 0 ? Eprev[i] : a.eall[((size_t)(j - 1) * em + e) * D + d];
+        }
+        __syncthreads();
+        const float c0 = a.c[(size_t)j * 3], c1 = a.c[(size_t)j * 3 + 1];
+        const float w = a.w4f[j];
+        float al[SIM_EMAX], evv[SIM_EMAX], pv[SIM_EMAX];
+        float Z = 0.f;
+#pragma unroll
+        for (int e = 0; e < SIM_EMAX; ++e) {
+            evv[e] = e < E ? a.e_out[(size_t)j * em + e] : 0.f;
+            pv[e] = (e < E && t > 0) ? a.e_out[(size_t)(j - 1) * em + e] : 0.f;
+            al[e] = e < E ? c0 * evv[e] + c1 * pv[e] : 0.f;
+            Z += al[e];
+        }
+        const float invZ = 1.0f / Z;
+        // per-thread partials of A1[e], dab[e], dw
+        float pA[SIM_EMAX], pB[SIM_EMAX];
+        float pw = 0.f;
+#pragma unroll
+        for (int e = 0; e < SIM_EMAX; ++e) { pA[e] = 0.f; pB[e] = 0.f; }
+        float debar_l[CPT], kq[CPT];
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int d = threadIdx.x + 256 * u;
+            debar_l[u] = 0.f; kq[u] = 0.f;
+            if (d < D) {
+                const float eb = a.ebar[(size_t)j * D + d];
+                const float k = fmaxf(w * eb, 0.f);
+                float dk = 0.f;
+#pragma unroll
+                for (int e = 0; e < SIM_EMAX; ++e) {
+                    if (e < E) {
+                        const float up = a.deall ? a.deall[((size_t)j * em + e) * D + d] : 0.f;
+                        const float g = dE[e][u] + up;
+                        const float Ev = Es[(size_t)e * D + d];
+                        pA[e] += g * (k - Ev);
+                        dk += g * al[e];
+                        dE[e][u] = g * (1.f - al[e]);
+                    }
+                }
+                const float dpre = k > 0.f ? dk : 0.f;
+                pw += dpre * eb;
+                const float deb = dpre * w + (a.debar ? a.debar[(size_t)j * D + d] : 0.f);
+                debar_l[u] = deb;
+#pragma unroll
+                for (int e = 0; e < SIM_EMAX; ++e) {
+                    if (e < E) {
+                        pB[e] += deb * Es[(size_t)e * D + d];
+                        dE[e][u] += al[e] * invZ * deb;
+                    }
+                }
+                kq[u] = a.q[(size_t)j * D + d];
+            }
+        }
+        // block reduction of 2E+1 scalars
+#pragma unroll
+        for (int e = 0; e < SIM_EMAX; ++e) {
+            if (e < E) {
+                const float ra = wave_sum(pA[e]), rb = wave_sum(pB[e]);
+                if (lane == 0) { red[e * 4 + wave] = ra; red[(SIM_EMAX + e) * 4 + wave] = rb; }
+            }
+        }
+        pw = wave_sum(pw);
+        if (lane == 0) red[(2 * SIM_EMAX) * 4 + wave] = pw;
+        __syncthreads();
+        // every thread finishes the scalar algebra redundantly (E <= 32)
+        float dab[SIM_EMAX], dal[SIM_EMAX];
+        float mix = 0.f;
+#pragma unroll
+        for (int e = 0; e < SIM_EMAX; ++e) {
+            dab[e] = 0.f; dal[e] = 0.f;
+            if (e < E) {
+                const float* rb = red + (SIM_EMAX + e) * 4;
+                dab[e] = rb[0] + rb[1] + rb[2] + rb[3];
+                mix += dab[e] * al[e] * invZ;
+            }
+        }
+        float dc0 = 0.f, dc1 = 0.f;
+        float dsv[SIM_EMAX];
+#pragma unroll
+        for (int e = 0; e < SIM_EMAX; ++e) {
+            dsv[e] = 0.f;
+            if (e < E) {
+                const float* ra = red + e * 4;
+                const float A1 = ra[0] + ra[1] + ra[2] + ra[3];
+                dal[e] = A1 + (dab[e] - mix) * invZ;
+                dc0 += dal[e] * evv[e];
+                dc1 += dal[e] * pv[e];
+                const float de_tot = c0 * dal[e] + (a.de ? a.de[(size_t)j * em + e] : 0.f) + dprev[e];
+                dsv[e] = de_tot * evv[e] * (1.f - evv[e]);
+            }
+        }
+        const float* rw = red + (2 * SIM_EMAX) * 4;
+        const float dw = rw[0] + rw[1] + rw[2] + rw[3];
+        __syncthreads();   // all threads have read dprev / red before they are overwritten
+        if (threadIdx.x < SIM_EMAX) dprev[threadIdx.x] = threadIdx.x < E ? c1 * dal[threadIdx.x] : 0.f;
+        if (threadIdx.x == 0) {
+            a.dc[(size_t)j * 3] = dc0; a.dc[(size_t)j * 3 + 1] = dc1; a.dc[(size_t)j * 3 + 2] = 0.f;
+            a.dw4f[j] = dw;
+        }
+        // dq and the last piece of dE
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int d = threadIdx.x + 256 * u;
+            if (d < D) {
+                float dqv = 0.f;
+#pragma unroll
+                for (int e = 0; e < SIM_EMAX; ++e) {
+                    if (e < E) {
+                        dqv += dsv[e] * Es[(size_t)e * D + d];
+                        dE[e][u] += dsv[e] * kq[u];
+                    }
+                }
+                a.dq[(size_t)j * D + d] = dqv;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const int d = threadIdx.x + 256 * u;
+        if (d < D) {
+#pragma unroll
+            for (int e = 0; e < SIM_EMAX; ++e)
+                if (e < E) a.dE0[((size_t)e0 + e) * D + d] = dE[e][u];
+        }
+    }
+}
+
+static int sim_set_lds(const void* fn, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { svpc_set_error("sim_recur: cannot raise dynamic LDS limit"); return (int)e; }
+    }
+    return 0;
+}
+
+extern "C" {
+
+int svpc_sim_recur_fwd(const float* q, const float* c, const float* w4f, const float* E0, const int* step_off, const int* step_len,
+                       const int* ent_off, const int* ent_len, int n_videos, int e_max, int D, float* e_out, float* ebar,
+                       float* eall, hipStream_t stream) {
+    if (n_videos == 0) return 0;
+    SVPC_REQUIRE(e_max >= 1 && e_max <= SIM_EMAX, "sim_recur: at most 32 entities per video");
+    const size_t lds = ((size_t)e_max * D + 3 * SIM_EMAX) * sizeof(float);
+    SVPC_REQUIRE(lds <= 150 * 1024, "sim_recur: entity state does not fit LDS");
+    SimArgs a{};
+    a.q = q; a.c = c; a.w4f = w4f; a.E0 = E0; a.step_off = step_off; a.step_len = step_len; a.ent_off = ent_off;
+    a.ent_len = ent_len; a.e_out = e_out; a.ebar = ebar; a.eall = eall; a.e_max = e_max; a.D = D;
+    int rc = sim_set_lds((const void*)sim_recur_fwd_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sim_recur_fwd_kernel, dim3(n_videos), dim3(256), lds, stream, a);
+    return svpc_check_launch("sim_recur_fwd");
+}
+
+int svpc_sim_recur_bwd(const float* q, const float* c, const float* w4f, const float* E0, const int* step_off, const int* step_len,
+                       const int* ent_off, const int* ent_len, int n_videos, int e_max, int D, const float* e_out,
+                       const float* ebar, const float* eall, const float* de, const float* debar, const float* deall, float* dq,
+                       float* dc, float* dw4f, float* dE0, hipStream_t stream) {
+    if (n_videos == 0) return 0;
+    SVPC_REQUIRE(e_max >= 1 && e_max <= SIM_EMAX, "sim_recur: at most 32 entities per video");
+    SVPC_REQUIRE(D <= 1024, "sim_recur: hidden size must be <= 1024");
+    const size_t lds = ((size_t)e_max * D + (2 * SIM_EMAX + 1) * 4 + 2 * SIM_EMAX) * sizeof(float);
+    SVPC_REQUIRE(lds <= 150 * 1024, "sim_recur: entity state does not fit LDS");
+    SimArgs a{};
+    a.q = q; a.c = c; a.w4f = w4f; a.E0 = E0; a.step_off = step_off; a.step_len = step_len; a.ent_off = ent_off;
+    a.ent_len = ent_len; a.e_out = const_cast<float*>(e_out); a.ebar = const_cast<float*>(ebar);
+    a.eall = const_cast<float*>(eall); a.e_max = e_max; a.D = D; a.de = de; a.debar = debar; a.deall = deall;
+    a.dq = dq; a.dc = dc; a.dw4f = dw4f; a.dE0 = dE0;
+    int rc;
+    if (D <= 256) {
+        rc = sim_set_lds((const void*)sim_recur_bwd_kernel<1>, lds); if (rc) return rc;
+        hipLaunchKernelGGL(sim_recur_bwd_kernel<1>, dim3(n_videos), dim3(256), lds, stream, a);
+    } else if (D <= 512) {
+        rc = sim_set_lds((const void*)sim_recur_bwd_kernel<2>, lds); if (rc) return rc;
+        hipLaunchKernelGGL(sim_recur_bwd_kernel<2>, dim3(n_videos), dim3(256), lds, stream, a);
+    } else if (D <= 768) {
+        rc = sim_set_lds((const void*)sim_recur_bwd_kernel<3>, lds); if (rc) return rc;
+        hipLaunchKernelGGL(sim_recur_bwd_kernel<3>, dim3(n_videos), dim3(256), lds, stream, a);
+    } else {
+        rc = sim_set_lds((const void*)sim_recur_bwd_kernel<4>, lds); if (rc) return rc;
+        hipLaunchKernelGGL(sim_recur_bwd_kernel<4>, dim3(n_videos), dim3(256), lds, stream, a);
+    }
+    return svpc_check_launch("sim_recur_bwd");
+}
+
+}  // extern "C"

@@ -1,3 +1,636 @@
-"""placeholder — replaced below by the HIP-backed implementation."""
-from .ops_common import *  # noqa
-from .ops_common import SeqInfo, Idx, FIdx  # noqa
+"""HIP-backed primitives of the hot path: thin ``torch.autograd.Function`` wrappers over the C-ABI
+(include/svpc_hip.h).  PyTorch supplies device memory, the current stream and autograd wiring; all arithmetic
+runs in the gfx950 kernels of svpc_amd/csrc.  No CPU path exists: tensors must live on the MI355X.
+
+The pure-torch statement of every function here (same signatures) lives in tests/emul_ops.py and is what the
+GPU tests compare against.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from .ops_common import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, FIdx, Idx, SeqInfo, as_idx  # noqa: F401
+
+_WS = {}
+_WS_BYTES = 256 << 20
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ws(device):
+    """One scratch arena per device (split-K slabs, reduction partials); ops on a stream use it one at a time."""
+    key = str(device)
+    w = _WS.get(key)
+    if w is None:
+        w = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
+        _WS[key] = w
+    return w
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise _lib.SvpcKernelError("svpc_amd.ops: tensors must be on the GPU (no CPU fallback exists)")
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _rows2d(t):
+    """2-D, unit inner stride (row stride may exceed the width: packed projection outputs are read in place)."""
+    assert t.dim() == 2
+    if t.stride(1) != 1 and t.shape[1] != 1:
+        t = t.contiguous()
+    if t.shape[1] == 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    return t
+
+
+# ------------------------------------------------------------------------------------------------ RNG
+class Rng:
+    """Counter-based dropout / Gumbel generator: one 64-bit seed word in HBM (bumped on device every training
+    step, so a captured graph draws fresh masks on every replay) + a per-call site id."""
+
+    def __init__(self, device, seed=2019):
+        self.device = torch.device(device)
+        self.seed = torch.tensor([seed], dtype=torch.int64, device=device)
+        self._site = 0
+
+    def begin_step(self):
+        self._site = 0
+        _lib.call("bump_seed", _p(self.seed), _stream())
+
+    def site(self):
+        self._site += 1
+        return self._site
+
+    def mask(self, site, n, p, device):
+        out = torch.empty(n, dtype=torch.float32, device=device)
+        _lib.call("dropout_mask", _p(out), n, float(p), int(site), _p(self.seed), _stream())
+        return out
+
+
+_DEFAULT_RNG = {}
+
+
+def make_rng(device, seed=2019):
+    return Rng(device, seed)
+
+
+def default_rng(device):
+    key = str(device)
+    if key not in _DEFAULT_RNG:
+        _DEFAULT_RNG[key] = Rng(device)
+    return _DEFAULT_RNG[key]
+
+
+def _drop_args(drop):
+    if drop is None or drop[0] <= 0.0:
+        return 0.0, 0, None
+    p, rng, site = drop
+    return float(p), int(site), rng.seed
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NONE, p=0.0, site=0, seed=None, accumulate=0):
+    ws = _ws(C.device)
+    _lib.call("gemm_f32", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
+              _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+
+
+def _colsum(x2d, idx=None, K=1):
+    R, Cc = x2d.shape
+    out = torch.empty(K, Cc, dtype=torch.float32, device=x2d.device)
+    if R == 0:
+        return out.zero_()
+    ws = _ws(x2d.device)
+    _lib.call("bucket_colsum", _p(x2d), x2d.stride(0), _p(idx), R, Cc, K, _p(out), 0, _p(ws), _stream())
+    return out
+
+
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act, trans_w, drop):
+        _need_gpu(x)
+        x = _rows2d(x)
+        w = _c(w)
+        M, K = x.shape
+        N = w.shape[1] if trans_w else w.shape[0]
+        p, site, seed = _drop_args(drop)
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        z = torch.empty_like(y) if act == ACT_GELU else None
+        _gemm(x, x.stride(0), 1, w, w.stride(0), 0 if trans_w else 1, y, M, N, K, Z=z, bias=b, act=act, p=p, site=site, seed=seed)
+        ctx.save_for_backward(x, w, z if act == ACT_GELU else (y if act != ACT_NONE else None))
+        ctx.cfg = (act, trans_w, p, site, seed, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, aux = ctx.saved_tensors
+        act, trans_w, p, site, seed, has_b = ctx.cfg
+        M, K = x.shape
+        N = w.shape[1] if trans_w else w.shape[0]
+        dy = _c(dy)
+        if act != ACT_NONE or p > 0.0:
+            dz = torch.empty_like(dy)
+            _lib.call("act_bwd", _p(dy), _p(aux if aux is not None else dy), _p(dz), dy.numel(), act, p, site, _p(seed), _stream())
+        else:
+            dz = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+            _gemm(dz, N, 1, w, w.stride(0), 1 if trans_w else 0, dx, M, K, N)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            if trans_w:   # w (K, N): dw = xᵀ dz
+                _gemm(x, x.stride(0), 0, dz, N, 0, dw, K, N, M)
+            else:         # w (N, K): dw = dzᵀ x
+                _gemm(dz, N, 0, x, x.stride(0), 0, dw, N, K, M)
+        if has_b and ctx.needs_input_grad[2]:
+            db = _colsum(dz).view(-1)
+        return dx, dw, db, None, None, None
+
+
+def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None):
+    return _Linear.apply(x, w, b, act, trans_w, drop)
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm family
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, add2, eps, src_rows, pad_row, pre_drop, post_drop, add1, add1_mod, add2_idx):
+        _need_gpu(x)
+        x = _c(x)
+        D = x.shape[1]
+        R = src_rows.numel() if src_rows is not None else x.shape[0]
+        p_pre, s_pre, seed1 = _drop_args(pre_drop)
+        p_post, s_post, seed2 = _drop_args(post_drop)
+        seed = seed1 if seed1 is not None else seed2
+        residual = _c(residual) if residual is not None else None
+        y = torch.empty(R, D, dtype=torch.float32, device=x.device)
+        mean = torch.empty(R, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(R, dtype=torch.float32, device=x.device)
+        add1 = _c(add1) if add1 is not None else None
+        _lib.call("ln_fwd", _p(x), _p(src_rows), _p(residual), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), R, D, float(eps),
+                  p_pre, s_pre, p_post, s_post, _p(seed), _p(add1), int(add1_mod), _p(add2), _p(add2_idx), _stream())
+        ctx.save_for_backward(x, gamma, residual, mean, rstd, src_rows, add2_idx, seed)
+        ctx.cfg = (R, D, p_pre, s_pre, p_post, s_post, pad_row, add2.shape[0] if add2 is not None else 0)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, residual, mean, rstd, src_rows, add2_idx, seed = ctx.saved_tensors
+        R, D, p_pre, s_pre, p_post, s_post, pad_row, k_add2 = ctx.cfg
+        dy = _c(dy)
+        dev = dy.device
+        need_x, need_res = ctx.needs_input_grad[0], (residual is not None and ctx.needs_input_grad[3])
+        dh = dx_rows = None
+        if need_res or (need_x and p_pre <= 0.0):
+            dh = torch.empty(R, D, dtype=torch.float32, device=dev)
+        if need_x:
+            dx_rows = dh if p_pre <= 0.0 else torch.empty(R, D, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(D, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(D, dtype=torch.float32, device=dev)
+        ws = _ws(dev)
+        _lib.call("ln_bwd", _p(dy), _p(x), _p(src_rows), _p(residual), _p(gamma), _p(mean), _p(rstd), _p(dh), _p(dx_rows),
+                  _p(dgamma), _p(dbeta), 0, _p(ws), R, D, p_pre, s_pre, p_post, s_post, _p(seed), _stream())
+        dx = None
+        if need_x:
+            if src_rows is not None:
+                dx = torch.zeros_like(x)
+                _lib.call("scatter_add_rows", _p(dx_rows), _p(src_rows), _p(dx), R, D, int(pad_row), _stream())
+            else:
+                dx = dx_rows
+        dadd2 = None
+        if k_add2 and ctx.needs_input_grad[4]:
+            dadd2 = _colsum(dy, add2_idx, k_add2)
+        return dx, dgamma, dbeta, (dh if need_res else None), dadd2, None, None, None, None, None, None, None, None
+
+
+def layernorm(x, gamma, beta, eps, residual=None, src_rows=None, pad_row=-1, pre_drop=None, post_drop=None,
+              add1=None, add1_mod=0, add2=None, add2_idx=None):
+    return _LayerNorm.apply(x, gamma, beta, residual, add2, eps, src_rows, pad_row, pre_drop, post_drop, add1, add1_mod,
+                            add2_idx)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+class _Attention(Function):
+    @staticmethod
+    def forward(ctx, qt, kvt, cols, D, H, seq, key_mask, causal, drop):
+        _need_gpu(qt)
+        qt, kvt_c = _rows2d(qt), None
+        same = kvt is qt or (kvt.data_ptr() == qt.data_ptr() and kvt.shape == qt.shape)
+        kvt_c = qt if same else _rows2d(kvt)
+        dh = D // H
+        p, site, seed = _drop_args(drop)
+        out = torch.empty(seq.n_q_rows, D, dtype=torch.float32, device=qt.device)
+        lse = torch.empty(seq.n, H, seq.max_q, dtype=torch.float32, device=qt.device)
+        tbl = seq.table if seq.table.device == qt.device else seq.table.to(qt.device)
+        es = 4
+        _lib.call("attn_fwd", qt.data_ptr() + cols[0] * es, qt.stride(0), kvt_c.data_ptr() + cols[1] * es, kvt_c.stride(0),
+                  kvt_c.data_ptr() + cols[2] * es, kvt_c.stride(0), _p(out), D, _p(lse), _p(tbl), seq.n, H, dh, seq.max_q, seq.max_k,
+                  _p(key_mask), 1 if causal else 0, 1.0 / math.sqrt(dh), p, site, _p(seed), _stream())
+        ctx.save_for_backward(qt, kvt_c, out, lse, key_mask, seed, tbl)
+        ctx.cfg = (cols, D, H, seq.n, seq.max_q, seq.max_k, causal, p, site, same)
+        ctx.n_k_rows = seq.n_k_rows
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        qt, kvt, out, lse, key_mask, seed, tbl = ctx.saved_tensors
+        cols, D, H, n, max_q, max_k, causal, p, site, same = ctx.cfg
+        dh = D // H
+        dO = _c(dO)
+        dev = dO.device
+        def covered(t, used_cols, used_rows):
+            full = t.shape[1] == used_cols and t.shape[0] == used_rows
+            mk = torch.empty_like if full else torch.zeros_like
+            return mk(t, memory_format=torch.contiguous_format)
+        n_q_rows, n_k_rows = out.shape[0], ctx.n_k_rows
+        if same:
+            dq_t = covered(qt, 3 * D, n_q_rows)
+            dkv_t = dq_t
+        else:
+            dq_t = covered(qt, D, n_q_rows)
+            dkv_t = covered(kvt, 2 * D, n_k_rows)
+        delta = torch.empty(n, H, max_q, dtype=torch.float32, device=dev)
+        es = 4
+        _lib.call("attn_bwd", qt.data_ptr() + cols[0] * es, qt.stride(0), kvt.data_ptr() + cols[1] * es, kvt.stride(0),
+                  kvt.data_ptr() + cols[2] * es, kvt.stride(0), _p(out), D, _p(lse), _p(dO), D,
+                  dq_t.data_ptr() + cols[0] * es, dq_t.stride(0), dkv_t.data_ptr() + cols[1] * es, dkv_t.stride(0),
+                  dkv_t.data_ptr() + cols[2] * es, dkv_t.stride(0), _p(delta), _p(tbl), n, H, dh, max_q, max_k, _p(key_mask),
+                  1 if causal else 0, 1.0 / math.sqrt(dh), p, site, _p(seed), _stream())
+        return dq_t, (None if same else dkv_t), None, None, None, None, None, None, None
+
+
+def attention(qt, kvt, cols, D, n_heads, seq, key_mask=None, causal=False, drop=None):
+    return _Attention.apply(qt, kvt, cols, D, n_heads, seq, key_mask, causal, drop)
+
+
+# ------------------------------------------------------------------------------------------------ spans / rows
+class _SpanMean(Function):
+    @staticmethod
+    def forward(ctx, x, starts, lens, weights, add, add_idx):
+        _need_gpu(x)
+        x = _c(x)
+        G, D = len(starts), x.shape[1]
+        dev = x.device
+        out = torch.empty(G, D, dtype=torch.float32, device=dev)
+        st, ln = starts.dev(dev), lens.dev(dev)
+        ai = add_idx.dev(dev) if add is not None else None
+        _lib.call("span_mean_fwd", _p(x), _p(st), _p(ln), _p(weights), _p(add), _p(ai), _p(out), G, D, _stream())
+        ctx.save_for_backward(st, ln, weights)
+        ctx.cfg = (tuple(x.shape), G, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        st, ln, weights = ctx.saved_tensors
+        shape, G, D = ctx.cfg
+        dout = _c(dout)
+        dx = torch.zeros(shape, dtype=torch.float32, device=dout.device)
+        _lib.call("span_mean_bwd", _p(dout), _p(st), _p(ln), _p(weights), _p(dx), G, D, _stream())
+        return dx, None, None, None, None, None
+
+
+def span_mean(x, starts, lens, weights=None, add=None, add_idx=None):
+    return _SpanMean.apply(x, as_idx(starts), as_idx(lens), weights, add, as_idx(add_idx) if add_idx is not None else None)
+
+
+class _RowNorm(Function):
+    @staticmethod
+    def forward(ctx, a, mode):
+        _need_gpu(a)
+        a = _c(a)
+        y = torch.empty_like(a)
+        _lib.call("rownorm_fwd", _p(a), _p(y), a.shape[0], a.shape[1], mode, _stream())
+        ctx.save_for_backward(a, y)
+        ctx.mode = mode
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, y = ctx.saved_tensors
+        dy = _c(dy)
+        da = torch.empty_like(a)
+        _lib.call("rownorm_bwd", _p(dy), _p(y), _p(a), _p(da), a.shape[0], a.shape[1], ctx.mode, _stream())
+        return da, None
+
+
+def row_normalize(a):
+    return _RowNorm.apply(a, 0)
+
+
+def softmax_rows(x):
+    return _RowNorm.apply(x, 1)
+
+
+class _SumAll(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        x = _c(x)
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        _lib.call("sum_all", _p(x), x.numel(), _p(out), 1.0, _stream())
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dout.device)
+        _lib.call("fill_from", _p(dx), dx.numel(), _p(_c(dout)), _stream())
+        return dx
+
+
+def sum_all(x):
+    return _SumAll.apply(x)
+
+
+class _Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        c = torch.empty_like(a)
+        _lib.call("add", _p(a), _p(b), _p(c), a.numel(), _stream())
+        return c
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+def take_rows(x, idx):
+    """Row gather (data movement only)."""
+    return torch.index_select(x, 0, idx)
+
+
+def clamp_labels(labels, vocab, unk):
+    out = torch.empty_like(labels)
+    _lib.call("clamp_labels", _p(labels), _p(out), labels.numel(), int(vocab), int(unk), _stream())
+    return out
+
+
+def row_any_eq1(x):
+    x = _c(x)
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _lib.call("row_any_eq1", _p(x), _p(out), x.shape[0], x.shape[1], _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ simulator recurrence
+class _SimRecur(Function):
+    @staticmethod
+    def forward(ctx, q, c, w4f, E0, step_off, step_len, ent_off, ent_len, e_max):
+        _need_gpu(q)
+        q, c, w4f, E0 = _c(q), _c(c), _c(w4f), _c(E0)
+        T, D = q.shape
+        dev = q.device
+        idx = [v.dev(dev) for v in (step_off, step_len, ent_off, ent_len)]
+        e = torch.empty(T, e_max, dtype=torch.float32, device=dev)
+        ebar = torch.empty(T, D, dtype=torch.float32, device=dev)
+        eall = torch.empty(T, e_max, D, dtype=torch.float32, device=dev)
+        _lib.call("sim_recur_fwd", _p(q), _p(c), _p(w4f), _p(E0), _p(idx[0]), _p(idx[1]), _p(idx[2]), _p(idx[3]), len(step_off), e_max,
+                  D, _p(e), _p(ebar), _p(eall), _stream())
+        ctx.save_for_backward(q, c, w4f, E0, e, ebar, eall, *idx)
+        ctx.cfg = (len(step_off), e_max, D)
+        ctx.set_materialize_grads(False)
+        return e, ebar, eall
+
+    @staticmethod
+    def backward(ctx, de, debar, deall):
+        q, c, w4f, E0, e, ebar, eall, so, sl, eo, el = ctx.saved_tensors
+        n, e_max, D = ctx.cfg
+        dev = q.device
+        de = _c(de) if de is not None else None
+        debar = _c(debar) if debar is not None else None
+        deall = _c(deall) if deall is not None else None
+        dq = torch.empty_like(q)
+        dc = torch.empty_like(c)
+        dw = torch.empty_like(w4f)
+        dE0 = torch.empty_like(E0)
+        _lib.call("sim_recur_bwd", _p(q), _p(c), _p(w4f), _p(E0), _p(so), _p(sl), _p(eo), _p(el), n, e_max, D, _p(e), _p(ebar),
+                  _p(eall), _p(de), _p(debar), _p(deall), _p(dq), _p(dc), _p(dw), _p(dE0), _stream())
+        return dq, dc, dw, dE0, None, None, None, None, None
+
+
+def sim_recur(q, c, w4f, E0, step_off, step_len, ent_off, ent_len, e_max):
+    return _SimRecur.apply(q, c, w4f, E0, as_idx(step_off), as_idx(step_len), as_idx(ent_off), as_idx(ent_len), int(e_max))
+
+
+# ------------------------------------------------------------------------------------------------ pointer-generator
+class _PtrAttn(Function):
+    @staticmethod
+    def forward(ctx, dec, proj, bank, step_ne, lt):
+        _need_gpu(dec)
+        dec, proj, bank = _c(dec), _c(proj), _c(bank)
+        T, e_max, D = bank.shape
+        dev = dec.device
+        ne = step_ne.dev(dev)
+        pi = torch.empty(T * lt, e_max, dtype=torch.float32, device=dev)
+        att = torch.empty(T * lt, D, dtype=torch.float32, device=dev)
+        _lib.call("ptr_attn_fwd", _p(dec), _p(proj), _p(bank), _p(ne), _p(pi), _p(att), T, lt, e_max, D, _stream())
+        ctx.save_for_backward(dec, proj, bank, ne, pi)
+        ctx.cfg = (T, lt, e_max, D)
+        ctx.set_materialize_grads(False)
+        return pi, att
+
+    @staticmethod
+    def backward(ctx, dpi, datt):
+        dec, proj, bank, ne, pi = ctx.saved_tensors
+        T, lt, e_max, D = ctx.cfg
+        if datt is None:
+            datt = torch.zeros(T * lt, D, dtype=torch.float32, device=dec.device)
+        datt = _c(datt)
+        dpi = _c(dpi) if dpi is not None else None
+        ddec = torch.empty_like(dec)
+        dproj = torch.empty_like(proj)
+        dbank = torch.empty_like(bank)
+        _lib.call("ptr_attn_bwd", _p(dec), _p(proj), _p(bank), _p(ne), _p(pi), _p(dpi), _p(datt), _p(ddec), _p(dproj), _p(dbank), T, lt,
+                  e_max, D, _stream())
+        return ddec, dproj, dbank, None, None
+
+
+def ptr_attn(dec, proj, bank, step_ne, lt):
+    return _PtrAttn.apply(dec, proj, bank, as_idx(step_ne), int(lt))
+
+
+class _PtrMixLoss(Function):
+    @staticmethod
+    def forward(ctx, logits, g, pi, labels, row_c, row_vid, csr_off, csr_ent, csr_id, csr_w, c_max, smoothing):
+        _need_gpu(logits)
+        logits = _c(logits)
+        R, V = logits.shape
+        dev = logits.device
+        g = _c(g) if g is not None else None
+        pi = _c(pi) if pi is not None else None
+        e_max = pi.shape[1] if pi is not None else 0
+        rc, rv = row_c.dev(dev), row_vid.dev(dev)
+        co, ce, ci, cw = csr_off.dev(dev), csr_ent.dev(dev), csr_id.dev(dev), csr_w.dev(dev)
+        P = torch.empty(R, c_max, dtype=torch.float32, device=dev)
+        loss_rows = torch.empty(R, dtype=torch.float32, device=dev)
+        _lib.call("ptr_mix_loss_fwd", _p(logits), _p(g), _p(pi), _p(labels), _p(rc), _p(rv), _p(co), _p(ce), _p(ci), _p(cw), _p(P),
+                  _p(loss_rows), R, V, c_max, e_max, float(smoothing), _stream())
+        ctx.save_for_backward(logits, g, pi, labels, rc, rv, co, ce, ci, cw, P)
+        ctx.cfg = (R, V, c_max, e_max, float(smoothing))
+        ctx.set_materialize_grads(False)
+        return P, loss_rows
+
+    @staticmethod
+    def backward(ctx, dP, dloss):
+        logits, g, pi, labels, rc, rv, co, ce, ci, cw, P = ctx.saved_tensors
+        R, V, c_max, e_max, smoothing = ctx.cfg
+        dev = logits.device
+        dP = _c(dP) if dP is not None else None
+        if dloss is None:
+            dloss = torch.zeros(R, dtype=torch.float32, device=dev)
+        dloss = _c(dloss)
+        dlogits = torch.empty_like(logits)
+        dg = torch.empty_like(g) if g is not None else None
+        dpi = torch.empty_like(pi) if pi is not None else None
+        _lib.call("ptr_mix_loss_bwd", _p(logits), _p(g), _p(pi), _p(labels), _p(rc), _p(rv), _p(co), _p(ce), _p(ci), _p(cw), _p(P),
+                  _p(dP), _p(dloss), _p(dlogits), _p(dg), _p(dpi), R, V, c_max, e_max, smoothing, _stream())
+        return dlogits, dg, dpi, None, None, None, None, None, None, None, None, None
+
+
+def ptr_mix_loss(logits, g, pi, labels, row_c, row_vid, csr_off, csr_ent, csr_id, csr_w, c_max, smoothing):
+    return _PtrMixLoss.apply(logits, g, pi, labels, as_idx(row_c), as_idx(row_vid), as_idx(csr_off), as_idx(csr_ent),
+                             as_idx(csr_id), csr_w if isinstance(csr_w, FIdx) else FIdx(csr_w), int(c_max), float(smoothing))
+
+
+# ------------------------------------------------------------------------------------------------ Gumbel bag of words
+class _GumbelBow(Function):
+    @staticmethod
+    def forward(ctx, P, emb, row_c, tau, noise):
+        _need_gpu(P)
+        P, emb, noise = _c(P), _c(emb), _c(noise)
+        R, c_max = P.shape
+        V, W = emb.shape
+        dev = P.device
+        rc = row_c.dev(dev)
+        bow = torch.empty(R, W, dtype=torch.float32, device=dev)
+        idx = torch.empty(R, dtype=torch.int32, device=dev)
+        stats = torch.empty(R, 2, dtype=torch.float32, device=dev)
+        _lib.call("gumbel_fwd", _p(P), _p(noise), _p(rc), _p(emb), _p(bow), _p(idx), _p(stats), R, c_max, V, W, float(tau), _stream())
+        ctx.save_for_backward(P, emb, noise, rc, idx, stats)
+        ctx.cfg = (R, c_max, V, W, float(tau))
+        return bow
+
+    @staticmethod
+    def backward(ctx, dbow):
+        P, emb, noise, rc, idx, stats = ctx.saved_tensors
+        R, c_max, V, W, tau = ctx.cfg
+        dev = P.device
+        dbow = _c(dbow)
+        dP = demb = None
+        if ctx.needs_input_grad[0]:
+            dy = torch.empty(R, V, dtype=torch.float32, device=dev)
+            _gemm(dbow, W, 1, emb, W, 1, dy, R, V, W)                      # dy = dbow @ embᵀ
+            dP = torch.empty_like(P)
+            _lib.call("gumbel_bwd", _p(P), _p(noise), _p(rc), _p(stats), _p(dy), _p(dP), R, c_max, V, tau, _stream())
+        if ctx.needs_input_grad[1]:
+            demb = torch.zeros_like(emb)
+            _lib.call("gumbel_emb_grad", _p(dbow), _p(idx), _p(stats), _p(demb), R, V, W, _stream())
+        return dP, demb, None, None, None
+
+
+def gumbel_bow(P, row_c, emb, tau, noise=None, rng=None, site=0):
+    if noise is None:
+        noise = torch.empty_like(P)
+        _lib.call("gumbel_noise", _p(noise), noise.numel(), int(site), _p(rng.seed), _stream())
+    return _GumbelBow.apply(P, emb, as_idx(row_c), float(tau), noise)
+
+
+# ------------------------------------------------------------------------------------------------ LSTM cell / losses
+class _LstmCell(Function):
+    @staticmethod
+    def forward(ctx, gx, gh, c_prev, h_prev, active):
+        _need_gpu(gx)
+        gx, gh, c_prev, h_prev = _c(gx), _c(gh), _c(c_prev), _c(h_prev)
+        N, D = c_prev.shape
+        h = torch.empty_like(c_prev)
+        c = torch.empty_like(c_prev)
+        gates = torch.empty_like(gx)
+        _lib.call("lstm_cell_fwd", _p(gx), _p(gh), _p(c_prev), _p(h_prev), _p(active), _p(h), _p(c), _p(gates), N, D, _stream())
+        ctx.save_for_backward(gates, c_prev, active)
+        ctx.cfg = (N, D)
+        ctx.set_materialize_grads(False)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        gates, c_prev, active = ctx.saved_tensors
+        N, D = ctx.cfg
+        dev = gates.device
+        dh = _c(dh) if dh is not None else torch.zeros(N, D, dtype=torch.float32, device=dev)
+        dc = _c(dc) if dc is not None else torch.zeros(N, D, dtype=torch.float32, device=dev)
+        dg = torch.empty_like(gates)
+        dcp = torch.empty_like(c_prev)
+        dhp = torch.empty_like(c_prev)
+        _lib.call("lstm_cell_bwd", _p(dh), _p(dc), _p(gates), _p(c_prev), _p(active), _p(dg), _p(dcp), _p(dhp), N, D, _stream())
+        return dg, dg, dcp, dhp, None
+
+
+def lstm_cell(gx, gh, c_prev, h_prev, active):
+    return _LstmCell.apply(gx, gh, c_prev, h_prev, active)
+
+
+class _BceRows(Function):
+    @staticmethod
+    def forward(ctx, p, y, widths):
+        _need_gpu(p)
+        p, y = _c(p), _c(y)
+        R, C = p.shape
+        w = widths.dev(p.device)
+        out = torch.empty(R, dtype=torch.float32, device=p.device)
+        _lib.call("bce_rows_fwd", _p(p), _p(y), _p(w), _p(out), R, C, _stream())
+        ctx.save_for_backward(p, y, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        p, y, w = ctx.saved_tensors
+        dp = torch.empty_like(p)
+        _lib.call("bce_rows_bwd", _p(_c(dout)), _p(p), _p(y), _p(w), _p(dp), p.shape[0], p.shape[1], _stream())
+        return dp, None, None
+
+
+def bce_rows(p, y, widths):
+    return _BceRows.apply(p, y, as_idx(widths))
+
+
+class _AslRows(Function):
+    @staticmethod
+    def forward(ctx, p, y, active, gneg, gpos, clip, eps):
+        _need_gpu(p)
+        p, y = _c(p), _c(y)
+        R, C = p.shape
+        out = torch.empty(R, dtype=torch.float32, device=p.device)
+        _lib.call("asl_rows_fwd", _p(p), _p(y), _p(active), _p(out), R, C, gneg, gpos, clip, eps, _stream())
+        ctx.save_for_backward(p, y, active)
+        ctx.cfg = (gneg, gpos, clip, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        p, y, active = ctx.saved_tensors
+        dp = torch.empty_like(p)
+        _lib.call("asl_rows_bwd", _p(_c(dout)), _p(p), _p(y), _p(active), _p(dp), p.shape[0], p.shape[1], *ctx.cfg, _stream())
+        return dp, None, None, None, None, None, None
+
+
+def asl_rows(p, y, row_active, gamma_neg=4.0, gamma_pos=1.0, clip=0.05, eps=1e-8):
+    return _AslRows.apply(p, y, row_active, float(gamma_neg), float(gamma_pos), float(clip), float(eps))

@@ -1,0 +1,273 @@
+"""Per-kernel parity: every HIP primitive (through the C-ABI, via svpc_amd.ops) against its plain-PyTorch fp32
+statement (tests/emul_ops.py) on the same seeded inputs, forward and backward.  Tolerances are written per test;
+index outputs are bit-exact.  Needs an MI355X: run with ``-m gpu``."""
+import math
+
+import pytest
+import torch
+
+import emul_ops as E
+from svpc_amd import ops as O
+from svpc_amd.ops_common import FIdx, Idx, SeqInfo
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0, grad=True):
+    g = torch.Generator().manual_seed(seed + sum(shape) * 7 + len(shape))
+    t = (torch.randn(*shape, generator=g) * scale).to(DEV)
+    return t.requires_grad_(grad)
+
+
+def compare(fn_hip, fn_ref, inputs, rtol=2e-4, atol=2e-5, grad_rtol=5e-4, grad_atol=5e-5, name=""):
+    """Run both on clones of `inputs` (list of tensors / None), compare outputs and input grads."""
+    def run(fn):
+        ins = [None if t is None else (t.detach().clone().requires_grad_(t.requires_grad) if t.dtype.is_floating_point else t)
+               for t in inputs]
+        out = fn(*ins)
+        outs = out if isinstance(out, (tuple, list)) else (out,)
+        g = torch.Generator().manual_seed(99)
+        loss = 0
+        for o in outs:
+            if o.dtype.is_floating_point:
+                w = torch.randn(o.shape, generator=g).to(o.device)
+                loss = loss + (o * w).sum()
+        if any(t is not None and t.dtype.is_floating_point and t.requires_grad for t in ins):
+            loss.backward()
+        return outs, [None if (t is None or not t.dtype.is_floating_point) else t.grad for t in ins]
+    o1, g1 = run(fn_hip)
+    o2, g2 = run(fn_ref)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(o1, o2)):
+        if a.dtype.is_floating_point:
+            err = (a - b).abs().max().item()
+            tol = atol + rtol * b.abs().max().item()
+            assert err <= tol, "%s out[%d]: err %.3e > tol %.3e" % (name, i, err, tol)
+        else:
+            assert torch.equal(a, b), "%s out[%d] index mismatch" % (name, i)
+    for i, (a, b) in enumerate(zip(g1, g2)):
+        if b is None:
+            continue
+        assert a is not None, "%s grad[%d] missing" % (name, i)
+        err = (a - b).abs().max().item()
+        tol = grad_atol + grad_rtol * b.abs().max().item()
+        assert err <= tol, "%s grad[%d]: err %.3e > tol %.3e" % (name, i, err, tol)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 5, 3), (64, 64, 16), (100, 33, 42), (192, 768, 768), (257, 129, 300),
+                                   (1000, 951, 128), (2048, 768, 3072), (16, 3072, 768), (192, 3, 768), (192, 1, 300)])
+@pytest.mark.parametrize("act", [E.ACT_NONE, E.ACT_RELU, E.ACT_GELU, E.ACT_SIGMOID])
+def test_linear(M, N, K, act):
+    if act != E.ACT_NONE and M * N * K > 5e7:
+        pytest.skip("big shapes only with the plain epilogue")
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3)
+    compare(lambda x, w, b: O.linear(x, w, b, act=act), lambda x, w, b: E.linear(x, w, b, act=act), [x, w, b],
+            rtol=3e-5 * math.sqrt(K) + 2e-4, grad_rtol=1e-3, name="linear")
+
+
+def test_linear_wgrad_splitk_long_k():
+    x, w = rnd(19200, 768, seed=4), rnd(768, 768, seed=5, scale=0.03)
+    compare(lambda x, w: O.linear(x, w, None), lambda x, w: E.linear(x, w, None), [x, w], rtol=1e-3, grad_rtol=2e-3, name="splitk")
+
+
+def test_linear_trans_w_and_strided_input():
+    big = rnd(50, 96, seed=6)
+    w = rnd(32, 40, seed=7)   # (K, N)
+    compare(lambda big, w: O.linear(big[:, 32:64], w, None, trans_w=True), lambda big, w: E.linear(big[:, 32:64], w, None, trans_w=True),
+            [big, w], name="trans_w")
+
+
+def test_linear_dropout_mask_consistency():
+    rng = O.make_rng(DEV, seed=5)
+    x, w, b = rnd(200, 64, seed=8), rnd(48, 64, seed=9), rnd(48, seed=10)
+    drop = (0.4, rng, 3)
+    compare(lambda x, w, b: O.linear(x, w, b, act=E.ACT_RELU, drop=drop), lambda x, w, b: E.linear(x, w, b, act=E.ACT_RELU, drop=drop),
+            [x, w, b], name="linear+dropout")
+    m = rng.mask(3, 200 * 48, 0.4, DEV)
+    assert 0.5 < m.mean().item() < 0.7 and set(m.unique().tolist()) <= {0.0, 1.0}
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm family
+@pytest.mark.parametrize("R,D", [(1, 4), (5, 20), (37, 32), (130, 300), (260, 768), (33, 3072), (9, 10), (7, 42)])
+def test_layernorm_plain(R, D):
+    x, g, b = rnd(R, D, seed=1, scale=2.0), rnd(D, seed=2), rnd(D, seed=3)
+    compare(lambda x, g, b: O.layernorm(x, g, b, 1e-12), lambda x, g, b: E.layernorm(x, g, b, 1e-12), [x, g, b], name="ln")
+
+
+def test_layernorm_zero_row_gives_beta():
+    x = torch.zeros(3, 64, device=DEV)
+    g, b = rnd(64, seed=1, grad=False), rnd(64, seed=2, grad=False)
+    y = O.layernorm(x, g, b, 1e-12)
+    assert torch.allclose(y, b.expand_as(y))
+
+
+def test_layernorm_fused_everything():
+    rng = O.make_rng(DEV, seed=11)
+    R, D, T = 96, 128, 50
+    table = rnd(T, D, seed=1)
+    src = torch.randint(0, T, (R,), generator=torch.Generator().manual_seed(1)).to(torch.int32).to(DEV)
+    res, g, b = rnd(R, D, seed=2), rnd(D, seed=3), rnd(D, seed=4)
+    pe = rnd(12, D, seed=5, grad=False)
+    tt = rnd(4, D, seed=6)
+    idx2 = torch.randint(0, 4, (R,), generator=torch.Generator().manual_seed(2)).to(torch.int32).to(DEV)
+    pre, post = (0.1, rng, 1), (0.2, rng, 2)
+
+    def hip(table, res, g, b, tt):
+        return O.layernorm(table, g, b, 1e-12, residual=res, src_rows=src, pad_row=0, pre_drop=pre, post_drop=post, add1=pe,
+                           add1_mod=12, add2=tt, add2_idx=idx2)
+
+    def ref(table, res, g, b, tt):
+        return E.layernorm(E.embedding_table(table, 0), g, b, 1e-12, residual=res, src_rows=src, pad_row=0, pre_drop=pre,
+                           post_drop=post, add1=pe, add1_mod=12, add2=tt, add2_idx=idx2)
+    compare(hip, ref, [table, res, g, b, tt], name="ln fused")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_case(seq, D, H, causal, with_mask, drop, packed=True, cross=False, seed=0):
+    Rq, Rk = seq.n_q_rows, seq.n_k_rows
+    km = None
+    if with_mask:
+        km = (torch.rand(Rk, generator=torch.Generator().manual_seed(seed)) > 0.3).float().to(DEV)
+        for o in seq.h_k_off:
+            km[o] = 1.0
+    if cross:
+        qt, kvt = rnd(Rq, D, seed=seed + 1), rnd(Rk, 2 * D, seed=seed + 2)
+        cols = (0, 0, D)
+        compare(lambda qt, kvt: O.attention(qt, kvt, cols, D, H, seq, km, causal, drop),
+                lambda qt, kvt: E.attention(qt, kvt, cols, D, H, seq, km, causal, drop), [qt, kvt], name="attn cross")
+    else:
+        qkv = rnd(Rq, 3 * D, seed=seed + 3)
+        cols = (0, D, 2 * D)
+        compare(lambda qkv: O.attention(qkv, qkv, cols, D, H, seq, km, causal, drop),
+                lambda qkv: E.attention(qkv, qkv, cols, D, H, seq, km, causal, drop), [qkv], name="attn self")
+
+
+def test_attention_encoder_shape():
+    _attn_case(SeqInfo.uniform(6, 100, 100, DEV), 768, 12, False, True, None)
+
+
+def test_attention_small_heads_and_causal():
+    _attn_case(SeqInfo.uniform(5, 6, 6, DEV), 32, 4, True, True, None)
+    _attn_case(SeqInfo.uniform(7, 22, 22, DEV), 128, 4, True, True, None, seed=3)
+
+
+def test_attention_cross_few_keys():
+    _attn_case(SeqInfo.uniform(9, 22, 3, DEV), 128, 4, False, False, None, cross=True)
+    _attn_case(SeqInfo.uniform(4, 6, 1, DEV), 32, 4, False, False, None, cross=True, seed=5)
+
+
+def test_attention_ragged_step_sequences():
+    lens = [3, 1, 12, 7]
+    off = [0, 3, 4, 16]
+    _attn_case(SeqInfo(off, lens, off, lens, DEV), 64, 4, False, False, None)
+
+
+def test_attention_long_keys_multi_chunk():
+    _attn_case(SeqInfo.uniform(2, 130, 130, DEV), 64, 2, False, True, None, seed=7)
+
+
+def test_attention_dropout():
+    rng = O.make_rng(DEV, seed=3)
+    _attn_case(SeqInfo.uniform(3, 20, 20, DEV), 64, 4, True, True, (0.1, rng, 4))
+
+
+# ------------------------------------------------------------------------------------------------ rows / spans / losses
+def test_span_mean_and_rownorm_softmax():
+    x = rnd(40, 96, seed=1)
+    starts, lens = Idx([0, 5, 6, 20, 33]), Idx([5, 1, 10, 13, 7])
+    w = (torch.rand(40, generator=torch.Generator().manual_seed(3)) > 0.4).float().to(DEV)
+    for s in starts.host:
+        w[s] = 1.0
+    pe = rnd(9, 96, seed=2, grad=False)
+    aidx = Idx([3, 0, 8, 1, 1])
+    compare(lambda x: O.span_mean(x, starts, lens, w, pe, aidx), lambda x: E.span_mean(x, starts, lens, w, pe, aidx), [x], name="span w")
+    compare(lambda x: O.span_mean(x, starts, lens), lambda x: E.span_mean(x, starts, lens), [x], name="span")
+    a = torch.sigmoid(rnd(17, 384, seed=4)).detach().requires_grad_(True)
+    compare(O.row_normalize, E.row_normalize, [a], name="row_normalize")
+    compare(O.softmax_rows, E.softmax_rows, [rnd(50, 3, seed=5)], name="softmax3")
+    compare(O.sum_all, E.sum_all, [rnd(1000, seed=6)], rtol=1e-4, name="sum")
+    compare(O.add, E.add, [rnd(10, 33, seed=7), rnd(10, 33, seed=8)], name="add")
+
+
+def test_losses():
+    p = torch.sigmoid(rnd(13, 31, seed=1)).detach().requires_grad_(True)
+    y = (torch.rand(13, 31, generator=torch.Generator().manual_seed(2)) < 0.2).float().to(DEV)
+    widths = Idx([31, 5, 1, 10, 31, 7, 8, 9, 2, 3, 30, 29, 11])
+    compare(lambda p: O.bce_rows(p, y, widths), lambda p: E.bce_rows(p, y, widths), [p], name="bce")
+    pa = torch.sigmoid(rnd(13, 384, seed=3, scale=3.0)).detach().requires_grad_(True)
+    ya = (torch.rand(13, 384, generator=torch.Generator().manual_seed(4)) < 0.02).float().to(DEV)
+    ya[3] = 0
+    act = O.row_any_eq1(ya)
+    assert torch.equal(act, E.row_any_eq1(ya))
+    compare(lambda p: O.asl_rows(p, ya, act), lambda p: E.asl_rows(p, ya, act), [pa], name="asl")
+    lab = torch.tensor([3, -1, 60, 49, 50], dtype=torch.int32, device=DEV)
+    assert torch.equal(O.clamp_labels(lab, 50, 6), E.clamp_labels(lab, 50, 6))
+
+
+def test_lstm_cell():
+    N, D = 5, 48
+    gx, gh, c, h = rnd(N, 4 * D, seed=1), rnd(N, 4 * D, seed=2), rnd(N, D, seed=3), rnd(N, D, seed=4)
+    active = torch.tensor([1, 1, 0, 1, 0], dtype=torch.float32, device=DEV)
+    compare(lambda gx, gh, c, h: O.lstm_cell(gx, gh, c, h, active), lambda gx, gh, c, h: E.lstm_cell(gx, gh, c, h, active),
+            [gx, gh, c, h], name="lstm")
+
+
+# ------------------------------------------------------------------------------------------------ simulator / pointer / gumbel
+@pytest.mark.parametrize("D", [32, 768])
+def test_sim_recur(D):
+    step_len, ent_len = [3, 1, 12], [3, 31, 10]
+    step_off, ent_off = [0, 3, 4], [0, 3, 34]
+    T, NE, em = 16, 44, 31
+    q = rnd(T, D, seed=1, scale=1 / math.sqrt(D))
+    c = torch.softmax(rnd(T, 3, seed=2), -1).detach().requires_grad_(True)
+    w4f = rnd(T, seed=3)
+    E0 = rnd(NE, D, seed=4)
+    args = (Idx(step_off), Idx(step_len), Idx(ent_off), Idx(ent_len), em)
+    compare(lambda q, c, w, e0: O.sim_recur(q, c, w, e0, *args), lambda q, c, w, e0: E.sim_recur(q, c, w, e0, *args),
+            [q, c, w4f, E0], rtol=5e-4, grad_rtol=2e-3, grad_atol=2e-4, name="sim_recur")
+
+
+def test_ptr_attn_and_mix_loss_and_gumbel():
+    T, lt, em, D, V = 5, 6, 4, 64, 50
+    step_ne = Idx([3, 3, 4, 2, 2])
+    dec, proj, bank = rnd(T * lt, D, seed=1, scale=0.3), rnd(T, em, D, seed=2, scale=0.3), rnd(T, em, D, seed=3)
+    compare(lambda d, p, b: O.ptr_attn(d, p, b, step_ne, lt), lambda d, p, b: E.ptr_attn(d, p, b, step_ne, lt), [dec, proj, bank],
+            name="ptr_attn")
+    R = T * lt
+    logits = rnd(R, V, seed=4)
+    g = torch.sigmoid(rnd(R, 1, seed=5)).detach().requires_grad_(True)
+    pi = torch.softmax(rnd(R, em, seed=6), -1).detach().requires_grad_(True)
+    row_vid = Idx([0] * 12 + [1] * 6 + [2] * 12)
+    c_list = [V + 1, V, V + 2]
+    row_c = Idx([c_list[b] for b in row_vid.host])
+    csr_off, csr_ent = Idx([0, 4, 6, 9]), Idx([0, 0, 1, 2, 0, 1, 0, 1, 1])
+    csr_id, csr_w = Idx([7, 50, 9, 7, 11, 12, 50, 51, 13]), FIdx([.5, .5, 1, 1, 1, 1, 1, .5, .5])
+    labels = torch.randint(7, V, (R,), generator=torch.Generator().manual_seed(7)).to(torch.int32)
+    labels[3] = -1; labels[5] = 50; labels[20] = 51; labels[21] = V - 1
+    labels = labels.to(DEV)
+    c_max = V + 2
+
+    def mk(mod):
+        return lambda logits, g, pi: mod.ptr_mix_loss(logits, g, pi, labels, row_c, row_vid, csr_off, csr_ent, csr_id, csr_w, c_max, 0.1)
+    compare(mk(O), mk(E), [logits, g, pi], grad_rtol=1e-3, name="ptr_mix_loss")
+    # MODEL_TYPE=v: plain softmax + loss
+    empty = Idx([])
+    mkv = lambda mod: (lambda logits: mod.ptr_mix_loss(logits, None, None, labels.clamp(max=V - 1), Idx([V] * R), row_vid, Idx([0, 0, 0, 0]),
+                                                       empty, empty, FIdx([]), V, 0.1))
+    compare(mkv(O), mkv(E), [logits], grad_rtol=1e-3, name="softmax loss")
+    # gumbel straight-through bag of words
+    with torch.no_grad():
+        P, _ = E.ptr_mix_loss(logits.detach(), g.detach(), pi.detach(), labels, row_c, row_vid, csr_off, csr_ent, csr_id, csr_w, c_max, 0.1)
+    P = P.detach().requires_grad_(True)
+    emb = rnd(V, 20, seed=8)
+    noise = -torch.empty(R, c_max).exponential_(generator=torch.Generator().manual_seed(9)).log().to(DEV)
+    compare(lambda P, emb: O.gumbel_bow(P, row_c, emb, 0.5, noise=noise), lambda P, emb: E.gumbel_bow(P, row_c, emb, 0.5, noise=noise),
+            [P, emb], grad_rtol=2e-3, grad_atol=1e-4, name="gumbel")
+    # device-generated noise is Gumbel(0,1): mean ≈ 0.5772, var ≈ 1.645
+    rng = O.make_rng(DEV)
+    n = torch.empty(200000, device=DEV)
+    from svpc_amd import _lib
+    _lib.call("gumbel_noise", n.data_ptr(), n.numel(), 1, rng.seed.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert abs(n.mean().item() - 0.5772) < 0.02 and abs(n.var().item() - 1.6449) < 0.05
