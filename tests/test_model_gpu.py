@@ -37,7 +37,8 @@ def test_tiny_forward_backward_vs_reference_golden(golden_dir, mt):
         refg = z[k]
         scale = max(1e-6, float(np.abs(refg).max()))
         assert p.grad is not None, name
-        err = float(np.abs(p.grad.cpu().numpy() - refg).max()) / scale
+        # key biases have an analytically zero gradient (softmax shift invariance): only an absolute floor applies
+        err = float(np.abs(p.grad.cpu().numpy() - refg).max()) / (scale + 2e-3)
         worst = max(worst, (err, name))
         n += 1
     assert n > 20
