@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""Headline benchmark: train steps/sec of the state-aware recurrent transformer (MODEL_TYPE=vivt, batch 16 clip sequences
+× 12 clips × 100 frames × 3072 features, D=768, 6+6+6 layers) on N MI355X, one process per GPU, RCCL gradient all-reduce.
+
+A step = {zero_grad, forward, backward, gradient all-reduce (N>1), global clip 1.0, BertAdam} on one synthetic batch that
+is already resident in HBM (reference: src/train.py:125-147 without EMA/logging).
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (metric/value/… + "roofline" for the dominant kernel + "cpu_baseline").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from svpc_amd import StateAwareRecursiveTransformer, make_batch, make_config  # noqa: E402
+from svpc_amd import ops, synthetic as syn  # noqa: E402
+from svpc_amd.optim import FusedBertAdam, GradReducer  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def build(args, device):
+    cfg = make_config(model_type=args.model_type, hidden_size=args.hidden, num_hidden_layers=args.layers,
+                      num_attention_heads=args.heads)
+    torch.manual_seed(2019)
+    model = StateAwareRecursiveTransformer(cfg)
+    g = torch.Generator().manual_seed(2019)
+    glove = 0.4 * torch.randn(cfg.vocab_size, cfg.word_vec_size, generator=g)
+    verb = 0.4 * torch.randn(cfg.action_vocab_size, cfg.word_vec_size, generator=g)
+    model.ingredient_embeddings.set_pretrained_embedding(glove.clone(), freeze=False)
+    model.text_embeddings.set_pretrained_embedding(glove.clone(), freeze=False)
+    if args.model_type in ("vivt", "viv"):
+        model.reasoner.set_pretrained_embedding(verb.clone(), freeze=False)
+    if args.model_type == "vivt":
+        model.recipe_reasoner.set_pretrained_embedding(verb.clone(), freeze=False)
+    return cfg, model.to(device)
+
+
+def device_batch(cfg, args, device, seed):
+    b = make_batch(cfg, n_videos=args.batch, max_steps=args.clips, n_ingr=10, n_oov=0, seed=seed, full_clips=True)
+    feats = torch.stack(b["video_features_list"]).to(device)           # one (S, N, L, F) buffer: consumed in place
+    b["video_features_list"] = [feats[s] for s in range(feats.shape[0])]
+    for k, v in list(b.items()):
+        if k == "video_features_list":
+            continue
+        if isinstance(v, list) and v and isinstance(v[0], torch.Tensor):
+            b[k] = [t.to(device) for t in v]
+        elif isinstance(v, torch.Tensor):
+            b[k] = v.to(device)
+    return b
+
+
+def cpu_baseline(cfg, model, args):
+    """The CPU oracle (a port of the reference path, pinned to it by tests/golden) timed on this host's cores on a
+    bounded sample of the same workload; reported next to the GPU number, never the target."""
+    from oracle import svpc_oracle as orc
+    n_vid = args.cpu_videos
+    torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
+    b = make_batch(cfg, n_videos=n_vid, max_steps=args.clips, n_ingr=10, n_oov=0, seed=7, full_clips=True)
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    names = [k for k, v in P.items() if v.dtype.is_floating_point and not k.endswith(".pe")]
+    state = {}
+    wd = {n: (0.0 if any(t in n for t in ("bias", "LayerNorm.bias", "LayerNorm.weight")) else 0.01) for n in names}
+
+    def one_step():
+        for n in names:
+            P[n].requires_grad_(True)
+            P[n].grad = None
+        total, _, _, _ = orc.forward(P, cfg, *syn.forward_args(b), training=True)
+        total.backward()
+        grads = {n: P[n].grad for n in names if P[n].grad is not None}
+        gn = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values()))
+        coef = float(min(1.0, 1.0 / (gn + 1e-6)))
+        with torch.no_grad():
+            for n in names:
+                P[n].requires_grad_(False)
+            orc.bert_adam_step({n: P[n] for n in grads}, {n: g * coef for n, g in grads.items()}, state, 1e-4, wd=wd)
+    one_step()
+    t0 = time.time()
+    k = 0
+    while k < args.cpu_steps:
+        one_step()
+        k += 1
+    dt = (time.time() - t0) / k
+    steps_per_s = (n_vid / float(args.batch)) / dt
+    return {"value": steps_per_s, "unit": "steps/s (16-video steps)", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d of %d videos per step (S=%d, L=%d, same model), %d timed steps of fwd+bwd+clip+BertAdam on torch-CPU fp32, "
+                      "%.2f s/step, scaled by %d/%d" % (n_vid, args.batch, args.clips, args.layers, k, dt, n_vid, args.batch)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model-type", default="vivt")
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--clips", type=int, default=12)
+    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--hidden", type=int, default=768)
+    ap.add_argument("--heads", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-videos", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+
+    cfg, model = build(args, device)
+    model.train()
+    batch = device_batch(cfg, args, device, seed=2019 + rank)
+    fargs = syn.forward_args(batch)
+    opt = FusedBertAdam(list(model.named_parameters()), lr=1e-4, warmup=0.1, t_total=100000, grad_clip=1.0, ema_decay=-1.0)
+    reducer = None
+
+    def step():
+        nonlocal reducer
+        opt.zero_grad()
+        loss = model(*fargs)[0]
+        loss.backward()
+        arena = opt.ensure_built()
+        if world > 1:
+            if reducer is None:
+                reducer = GradReducer(arena, overlap=True)
+                reducer.reset()
+                for bi in range(len(reducer.buckets)):   # first step: hooks were not installed during this backward
+                    reducer.launched[bi] = False
+            reducer.finish()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    # roofline leg: HIP events around the encoder-sized GEMM launches inside the timed region
+    big = 2.0 * (args.batch * args.clips * cfg.max_v_len) * cfg.hidden_size * cfg.hidden_size * 0.99
+    ops.GEMM_TIMER = ops.KernelTimer(min_flops=big)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    gsum = timer.summary()
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ms = 1000.0 * elapsed / args.steps
+        achieved = gsum["work"] / (gsum["ms"] * 1e-3) / 1e12 if gsum["ms"] > 0 else 0.0
+        out = {
+            "metric": "train steps/sec (vivt, batch=16, clip_seq=12)", "value": world * args.steps / elapsed,
+            "unit": "steps/s (one step = 16 clip-sequences per GPU; whole-job aggregate)", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MODEL_TYPE=%s train step: N=%d videos/GPU x S=%d clips x Lv=%d frames x F=%d, Lt=%d, D=%d, H=%d, "
+                                   "L=%d (enc+step-enc+dec), V=%d, A=%d, E=10; dropout .1/.1/.4; fwd+bwd+allreduce+clip+BertAdam"
+                                   % (args.model_type, args.batch, args.clips, cfg.max_v_len, cfg.video_feature_size, cfg.max_t_len,
+                                      cfg.hidden_size, cfg.num_attention_heads, cfg.num_hidden_layers, cfg.vocab_size, cfg.action_vocab_size),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128> (encoder-sized GEMMs: M>=%d)" % (args.batch * args.clips * cfg.max_v_len),
+                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "launches": gsum["launches"], "avg_launch_ms": gsum["ms"] / max(1, gsum["launches"]),
+                         "share_of_step": gsum["ms"] / (ms * args.steps)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, model, args)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,10 +102,40 @@ def _drop_args(drop):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+class KernelTimer:
+    """Optional HIP-event bracket around launches of one kernel class (bench.py's roofline leg).  Events are
+    recorded on the stream the kernel is launched on (PyTorch's current stream)."""
+
+    def __init__(self, min_flops=0.0):
+        self.min_flops = min_flops
+        self.records = []   # (work, start_event, end_event)
+
+    def bracket(self, work):
+        if work < self.min_flops:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append((work, e0, e1))
+        return e0, e1
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in self.records)
+        work = sum(w for w, _, _ in self.records)
+        return dict(launches=len(self.records), work=work, ms=ms)
+
+
+GEMM_TIMER = None   # set by bench.py
+
+
 def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NONE, p=0.0, site=0, seed=None, accumulate=0):
     ws = _ws(C.device)
+    ev = GEMM_TIMER.bracket(2.0 * M * N * K) if GEMM_TIMER is not None else None
+    if ev:
+        ev[0].record()
     _lib.call("gemm_f32", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
               _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+    if ev:
+        ev[1].record()
 
 
 def _colsum(x2d, idx=None, K=1):

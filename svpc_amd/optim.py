@@ -1,0 +1,223 @@
+"""Training-step tail on the MI355X: flat gradient arena + fused BertAdam/EMA + bucketed RCCL gradient all-reduce.
+
+reference: src/rtransformer/optimization.py:219-338 (BertAdam: per-tensor clip to 1.0, no bias correction, decay added
+to the update, warmup-linear schedule :162-171), :183-216 (EMA), src/train.py:140-147 (backward → global clip → step →
+EMA), :338-343 (weight-decay grouping by name).
+
+Design: every trainable tensor that receives a gradient gets its ``.grad`` re-pointed into ONE contiguous fp32 arena
+(likewise m, v, EMA shadows).  That makes zero_grad one memset, the data-parallel exchange a handful of large
+all-reduces over arena slices (xGMI is per-link bound: few big messages, overlapped with backward through
+post-accumulate hooks), and clip + Adam + EMA three kernel launches over a chunk table (svpc_opt_step).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")  # src/train.py:339
+
+
+def warmup_linear(progress, warmup):
+    """optimization.py:166-171."""
+    if progress < warmup:
+        return progress / warmup
+    return max((progress - 1.0) / (warmup - 1.0), 0.0)
+
+
+class _Meta(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
+                ("ema", ctypes.c_void_p), ("n", ctypes.c_longlong), ("wd", ctypes.c_float), ("pad", ctypes.c_int)]
+
+
+class GradArena:
+    """Contiguous fp32 gradient storage; ``p.grad`` of every member is a view into it."""
+
+    def __init__(self, named_params):
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        dev = self.params[0].device
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            view = self.flat[o:o + p.numel()].view_as(p)
+            if p.grad is not None:
+                view.copy_(p.grad)
+            p.grad = view
+
+    def zero(self):
+        self.flat.zero_()
+
+    def slice_of(self, i):
+        return self.offsets[i], self.params[i].numel()
+
+
+class FusedBertAdam:
+    """BertAdam + optional global clip + optional EMA in three launches (clip semantics identical to
+    clip_grad_norm_(model.parameters(), grad_clip) followed by BertAdam.step())."""
+
+    def __init__(self, named_params, lr=1e-4, warmup=0.1, t_total=-1, weight_decay=0.01, max_grad_norm=1.0, grad_clip=1.0,
+                 ema_decay=-1.0, b1=0.9, b2=0.999, eps=1e-6):
+        self.named = [(n, p) for n, p in named_params if p.requires_grad]
+        self.lr, self.warmup, self.t_total = lr, warmup, t_total
+        self.weight_decay, self.max_grad_norm, self.grad_clip = weight_decay, max_grad_norm, grad_clip
+        self.ema_decay, self.b1, self.b2, self.eps = ema_decay, b1, b2, eps
+        self.step_count = 0
+        self.arena = None
+
+    # -- lazily built after the first backward: tensors whose grad is None are skipped, as BertAdam does (:290-291)
+    def _build(self):
+        live = [(n, p) for n, p in self.named if p.grad is not None]
+        assert live, "no parameter received a gradient"
+        self.arena = GradArena(live)
+        dev = self.arena.flat.device
+        self.m = torch.zeros_like(self.arena.flat)
+        self.v = torch.zeros_like(self.arena.flat)
+        self.ema = None
+        if self.ema_decay >= 0:
+            self.ema = torch.zeros_like(self.arena.flat)
+            for p, o in zip(self.arena.params, self.arena.offsets):
+                self.ema[o:o + p.numel()].copy_(p.detach().reshape(-1))
+        lib = _lib.load()
+        chunk = lib.svpc_opt_chunk()
+        assert lib.svpc_opt_meta_bytes() == ctypes.sizeof(_Meta)
+        metas = (_Meta * len(live))()
+        chunk_tid, chunk_start, tco = [], [], [0]
+        for i, ((name, p), o) in enumerate(zip(live, self.arena.offsets)):
+            n = p.numel()
+            assert p.is_contiguous() and p.dtype == torch.float32
+            wd = 0.0 if any(nd in name for nd in NO_DECAY) else self.weight_decay
+            es = 4
+            metas[i] = _Meta(p.data_ptr(), self.arena.flat.data_ptr() + o * es, self.m.data_ptr() + o * es,
+                             self.v.data_ptr() + o * es, (self.ema.data_ptr() + o * es) if self.ema is not None else None,
+                             n, wd, 0)
+            for s in range(0, n, chunk):
+                chunk_tid.append(i)
+                chunk_start.append(s)
+            tco.append(len(chunk_tid))
+        raw = bytes(metas)
+        self.meta = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.chunk_tid = torch.tensor(chunk_tid, dtype=torch.int32, device=dev)
+        self.chunk_start = torch.tensor(chunk_start, dtype=torch.int64, device=dev)
+        self.tensor_chunk_off = torch.tensor(tco, dtype=torch.int32, device=dev)
+        self.n_tensors, self.n_chunks = len(live), len(chunk_tid)
+        self.partial = torch.empty(self.n_chunks, dtype=torch.float32, device=dev)
+        self.norms_sq = torch.empty(self.n_tensors + 1, dtype=torch.float32, device=dev)
+        self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(8)
+
+    def ensure_built(self):
+        if self.arena is None:
+            self._build()
+        return self.arena
+
+    def zero_grad(self):
+        if self.arena is None:
+            for _, p in self.named:
+                p.grad = None
+        else:
+            self.arena.zero()
+
+    def scheduled_lr(self):
+        if self.t_total <= 0:
+            return self.lr
+        return self.lr * warmup_linear(self.step_count / self.t_total, self.warmup)
+
+    def set_hyper(self):
+        """Refresh the device hyper-parameter words (lr of this step, EMA decay of this step: optimization.py:197)."""
+        h = self._hyper_host
+        h[0] = self.scheduled_lr()
+        h[1] = min(self.ema_decay, (1.0 + self.step_count) / (10.0 + self.step_count)) if self.ema_decay >= 0 else -1.0
+        h[2] = self.grad_clip if self.grad_clip and self.grad_clip > 0 else -1.0
+        h[3] = self.max_grad_norm if self.max_grad_norm and self.max_grad_norm > 0 else -1.0
+        h[4], h[5], h[6] = self.b1, self.b2, self.eps
+        self.hyper.copy_(h, non_blocking=True)
+
+    def launch(self):
+        """The three kernels only (graph-capturable)."""
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.call("opt_step", self.meta.data_ptr(), self.chunk_tid.data_ptr(), self.chunk_start.data_ptr(),
+                  self.tensor_chunk_off.data_ptr(), self.n_tensors, self.n_chunks, self.partial.data_ptr(),
+                  self.norms_sq.data_ptr(), self.hyper.data_ptr(), stream)
+
+    def step(self):
+        self.ensure_built()
+        self.set_hyper()
+        self.launch()
+        self.step_count += 1
+
+    def grad_norm(self):
+        """global gradient norm seen by the last step (device scalar, no sync)."""
+        return self.norms_sq[self.n_tensors].sqrt()
+
+
+class GradReducer:
+    """Data-parallel gradient exchange: SUM all-reduce of the arena in large buckets over RCCL (backend "nccl" on
+    ROCm) — or gloo in the CPU tests.  Buckets are contiguous arena slices; a bucket is launched asynchronously as soon
+    as all of its tensors have accumulated their gradient (post-accumulate hooks), so the exchange overlaps the rest of
+    backward; ``finish()`` waits before the clip/optimizer kernels read the arena.  SUM (not mean) keeps the reference's
+    sum-over-videos loss semantics (model.py:1110-1115, :1188): N ranks × 16 videos ≡ one process with 16·N videos."""
+
+    def __init__(self, arena, process_group=None, bucket_bytes=64 << 20, overlap=True):
+        import torch.distributed as dist
+        self.dist, self.arena, self.pg = dist, arena, process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.buckets = []          # (start, end, [param indices])
+        cur, cur_start, cur_bytes = [], 0, 0
+        # parameters are registered in forward order, so backward finishes them roughly last-to-first:
+        # walk the arena from the end so the first bucket to complete is the first launched
+        order = list(range(len(arena.params)))
+        for i in reversed(order):
+            cur.append(i)
+            cur_bytes += arena.params[i].numel() * 4
+            if cur_bytes >= bucket_bytes:
+                self._close(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            self._close(cur)
+        self.pending, self.works = [], []
+        self.overlap = overlap and self.world > 1
+        self._handles = []
+        if self.overlap:
+            for bi, (s, e, members) in enumerate(self.buckets):
+                for i in members:
+                    self._handles.append(arena.params[i].register_post_accumulate_grad_hook(self._make_hook(bi)))
+        self.reset()
+
+    def _close(self, members):
+        lo = min(self.arena.offsets[i] for i in members)
+        hi = max(self.arena.offsets[i] + (self.arena.params[i].numel() + 3) // 4 * 4 for i in members)
+        self.buckets.append((lo, hi, list(members)))
+
+    def reset(self):
+        self.pending = [len(m) for _, _, m in self.buckets]
+        self.works = []
+        self.launched = [False] * len(self.buckets)
+
+    def _launch(self, bi):
+        s, e, _ = self.buckets[bi]
+        self.launched[bi] = True
+        self.works.append(self.dist.all_reduce(self.arena.flat[s:e], op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _make_hook(self, bi):
+        def hook(param):
+            self.pending[bi] -= 1
+            if self.pending[bi] == 0 and not self.launched[bi]:
+                self._launch(bi)
+        return hook
+
+    def finish(self):
+        """Launch whatever has not been launched (tensors without a gradient this step never fire a hook) and wait."""
+        if self.world > 1:
+            for bi in range(len(self.buckets)):
+                if not self.launched[bi]:
+                    self._launch(bi)
+            for w in self.works:
+                w.wait()
+        self.reset()
