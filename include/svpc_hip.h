@@ -119,6 +119,9 @@ int svpc_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, co
                        float* c, float* gates_act, int N, int D, svpc_stream_t stream);
 int svpc_lstm_cell_bwd(const float* dh, const float* dc, const float* gates_act, const float* c_prev, const float* active,
                        float* dgates, float* dc_prev, float* dh_prev, int N, int D, svpc_stream_t stream);
+/* greedy decoding step: argmax with the UNK column suppressed + OOV→UNK remap, src/translator.py:104-112 */
+int svpc_greedy_pick(const float* scores, int ld, const int* row_c, const int* row_x, int n_sent, int lt, int pos, int unk,
+                     int* next_ext, int* next_model, svpc_stream_t stream);
 int svpc_add(const float* a, const float* b, float* c, size_t n, svpc_stream_t stream);
 int svpc_sum_all(const float* x, size_t n, float* out, float scale, svpc_stream_t stream);
 int svpc_fill_from(float* x, size_t n, const float* v, svpc_stream_t stream);

@@ -280,6 +280,38 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
     dh_prev[i] = (1.f - a) * dh[i];
 }
 
+// ---- greedy pick (src/translator.py:104-112): per sentence j take row j*lt+pos of the score matrix, suppress the UNK
+// column (-1e10), first-index argmax over the row's C_j classes; the emitted stream keeps the extended id, the model
+// side sees UNK for copied out-of-vocabulary words (id >= C_j - X_j).
+__global__ __launch_bounds__(256) void greedy_pick_kernel(const float* __restrict__ scores, int ld, const int* __restrict__ row_c,
+                                                          const int* __restrict__ row_x, int lt, int pos, int unk,
+                                                          int* __restrict__ next_ext, int* __restrict__ next_model) {
+    __shared__ float sval[4];
+    __shared__ int sidx[4];
+    const int j = blockIdx.x, r = j * lt + pos;
+    const int C = row_c[r], X = row_x[r];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int v = threadIdx.x; v < C; v += 256) {
+        const float sc = v == unk ? -1e10f : scores[(size_t)r * ld + v];
+        if (sc > best) { best = sc; bi = v; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { sval[wave] = best; sidx[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best = sval[0]; bi = sidx[0];
+        for (int w = 1; w < 4; ++w)
+            if (sval[w] > best || (sval[w] == best && sidx[w] < bi)) { best = sval[w]; bi = sidx[w]; }
+        next_ext[j] = bi;
+        next_model[j] = bi >= C - X ? unk : bi;
+    }
+}
+
 static inline unsigned grid1d(size_t n) { size_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
 extern "C" {
@@ -377,6 +409,12 @@ int svpc_clamp_labels(const int* in, int* out, int n, int vocab, int unk, hipStr
     if (n == 0) return 0;
     hipLaunchKernelGGL(clamp_labels_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, n, vocab, unk);
     return svpc_check_launch("clamp_labels");
+}
+int svpc_greedy_pick(const float* scores, int ld, const int* row_c, const int* row_x, int n_sent, int lt, int pos, int unk,
+                     int* next_ext, int* next_model, hipStream_t s) {
+    if (n_sent == 0) return 0;
+    hipLaunchKernelGGL(greedy_pick_kernel, dim3(n_sent), dim3(256), 0, s, scores, ld, row_c, row_x, lt, pos, unk, next_ext, next_model);
+    return svpc_check_launch("greedy_pick");
 }
 int svpc_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, const float* h_prev, const float* active, float* h,
                        float* c, float* gates_act, int N, int D, hipStream_t s) {

@@ -226,16 +226,18 @@ int svpc_gemm_f32(const float* A, int lda, int a_kc, const float* B, int ldb, in
     if (M == 0 || N == 0) return 0;
     SVPC_REQUIRE(p_drop <= 0.f || seed != nullptr, "gemm: dropout needs a seed pointer");
     Epi epi{bias, act, p_drop, site, seed, accumulate, Z};
-    const bool big = ((long long)M * N >= 128LL * 128 * 192) ;
+    // 128×128 tiles whenever both output dims can fill one; long-K problems with few tiles are split along K so
+    // that ≥ ~2 workgroups per CU are in flight (wgrad: 36 tiles × K = 19,200 → 15 slabs).
+    const bool big = (M >= 96 && N >= 96);
     const int BMN = big ? 128 : 64;
     const int tiles_m = ceil_div(M, BMN), tiles_n = ceil_div(N, BMN);
     const int tiles = tiles_m * tiles_n;
     int splitk = 1;
-    if (K >= 1024 && tiles < 256) {
-        splitk = 512 / tiles;
-        const int max_by_k = K / 256;
+    if (K >= 512 && tiles < 256) {
+        splitk = ceil_div(512, tiles);
+        const int max_by_k = K / 128;
         if (splitk > max_by_k) splitk = max_by_k;
-        if (splitk > 32) splitk = 32;
+        if (splitk > 64) splitk = 64;
         while (splitk > 1 && (size_t)splitk * M * N * sizeof(float) > workspace_bytes) --splitk;
         if (splitk < 1) splitk = 1;
     }

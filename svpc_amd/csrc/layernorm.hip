@@ -229,14 +229,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     for (int c = threadIdx.x; c < 2 * D; c += 256) out[c] = smem[c];
 }
 
-// out[c] (+)= sum_g partial[g][c]
+// out[c] (+)= sum_g partial[g][c] : 32 columns × 8 row-groups per workgroup, LDS tree for the 8 partial sums
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int G, int ncols,
                                                               float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= ncols) return;
+    __shared__ float red[8][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += partial[(size_t)g * ncols + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < ncols)
+        for (int g = rg; g < G; g += 8) s += partial[(size_t)g * ncols + c];
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && c < ncols) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][cl];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // partial[chunk][k][c] = sum over rows r of the chunk with idx[r]==k (idx null → k = 0) of x[r][c]
@@ -327,14 +336,14 @@ int svpc_ln_bwd(const float* dy, const float* x, const int* src_rows, const floa
     }
     if (rc != 0) { if (rc == -1) svpc_set_error("ln_bwd: row width not supported"); return rc; }
     // partial layout per group: [dgamma(D) ; dbeta(D)] → two strided reductions
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(2 * D, 256)), dim3(256), 0, stream, workspace, G, 2 * D,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(2 * D, 32)), dim3(256), 0, stream, workspace, G, 2 * D,
                        workspace + (size_t)G * 2 * D, 0);
     rc = svpc_check_launch("ln_bwd finalize");
     if (rc) return rc;
     // scatter the two halves (tiny): reuse finalize with G=1 to honour `accumulate`
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(D, 32)), dim3(256), 0, stream,
                        workspace + (size_t)G * 2 * D, 1, D, dgamma, accumulate);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(D, 32)), dim3(256), 0, stream,
                        workspace + (size_t)G * 2 * D + D, 1, D, dbeta, accumulate);
     return svpc_check_launch("ln_bwd scatter");
 }
@@ -355,7 +364,7 @@ int svpc_bucket_colsum(const float* x, int ldx, const int* idx, int R, int C, in
     else hipLaunchKernelGGL((bucket_colsum_kernel<8>), grid, dim3(256), 0, stream, x, ldx, idx, R, C, K, rpc, workspace);
     int rc = svpc_check_launch("bucket_colsum");
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(K * C, 256)), dim3(256), 0, stream, workspace, chunks, K * C,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(K * C, 32)), dim3(256), 0, stream, workspace, chunks, K * C,
                        out, accumulate);
     return svpc_check_launch("bucket_colsum finalize");
 }

@@ -664,3 +664,15 @@ class _AslRows(Function):
 
 def asl_rows(p, y, row_active, gamma_neg=4.0, gamma_pos=1.0, clip=0.05, eps=1e-8):
     return _AslRows.apply(p, y, row_active, float(gamma_neg), float(gamma_pos), float(clip), float(eps))
+
+
+def greedy_pick(scores, row_c, row_x, lt, pos, unk):
+    """scores (T*lt, ≥C): → (next_ext, next_model) int32 (T,), see svpc_greedy_pick."""
+    scores = _c(scores)
+    dev = scores.device
+    n = scores.shape[0] // lt
+    ext = torch.empty(n, dtype=torch.int32, device=dev)
+    mod = torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.call("greedy_pick", _p(scores), scores.stride(0), _p(as_idx(row_c).dev(dev)), _p(as_idx(row_x).dev(dev)), n, lt, int(pos),
+              int(unk), _p(ext), _p(mod), _stream())
+    return ext, mod

@@ -1,0 +1,119 @@
+"""Greedy caption decoding on the MI355X — drop-in for the reference's ``Translator`` (src/translator.py:27-228).
+
+Same constructor and ``translate_batch`` contract (12-element ``model_inputs`` list in, ``(dec_seq_list, oov_word_dict)``
+out, one ``(S_b, Lt)`` int64 id matrix per video, extended ids ≥ V kept for copied OOV words).  Restructured for the GPU:
+all videos of the batch are decoded together — clip encoder, step-wise encoder and visual simulator run once over every
+clip of the batch, then the ``max_t_len`` decoding iterations advance all T = Σ_b S_b sentences at once with arg-max, UNK
+suppression and OOV→UNK remapping done by a kernel (no host synchronisation inside the loop).  Each iteration re-runs the
+decoder over all Lt positions exactly like the reference (translator.py:88-100), so ids are bit-identical in fp32.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .model import BatchPlan, _Ctx
+from .ops_common import ACT_RELU, Idx
+from .synthetic import BOS, PAD, UNK
+
+
+class Translator(object):
+    def __init__(self, opt, checkpoint, model=None):
+        self.opt = opt
+        self.device = torch.device("cuda" if getattr(opt, "cuda", True) else "cpu")
+        self.model_config = checkpoint["model_cfg"]
+        self.max_t_len = self.model_config.max_t_len
+        self.max_v_len = self.model_config.max_v_len
+        self.num_hidden_layers = self.model_config.num_hidden_layers
+        model.load_state_dict(checkpoint["model"])
+        self.model = model
+        self.model.eval()
+
+    @classmethod
+    def prepare_video_only_inputs(cls, input_ids, input_masks, segment_ids):
+        """reference: translator.py:205-228 — overwrites the caller's text half in place, as the reference does."""
+        if isinstance(input_ids, list):
+            for e1, e2, e3 in zip(input_ids, input_masks, segment_ids):
+                text_mask = e3 == 1
+                e1[text_mask] = PAD
+                e2[text_mask] = 0
+            return input_ids, input_masks
+        text_mask = segment_ids == 1
+        input_ids[text_mask] = PAD
+        input_masks[text_mask] = 0
+        return input_ids, input_masks
+
+    def translate_batch(self, model_inputs, use_beam=False, recurrent=True, untied=False, xl=False, mtrans=False):
+        (input_ids_list, video_features_list, input_masks_list, token_type_ids_list, ingr_input_ids, ingr_masks,
+         ingr_sep_masks, ingr_id_dict, oov_word_dict, alignments, actions, batch_step_num) = model_inputs
+        return self.translate_batch_greedy(input_ids_list, video_features_list, input_masks_list, token_type_ids_list,
+                                           ingr_input_ids, ingr_masks, ingr_sep_masks, ingr_id_dict, oov_word_dict,
+                                           alignments, actions, batch_step_num, self.model)
+
+    @torch.no_grad()
+    def translate_batch_greedy(self, input_ids_list, video_features_list, input_masks_list, token_type_ids_list,
+                               ingr_input_ids, ingr_masks, ingr_sep_masks, ingr_id_dict, oov_word_dict, alignments, actions,
+                               batch_step_num, rt_model):
+        model = rt_model
+        cfg = model.config
+        mode = cfg.model_mode
+        input_ids_list, input_masks_list = self.prepare_video_only_inputs(input_ids_list, input_masks_list, token_type_ids_list)
+        dev = video_features_list[0].device
+        N, L, F = video_features_list[0].shape
+        S_pad = len(input_ids_list)
+        Lv, Lt, D, V = cfg.max_v_len, cfg.max_t_len, cfg.hidden_size, cfg.vocab_size
+        cx = _Ctx(cfg, False, model.rng(dev))
+        ingr_ids_t = torch.as_tensor(ingr_input_ids).to(dev)
+        sep_t = torch.as_tensor(ingr_sep_masks)
+        spans = model.ingredient_embeddings.spans(sep_t.cpu())
+        plan = model.plan_for(batch_step_num, spans[3], S_pad, N, L, dev)
+        T = plan.T
+
+        feats = model._stacked(video_features_list).reshape(S_pad * N * L, F)
+        ids_all = torch.stack(input_ids_list).reshape(-1).to(torch.int32)
+        masks_all = torch.stack(input_masks_list).reshape(-1).float()
+        ents = model.ingredient_embeddings.run(ingr_ids_t.reshape(-1).to(torch.int32), spans, cx)
+        h = model._encode_clips(feats, plan.video_rows, ops.take_rows(ids_all, plan.video_rows),
+                                ops.take_rows(masks_all, plan.video_rows), plan.seq_enc, cx)
+        x = ops.span_mean(h, plan.cls_rows, plan.ones_T, add=model.step_positional_encoding.pe, add_idx=plan.step_idx)
+        g = model.step_wise_encoder.run(x, plan.seq_step, None, cx)
+        if mode in ("full", "reason_copy"):
+            _, _, ebar, eall, fbar = model.reasoner.run(g, ents, plan.sim, cx)
+            went = ops.linear(ebar, model.Went[0].weight, model.Went[0].bias, act=ACT_RELU)
+            wac = ops.linear(fbar, model.Wac[0].weight, model.Wac[0].bias, act=ACT_RELU)
+            mem = torch.stack([g, went, wac], 1).reshape(T * 3, D)
+            bank = eall
+        elif mode == "copy":
+            mean_ing = ops.span_mean(ents, plan.ent_off, plan.ent_len)
+            mem = torch.stack([g, ops.take_rows(mean_ing, plan.step_vid_dev)], 1).reshape(T * 2, D)
+            bank = model._padded_bank(ents, plan)
+        else:
+            mem = g
+            bank = None
+
+        n_oov = [len(d) if mode != "video" else 0 for d in oov_word_dict]
+        c_list = [V + x_ for x_ in n_oov]
+        pl = model._ptr_plan(ingr_id_dict if mode != "video" else [{}] * N, c_list, Lt, plan.step_ne, plan.row_vid)
+        row_x = Idx([n_oov[b] for b in plan.row_vid.host])
+        text = torch.full((T, Lt), PAD, dtype=torch.int32, device=dev)
+        ext = torch.full((T, Lt), PAD, dtype=torch.int32, device=dev)
+        tmask = torch.zeros(T, Lt, dtype=torch.float32, device=dev)
+        nxt = torch.full((T,), BOS, dtype=torch.int32, device=dev)
+        nxt_ext = nxt.clone()
+        for i in range(Lt):
+            text[:, i] = nxt
+            ext[:, i] = nxt_ext
+            tmask[:, i] = 1.0
+            xt = model.text_embeddings.run(text.reshape(-1), Lt, cx)
+            dec = model.decoder.run(xt, tmask.reshape(-1), mem, plan.seq_dec_self, plan.seq_dec_cross, None, cx)
+            if mode == "video":
+                scores = model.decoder_classifier.run(dec, cx.eps)          # raw logits (translator.py:159)
+            else:
+                scores, _ = model._lm_probs(dec, bank, pl, cx)
+            nxt_ext, nxt = ops.greedy_pick(scores, pl["row_c"], row_x, Lt, i, UNK)
+        out = text if mode == "video" else ext
+        res = []
+        for b in range(N):
+            o, n = plan.h_step_off[b], plan.h_step_len[b]
+            res.append(out[o:o + n].to(torch.int64))
+        return res, oov_word_dict

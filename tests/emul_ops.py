@@ -310,3 +310,18 @@ class EmulRng:
     def mask(self, site, n, p, device):
         g = torch.Generator().manual_seed(self.seed * 7919 + site)
         return (torch.rand(n, generator=g) >= p).float().to(device)
+
+
+def greedy_pick(scores, row_c, row_x, lt, pos, unk):
+    row_c, row_x = _h(row_c), _h(row_x)
+    n = scores.shape[0] // lt
+    ext, mod = [], []
+    for j in range(n):
+        r = j * lt + pos
+        sc = scores[r, :row_c[r]].clone()
+        sc[unk] = -1e10
+        i = int(sc.max(0)[1])
+        ext.append(i)
+        mod.append(unk if i >= row_c[r] - row_x[r] else i)
+    t = lambda v: torch.tensor(v, dtype=torch.int32, device=scores.device)
+    return t(ext), t(mod)
