@@ -3,7 +3,7 @@
 Layouts follow what the reference's data layer hands to ``model.forward``
 (reference: src/rtransformer/recursive_caption_dataset.py:289-330 clip_sentence_to_feature,
 :389-416 _load_indexed_video_feature, :528-576 caption_collate; src/train.py:91-112 marshalling).
-Nothing here reads the reference or the oracle; it only produces tensors of the same shape,
+Nothing here reads the reference or any test code; it only produces tensors of the same shape,
 dtype and token conventions (PAD=0 CLS=1 SEP=2 VID=3 BOS=4 EOS=5 UNK=6, IGNORE=-1).
 """
 from __future__ import annotations
