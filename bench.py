@@ -25,7 +25,7 @@ from svpc_amd import StateAwareRecursiveTransformer, make_batch, make_config  # 
 from svpc_amd import ops, synthetic as syn  # noqa: E402
 from svpc_amd.optim import FusedBertAdam, GradReducer  # noqa: E402
 
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense peaks (f32-in MFMA; bf16 MFMA)
 
 
 def build(args, device):
@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--hidden", type=int, default=768)
     ap.add_argument("--heads", type=int, default=12)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+                    help="arithmetic type of the GEMM operands (accumulation and storage are fp32 either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-videos", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -127,6 +129,7 @@ def main():
         torch.cuda.set_device(0)
     device = torch.device("cuda", local_rank if world > 1 else 0)
 
+    ops.set_precision(args.precision)
     cfg, model = build(args, device)
     model.train()
     batch = device_batch(cfg, args, device, seed=2019 + rank)
@@ -181,14 +184,15 @@ def main():
             "metric": "train steps/sec (vivt, batch=16, clip_seq=12)", "value": world * args.steps / elapsed,
             "unit": "steps/s (one step = 16 clip-sequences per GPU; whole-job aggregate)", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "MODEL_TYPE=%s train step: N=%d videos/GPU x S=%d clips x Lv=%d frames x F=%d, Lt=%d, D=%d, H=%d, "
                                    "L=%d (enc+step-enc+dec), V=%d, A=%d, E=10; dropout .1/.1/.4; fwd+bwd+allreduce+clip+BertAdam"
                                    % (args.model_type, args.batch, args.clips, cfg.max_v_len, cfg.video_feature_size, cfg.max_t_len,
                                       cfg.hidden_size, cfg.num_attention_heads, cfg.num_hidden_layers, cfg.vocab_size, cfg.action_vocab_size),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128> (encoder-sized GEMMs: M>=%d)" % (args.batch * args.clips * cfg.max_v_len),
-                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "gemm_%s_kernel<128,128> (encoder-sized GEMMs: M>=%d)" % (args.precision, args.batch * args.clips * cfg.max_v_len),
+                         "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_PEAK_TFLOPS[args.precision],
                          "traffic": None, "launches": gsum["launches"], "avg_launch_ms": gsum["ms"] / max(1, gsum["launches"]),
                          "share_of_step": gsum["ms"] / (ms * args.steps)},
         }

@@ -50,6 +50,10 @@ int svpc_bucket_colsum(const float* x, int ldx, const int* idx, int R, int C, in
 int svpc_gemm_f32(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, int M, int N,
                   int K, const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed, int accumulate,
                   float* workspace, size_t workspace_bytes, svpc_stream_t stream);
+/* same contract on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16): fp32 operands are rounded to bf16 while staged, fp32 accumulate */
+int svpc_gemm_bf16(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, int M, int N,
+                   int K, const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed, int accumulate,
+                   float* workspace, size_t workspace_bytes, svpc_stream_t stream);
 /* dz = dy · act'(aux) · dropout  (aux = pre-activation for GELU, activated output for ReLU / sigmoid) */
 int svpc_act_bwd(const float* dy, const float* aux, float* dz, size_t n, int act, float p, unsigned site, const svpc_u64* seed,
                  svpc_stream_t stream);

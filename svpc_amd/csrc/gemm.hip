@@ -15,25 +15,7 @@
 // Workgroup ids are remapped so that the tiles sharing an A row-panel run on one XCD (private L2).
 // Long-K / few-tile problems (the wgrad products) are split along K into fp32 slabs reduced in a fixed order
 // (deterministic, no atomics).  Bound: fp32 MFMA peak 157 TFLOP/s.
-#include "common.h"
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-struct Epi {
-    const float* bias; int act; float p_drop; uint32_t site; const u64* seed; int accumulate;
-    float* Z;   // optional pre-activation output (same ldc)
-};
-
-__device__ __forceinline__ void epilogue_store(float v, int row, int col, float* __restrict__ C, int ldc, const Epi& e,
-                                               u64 seed, float inv_keep) {
-    if (e.bias) v += e.bias[col];
-    const size_t o = (size_t)row * ldc + col;
-    if (e.Z) e.Z[o] = v;
-    v = apply_act(v, e.act);
-    if (e.p_drop > 0.f) v *= drop_scale(seed, e.site, o, e.p_drop, inv_keep);
-    if (e.accumulate) v += C[o];
-    C[o] = v;
-}
+#include "gemm_common.h"
 
 constexpr int BK = 16;
 

@@ -126,14 +126,28 @@ class KernelTimer:
 
 GEMM_TIMER = None   # set by bench.py
 
+# Arithmetic type of the dense contractions: "fp32" (v_mfma_f32_32x32x2_f32, bit-level parity mode) or "bf16"
+# (v_mfma_f32_32x32x16_bf16 with fp32 accumulate — the throughput mode the baseline names).
+_PRECISION = "fp32"
+
+
+def set_precision(p):
+    global _PRECISION
+    assert p in ("fp32", "bf16")
+    _PRECISION = p
+
+
+def get_precision():
+    return _PRECISION
+
 
 def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NONE, p=0.0, site=0, seed=None, accumulate=0):
     ws = _ws(C.device)
     ev = GEMM_TIMER.bracket(2.0 * M * N * K) if GEMM_TIMER is not None else None
     if ev:
         ev[0].record()
-    _lib.call("gemm_f32", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
-              _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+    _lib.call("gemm_bf16" if _PRECISION == "bf16" else "gemm_f32", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z),
+              M, N, K, _p(bias), act, p, site, _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
     if ev:
         ev[1].record()
 

@@ -141,3 +141,21 @@ def test_fused_bert_adam_matches_reference_semantics(golden_dir):
     for (n, p), o in zip(zip(opt.arena.names, opt.arena.params), opt.arena.offsets):
         np.testing.assert_allclose(opt.ema[o:o + p.numel()].cpu().numpy(), ref_ema[n].reshape(-1).numpy(), rtol=2e-4, atol=2e-6)
     assert all("memory_intermediate" not in n for n in opt.arena.names)
+
+
+def test_bf16_compute_mode_stays_close_to_reference(golden_dir):
+    """Throughput mode: GEMM operands rounded to bf16 (fp32 accumulate, fp32 everything else).  Stated tolerance vs the fp32
+    reference: loss ≤ 5e-3 relative at the config-1 shape."""
+    from svpc_amd import ops
+    z, cfg, batch, model = build_model("c1", "vivt", golden_dir, DEV)
+    ops.set_precision("bf16")
+    try:
+        loss = model(*syn.forward_args(batch))[0]
+        loss.backward()
+    finally:
+        ops.set_precision("fp32")
+    ref = float(z["loss"])
+    assert abs(loss.item() - ref) <= 5e-3 * abs(ref), (loss.item(), ref)
+    gn = dict(model.named_parameters())["encoder.layer.0.attention.output.dense.weight"].grad.double().norm().item()
+    refn = float(z["gradnorm/encoder.layer.0.attention.output.dense.weight"])
+    assert abs(gn - refn) <= 0.05 * refn

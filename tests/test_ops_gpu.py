@@ -271,3 +271,36 @@ def test_ptr_attn_and_mix_loss_and_gumbel():
     from svpc_amd import _lib
     _lib.call("gumbel_noise", n.data_ptr(), n.numel(), 1, rng.seed.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert abs(n.mean().item() - 0.5772) < 0.02 and abs(n.var().item() - 1.6449) < 0.05
+
+
+# ------------------------------------------------------------------------------------------------ bf16 MFMA GEMM
+@pytest.fixture
+def bf16_mode():
+    O.set_precision("bf16")
+    yield
+    O.set_precision("fp32")
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 5, 3), (64, 64, 32), (100, 33, 42), (130, 257, 300), (192, 768, 768),
+                                   (2048, 768, 3072), (768, 768, 19200), (768, 3072, 4096), (33, 951, 128)])
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_gemm_bf16_all_layouts_exact_on_bf16_rounded_operands(bf16_mode, M, N, K, a_kc, b_kc):
+    """Operands that are exactly representable in bf16 make the product independent of the rounding step: the kernel must
+    then agree with an fp32 matmul up to accumulation order.  Exercises both LDS images (ds_read_b128 rows and the
+    ds_read_b64_tr_b16 transposed read) for both operands, split-K, ragged edges and unaligned leading dimensions."""
+    g = torch.Generator().manual_seed(M * 31 + N * 7 + K)
+    A = torch.randn(M, K, generator=g).bfloat16().float().to(DEV)
+    B = torch.randn(N, K, generator=g).bfloat16().float().to(DEV)
+    ref = A.double() @ B.double().t()
+    Am = A if a_kc else A.t().contiguous()          # [K][M] when the reduction index is strided
+    Bm = B if b_kc else B.t().contiguous()
+    C = torch.empty(M, N, device=DEV)
+    O._gemm(Am, Am.stride(0), a_kc, Bm, Bm.stride(0), b_kc, C, M, N, K)
+    err = (C.double() - ref).abs().max().item()
+    assert err <= 2e-6 * math.sqrt(K) * max(1.0, ref.abs().max().item()), err
+
+
+def test_linear_bf16_forward_backward_close_to_fp32(bf16_mode):
+    x, w, b = rnd(300, 768, seed=1), rnd(768, 768, seed=2, scale=1 / math.sqrt(768)), rnd(768, seed=3)
+    compare(lambda x, w, b: O.linear(x, w, b, act=E.ACT_GELU), lambda x, w, b: E.linear(x, w, b, act=E.ACT_GELU), [x, w, b],
+            rtol=1e-2, atol=1e-2, grad_rtol=2e-2, grad_atol=2e-2, name="linear bf16")
