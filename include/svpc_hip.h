@@ -68,6 +68,16 @@ int svpc_attn_bwd(const float* Q, int ldq, const float* K, int ldk, const float*
                   float* delta, const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,
                   float scale, float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
 
+/* MFMA (bf16 operands, fp32 softmax/accumulate) form of the same core for ≤128×128 (queries×keys) per sequence, dh 32/64 */
+int svpc_attn_mfma_supported(int dh, int max_q, int max_k, int ldq, int ldk, int ldv);
+int svpc_attn_mfma_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, float* LSE,
+                       const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,
+                       float scale, float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
+int svpc_attn_mfma_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                       const float* LSE, const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
+                       const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal, float scale,
+                       float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
+
 /* ---- simulator recurrence: EntitiyReasoningNetwork.forward model.py:792-820 (Eqs. 2-7), one workgroup per video */
 int svpc_sim_recur_fwd(const float* q, const float* c, const float* w4f, const float* E0, const int* step_off, const int* step_len,
                        const int* ent_off, const int* ent_len, int n_videos, int e_max, int D, float* e_out, float* ebar,

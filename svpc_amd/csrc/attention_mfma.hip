@@ -1,0 +1,363 @@
+// MFMA attention core for sequences of ≤128 queries × ≤128 keys per (sequence, head), head dim 32 or 64 — the clip
+// encoder (100×100×64), decoder self/cross attention and the step encoder of the hot path (reference semantics:
+// src/rtransformer/model.py:194-219).  bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 softmax.
+//
+// One workgroup (4 waves) owns one (sequence, head).  Q (pre-scaled by 1/sqrt(dh)), K, V (and dO in backward) are read
+// once from the packed fp32 projection output, rounded to bf16 and kept in LDS as [row][dh] images with (2·dh+16)-byte rows:
+// the same image serves ds_read_b128 row fragments (conflict-free) and ds_read_b64_tr_b16 transposed fragments.
+//
+// Forward, wave w = query tile w (32 queries): Sᵀ = K·Qᵀ puts a query on a lane and its keys in registers, so the softmax
+// row reduction is in-lane (+ one cross-half shuffle); the normalised (and dropped-out) P registers are directly the A operand
+// of O = P·V ("accumulator as next operand", permuted-k form) with V fragments fetched by the transposed read in the same
+// permuted key order.  Backward is one launch: pass 1 (wave = key tile) recomputes S, dP in the natural layout and
+// accumulates dV = P̃ᵀ·dO, dK = dSᵀ·Q; pass 2 (wave = query tile) recomputes Sᵀ, dPᵀ and accumulates dQ = dS·K.
+// No atomics, no HBM intermediates.  Bound: HBM (AI ≈ 25–50 FLOP/B): algorithmic bytes per (sequence, head) forward =
+// (2·Lq + 2·Lk)·dh·4.
+#include "common.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+struct MAttnArgs {
+    const float* Q; int ldq; const float* K; int ldk; const float* V; int ldv;
+    float* O; int ldo; float* LSE;
+    const int* seq; int n_seq, H, max_q, max_k;
+    const float* key_mask; int causal; float scale; float p_drop; uint32_t site; const u64* seed;
+    const float* dO; int lddo; float* dQ; int lddq; float* dK; int lddk; float* dV; int lddv;
+};
+
+constexpr int AT = 128;   // rows per image (max queries / keys)
+
+template <int DH> struct AImg { static constexpr int RS = DH * 2 + 16; static constexpr int BYTES = AT * RS; };
+
+// rows [0, len) of a (·, DH) fp32 matrix → bf16 image (zero rows beyond len), optionally scaled
+template <int DH>
+__device__ __forceinline__ void stage_rows(char* __restrict__ img, const float* __restrict__ src, int ld, int len, float scale) {
+    constexpr int UPR = DH / 4;
+    for (int u = threadIdx.x; u < AT * UPR; u += 256) {
+        const int row = u / UPR, c4 = u - row * UPR;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < len) v = *reinterpret_cast<const float4*>(src + (size_t)row * ld + 4 * c4);
+        bf16x4 b;
+        b[0] = (__bf16)(v.x * scale); b[1] = (__bf16)(v.y * scale); b[2] = (__bf16)(v.z * scale); b[3] = (__bf16)(v.w * scale);
+        *reinterpret_cast<bf16x4*>(img + row * AImg<DH>::RS + c4 * 8) = b;
+    }
+}
+// MFMA operand fragment: 32 image rows starting at row0, 16 columns starting at 16·ds (lane = (row, half) → 8 columns)
+template <int DH>
+__device__ __forceinline__ bf16x8 frag_rows(const char* __restrict__ img, int row0, int ds, int lane) {
+    return *reinterpret_cast<const bf16x8*>(img + (row0 + (lane & 31)) * AImg<DH>::RS + ds * 32 + (lane >> 5) * 16);
+}
+// transposed fragment for a product that sums over image ROWS r0..r0+15 in the accumulator-permuted order
+// (element j of lane half h ↔ row r0 + 8(j>>2) + 4h + (j&3)); lane ↔ image column c0 + (lane & 31)
+template <int DH>
+__device__ __forceinline__ bf16x8 frag_tr(const char* __restrict__ img, int r0, int c0, int lane) {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, h = g >> 1;
+    const char* a = img + (r0 + 4 * h + q) * AImg<DH>::RS + (c0 + 16 * (g & 1) + 4 * p) * 2;
+    typedef short4v __attribute__((address_space(3))) * lds_ptr;
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 8 * AImg<DH>::RS));
+    union { short s[8]; bf16x8 v; } u;
+    u.s[0] = lo[0]; u.s[1] = lo[1]; u.s[2] = lo[2]; u.s[3] = lo[3];
+    u.s[4] = hi[0]; u.s[5] = hi[1]; u.s[6] = hi[2]; u.s[7] = hi[3];
+    return u.v;
+}
+__device__ __forceinline__ int acc_row(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)v[j];
+    return r;
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(MAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int IB = AImg<DH>::BYTES;
+    char* Qs = smem; char* Ks = smem + IB; char* Vs = smem + 2 * IB;
+    float* mterm = reinterpret_cast<float*>(smem + 3 * IB);
+    const int sh = blockIdx.x, s = sh / a.H, h = sh - s * a.H;
+    const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
+    stage_rows<DH>(Qs, a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale);
+    stage_rows<DH>(Ks, a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f);
+    stage_rows<DH>(Vs, a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
+    for (int j = threadIdx.x; j < AT; j += 256)
+        mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
+    __syncthreads();
+    const int q0 = 32 * wave;
+    if (q0 >= q_len) return;
+    const int nkt = (k_len + 31) >> 5;
+
+    floatx16 st[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[jt][e] = 0.f;
+        if (jt < nkt) {
+#pragma unroll
+            for (int ds = 0; ds < DH / 16; ++ds)
+                st[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(Ks, 32 * jt, ds, lane), frag_rows<DH>(Qs, q0, ds, lane),
+                                                                 st[jt], 0, 0, 0);
+        }
+    }
+    const int q = q0 + l31;                 // this lane's query
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = 32 * jt + acc_row(e, lane);
+            float t = mterm[key];
+            if (a.causal && key > q && key < k_len) t = -10000.0f;
+            const float v = st[jt][e] + t;
+            st[jt][e] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const float p = expf(st[jt][e] - mx); st[jt][e] = p; sum += p; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (lane < 32 && q < q_len && a.LSE) a.LSE[((size_t)s * a.H + h) * a.max_q + q] = mx + logf(sum);
+    const u64 seed = a.p_drop > 0.f ? a.seed[0] : 0ull;
+    const float ik = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    floatx16 acc[DH / 32];
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[dt][e] = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+        if (jt < nkt) {
+            float pv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float p = st[jt][e] * inv;
+                if (a.p_drop > 0.f) {
+                    const int key = 32 * jt + acc_row(e, lane);
+                    p *= drop_scale(seed, a.site, ((u64)(s * a.H + h) * a.max_q + q) * a.max_k + key, a.p_drop, ik);
+                }
+                pv[e] = p;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pa = pack8(&pv[8 * s2]);
+#pragma unroll
+                for (int dt = 0; dt < DH / 32; ++dt)
+                    acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<DH>(Vs, 32 * jt + 16 * s2, 32 * dt, lane), acc[dt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int qr = q0 + acc_row(e, lane);
+            if (qr < q_len) a.O[(size_t)(q_off + qr) * a.ldo + h * DH + 32 * dt + l31] = acc[dt][e];
+        }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int IB = AImg<DH>::BYTES;
+    char* Qs = smem; char* Ks = smem + IB; char* Vs = smem + 2 * IB; char* Ds = smem + 3 * IB;
+    float* mterm = reinterpret_cast<float*>(smem + 4 * IB);
+    float* lse = mterm + AT;
+    float* delta = lse + AT;
+    const int sh = blockIdx.x, s = sh / a.H, h = sh - s * a.H;
+    const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
+    stage_rows<DH>(Qs, a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale);
+    stage_rows<DH>(Ks, a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f);
+    stage_rows<DH>(Vs, a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
+    stage_rows<DH>(Ds, a.dO + (size_t)q_off * a.lddo + h * DH, a.lddo, q_len, 1.0f);
+    for (int j = threadIdx.x; j < AT; j += 256) {
+        mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
+        lse[j] = j < q_len ? a.LSE[((size_t)s * a.H + h) * a.max_q + j] : 0.f;
+    }
+    for (int r = wave; r < AT; r += 4) {          // delta = rowsum(dO ⊙ O)
+        float d = 0.f;
+        if (r < q_len && lane < DH)
+            d = a.dO[(size_t)(q_off + r) * a.lddo + h * DH + lane] * a.O[(size_t)(q_off + r) * a.ldo + h * DH + lane];
+        d = wave_sum(d);
+        if (lane == 0) delta[r] = d;
+    }
+    __syncthreads();
+    const u64 seed = a.p_drop > 0.f ? a.seed[0] : 0ull;
+    const float ik = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    const u64 dbase = (u64)(s * a.H + h) * a.max_q;
+    const int nqt = (q_len + 31) >> 5, nkt = (k_len + 31) >> 5;
+
+    // ---------------- pass 1: wave = key tile → dV, dK (natural layout: key on lane, queries in registers)
+    if (wave < nkt) {
+        const int k0 = 32 * wave, key = k0 + l31;
+        const float mt = mterm[key];
+        floatx16 dv[DH / 32], dk[DH / 32];
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { dv[dt][e] = 0.f; dk[dt][e] = 0.f; }
+        for (int qt = 0; qt < nqt; ++qt) {
+            floatx16 sc, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sc[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int ds = 0; ds < DH / 16; ++ds) {
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(Qs, 32 * qt, ds, lane), frag_rows<DH>(Ks, k0, ds, lane), sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(Ds, 32 * qt, ds, lane), frag_rows<DH>(Vs, k0, ds, lane), dp, 0, 0, 0);
+            }
+            float pt[16], dsv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int q = 32 * qt + acc_row(e, lane);
+                float t = mt;
+                if (a.causal && key > q && key < k_len) t = -10000.0f;
+                float p = (q < q_len && key < k_len) ? expf(sc[e] + t - lse[q]) : 0.f;
+                float dm = 1.0f;
+                if (a.p_drop > 0.f) dm = drop_scale(seed, a.site, (dbase + q) * a.max_k + key, a.p_drop, ik);
+                pt[e] = p * dm;
+                dsv[e] = p * (dp[e] * dm - delta[q]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pa = pack8(&pt[8 * s2]), da = pack8(&dsv[8 * s2]);
+#pragma unroll
+                for (int dt = 0; dt < DH / 32; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<DH>(Ds, 32 * qt + 16 * s2, 32 * dt, lane), dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_tr<DH>(Qs, 32 * qt + 16 * s2, 32 * dt, lane), dk[dt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int kr = k0 + acc_row(e, lane);
+                if (kr < k_len) {
+                    a.dV[(size_t)(k_off + kr) * a.lddv + h * DH + 32 * dt + l31] = dv[dt][e];
+                    a.dK[(size_t)(k_off + kr) * a.lddk + h * DH + 32 * dt + l31] = dk[dt][e];   // Qs carries 1/sqrt(dh)
+                }
+            }
+    }
+    // ---------------- pass 2: wave = query tile → dQ (transposed layout: query on lane, keys in registers)
+    if (wave < nqt) {
+        const int q0 = 32 * wave, q = q0 + l31;
+        const float lq = lse[q], dq_ = delta[q];
+        floatx16 dq[DH / 32];
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
+        for (int kt = 0; kt < nkt; ++kt) {
+            floatx16 sc, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sc[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int ds = 0; ds < DH / 16; ++ds) {
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(Ks, 32 * kt, ds, lane), frag_rows<DH>(Qs, q0, ds, lane), sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(Vs, 32 * kt, ds, lane), frag_rows<DH>(Ds, q0, ds, lane), dp, 0, 0, 0);
+            }
+            float dsv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = 32 * kt + acc_row(e, lane);
+                float t = mterm[key];
+                if (a.causal && key > q && key < k_len) t = -10000.0f;
+                const float p = (q < q_len && key < k_len) ? expf(sc[e] + t - lq) : 0.f;
+                float dm = 1.0f;
+                if (a.p_drop > 0.f) dm = drop_scale(seed, a.site, (dbase + q) * a.max_k + key, a.p_drop, ik);
+                dsv[e] = p * (dp[e] * dm - dq_);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 da = pack8(&dsv[8 * s2]);
+#pragma unroll
+                for (int dt = 0; dt < DH / 32; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_tr<DH>(Ks, 32 * kt + 16 * s2, 32 * dt, lane), dq[dt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int qr = q0 + acc_row(e, lane);
+                if (qr < q_len) a.dQ[(size_t)(q_off + qr) * a.lddq + h * DH + 32 * dt + l31] = dq[dt][e] * a.scale;
+            }
+    }
+}
+
+static int mattn_set_lds(const void* fn, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { svpc_set_error("attn_mfma: cannot raise dynamic LDS limit"); return (int)e; }
+    }
+    return 0;
+}
+static bool mattn_ok(int dh, int max_q, int max_k, int ldq, int ldk, int ldv, const void* Q, const void* K, const void* V) {
+    return (dh == 64 || dh == 32) && max_q <= AT && max_k <= AT && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 &&
+           (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0;
+}
+
+extern "C" {
+
+// 1 if the MFMA path supports this problem (head dim 32/64, ≤128 rows per sequence, 16-byte aligned rows)
+int svpc_attn_mfma_supported(int dh, int max_q, int max_k, int ldq, int ldk, int ldv) {
+    return mattn_ok(dh, max_q, max_k, ldq, ldk, ldv, nullptr, nullptr, nullptr) ? 1 : 0;
+}
+
+int svpc_attn_mfma_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, float* LSE,
+                       const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,
+                       float scale, float p_drop, unsigned site, const u64* seed, hipStream_t stream) {
+    if (n_seq == 0) return 0;
+    SVPC_REQUIRE(mattn_ok(dh, max_q, max_k, ldq, ldk, ldv, Q, K, V), "attn_mfma: unsupported shape/alignment");
+    SVPC_REQUIRE(p_drop <= 0.f || seed != nullptr, "attn_mfma: dropout needs a seed pointer");
+    MAttnArgs a{};
+    a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.LSE = LSE; a.seq = seq; a.n_seq = n_seq;
+    a.H = H; a.max_q = max_q; a.max_k = max_k; a.key_mask = key_mask; a.causal = causal; a.scale = scale; a.p_drop = p_drop;
+    a.site = site; a.seed = seed;
+    int rc;
+    if (dh == 64) {
+        const size_t lds = 3 * AImg<64>::BYTES + AT * sizeof(float);
+        rc = mattn_set_lds((const void*)attn_mfma_fwd_kernel<64>, lds); if (rc) return rc;
+        hipLaunchKernelGGL(attn_mfma_fwd_kernel<64>, dim3(n_seq * H), dim3(256), lds, stream, a);
+    } else {
+        const size_t lds = 3 * AImg<32>::BYTES + AT * sizeof(float);
+        rc = mattn_set_lds((const void*)attn_mfma_fwd_kernel<32>, lds); if (rc) return rc;
+        hipLaunchKernelGGL(attn_mfma_fwd_kernel<32>, dim3(n_seq * H), dim3(256), lds, stream, a);
+    }
+    return svpc_check_launch("attn_mfma_fwd");
+}
+
+int svpc_attn_mfma_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                       const float* LSE, const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
+                       const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal, float scale,
+                       float p_drop, unsigned site, const u64* seed, hipStream_t stream) {
+    if (n_seq == 0) return 0;
+    SVPC_REQUIRE(mattn_ok(dh, max_q, max_k, ldq, ldk, ldv, Q, K, V) && lddo % 4 == 0 && ((((uintptr_t)dO) & 15) == 0),
+                 "attn_mfma: unsupported shape/alignment");
+    MAttnArgs a{};
+    a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = const_cast<float*>(O); a.ldo = ldo;
+    a.LSE = const_cast<float*>(LSE); a.seq = seq; a.n_seq = n_seq; a.H = H; a.max_q = max_q; a.max_k = max_k; a.key_mask = key_mask;
+    a.causal = causal; a.scale = scale; a.p_drop = p_drop; a.site = site; a.seed = seed;
+    a.dO = dO; a.lddo = lddo; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
+    int rc;
+    if (dh == 64) {
+        const size_t lds = 4 * AImg<64>::BYTES + 3 * AT * sizeof(float);
+        rc = mattn_set_lds((const void*)attn_mfma_bwd_kernel<64>, lds); if (rc) return rc;
+        hipLaunchKernelGGL(attn_mfma_bwd_kernel<64>, dim3(n_seq * H), dim3(256), lds, stream, a);
+    } else {
+        const size_t lds = 4 * AImg<32>::BYTES + 3 * AT * sizeof(float);
+        rc = mattn_set_lds((const void*)attn_mfma_bwd_kernel<32>, lds); if (rc) return rc;
+        hipLaunchKernelGGL(attn_mfma_bwd_kernel<32>, dim3(n_seq * H), dim3(256), lds, stream, a);
+    }
+    return svpc_check_launch("attn_mfma_bwd");
+}
+
+}  // extern "C"

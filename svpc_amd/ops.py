@@ -281,11 +281,15 @@ class _Attention(Function):
         lse = torch.empty(seq.n, H, seq.max_q, dtype=torch.float32, device=qt.device)
         tbl = seq.table if seq.table.device == qt.device else seq.table.to(qt.device)
         es = 4
-        _lib.call("attn_fwd", qt.data_ptr() + cols[0] * es, qt.stride(0), kvt_c.data_ptr() + cols[1] * es, kvt_c.stride(0),
-                  kvt_c.data_ptr() + cols[2] * es, kvt_c.stride(0), _p(out), D, _p(lse), _p(tbl), seq.n, H, dh, seq.max_q, seq.max_k,
-                  _p(key_mask), 1 if causal else 0, 1.0 / math.sqrt(dh), p, site, _p(seed), _stream())
+        qp, kp, vp = qt.data_ptr() + cols[0] * es, kvt_c.data_ptr() + cols[1] * es, kvt_c.data_ptr() + cols[2] * es
+        mfma = (_PRECISION == "bf16" and ((qp | kp | vp) & 15) == 0 and
+                _lib.load().svpc_attn_mfma_supported(dh, seq.max_q, seq.max_k, qt.stride(0), kvt_c.stride(0), kvt_c.stride(0)) == 1)
+        _lib.call("attn_mfma_fwd" if mfma else "attn_fwd", qp, qt.stride(0), kp, kvt_c.stride(0), vp, kvt_c.stride(0), _p(out), D,
+                  _p(lse), _p(tbl), seq.n, H, dh, seq.max_q, seq.max_k, _p(key_mask), 1 if causal else 0, 1.0 / math.sqrt(dh), p,
+                  site, _p(seed), _stream())
         ctx.save_for_backward(qt, kvt_c, out, lse, key_mask, seed, tbl)
         ctx.cfg = (cols, D, H, seq.n, seq.max_q, seq.max_k, causal, p, site, same)
+        ctx.mfma = mfma
         ctx.n_k_rows = seq.n_k_rows
         return out
 
@@ -307,8 +311,15 @@ class _Attention(Function):
         else:
             dq_t = covered(qt, D, n_q_rows)
             dkv_t = covered(kvt, 2 * D, n_k_rows)
-        delta = torch.empty(n, H, max_q, dtype=torch.float32, device=dev)
         es = 4
+        if ctx.mfma:
+            _lib.call("attn_mfma_bwd", qt.data_ptr() + cols[0] * es, qt.stride(0), kvt.data_ptr() + cols[1] * es, kvt.stride(0),
+                      kvt.data_ptr() + cols[2] * es, kvt.stride(0), _p(out), D, _p(lse), _p(dO), D,
+                      dq_t.data_ptr() + cols[0] * es, dq_t.stride(0), dkv_t.data_ptr() + cols[1] * es, dkv_t.stride(0),
+                      dkv_t.data_ptr() + cols[2] * es, dkv_t.stride(0), _p(tbl), n, H, dh, max_q, max_k, _p(key_mask),
+                      1 if causal else 0, 1.0 / math.sqrt(dh), p, site, _p(seed), _stream())
+            return dq_t, (None if same else dkv_t), None, None, None, None, None, None, None
+        delta = torch.empty(n, H, max_q, dtype=torch.float32, device=dev)
         _lib.call("attn_bwd", qt.data_ptr() + cols[0] * es, qt.stride(0), kvt.data_ptr() + cols[1] * es, kvt.stride(0),
                   kvt.data_ptr() + cols[2] * es, kvt.stride(0), _p(out), D, _p(lse), _p(dO), D,
                   dq_t.data_ptr() + cols[0] * es, dq_t.stride(0), dkv_t.data_ptr() + cols[1] * es, dkv_t.stride(0),

@@ -304,3 +304,39 @@ def test_linear_bf16_forward_backward_close_to_fp32(bf16_mode):
     x, w, b = rnd(300, 768, seed=1), rnd(768, 768, seed=2, scale=1 / math.sqrt(768)), rnd(768, seed=3)
     compare(lambda x, w, b: O.linear(x, w, b, act=E.ACT_GELU), lambda x, w, b: E.linear(x, w, b, act=E.ACT_GELU), [x, w, b],
             rtol=1e-2, atol=1e-2, grad_rtol=2e-2, grad_atol=2e-2, name="linear bf16")
+
+
+# ------------------------------------------------------------------------------------------------ MFMA attention
+def _bf16_attn_compare(seq, D, H, causal, with_mask, drop, cross=False, seed=0):
+    Rq, Rk = seq.n_q_rows, seq.n_k_rows
+    km = None
+    if with_mask:
+        km = (torch.rand(Rk, generator=torch.Generator().manual_seed(seed)) > 0.3).float().to(DEV)
+        for o in seq.h_k_off:
+            km[o] = 1.0
+    tol = dict(rtol=2e-2, atol=2e-2, grad_rtol=3e-2, grad_atol=3e-2)
+    if cross:
+        qt, kvt = rnd(Rq, D, seed=seed + 1), rnd(Rk, 2 * D, seed=seed + 2)
+        cols = (0, 0, D)
+        compare(lambda qt, kvt: O.attention(qt, kvt, cols, D, H, seq, km, causal, drop),
+                lambda qt, kvt: E.attention(qt, kvt, cols, D, H, seq, km, causal, drop), [qt, kvt], name="mfma attn cross", **tol)
+    else:
+        qkv = rnd(Rq, 3 * D, seed=seed + 3)
+        cols = (0, D, 2 * D)
+        compare(lambda qkv: O.attention(qkv, qkv, cols, D, H, seq, km, causal, drop),
+                lambda qkv: E.attention(qkv, qkv, cols, D, H, seq, km, causal, drop), [qkv], name="mfma attn self", **tol)
+
+
+def test_mfma_attention_encoder_decoder_cross_ragged(bf16_mode):
+    _bf16_attn_compare(SeqInfo.uniform(6, 100, 100, DEV), 768, 12, False, True, None)
+    _bf16_attn_compare(SeqInfo.uniform(7, 22, 22, DEV), 768, 12, True, True, None, seed=3)
+    _bf16_attn_compare(SeqInfo.uniform(9, 22, 3, DEV), 768, 12, False, False, None, cross=True, seed=4)
+    _bf16_attn_compare(SeqInfo.uniform(3, 128, 128, DEV), 128, 4, False, True, None, seed=5)     # dh = 32, full tiles
+    lens, off = [3, 1, 12, 7], [0, 3, 4, 16]
+    _bf16_attn_compare(SeqInfo(off, lens, off, lens, DEV), 128, 2, False, False, None, seed=6)
+    _bf16_attn_compare(SeqInfo.uniform(2, 33, 65, DEV), 64, 1, False, True, None, cross=True, seed=7)
+
+
+def test_mfma_attention_dropout(bf16_mode):
+    rng = O.make_rng(DEV, seed=3)
+    _bf16_attn_compare(SeqInfo.uniform(3, 40, 40, DEV), 128, 2, True, True, (0.1, rng, 4), seed=8)
