@@ -156,6 +156,11 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
+    # host-side enqueue cost of one step (GPU idle at start, no sync at the end): tells whether the step is launch-bound
+    th = time.perf_counter()
+    loss = step()
+    host_enqueue_ms = 1000.0 * (time.perf_counter() - th)
+    torch.cuda.synchronize()
     # roofline leg: HIP events around the encoder-sized GEMM launches inside the timed region
     big = 2.0 * (args.batch * args.clips * cfg.max_v_len) * cfg.hidden_size * cfg.hidden_size * 0.99
     ops.GEMM_TIMER = ops.KernelTimer(min_flops=big)
@@ -189,7 +194,8 @@ def main():
                                    "L=%d (enc+step-enc+dec), V=%d, A=%d, E=10; dropout .1/.1/.4; fwd+bwd+allreduce+clip+BertAdam"
                                    % (args.model_type, args.batch, args.clips, cfg.max_v_len, cfg.video_feature_size, cfg.max_t_len,
                                       cfg.hidden_size, cfg.num_attention_heads, cfg.num_hidden_layers, cfg.vocab_size, cfg.action_vocab_size),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss},
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
+                       "host_enqueue_ms_per_step": host_enqueue_ms},
             "roofline": {"bound": "mfma", "kernel": "gemm_%s_kernel<128,128> (encoder-sized GEMMs: M>=%d)" % (args.precision, args.batch * args.clips * cfg.max_v_len),
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS[args.precision],

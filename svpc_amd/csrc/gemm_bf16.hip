@@ -15,6 +15,7 @@
 // Global → register prefetch of k-tile t+1 runs under the MFMAs of tile t (two LDS buffers, one barrier per k-tile);
 // XCD-aware workgroup remap; split-K slabs reduced in a fixed order for the long-K / few-tile products.
 #include "gemm_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -35,6 +36,24 @@ template <int BM, bool KC>
 struct Stage {
     static constexpr int NU = (BM * GBK / 4) / 256;   // float4 units per thread: 4 (BM=128) or 2 (BM=64)
     float4 reg[NU];
+    const float* ptr[NU];                             // interior-tile fast path: per-unit source pointers
+
+    // interior tiles (no edge in m or k): pointers are set once, each k-tile is NU unguarded 16-byte loads
+    __device__ __forceinline__ void init_full(const float* __restrict__ P, int ld, int m0, int k0) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = threadIdx.x + 256 * i;
+            if (KC) ptr[i] = P + (size_t)(m0 + (u >> 3)) * ld + k0 + 4 * (u & 7);
+            else { constexpr int UPR = BM / 4; ptr[i] = P + (size_t)(k0 + u / UPR) * ld + m0 + 4 * (u % UPR); }
+        }
+    }
+    __device__ __forceinline__ void load_full(int ld) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            reg[i] = *reinterpret_cast<const float4*>(ptr[i]);
+            ptr[i] += KC ? GBK : (size_t)GBK * ld;
+        }
+    }
 
     __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int m0, int k0, int Mdim, int Kend, bool vec_ok) {
 #pragma unroll
@@ -110,20 +129,21 @@ __device__ __forceinline__ bf16x8 fragment(const char* __restrict__ img, int row
 
 template <int BM, bool KC> struct ImgBytes { static constexpr int value = KC ? BM * RS_K : GBK * ImgM<BM>::RS; };
 
-template <int BM, int BN, bool A_KC, bool B_KC>
+template <int BM, int BN, bool A_KC, bool B_KC, bool FULL>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                         float* __restrict__ C, int ldc, int M, int N, int K, Epi epi,
                                                         int tiles_m, int tiles_n, int splitk, int k_chunk,
-                                                        float* __restrict__ slabs, int a_vec, int b_vec) {
+                                                        float* __restrict__ slabs, int a_vec, int b_vec, int remap) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int ABYTES = ImgBytes<BM, A_KC>::value, BBYTES = ImgBytes<BN, B_KC>::value;
     __shared__ __attribute__((aligned(16))) char smem[2 * (ABYTES + BBYTES)];
     constexpr int BUF = ABYTES + BBYTES;   // buffer b: A image at b*BUF, B image at b*BUF + ABYTES
 
-    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n * splitk);
+    const int wg = remap ? xcd_remap(blockIdx.x, tiles_m * tiles_n * splitk) : (int)blockIdx.x;
     const int ks_id = wg / (tiles_m * tiles_n);
     const int tile = wg - ks_id * (tiles_m * tiles_n);
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    if (remap == 2) { tn = tile / tiles_m; tm = tile - tn * tiles_m; }   // m fastest: neighbours share the B panel
     const int m0 = tm * BM, n0 = tn * BN;
     const int k_begin = ks_id * k_chunk;
     const int k_end = min(K, k_begin + k_chunk);
@@ -142,9 +162,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
     Stage<BM, A_KC> sa;
     Stage<BN, B_KC> sb;
     const int nk = (k_end - k_begin + GBK - 1) / GBK;
+    if (FULL) { sa.init_full(A, lda, m0, k_begin); sb.init_full(B, ldb, n0, k_begin); }
     if (nk > 0) {
-        sa.load(A, lda, m0, k_begin, M, k_end, a_vec);
-        sb.load(B, ldb, n0, k_begin, N, k_end, b_vec);
+        if (FULL) { sa.load_full(lda); sb.load_full(ldb); }
+        else {
+            sa.load(A, lda, m0, k_begin, M, k_end, a_vec);
+            sb.load(B, ldb, n0, k_begin, N, k_end, b_vec);
+        }
         sa.store(smem);
         sb.store(smem + ABYTES);
     }
@@ -152,8 +176,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            sa.load(A, lda, m0, k_begin + (kt + 1) * GBK, M, k_end, a_vec);
-            sb.load(B, ldb, n0, k_begin + (kt + 1) * GBK, N, k_end, b_vec);
+            if (FULL) { sa.load_full(lda); sb.load_full(ldb); }
+            else {
+                sa.load(A, lda, m0, k_begin + (kt + 1) * GBK, M, k_end, a_vec);
+                sb.load(B, ldb, n0, k_begin + (kt + 1) * GBK, N, k_end, b_vec);
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < GBK / 16; ++ks) {
@@ -210,9 +237,19 @@ template <int BM, int BN>
 static void launch_gemm_bf16(bool a_kc, bool b_kc, dim3 grid, hipStream_t s, const float* A, int lda, const float* B, int ldb,
                              float* C, int ldc, int M, int N, int K, Epi epi, int tiles_m, int tiles_n, int splitk, int k_chunk,
                              float* slabs, int a_vec, int b_vec) {
-#define SVPC_GEMM_LAUNCH(AK, BKC)                                                                                           \
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, epi, \
-                       tiles_m, tiles_n, splitk, k_chunk, slabs, a_vec, b_vec)
+    static int remap = -1;
+    if (remap < 0) { const char* e = getenv("SVPC_GEMM_REMAP"); remap = e ? atoi(e) : 1; }
+    // interior-only problems (every tile full in m, n and k, 16-byte aligned rows) take the unguarded staging path
+    const bool full = (M % BM == 0) && (N % BN == 0) && (K % k_chunk == 0) && (k_chunk % GBK == 0) && a_vec && b_vec;
+#define SVPC_GEMM_LAUNCH(AK, BKC)                                                                                                  \
+    do {                                                                                                                           \
+        if (full)                                                                                                                  \
+            hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, true>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, \
+                               epi, tiles_m, tiles_n, splitk, k_chunk, slabs, a_vec, b_vec, remap);                               \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, false>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, \
+                               epi, tiles_m, tiles_n, splitk, k_chunk, slabs, a_vec, b_vec, remap);                               \
+    } while (0)
     if (a_kc && b_kc) SVPC_GEMM_LAUNCH(true, true);
     else if (a_kc && !b_kc) SVPC_GEMM_LAUNCH(true, false);
     else if (!a_kc && b_kc) SVPC_GEMM_LAUNCH(false, true);

@@ -350,7 +350,7 @@ int svpc_ln_bwd(const float* dy, const float* x, const int* src_rows, const floa
 
 // out[k][c] (+)= sum_{r : idx[r]==k} x[r][c]   (idx null → plain column sum, K must be 1).  K <= 8.
 // workspace: svpc_colsum_chunks(R) * K * C floats
-int svpc_colsum_chunks(int R) { int g = ceil_div(R, 128); return g < 1 ? 1 : (g > 128 ? 128 : g); }
+int svpc_colsum_chunks(int R) { int g = ceil_div(R, 32); return g < 1 ? 1 : (g > 600 ? 600 : g); }
 
 int svpc_bucket_colsum(const float* x, int ldx, const int* idx, int R, int C, int K, float* out, int accumulate,
                        float* workspace, hipStream_t stream) {
