@@ -54,6 +54,11 @@ int svpc_gemm_f32(const float* A, int lda, int a_kc, const float* B, int ldb, in
 int svpc_gemm_bf16(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, int M, int N,
                    int K, const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed, int accumulate,
                    float* workspace, size_t workspace_bytes, svpc_stream_t stream);
+/* typed form (dtype codes 0 = fp32, 1 = bf16): (f32,f32→f32) any shape; (bf16,f32→bf16) NT/NN and (bf16,bf16→f32) TN for
+ * interior-only shapes — the bf16 activation stream of the clip encoder */
+int svpc_gemm_mx(const void* A, int a_dt, int lda, int a_kc, const void* B, int b_dt, int ldb, int b_kc, void* C, int c_dt, int ldc,
+                 void* Z, int M, int N, int K, const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed,
+                 int accumulate, float* workspace, size_t workspace_bytes, svpc_stream_t stream);
 /* dz = dy · act'(aux) · dropout  (aux = pre-activation for GELU, activated output for ReLU / sigmoid) */
 int svpc_act_bwd(const float* dy, const float* aux, float* dz, size_t n, int act, float p, unsigned site, const svpc_u64* seed,
                  svpc_stream_t stream);

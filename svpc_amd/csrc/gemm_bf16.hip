@@ -32,19 +32,23 @@ __device__ __forceinline__ bf16x4 cvt4(float4 v) {
 }
 
 // stages one BM × GBK operand tile: global (fp32) → registers → LDS (bf16)
-template <int BM, bool KC>
+template <int BM, bool KC, int NT, typename T>
 struct Stage {
-    static constexpr int NU = (BM * GBK / 4) / 256;   // float4 units per thread: 4 (BM=128) or 2 (BM=64)
-    float4 reg[NU];
-    const float* ptr[NU];                             // interior-tile fast path: per-unit source pointers
+    static constexpr bool F32 = sizeof(T) == 4;
+    static constexpr int EPU = F32 ? 4 : 8;           // elements per 16-byte unit
+    static constexpr int NU = (BM * GBK / EPU) / NT;  // 16-byte units per thread
+    float4 reg[NU];                                   // raw 16 bytes (4 fp32 or 8 bf16)
+    const T* ptr[NU];                                 // interior-tile fast path: per-unit source pointers
 
     // interior tiles (no edge in m or k): pointers are set once, each k-tile is NU unguarded 16-byte loads
-    __device__ __forceinline__ void init_full(const float* __restrict__ P, int ld, int m0, int k0) {
+    __device__ __forceinline__ void init_full(const T* __restrict__ P, int ld, int m0, int k0) {
+        constexpr int UK = GBK / EPU;                 // units per row of the k-contiguous image
+        constexpr int UPR = BM / EPU;                 // units per k-row of the k-strided image
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            const int u = threadIdx.x + 256 * i;
-            if (KC) ptr[i] = P + (size_t)(m0 + (u >> 3)) * ld + k0 + 4 * (u & 7);
-            else { constexpr int UPR = BM / 4; ptr[i] = P + (size_t)(k0 + u / UPR) * ld + m0 + 4 * (u % UPR); }
+            const int u = threadIdx.x + NT * i;
+            if (KC) ptr[i] = P + (size_t)(m0 + u / UK) * ld + k0 + EPU * (u % UK);
+            else ptr[i] = P + (size_t)(k0 + u / UPR) * ld + m0 + EPU * (u % UPR);
         }
     }
     __device__ __forceinline__ void load_full(int ld) {
@@ -55,10 +59,12 @@ struct Stage {
         }
     }
 
-    __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int m0, int k0, int Mdim, int Kend, bool vec_ok) {
+    // general (edge-guarded) path: fp32 sources only
+    __device__ __forceinline__ void load(const T* __restrict__ Pt, int ld, int m0, int k0, int Mdim, int Kend, bool vec_ok) {
+        const float* __restrict__ P = reinterpret_cast<const float*>(Pt);
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            const int u = threadIdx.x + 256 * i;
+            const int u = threadIdx.x + NT * i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (KC) {
                 const int row = u >> 3, k = k0 + 4 * (u & 7), m = m0 + row;
@@ -90,18 +96,13 @@ struct Stage {
         }
     }
     __device__ __forceinline__ void store(char* __restrict__ img) const {
+        constexpr int UK = GBK / EPU, UPR = BM / EPU;
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            const int u = threadIdx.x + 256 * i;
-            const bf16x4 b = cvt4(reg[i]);
-            if (KC) {
-                const int row = u >> 3, kq = u & 7;
-                *reinterpret_cast<bf16x4*>(img + row * RS_K + kq * 8) = b;
-            } else {
-                constexpr int UPR = BM / 4;
-                const int krow = u / UPR, c4 = u % UPR;
-                *reinterpret_cast<bf16x4*>(img + krow * ImgM<BM>::RS + c4 * 8) = b;
-            }
+            const int u = threadIdx.x + NT * i;
+            char* dst = KC ? img + (u / UK) * RS_K + (u % UK) * (EPU * 2) : img + (u / UPR) * ImgM<BM>::RS + (u % UPR) * (EPU * 2);
+            if (F32) *reinterpret_cast<bf16x4*>(dst) = cvt4(reg[i]);
+            else *reinterpret_cast<float4*>(dst) = reg[i];
         }
     }
 };
@@ -129,12 +130,15 @@ __device__ __forceinline__ bf16x8 fragment(const char* __restrict__ img, int row
 
 template <int BM, bool KC> struct ImgBytes { static constexpr int value = KC ? BM * RS_K : GBK * ImgM<BM>::RS; };
 
-template <int BM, int BN, bool A_KC, bool B_KC, bool FULL>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                        float* __restrict__ C, int ldc, int M, int N, int K, Epi epi,
+// NWN = waves along n (2 → 4 waves of 64×64, 4 → 8 waves of 64×32 for BM = BN = 128): more resident waves per SIMD hide
+// the staging-load latency that bounds this one-tile-deep pipeline
+template <int BM, int BN, bool A_KC, bool B_KC, bool FULL, int NWN, typename TA, typename TB, typename TC>
+__global__ __launch_bounds__(128 * NWN) void gemm_bf16_kernel(const TA* __restrict__ A, int lda, const TB* __restrict__ B, int ldb,
+                                                        TC* __restrict__ C, int ldc, int M, int N, int K, Epi epi,
                                                         int tiles_m, int tiles_n, int splitk, int k_chunk,
                                                         float* __restrict__ slabs, int a_vec, int b_vec, int remap) {
-    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int NT = 128 * NWN;
+    constexpr int TM = BM / 64, TN = BN / (32 * NWN);
     constexpr int ABYTES = ImgBytes<BM, A_KC>::value, BBYTES = ImgBytes<BN, B_KC>::value;
     __shared__ __attribute__((aligned(16))) char smem[2 * (ABYTES + BBYTES)];
     constexpr int BUF = ABYTES + BBYTES;   // buffer b: A image at b*BUF, B image at b*BUF + ABYTES
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
     const int k_end = min(K, k_begin + k_chunk);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / NWN, wc = wave % NWN;
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -159,8 +163,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    Stage<BM, A_KC> sa;
-    Stage<BN, B_KC> sb;
+    Stage<BM, A_KC, NT, TA> sa;
+    Stage<BN, B_KC, NT, TB> sb;
     const int nk = (k_end - k_begin + GBK - 1) / GBK;
     if (FULL) { sa.init_full(A, lda, m0, k_begin); sb.init_full(B, ldb, n0, k_begin); }
     if (nk > 0) {
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = fragment<BM, A_KC>(smem + cur * BUF, wr * (BM / 2) + i * 32, ks, lane);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = fragment<BN, B_KC>(smem + cur * BUF + ABYTES, wc * (BN / 2) + j * 32, ks, lane);
+            for (int j = 0; j < TN; ++j) b[j] = fragment<BN, B_KC>(smem + cur * BUF + ABYTES, wc * (BN / NWN) + j * 32, ks, lane);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -209,19 +213,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wc * (BN / 2) + j * 32 + l31;
+            const int col = n0 + wc * (BN / NWN) + j * 32 + l31;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
                 if (row < M && col < N) {
-                    if (splitk == 1) epilogue_store(acc[i][j][e], row, col, C, ldc, epi, seed, inv_keep);
+                    if (splitk == 1) epilogue_store_t<TC>(acc[i][j][e], row, col, C, ldc, epi, seed, inv_keep);
                     else slabs[((size_t)ks_id * M + row) * N + col] = acc[i][j][e];
                 }
             }
         }
 }
 
-__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ slabs, int splitk, float* __restrict__ C,
+template <typename TC>
+__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ slabs, int splitk, TC* __restrict__ C,
                                                                  int ldc, int M, int N, Epi epi) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)M * N) return;
@@ -230,42 +235,45 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __
     for (int k = 0; k < splitk; ++k) s += slabs[(size_t)k * M * N + i];
     const u64 seed = epi.p_drop > 0.f ? epi.seed[0] : 0ull;
     const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
-    epilogue_store(s, row, col, C, ldc, epi, seed, inv_keep);
+    epilogue_store_t<TC>(s, row, col, C, ldc, epi, seed, inv_keep);
 }
 
-template <int BM, int BN>
-static void launch_gemm_bf16(bool a_kc, bool b_kc, dim3 grid, hipStream_t s, const float* A, int lda, const float* B, int ldb,
-                             float* C, int ldc, int M, int N, int K, Epi epi, int tiles_m, int tiles_n, int splitk, int k_chunk,
-                             float* slabs, int a_vec, int b_vec) {
-    static int remap = -1;
-    if (remap < 0) { const char* e = getenv("SVPC_GEMM_REMAP"); remap = e ? atoi(e) : 1; }
-    // interior-only problems (every tile full in m, n and k, 16-byte aligned rows) take the unguarded staging path
-    const bool full = (M % BM == 0) && (N % BN == 0) && (K % k_chunk == 0) && (k_chunk % GBK == 0) && a_vec && b_vec;
-#define SVPC_GEMM_LAUNCH(AK, BKC)                                                                                                  \
-    do {                                                                                                                           \
-        if (full)                                                                                                                  \
-            hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, true>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, \
-                               epi, tiles_m, tiles_n, splitk, k_chunk, slabs, a_vec, b_vec, remap);                               \
-        else                                                                                                                       \
-            hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, false>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, \
-                               epi, tiles_m, tiles_n, splitk, k_chunk, slabs, a_vec, b_vec, remap);                               \
-    } while (0)
-    if (a_kc && b_kc) SVPC_GEMM_LAUNCH(true, true);
-    else if (a_kc && !b_kc) SVPC_GEMM_LAUNCH(true, false);
-    else if (!a_kc && b_kc) SVPC_GEMM_LAUNCH(false, true);
-    else SVPC_GEMM_LAUNCH(false, false);
-#undef SVPC_GEMM_LAUNCH
+template <int BM, int BN, int NWN, bool AK, bool BKC, bool FULL, typename TA, typename TB, typename TC>
+static void launch_one(dim3 grid, hipStream_t s, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                       Epi epi, int tiles_m, int tiles_n, int splitk, int k_chunk, float* slabs, int a_vec, int b_vec, int remap) {
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AK, BKC, FULL, NWN, TA, TB, TC>), grid, dim3(128 * NWN), 0, s, (const TA*)A, lda,
+                       (const TB*)B, ldb, (TC*)C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, slabs, a_vec, b_vec, remap);
+}
+
+// fp32 operands in HBM: every layout, every shape (edge-guarded path when a tile is ragged)
+template <int BM, int BN, int NWN>
+static void launch_f32(bool a_kc, bool b_kc, bool full, dim3 grid, hipStream_t s, const void* A, int lda, const void* B, int ldb, void* C,
+                       int ldc, int M, int N, int K, Epi epi, int tiles_m, int tiles_n, int splitk, int k_chunk, float* slabs, int a_vec,
+                       int b_vec, int remap) {
+#define SVPC_L(AK, BKC, FU) launch_one<BM, BN, NWN, AK, BKC, FU, float, float, float>(grid, s, A, lda, B, ldb, C, ldc, M, N, K, epi, \
+                                                                                     tiles_m, tiles_n, splitk, k_chunk, slabs, a_vec, b_vec, remap)
+    if (full) {
+        if (a_kc && b_kc) SVPC_L(true, true, true); else if (a_kc) SVPC_L(true, false, true);
+        else if (b_kc) SVPC_L(false, true, true); else SVPC_L(false, false, true);
+    } else {
+        if (a_kc && b_kc) SVPC_L(true, true, false); else if (a_kc) SVPC_L(true, false, false);
+        else if (b_kc) SVPC_L(false, true, false); else SVPC_L(false, false, false);
+    }
+#undef SVPC_L
 }
 
 extern "C" {
 
-// Same contract as svpc_gemm_f32; operands are rounded to bf16 (RNE) on their way into LDS, products accumulate in fp32.
-int svpc_gemm_bf16(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, int M, int N,
-                   int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
-                   float* workspace, size_t workspace_bytes, hipStream_t stream) {
+// dtype codes: 0 = fp32, 1 = bf16.  Supported operand/output combinations:
+//   (A f32, B f32, C f32)   any shape, any layout
+//   (A bf16, B f32, C bf16) forward / dgrad of a bf16 activation stream (layouts NT, NN), interior-only shapes
+//   (A bf16, B bf16, C f32) wgrad of a bf16 activation stream (layout TN), interior-only shapes
+int svpc_gemm_mx(const void* A, int a_dt, int lda, int a_kc, const void* B, int b_dt, int ldb, int b_kc, void* C, int c_dt, int ldc,
+                 void* Z, int M, int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
+                 float* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (M == 0 || N == 0) return 0;
     SVPC_REQUIRE(p_drop <= 0.f || seed != nullptr, "gemm: dropout needs a seed pointer");
-    Epi epi{bias, act, p_drop, site, seed, accumulate, Z};
+    Epi epi{bias, act, p_drop, site, seed, accumulate, (float*)Z};
     const bool big = (M >= 96 && N >= 96);
     const int BMN = big ? 128 : 64;
     const int tiles_m = ceil_div(M, BMN), tiles_n = ceil_div(N, BMN);
@@ -282,22 +290,57 @@ int svpc_gemm_bf16(const float* A, int lda, int a_kc, const float* B, int ldb, i
     int k_chunk = ceil_div(ceil_div(K, splitk), GBK) * GBK;
     splitk = ceil_div(K, k_chunk);
     if (K == 0) { splitk = 1; k_chunk = GBK; }
-    const int a_vec = (lda % 4 == 0) && ((((uintptr_t)A) & 15) == 0);
-    const int b_vec = (ldb % 4 == 0) && ((((uintptr_t)B) & 15) == 0);
+    const int a_el = a_dt ? 8 : 4, b_el = b_dt ? 8 : 4;   // elements per 16 bytes
+    const int a_vec = (lda % a_el == 0) && ((((uintptr_t)A) & 15) == 0);
+    const int b_vec = (ldb % b_el == 0) && ((((uintptr_t)B) & 15) == 0);
+    const bool full = (M % BMN == 0) && (N % BMN == 0) && (K % k_chunk == 0) && (k_chunk % GBK == 0) && a_vec && b_vec;
+    static int remap = -1, nwn_env = -1;
+    if (remap < 0) { const char* e = getenv("SVPC_GEMM_REMAP"); remap = e ? atoi(e) : 1; }
+    if (nwn_env < 0) { const char* e = getenv("SVPC_GEMM_NWN"); nwn_env = e ? atoi(e) : 0; }
+    // 8 waves (64×32 per wave) hide the staging latency better when A is k-contiguous and the grid is not huge;
+    // the transposed-read (wgrad) and very wide problems run better with 4 waves of 64×64
+    int nwn = (a_kc && tiles <= 1200) ? 4 : 2;
+    if (nwn_env == 2 || nwn_env == 4) nwn = nwn_env;
     dim3 grid(tiles * splitk);
-    if (big) launch_gemm_bf16<128, 128>(a_kc, b_kc, grid, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk,
-                                        k_chunk, workspace, a_vec, b_vec);
-    else launch_gemm_bf16<64, 64>(a_kc, b_kc, grid, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk,
-                                  workspace, a_vec, b_vec);
-    int rc = svpc_check_launch("gemm_bf16");
+#define SVPC_ARGS grid, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, workspace, a_vec, b_vec, remap
+    if (a_dt == 0 && b_dt == 0 && c_dt == 0) {
+        if (big && nwn == 4) launch_f32<128, 128, 4>(a_kc, b_kc, full, SVPC_ARGS);
+        else if (big) launch_f32<128, 128, 2>(a_kc, b_kc, full, SVPC_ARGS);
+        else launch_f32<64, 64, 2>(a_kc, b_kc, full, SVPC_ARGS);
+    } else {
+        SVPC_REQUIRE(big && full, "gemm_mx: bf16 operands need interior-only shapes (multiples of 128 × 128 × 32, 16-byte rows)");
+        if (a_dt == 1 && b_dt == 0 && c_dt == 1 && a_kc && b_kc) {
+            if (nwn == 4) launch_one<128, 128, 4, true, true, true, __bf16, float, __bf16>(SVPC_ARGS);
+            else launch_one<128, 128, 2, true, true, true, __bf16, float, __bf16>(SVPC_ARGS);
+        } else if (a_dt == 1 && b_dt == 0 && c_dt == 1 && a_kc && !b_kc) {
+            if (nwn == 4) launch_one<128, 128, 4, true, false, true, __bf16, float, __bf16>(SVPC_ARGS);
+            else launch_one<128, 128, 2, true, false, true, __bf16, float, __bf16>(SVPC_ARGS);
+        } else if (a_dt == 1 && b_dt == 1 && c_dt == 0 && !a_kc && !b_kc) {
+            launch_one<128, 128, 2, false, false, true, __bf16, __bf16, float>(SVPC_ARGS);
+        } else {
+            svpc_set_error("gemm_mx: unsupported dtype/layout combination");
+            return -1;
+        }
+    }
+#undef SVPC_ARGS
+    int rc = svpc_check_launch("gemm_mx");
     if (rc) return rc;
     if (splitk > 1) {
         const size_t n = (size_t)M * N;
-        hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, workspace, splitk, C, ldc,
-                           M, N, epi);
-        rc = svpc_check_launch("gemm_bf16 splitk reduce");
+        const dim3 g((unsigned)((n + 255) / 256));
+        if (c_dt == 0) hipLaunchKernelGGL(splitk_reduce_bf16_kernel<float>, g, dim3(256), 0, stream, workspace, splitk, (float*)C, ldc, M, N, epi);
+        else hipLaunchKernelGGL(splitk_reduce_bf16_kernel<__bf16>, g, dim3(256), 0, stream, workspace, splitk, (__bf16*)C, ldc, M, N, epi);
+        rc = svpc_check_launch("gemm_mx splitk reduce");
     }
     return rc;
+}
+
+// fp32-in / fp32-out form (same contract as svpc_gemm_f32): operands are rounded to bf16 (RNE) on their way into LDS
+int svpc_gemm_bf16(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, int M, int N,
+                   int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
+                   float* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return svpc_gemm_mx(A, 0, lda, a_kc, B, 0, ldb, b_kc, C, 0, ldc, Z, M, N, K, bias, act, p_drop, site, seed, accumulate, workspace,
+                        workspace_bytes, stream);
 }
 
 }  // extern "C"

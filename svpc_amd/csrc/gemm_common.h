@@ -21,6 +21,19 @@ __device__ __forceinline__ void epilogue_store(float v, int row, int col, float*
 }
 
 
+// typed variant: C and the optional pre-activation copy Z are stored as TC (float or __bf16)
+template <typename TC>
+__device__ __forceinline__ void epilogue_store_t(float v, int row, int col, TC* __restrict__ C, int ldc, const Epi& e, u64 seed,
+                                                 float inv_keep) {
+    if (e.bias) v += e.bias[col];
+    const size_t o = (size_t)row * ldc + col;
+    if (e.Z) reinterpret_cast<TC*>(e.Z)[o] = (TC)v;
+    v = apply_act(v, e.act);
+    if (e.p_drop > 0.f) v *= drop_scale(seed, e.site, o, e.p_drop, inv_keep);
+    if (e.accumulate) v += (float)C[o];
+    C[o] = (TC)v;
+}
+
 // XCD-aware bijective remap of a linear workgroup id: ids that share an XCD (id % 8) get a contiguous tile range,
 // so tiles sharing an operand panel hit the same private L2.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {

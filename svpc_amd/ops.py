@@ -146,8 +146,13 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NON
     ev = GEMM_TIMER.bracket(2.0 * M * N * K) if GEMM_TIMER is not None else None
     if ev:
         ev[0].record()
-    _lib.call("gemm_bf16" if _PRECISION == "bf16" else "gemm_f32", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z),
-              M, N, K, _p(bias), act, p, site, _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+    if _PRECISION == "bf16":
+        dt = lambda t: 1 if t.dtype == torch.bfloat16 else 0
+        _lib.call("gemm_mx", _p(A), dt(A), lda, a_kc, _p(B), dt(B), ldb, b_kc, _p(C), dt(C), C.stride(0), _p(Z), M, N, K, _p(bias),
+                  act, p, site, _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+    else:
+        _lib.call("gemm_f32", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
+                  _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
     if ev:
         ev[1].record()
 

@@ -340,3 +340,22 @@ def test_mfma_attention_encoder_decoder_cross_ragged(bf16_mode):
 def test_mfma_attention_dropout(bf16_mode):
     rng = O.make_rng(DEV, seed=3)
     _bf16_attn_compare(SeqInfo.uniform(3, 40, 40, DEV), 128, 2, True, True, (0.1, rng, 4), seed=8)
+
+
+@pytest.mark.parametrize("M,N,K,a_kc,b_kc,dts", [
+    (256, 768, 768, 1, 1, ("bf16", "f32", "bf16")), (19200, 768, 768, 1, 1, ("bf16", "f32", "bf16")),
+    (256, 768, 2304, 1, 0, ("bf16", "f32", "bf16")), (768, 2304, 19200, 0, 0, ("bf16", "bf16", "f32")),
+    (128, 128, 4096, 0, 0, ("bf16", "bf16", "f32"))])
+def test_gemm_mx_bf16_storage(bf16_mode, M, N, K, a_kc, b_kc, dts):
+    """bf16 activation-stream variants: bf16 operands are consumed as they are (no rounding step), fp32 ones rounded to bf16."""
+    T = {"bf16": torch.bfloat16, "f32": torch.float32}
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).bfloat16().float().to(DEV)
+    B = torch.randn(N, K, generator=g).bfloat16().float().to(DEV)
+    ref = A.double() @ B.double().t()
+    Am = (A if a_kc else A.t().contiguous()).to(T[dts[0]])
+    Bm = (B if b_kc else B.t().contiguous()).to(T[dts[1]])
+    C = torch.empty(M, N, device=DEV, dtype=T[dts[2]])
+    O._gemm(Am, Am.stride(0), a_kc, Bm, Bm.stride(0), b_kc, C, M, N, K)
+    tol = (1e-2 if dts[2] == "bf16" else 2e-6 * math.sqrt(K)) * max(1.0, ref.abs().max().item())
+    assert (C.double() - ref).abs().max().item() <= tol
