@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--heads", type=int, default=12)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
                     help="arithmetic type of the GEMM operands (accumulation and storage are fp32 either way)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-videos", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -123,11 +125,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        n_dev = torch.cuda.device_count()
+        dev_index = local_rank % max(1, n_dev)
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
     else:
+        dev_index = 0
         torch.cuda.set_device(0)
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    device = torch.device("cuda", dev_index)
 
     ops.set_precision(args.precision)
     cfg, model = build(args, device)
@@ -153,17 +161,37 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2)):
         loss = step()
     torch.cuda.synchronize()
+
+    # ---- capture the whole step (zero_grad → forward → backward → clip+BertAdam) in one hipGraph: ≈2,000 launches per step
+    # would otherwise make the step host-bound.  Single-GPU only (the RCCL exchange stays eager); falls back to eager on failure.
+    graph = None
+    if not args.no_graph and world == 1:
+        try:
+            from svpc_amd.graph import GraphedTrainStep
+            loss = None          # drop the last eager autograd graph before capture
+            graph = GraphedTrainStep(model, opt, fargs, warmup=2)
+            eager_step = step
+            step = graph
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            print("[bench] hipGraph capture failed (%s: %s) - running eagerly" % (type(e).__name__, e), file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
     # host-side enqueue cost of one step (GPU idle at start, no sync at the end): tells whether the step is launch-bound
     th = time.perf_counter()
     loss = step()
     host_enqueue_ms = 1000.0 * (time.perf_counter() - th)
     torch.cuda.synchronize()
-    # roofline leg: HIP events around the encoder-sized GEMM launches inside the timed region
+    # roofline leg: HIP events around the encoder-sized GEMM launches.  Eager mode: inside the timed region.  Graph mode: events
+    # cannot be recorded inside a replay, so the same kernels are bracketed in instrumented eager steps right after it.
     big = 2.0 * (args.batch * args.clips * cfg.max_v_len) * cfg.hidden_size * cfg.hidden_size * 0.99
-    ops.GEMM_TIMER = ops.KernelTimer(min_flops=big)
+    if graph is None:
+        ops.GEMM_TIMER = ops.KernelTimer(min_flops=big)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -174,6 +202,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if graph is not None:
+        ops.GEMM_TIMER = ops.KernelTimer(min_flops=big)
+        for _ in range(3):
+            eager_step()
+        torch.cuda.synchronize()
     timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -195,12 +228,14 @@ def main():
                                    % (args.model_type, args.batch, args.clips, cfg.max_v_len, cfg.video_feature_size, cfg.max_t_len,
                                       cfg.hidden_size, cfg.num_attention_heads, cfg.num_hidden_layers, cfg.vocab_size, cfg.action_vocab_size),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
-                       "host_enqueue_ms_per_step": host_enqueue_ms},
+                       "host_enqueue_ms_per_step": host_enqueue_ms,
+                       "launch": "hipGraph replay" if graph is not None else "eager"},
             "roofline": {"bound": "mfma", "kernel": "gemm_%s_kernel<128,128> (encoder-sized GEMMs: M>=%d)" % (args.precision, args.batch * args.clips * cfg.max_v_len),
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS[args.precision],
                          "traffic": None, "launches": gsum["launches"], "avg_launch_ms": gsum["ms"] / max(1, gsum["launches"]),
-                         "share_of_step": gsum["ms"] / (ms * args.steps)},
+                         "measured": "HIP events on the launch stream, " + ("3 instrumented eager steps after the timed graph replays"
+                                                                            if graph is not None else "inside the timed region")},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, args)

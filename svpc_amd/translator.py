@@ -65,7 +65,7 @@ class Translator(object):
         cx = _Ctx(cfg, False, model.rng(dev))
         ingr_ids_t = torch.as_tensor(ingr_input_ids).to(dev)
         sep_t = torch.as_tensor(ingr_sep_masks)
-        spans = model.ingredient_embeddings.spans(sep_t.cpu())
+        spans = model.ingredient_embeddings.spans(sep_t.cpu())   # one host read per batch
         plan = model.plan_for(batch_step_num, spans[3], S_pad, N, L, dev)
         T = plan.T
 

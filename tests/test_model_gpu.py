@@ -159,3 +159,33 @@ def test_bf16_compute_mode_stays_close_to_reference(golden_dir):
     gn = dict(model.named_parameters())["encoder.layer.0.attention.output.dense.weight"].grad.double().norm().item()
     refn = float(z["gradnorm/encoder.layer.0.attention.output.dense.weight"])
     assert abs(gn - refn) <= 0.05 * refn
+
+
+def test_graph_replay_equals_eager_training(golden_dir):
+    """The captured step (zero_grad → fwd → bwd → clip+BertAdam) must train exactly like the eager one: same number of steps
+    from the same initial state (training mode: dropout/Gumbel seeds are device-side and advance identically)."""
+    from svpc_amd.graph import GraphedTrainStep
+    from svpc_amd.optim import FusedBertAdam
+
+    def run(graphed):
+        z, cfg, batch, model = build_model("tiny", "vivt", golden_dir, DEV)
+        model.gumbel_noise = None
+        model.train()
+        opt = FusedBertAdam(list(model.named_parameters()), lr=1e-3, warmup=0.1, t_total=100, grad_clip=1.0)
+        fargs = syn.forward_args(batch)
+
+        def eager():
+            opt.zero_grad(); l = model(*fargs)[0]; l.backward(); opt.step(); return l
+        eager()
+        if graphed:
+            step = GraphedTrainStep(model, opt, fargs, warmup=2)
+        else:
+            eager(); eager()
+            step = eager
+        losses = [float(step().item()) for _ in range(3)]
+        return losses, {n: p.detach().clone() for n, p in model.named_parameters()}
+    l_e, p_e = run(False)
+    l_g, p_g = run(True)
+    assert all(np.isfinite(l_g)) and np.allclose(l_e, l_g, rtol=1e-4), (l_e, l_g)
+    for n in p_e:
+        assert torch.allclose(p_e[n], p_g[n], rtol=1e-4, atol=1e-6), n
