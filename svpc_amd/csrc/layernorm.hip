@@ -248,6 +248,26 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     }
 }
 
+// LayerNorm backward tail: [dgamma ; dbeta] = sum_g partial[g][0:2D], one launch for both vectors
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ partial, int G, int D, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int accumulate) {
+    __shared__ float red[8][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl, ncols = 2 * D;
+    float s = 0.f;
+    if (c < ncols)
+        for (int g = rg; g < G; g += 8) s += partial[(size_t)g * ncols + c];
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && c < ncols) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][cl];
+        float* out = c < D ? dgamma + c : dbeta + (c - D);
+        *out = accumulate ? *out + t : t;
+    }
+}
+
 // partial[chunk][k][c] = sum over rows r of the chunk with idx[r]==k (idx null → k = 0) of x[r][c]
 template <int KMAX>
 __global__ __launch_bounds__(256) void bucket_colsum_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ idx,
@@ -335,16 +355,7 @@ int svpc_ln_bwd(const float* dy, const float* x, const int* src_rows, const floa
         else if (D <= 3072) rc = launch_ln_bwd<48, 1>(a, G, stream);
     }
     if (rc != 0) { if (rc == -1) svpc_set_error("ln_bwd: row width not supported"); return rc; }
-    // partial layout per group: [dgamma(D) ; dbeta(D)] → two strided reductions
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(2 * D, 32)), dim3(256), 0, stream, workspace, G, 2 * D,
-                       workspace + (size_t)G * 2 * D, 0);
-    rc = svpc_check_launch("ln_bwd finalize");
-    if (rc) return rc;
-    // scatter the two halves (tiny): reuse finalize with G=1 to honour `accumulate`
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(D, 32)), dim3(256), 0, stream,
-                       workspace + (size_t)G * 2 * D, 1, D, dgamma, accumulate);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(D, 32)), dim3(256), 0, stream,
-                       workspace + (size_t)G * 2 * D + D, 1, D, dbeta, accumulate);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(ceil_div(2 * D, 32)), dim3(256), 0, stream, workspace, G, D, dgamma, dbeta, accumulate);
     return svpc_check_launch("ln_bwd scatter");
 }
 

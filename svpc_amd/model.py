@@ -198,6 +198,27 @@ class BertLayerNoMemoryUntied(nn.Module):
                              residual=x1, pre_drop=cx.drop(cx.p_h))
 
 
+    def run_rows(self, h, sel_rows, seq_sel, key_mask, cx):
+        """Same layer, evaluated only for the query rows ``sel_rows`` (keys/values still come from every row of ``h``).
+        The training forward consumes nothing but the [CLS] row of the last clip-encoder layer (model.py:1062-1064), so the
+        other 99 % of that layer's query/output/FFN rows — which the reference computes and discards — are never formed;
+        the selected rows are bit-for-bit what ``run`` produces for them (in eval mode)."""
+        D = h.shape[1]
+        att = self.attention.self
+        hq = ops.take_rows(h, sel_rows)
+        q = ops.linear(hq, att.query.weight, att.query.bias)
+        wkv, bkv = att.packed("kv")
+        kv = ops.linear(h, wkv, bkv)
+        ctx = ops.attention(q, kv, (0, 0, D), D, cx.H, seq_sel, key_mask=key_mask, causal=False, drop=cx.drop(cx.p_a))
+        so = self.attention.output
+        ao = ops.linear(ctx, so.dense.weight, so.dense.bias)
+        x1 = ops.layernorm(ao, so.LayerNorm.weight, so.LayerNorm.bias, cx.eps, residual=hq, pre_drop=cx.drop(cx.p_h))
+        it = ops.linear(x1, self.hidden_intermediate.dense.weight, self.hidden_intermediate.dense.bias, act=ACT_GELU)
+        o = ops.linear(it, self.output.dense.weight, self.output.dense.bias)
+        return ops.layernorm(o, self.output.LayerNorm.weight, self.output.LayerNorm.bias, cx.eps,
+                             residual=x1, pre_drop=cx.drop(cx.p_h))
+
+
 class BertEncoderNoMemoryUntied(nn.Module):
     """reference: model.py:594-617."""
 
@@ -206,9 +227,14 @@ class BertEncoderNoMemoryUntied(nn.Module):
         self.config = config
         self.layer = nn.ModuleList([BertLayerNoMemoryUntied(config) for _ in range(config.num_hidden_layers)])
 
-    def run(self, h, seq, key_mask, cx):
-        for layer in self.layer:
-            h = layer.run(h, seq, key_mask, cx)
+    def run(self, h, seq, key_mask, cx, last_rows=None, last_seq=None):
+        """All layers; with ``last_rows`` the last layer is evaluated for those query rows only (returns (len(rows), D))."""
+        n = len(self.layer)
+        for i, layer in enumerate(self.layer):
+            if last_rows is not None and i == n - 1:
+                h = layer.run_rows(h, last_rows, last_seq, key_mask, cx)
+            else:
+                h = layer.run(h, seq, key_mask, cx)
         return h
 
     def forward(self, hidden_states, attention_mask, diagonal_mask=False, output_all_encoded_layers=True):
@@ -499,6 +525,9 @@ class BatchPlan:
         self.e_max = max(ent_nums) if ent_nums else 0
         self.step_ne = Idx([ent_nums[b] for b in clip_b])
         self.seq_enc = ops.SeqInfo.uniform(T, Lv, Lv, device)
+        self.cls_rows_dev = _i32([c * Lv for c in range(T)], device)
+        self.seq_enc_cls = ops.SeqInfo(list(range(T)), [1] * T, [c * Lv for c in range(T)], [Lv] * T, device)
+        self.arange_T = Idx(range(T))
         self.seq_step = ops.SeqInfo(off[:-1], step_nums, off[:-1], step_nums, device)
         self.seq_dec_self = ops.SeqInfo.uniform(T, Lt, Lt, device)
         self.seq_dec_cross = ops.SeqInfo.uniform(T, Lt, n_mem, device)
@@ -639,12 +668,14 @@ class StateAwareRecursiveTransformer(nn.Module):
                                ops.SeqInfo.uniform(B, Lv, Lv, dev), cx)
         return h.view(B, Lv, -1)
 
-    def _encode_clips(self, feats_flat, video_rows, ids_v, key_mask_v, seq, cx):
+    def _encode_clips(self, feats_flat, video_rows, ids_v, key_mask_v, seq, cx, cls_only=None):
         Lv = self.config.max_v_len
         ve = self.video_embeddings
         h = ve.video_embeddings.run(feats_flat, cx.eps, src_rows=video_rows, drop=cx.drop(cx.p_h),
                                     add1=ve.position_embeddings_video.pe[:Lv].contiguous(), add1_mod=Lv,
                                     add2=self.token_type_embeddings.weight, add2_idx=ids_v)
+        if cls_only is not None:      # (cls_rows, one-query segmentation): last layer only for the [CLS] rows
+            return self.encoder.run(h, seq, key_mask_v, cx, last_rows=cls_only[0], last_seq=cls_only[1])
         return self.encoder.run(h, seq, key_mask_v, cx)
 
     def _lm_probs(self, dec, bank, plan_like, cx, labels=None):
@@ -724,11 +755,12 @@ class StateAwareRecursiveTransformer(nn.Module):
         ents = self.ingredient_embeddings.run(ingr_input_ids.reshape(-1).to(torch.int32), spans, cx)
 
         # (2) clip encoder over all valid clips at once (reference loops S × forward_step, :1038-1042)
-        h = self._encode_clips(feats, plan.video_rows, ops.take_rows(ids_all, plan.video_rows),
-                               ops.take_rows(masks_all, plan.video_rows), plan.seq_enc, cx)
+        cls = self._encode_clips(feats, plan.video_rows, ops.take_rows(ids_all, plan.video_rows),
+                                 ops.take_rows(masks_all, plan.video_rows), plan.seq_enc, cx,
+                                 cls_only=(plan.cls_rows_dev, plan.seq_enc_cls))                  # (T, D): [CLS] rows only
 
         # (3) [CLS] rows + step PE → step-wise encoder over ragged per-video step sequences (:1062-1065)
-        x = ops.span_mean(h, plan.cls_rows, plan.ones_T, add=self.step_positional_encoding.pe, add_idx=plan.step_idx)
+        x = ops.span_mean(cls, plan.arange_T, plan.ones_T, add=self.step_positional_encoding.pe, add_idx=plan.step_idx)
         g = self.step_wise_encoder.run(x, plan.seq_step, None, cx)
 
         # (4) visual simulator, decoder memory

@@ -73,9 +73,10 @@ class Translator(object):
         ids_all = torch.stack(input_ids_list).reshape(-1).to(torch.int32)
         masks_all = torch.stack(input_masks_list).reshape(-1).float()
         ents = model.ingredient_embeddings.run(ingr_ids_t.reshape(-1).to(torch.int32), spans, cx)
-        h = model._encode_clips(feats, plan.video_rows, ops.take_rows(ids_all, plan.video_rows),
-                                ops.take_rows(masks_all, plan.video_rows), plan.seq_enc, cx)
-        x = ops.span_mean(h, plan.cls_rows, plan.ones_T, add=model.step_positional_encoding.pe, add_idx=plan.step_idx)
+        cls = model._encode_clips(feats, plan.video_rows, ops.take_rows(ids_all, plan.video_rows),
+                                  ops.take_rows(masks_all, plan.video_rows), plan.seq_enc, cx,
+                                  cls_only=(plan.cls_rows_dev, plan.seq_enc_cls))
+        x = ops.span_mean(cls, plan.arange_T, plan.ones_T, add=model.step_positional_encoding.pe, add_idx=plan.step_idx)
         g = model.step_wise_encoder.run(x, plan.seq_step, None, cx)
         if mode in ("full", "reason_copy"):
             _, _, ebar, eall, fbar = model.reasoner.run(g, ents, plan.sim, cx)
