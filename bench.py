@@ -97,6 +97,46 @@ def cpu_baseline(cfg, model, args):
                       "%.2f s/step, scaled by %d/%d" % (n_vid, args.batch, args.clips, args.layers, k, dt, n_vid, args.batch)}
 
 
+def decode_bench(cfg, model, args, device, world, rank, dist):
+    """captions/s of Translator.translate_batch (greedy) on synthetic clips, videos sharded over ranks (replicas only)."""
+    from svpc_amd.translator import Translator
+    n_vid = args.decode_videos
+    b = make_batch(cfg, n_videos=n_vid, max_steps=args.clips, n_ingr=10, n_oov=0, seed=2019 + rank, full_clips=True)
+    for k, v in list(b.items()):
+        if isinstance(v, list) and v and isinstance(v[0], torch.Tensor):
+            b[k] = [t.to(device) for t in v]
+        elif isinstance(v, torch.Tensor):
+            b[k] = v.to(device)
+    tr = Translator(type("O", (), {"cuda": True})(), {"model_cfg": cfg, "model": model.state_dict()}, model=model)
+    for _ in range(max(1, args.warmup)):
+        tr.translate_batch(syn.translate_inputs(b))
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, _ = tr.translate_batch(syn.translate_inputs(b))
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        caps = world * args.steps * n_vid * args.clips
+        print(json.dumps({"metric": "greedy-decode captions/sec (vivt, 64 videos)", "value": caps / elapsed, "unit": "captions/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+                          "config": {"workload": "MODEL_TYPE=%s translate_batch greedy: %d videos/GPU x %d clips, Lt=%d, L=%d; full decoder "
+                                                 "re-run per position (reference semantics), batched over videos, on-device pick"
+                                                 % (args.model_type, n_vid, args.clips, cfg.max_t_len, cfg.num_hidden_layers)}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +150,8 @@ def main():
     ap.add_argument("--heads", type=int, default=12)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
                     help="arithmetic type of the GEMM operands (accumulation and storage are fp32 either way)")
+    ap.add_argument("--decode", action="store_true", help="secondary metric: greedy-decode captions/s (BASELINE config 5: 64 videos)")
+    ap.add_argument("--decode-videos", type=int, default=64)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -139,6 +181,8 @@ def main():
 
     ops.set_precision(args.precision)
     cfg, model = build(args, device)
+    if args.decode:
+        return decode_bench(cfg, model, args, device, world, rank, dist)
     model.train()
     batch = device_batch(cfg, args, device, seed=2019 + rank)
     fargs = syn.forward_args(batch)
