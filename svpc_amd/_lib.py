@@ -10,7 +10,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsvpc_hip.so")
+LIB_PATH = os.environ.get("SVPC_LIB", os.path.join(_HERE, "csrc", "libsvpc_hip.so"))   # override: kernel experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "svpc_hip.h")
 
 _lib = None

@@ -21,7 +21,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short short4v __attribute__((ext_vector_type(4)));
 
-constexpr int GBK = 32;            // k-tile depth
+#ifndef SVPC_GBK
+#define SVPC_GBK 32
+#endif
+constexpr int GBK = SVPC_GBK;      // k-tile depth
 constexpr int RS_K = GBK * 2 + 16; // row stride (bytes) of the k-contiguous image
 template <int BM> struct ImgM { static constexpr int RS = BM * 2 + 64; };   // row stride (bytes) of the k-strided image
 

@@ -124,10 +124,13 @@ class BertSelfAttention(nn.Module):
         self.query, self.key, self.value = nn.Linear(D, D), nn.Linear(D, D), nn.Linear(D, D)
 
     def packed(self, which="qkv"):
+        """Packed projection weight/bias (+ the packed views of their gradients inside the optimizer's arena, when built)."""
         mods = {"q": self.query, "k": self.key, "v": self.value}
         w = torch.cat([mods[c].weight for c in which], 0)
         b = torch.cat([mods[c].bias for c in which], 0)
-        return w, b
+        pg = getattr(self.query.weight, "_svpc_packed", None)
+        wg, bg = pg[which] if pg is not None and which in pg else (None, None)
+        return w, b, wg, bg
 
 
 class BertSelfOutput(nn.Module):
@@ -186,8 +189,8 @@ class BertLayerNoMemoryUntied(nn.Module):
 
     def run(self, h, seq, key_mask, cx):
         D = h.shape[1]
-        w, b = self.attention.self.packed()
-        qkv = ops.linear(h, w, b)
+        w, b, wg, bg = self.attention.self.packed()
+        qkv = ops.linear(h, w, b, wgrad=wg, bgrad=bg)
         ctx = ops.attention(qkv, qkv, (0, D, 2 * D), D, cx.H, seq, key_mask=key_mask, causal=False, drop=cx.drop(cx.p_a))
         so = self.attention.output
         ao = ops.linear(ctx, so.dense.weight, so.dense.bias)
@@ -207,8 +210,8 @@ class BertLayerNoMemoryUntied(nn.Module):
         att = self.attention.self
         hq = ops.take_rows(h, sel_rows)
         q = ops.linear(hq, att.query.weight, att.query.bias)
-        wkv, bkv = att.packed("kv")
-        kv = ops.linear(h, wkv, bkv)
+        wkv, bkv, wg, bg = att.packed("kv")
+        kv = ops.linear(h, wkv, bkv, wgrad=wg, bgrad=bg)
         ctx = ops.attention(q, kv, (0, 0, D), D, cx.H, seq_sel, key_mask=key_mask, causal=False, drop=cx.drop(cx.p_a))
         so = self.attention.output
         ao = ops.linear(ctx, so.dense.weight, so.dense.bias)
@@ -259,15 +262,15 @@ class BertDecoderLayerNoMemoryUntied(nn.Module):
 
     def run(self, x, text_mask, mem, seq_self, seq_cross, mem_mask, cx):
         D = x.shape[1]
-        w, b = self.self_attention.packed()
-        qkv = ops.linear(x, w, b)
+        w, b, wg, bg = self.self_attention.packed()
+        qkv = ops.linear(x, w, b, wgrad=wg, bgrad=bg)
         sa = ops.attention(qkv, qkv, (0, D, 2 * D), D, cx.H, seq_self, key_mask=text_mask, causal=True,
                            drop=cx.drop(cx.p_a))
         x1 = ops.layernorm(sa, self.norm1.weight, self.norm1.bias, cx.eps, residual=x)
         ca_m = self.dec_enc_attention
         qc = ops.linear(x1, ca_m.query.weight, ca_m.query.bias)
-        wkv, bkv = ca_m.packed("kv")
-        kvc = ops.linear(mem, wkv, bkv)
+        wkv, bkv, wg, bg = ca_m.packed("kv")
+        kvc = ops.linear(mem, wkv, bkv, wgrad=wg, bgrad=bg)
         ca = ops.attention(qc, kvc, (0, 0, D), D, cx.H, seq_cross, key_mask=mem_mask, causal=False, drop=cx.drop(cx.p_a))
         x2 = ops.layernorm(ca, self.norm2.weight, self.norm2.bias, cx.eps, residual=x1)
         o = ops.linear(x2, self.output.dense.weight, self.output.dense.bias)

@@ -157,19 +157,40 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NON
         ev[1].record()
 
 
-def _colsum(x2d, idx=None, K=1):
+def _colsum(x2d, idx=None, K=1, out=None, accumulate=0):
     R, Cc = x2d.shape
-    out = torch.empty(K, Cc, dtype=torch.float32, device=x2d.device)
+    if out is None:
+        out = torch.empty(K, Cc, dtype=torch.float32, device=x2d.device)
+        if R == 0:
+            return out.zero_()
     if R == 0:
-        return out.zero_()
+        return out
     ws = _ws(x2d.device)
-    _lib.call("bucket_colsum", _p(x2d), x2d.stride(0), _p(idx), R, Cc, K, _p(out), 0, _p(ws), _stream())
+    _lib.call("bucket_colsum", _p(x2d), x2d.stride(0), _p(idx), R, Cc, K, _p(out), accumulate, _p(ws), _stream())
     return out
+
+
+# Direct-to-arena parameter gradients: once the optimizer has re-pointed ``p.grad`` into its contiguous arena (and marked
+# the parameter), backward kernels accumulate weight / bias / gain gradients straight into that storage (GEMM epilogue
+# ``accumulate``, reduction finalizers) instead of returning a tensor for autograd to add — no temporaries, no add kernels.
+GRAD_READY_HOOK = None     # set by GradReducer: called with the data_ptr of every arena gradient that has just been written
+
+
+def _direct(p):
+    if p is None or not p.is_leaf:
+        return None
+    g = getattr(p, "grad", None)
+    return g if (g is not None and getattr(p, "_svpc_direct", False)) else None
+
+
+def _ready(t, kind=None):
+    if GRAD_READY_HOOK is not None and t is not None:
+        GRAD_READY_HOOK(t.data_ptr(), t.numel(), kind)
 
 
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, w, b, act, trans_w, drop):
+    def forward(ctx, x, w, b, act, trans_w, drop, wgrad, bgrad):
         _need_gpu(x)
         x = _rows2d(x)
         w = _c(w)
@@ -181,6 +202,7 @@ class _Linear(Function):
         _gemm(x, x.stride(0), 1, w, w.stride(0), 0 if trans_w else 1, y, M, N, K, Z=z, bias=b, act=act, p=p, site=site, seed=seed)
         ctx.save_for_backward(x, w, z if act == ACT_GELU else (y if act != ACT_NONE else None))
         ctx.cfg = (act, trans_w, p, site, seed, b is not None)
+        ctx.direct = (wgrad, bgrad)
         return y
 
     @staticmethod
@@ -199,19 +221,32 @@ class _Linear(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
             _gemm(dz, N, 1, w, w.stride(0), 1 if trans_w else 0, dx, M, K, N)
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+        wgrad, bgrad = ctx.direct
+        if wgrad is not None or ctx.needs_input_grad[1]:
+            acc = 1 if wgrad is not None else 0
+            dw = wgrad if wgrad is not None else torch.empty_like(w)
             if trans_w:   # w (K, N): dw = xᵀ dz
-                _gemm(x, x.stride(0), 0, dz, N, 0, dw, K, N, M)
+                _gemm(x, x.stride(0), 0, dz, N, 0, dw, K, N, M, accumulate=acc)
             else:         # w (N, K): dw = dzᵀ x
-                _gemm(dz, N, 0, x, x.stride(0), 0, dw, N, K, M)
-        if has_b and ctx.needs_input_grad[2]:
-            db = _colsum(dz).view(-1)
-        return dx, dw, db, None, None, None
+                _gemm(dz, N, 0, x, x.stride(0), 0, dw, N, K, M, accumulate=acc)
+            if wgrad is not None:
+                _ready(wgrad, "w")
+                dw = None
+        if has_b and (bgrad is not None or ctx.needs_input_grad[2]):
+            if bgrad is not None:
+                _colsum(dz, out=bgrad.view(1, -1), accumulate=1)
+                _ready(bgrad, "b")
+            else:
+                db = _colsum(dz).view(-1)
+        return dx, dw, db, None, None, None, None, None
 
 
-def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None):
-    return _Linear.apply(x, w, b, act, trans_w, drop)
+def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgrad=None):
+    if wgrad is None:
+        wgrad = _direct(w)
+    if bgrad is None and b is not None:
+        bgrad = _direct(b)
+    return _Linear.apply(x, w, b, act, trans_w, drop, wgrad, bgrad)
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm family
@@ -219,6 +254,8 @@ class _LayerNorm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, add2, eps, src_rows, pad_row, pre_drop, post_drop, add1, add1_mod, add2_idx):
         _need_gpu(x)
+        ctx.direct = (_direct(gamma), _direct(beta), _direct(x) if src_rows is not None else None,
+                      _direct(add2) if add2 is not None else None)
         x = _c(x)
         D = x.shape[1]
         R = src_rows.numel() if src_rows is not None else x.shape[0]
@@ -248,21 +285,33 @@ class _LayerNorm(Function):
             dh = torch.empty(R, D, dtype=torch.float32, device=dev)
         if need_x:
             dx_rows = dh if p_pre <= 0.0 else torch.empty(R, D, dtype=torch.float32, device=dev)
-        dgamma = torch.empty(D, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(D, dtype=torch.float32, device=dev)
+        g_dir, b_dir, x_dir, a2_dir = ctx.direct
+        direct_gb = g_dir is not None and b_dir is not None
+        dgamma = g_dir if direct_gb else torch.empty(D, dtype=torch.float32, device=dev)
+        dbeta = b_dir if direct_gb else torch.empty(D, dtype=torch.float32, device=dev)
         ws = _ws(dev)
         _lib.call("ln_bwd", _p(dy), _p(x), _p(src_rows), _p(residual), _p(gamma), _p(mean), _p(rstd), _p(dh), _p(dx_rows),
-                  _p(dgamma), _p(dbeta), 0, _p(ws), R, D, p_pre, s_pre, p_post, s_post, _p(seed), _stream())
+                  _p(dgamma), _p(dbeta), 1 if direct_gb else 0, _p(ws), R, D, p_pre, s_pre, p_post, s_post, _p(seed), _stream())
+        if direct_gb:
+            _ready(dgamma); _ready(dbeta)
+            dgamma = dbeta = None
         dx = None
         if need_x:
             if src_rows is not None:
-                dx = torch.zeros_like(x)
+                dx = x_dir if x_dir is not None else torch.zeros_like(x)
                 _lib.call("scatter_add_rows", _p(dx_rows), _p(src_rows), _p(dx), R, D, int(pad_row), _stream())
+                if x_dir is not None:
+                    _ready(dx)
+                    dx = None
             else:
                 dx = dx_rows
         dadd2 = None
         if k_add2 and ctx.needs_input_grad[4]:
-            dadd2 = _colsum(dy, add2_idx, k_add2)
+            if a2_dir is not None:
+                _colsum(dy, add2_idx, k_add2, out=a2_dir, accumulate=1)
+                _ready(a2_dir)
+            else:
+                dadd2 = _colsum(dy, add2_idx, k_add2)
         return dx, dgamma, dbeta, (dh if need_res else None), dadd2, None, None, None, None, None, None, None, None
 
 
@@ -576,6 +625,7 @@ class _GumbelBow(Function):
     @staticmethod
     def forward(ctx, P, emb, row_c, tau, noise):
         _need_gpu(P)
+        ctx.emb_direct = _direct(emb)
         P, emb, noise = _c(P), _c(emb), _c(noise)
         R, c_max = P.shape
         V, W = emb.shape
@@ -602,8 +652,11 @@ class _GumbelBow(Function):
             dP = torch.empty_like(P)
             _lib.call("gumbel_bwd", _p(P), _p(noise), _p(rc), _p(stats), _p(dy), _p(dP), R, c_max, V, tau, _stream())
         if ctx.needs_input_grad[1]:
-            demb = torch.zeros_like(emb)
+            demb = ctx.emb_direct if ctx.emb_direct is not None else torch.zeros_like(emb)
             _lib.call("gumbel_emb_grad", _p(dbow), _p(idx), _p(stats), _p(demb), R, V, W, _stream())
+            if ctx.emb_direct is not None:
+                _ready(demb)
+                demb = None
         return dP, demb, None, None, None
 
 

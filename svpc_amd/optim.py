@@ -35,7 +35,27 @@ class _Meta(ctypes.Structure):
 class GradArena:
     """Contiguous fp32 gradient storage; ``p.grad`` of every member is a view into it."""
 
+    _QKV = {"query.weight": 0, "key.weight": 1, "value.weight": 2, "query.bias": 3, "key.bias": 4, "value.bias": 5}
+
+    @classmethod
+    def _ordered(cls, named_params):
+        """Keep registration order, but lay each attention block out as [Wq Wk Wv | bq bk bv] so the packed projection
+        gradient ((3D, D) / (2D, D)) is one contiguous arena region the wgrad GEMM can write in place."""
+        first, keyed = {}, []
+        for i, (n, p) in enumerate(named_params):
+            for suf, k in cls._QKV.items():
+                if n.endswith("." + suf):
+                    pre = n[:-len(suf)]
+                    first.setdefault(pre, i)
+                    keyed.append(((first[pre], k), n, p))
+                    break
+            else:
+                keyed.append(((i, -1), n, p))
+        keyed.sort(key=lambda t: t[0])
+        return [(n, p) for _, n, p in keyed]
+
     def __init__(self, named_params):
+        named_params = self._ordered(list(named_params))
         self.names = [n for n, _ in named_params]
         self.params = [p for _, p in named_params]
         dev = self.params[0].device
@@ -50,6 +70,31 @@ class GradArena:
             if p.grad is not None:
                 view.copy_(p.grad)
             p.grad = view
+            p._svpc_direct = True       # ops write this parameter's gradient in place from now on
+        # packed views for the fused Q/K/V (and K/V) projections
+        idx = {n: i for i, n in enumerate(self.names)}
+        for n, i in idx.items():
+            if not n.endswith(".query.weight"):
+                continue
+            pre = n[:-len("query.weight")]
+            need = [pre + s for s in ("query.weight", "key.weight", "value.weight", "query.bias", "key.bias", "value.bias")]
+            if not all(k in idx for k in need):
+                continue
+            ids = [idx[k] for k in need]
+            if ids != list(range(ids[0], ids[0] + 6)):
+                continue
+            q = self.params[ids[0]]
+            D_out, D_in = q.shape
+            if (D_out * D_in) % 4 or D_out % 4:
+                continue
+            ow, ob = self.offsets[ids[0]], self.offsets[ids[3]]
+            q._svpc_packed = {
+                "qkv": (self.flat[ow:ow + 3 * D_out * D_in].view(3 * D_out, D_in), self.flat[ob:ob + 3 * D_out]),
+                "kv": (self.flat[self.offsets[ids[1]]:self.offsets[ids[1]] + 2 * D_out * D_in].view(2 * D_out, D_in),
+                       self.flat[self.offsets[ids[4]]:self.offsets[ids[4]] + 2 * D_out]),
+                "q": (self.flat[ow:ow + D_out * D_in].view(D_out, D_in), self.flat[ob:ob + D_out]),
+            }
+            q._svpc_packed_members = {"qkv": ids, "kv": [ids[1], ids[2], ids[4], ids[5]], "q": [ids[0], ids[3]]}
 
     def zero(self):
         self.flat.zero_()
@@ -87,6 +132,7 @@ class FusedBertAdam:
         lib = _lib.load()
         chunk = lib.svpc_opt_chunk()
         assert lib.svpc_opt_meta_bytes() == ctypes.sizeof(_Meta)
+        live = list(zip(self.arena.names, self.arena.params))      # arena order (attention blocks are regrouped)
         metas = (_Meta * len(live))()
         chunk_tid, chunk_start, tco = [], [], [0]
         for i, ((name, p), o) in enumerate(zip(live, self.arena.offsets)):
@@ -185,9 +231,28 @@ class GradReducer:
         self.overlap = overlap and self.world > 1
         self._handles = []
         if self.overlap:
+            from . import ops
+            bucket_of = {}
             for bi, (s, e, members) in enumerate(self.buckets):
                 for i in members:
+                    bucket_of[i] = bi
                     self._handles.append(arena.params[i].register_post_accumulate_grad_hook(self._make_hook(bi)))
+            # gradients written in place by the kernels never pass through AccumulateGrad: ops report them by pointer
+            self._by_ptr = {}
+            for i, p in enumerate(arena.params):
+                self._by_ptr.setdefault(p.grad.data_ptr(), []).append(bucket_of[i])
+                packed = getattr(p, "_svpc_packed", None)
+                if packed is not None:
+                    for which, (wg, bg) in packed.items():
+                        mem = p._svpc_packed_members[which]
+                        half = len(mem) // 2
+                        self._by_ptr[("w", wg.data_ptr(), wg.numel())] = [bucket_of[j] for j in mem[:half]]
+                        self._by_ptr[("b", bg.data_ptr(), bg.numel())] = [bucket_of[j] for j in mem[half:]]
+            ops.GRAD_READY_HOOK = self._ready_ptr
+        # a parameter may be written by several kernels per step (LSTM recurrent weights: once per time step; the word table:
+        # text embedding + re-simulation).  The first step after construction only COUNTS the in-place writes per gradient;
+        # from then on a bucket is released when every member has received its full count.
+        self._expected, self._count, self._calibrating = {}, {}, True
         self.reset()
 
     def _close(self, members):
@@ -199,11 +264,28 @@ class GradReducer:
         self.pending = [len(m) for _, _, m in self.buckets]
         self.works = []
         self.launched = [False] * len(self.buckets)
+        self._count = {}
 
     def _launch(self, bi):
         s, e, _ = self.buckets[bi]
         self.launched[bi] = True
         self.works.append(self.dist.all_reduce(self.arena.flat[s:e], op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _ready_ptr(self, ptr, numel=None, kind=None):
+        """a kernel has just finished (enqueued) writing the arena gradient at ``ptr``"""
+        key = (kind, ptr, numel)
+        ids = self._by_ptr.get(key) if kind is not None else None
+        if ids is None:
+            key = ptr
+            ids = self._by_ptr.get(ptr, ())
+        c = self._count.get(key, 0) + 1
+        self._count[key] = c
+        if self._calibrating or c != self._expected.get(key, 1):
+            return
+        for bi in ids:
+            self.pending[bi] -= 1
+            if self.pending[bi] == 0 and not self.launched[bi]:
+                self._launch(bi)
 
     def _make_hook(self, bi):
         def hook(param):
@@ -220,4 +302,6 @@ class GradReducer:
                     self._launch(bi)
             for w in self.works:
                 w.wait()
+        if self._calibrating and self._count:
+            self._expected, self._calibrating = dict(self._count), False
         self.reset()
