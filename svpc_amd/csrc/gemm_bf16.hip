@@ -40,7 +40,7 @@ struct Stage {
     static constexpr bool F32 = sizeof(T) == 4;
     static constexpr int EPU = F32 ? 4 : 8;           // elements per 16-byte unit
     static constexpr int NU = (BM * GBK / EPU) / NT;  // 16-byte units per thread
-    float4 reg[NU];                                   // raw 16 bytes (4 fp32 or 8 bf16)
+    uint4 reg[NU];                                    // raw 16 bytes (4 fp32 or 8 bf16)
     const T* ptr[NU];                                 // interior-tile fast path: per-unit source pointers
 
     // interior tiles (no edge in m or k): pointers are set once, each k-tile is NU unguarded 16-byte loads
@@ -57,7 +57,7 @@ struct Stage {
     __device__ __forceinline__ void load_full(int ld) {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            reg[i] = *reinterpret_cast<const float4*>(ptr[i]);
+            reg[i] = *reinterpret_cast<const uint4*>(ptr[i]);
             ptr[i] += KC ? GBK : (size_t)GBK * ld;
         }
     }
@@ -95,7 +95,7 @@ struct Stage {
                     }
                 }
             }
-            reg[i] = v;
+            reg[i] = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w));
         }
     }
     __device__ __forceinline__ void store(char* __restrict__ img) const {
@@ -104,8 +104,14 @@ struct Stage {
         for (int i = 0; i < NU; ++i) {
             const int u = threadIdx.x + NT * i;
             char* dst = KC ? img + (u / UK) * RS_K + (u % UK) * (EPU * 2) : img + (u / UPR) * ImgM<BM>::RS + (u % UPR) * (EPU * 2);
-            if (F32) *reinterpret_cast<bf16x4*>(dst) = cvt4(reg[i]);
-            else *reinterpret_cast<float4*>(dst) = reg[i];
+            if (F32) {
+                bf16x4 b;
+                b[0] = (__bf16)__uint_as_float(reg[i].x); b[1] = (__bf16)__uint_as_float(reg[i].y);
+                b[2] = (__bf16)__uint_as_float(reg[i].z); b[3] = (__bf16)__uint_as_float(reg[i].w);
+                *reinterpret_cast<bf16x4*>(dst) = b;
+            } else {
+                *reinterpret_cast<uint4*>(dst) = reg[i];
+            }
         }
     }
 };
@@ -212,6 +218,36 @@ __global__ __launch_bounds__(128 * NWN) void gemm_bf16_kernel(const TA* __restri
     const u64 seed = (epi.p_drop > 0.f && splitk == 1) ? epi.seed[0] : 0ull;
     const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
     const int l31 = lane & 31, lhi = lane >> 5;
+    if (sizeof(TC) == 2 && FULL && splitk == 1 && epi.p_drop <= 0.f && !epi.accumulate) {
+        // bf16 output, interior tile: sub-dword stores are slow, so neighbouring lanes swap one value and every lane stores
+        // two adjacent columns of one row as a single dword (even lanes take rows e, odd lanes rows e+1)
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wc * (BN / NWN) + j * 32 + l31;
+                const float bias = epi.bias ? epi.bias[col] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const float z0 = acc[i][j][e] + bias, z1 = acc[i][j][e + 1] + bias;
+                    const float y0 = apply_act(z0, epi.act), y1 = apply_act(z1, epi.act);
+                    // even lane keeps (row e: own y0, partner y0); odd lane keeps (row e+1: partner y1, own y1)
+                    const float py = __shfl_xor(odd ? y0 : y1, 1, 64);
+                    const float pz = __shfl_xor(odd ? z0 : z1, 1, 64);
+                    const int row = m0 + wr * (BM / 2) + i * 32 + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2) + 4 * lhi;
+                    const size_t o = (size_t)row * ldc + (col & ~1);
+                    union { __bf16 h[2]; uint32_t u; } pk;
+                    pk.h[0] = (__bf16)(odd ? py : y0); pk.h[1] = (__bf16)(odd ? y1 : py);
+                    *reinterpret_cast<uint32_t*>(reinterpret_cast<__bf16*>(C) + o) = pk.u;
+                    if (epi.Z) {
+                        pk.h[0] = (__bf16)(odd ? pz : z0); pk.h[1] = (__bf16)(odd ? z1 : pz);
+                        *reinterpret_cast<uint32_t*>(reinterpret_cast<__bf16*>(epi.Z) + o) = pk.u;
+                    }
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -312,14 +348,13 @@ int svpc_gemm_mx(const void* A, int a_dt, int lda, int a_kc, const void* B, int 
         else launch_f32<64, 64, 2>(a_kc, b_kc, full, SVPC_ARGS);
     } else {
         SVPC_REQUIRE(big && full, "gemm_mx: bf16 operands need interior-only shapes (multiples of 128 × 128 × 32, 16-byte rows)");
+        // bf16-operand variants always use the 8-wave form (one 16-byte staging unit per thread and operand)
         if (a_dt == 1 && b_dt == 0 && c_dt == 1 && a_kc && b_kc) {
-            if (nwn == 4) launch_one<128, 128, 4, true, true, true, __bf16, float, __bf16>(SVPC_ARGS);
-            else launch_one<128, 128, 2, true, true, true, __bf16, float, __bf16>(SVPC_ARGS);
+            launch_one<128, 128, 4, true, true, true, __bf16, float, __bf16>(SVPC_ARGS);
         } else if (a_dt == 1 && b_dt == 0 && c_dt == 1 && a_kc && !b_kc) {
-            if (nwn == 4) launch_one<128, 128, 4, true, false, true, __bf16, float, __bf16>(SVPC_ARGS);
-            else launch_one<128, 128, 2, true, false, true, __bf16, float, __bf16>(SVPC_ARGS);
+            launch_one<128, 128, 4, true, false, true, __bf16, float, __bf16>(SVPC_ARGS);
         } else if (a_dt == 1 && b_dt == 1 && c_dt == 0 && !a_kc && !b_kc) {
-            launch_one<128, 128, 2, false, false, true, __bf16, __bf16, float>(SVPC_ARGS);
+            launch_one<128, 128, 4, false, false, true, __bf16, __bf16, float>(SVPC_ARGS);
         } else {
             svpc_set_error("gemm_mx: unsupported dtype/layout combination");
             return -1;
