@@ -34,6 +34,17 @@ int svpc_ln_fwd(const float* x, const int* src_rows, const float* res, const flo
                 float* mean, float* rstd, int R, int D, float eps, float p_pre, unsigned site_pre, float p_post,
                 unsigned site_post, const svpc_u64* seed, const float* add1, int mod1, const float* add2, const int* idx2,
                 svpc_stream_t stream);
+/* typed forms (dtype codes 0 = fp32, 1 = bf16; x_dt: x/dx, y_dt: residual/y/dy/dh; (0,0), (0,1), (1,1)); statistics stay fp32 */
+int svpc_ln_fwd_t(const void* x, int x_dt, const int* src_rows, const void* res, const float* gamma, const float* beta, void* y,
+                  int y_dt, float* mean, float* rstd, int R, int D, float eps, float p_pre, unsigned site_pre, float p_post,
+                  unsigned site_post, const svpc_u64* seed, const float* add1, int mod1, const float* add2, const int* idx2,
+                  svpc_stream_t stream);
+int svpc_ln_bwd_t(const void* dy, const void* x, int x_dt, int y_dt, const int* src_rows, const void* res, const float* gamma,
+                  const float* mean, const float* rstd, void* dh, void* dx, float* dgamma, float* dbeta, int accumulate,
+                  float* workspace, int R, int D, float p_pre, unsigned site_pre, float p_post, unsigned site_post,
+                  const svpc_u64* seed, svpc_stream_t stream);
+int svpc_bucket_colsum_t(const void* x, int x_dt, int ldx, const int* idx, int R, int C, int K, float* out, int accumulate,
+                         float* workspace, svpc_stream_t stream);
 int svpc_ln_bwd_groups(int R); /* workspace floats needed by svpc_ln_bwd = (groups + 1) * 2 * D */
 int svpc_ln_bwd(const float* dy, const float* x, const int* src_rows, const float* res, const float* gamma,
                 const float* mean, const float* rstd, float* dh, float* dx, float* dgamma, float* dbeta, int accumulate,
@@ -63,6 +74,9 @@ int svpc_gemm_mx(const void* A, int a_dt, int lda, int a_kc, const void* B, int 
 int svpc_act_bwd(const float* dy, const float* aux, float* dz, size_t n, int act, float p, unsigned site, const svpc_u64* seed,
                  svpc_stream_t stream);
 
+int svpc_act_bwd_t(const void* dy, const void* aux, void* dz, int dt, size_t n, int act, float p, unsigned site, const svpc_u64* seed,
+                   svpc_stream_t stream);
+
 /* ---- attention core: BertSelfAttention.forward model.py:194-219 (scale, additive -10000 mask, softmax, dropout, PV).
  *      seq = int32[4][n_seq]: q_off, q_len, k_off, k_len.  LSE: (n_seq, H, max_q). */
 int svpc_attn_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, float* LSE,
@@ -82,6 +96,14 @@ int svpc_attn_mfma_bwd(const float* Q, int ldq, const float* K, int ldk, const f
                        const float* LSE, const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
                        const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal, float scale,
                        float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
+
+int svpc_attn_mfma_fwd_t(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int dt, float* LSE,
+                         const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,
+                         float scale, float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
+int svpc_attn_mfma_bwd_t(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O, int ldo, int dt,
+                         const float* LSE, const void* dO, int lddo, void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv,
+                         const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal, float scale,
+                         float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
 
 /* ---- simulator recurrence: EntitiyReasoningNetwork.forward model.py:792-820 (Eqs. 2-7), one workgroup per video */
 int svpc_sim_recur_fwd(const float* q, const float* c, const float* w4f, const float* E0, const int* step_off, const int* step_len,

@@ -21,28 +21,64 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short short4v __attribute__((ext_vector_type(4)));
 
 struct MAttnArgs {
-    const float* Q; int ldq; const float* K; int ldk; const float* V; int ldv;
-    float* O; int ldo; float* LSE;
+    const void* Q; int ldq; const void* K; int ldk; const void* V; int ldv;
+    void* O; int ldo; float* LSE;
     const int* seq; int n_seq, H, max_q, max_k;
     const float* key_mask; int causal; float scale; float p_drop; uint32_t site; const u64* seed;
-    const float* dO; int lddo; float* dQ; int lddq; float* dK; int lddk; float* dV; int lddv;
+    const void* dO; int lddo; void* dQ; int lddq; void* dK; int lddk; void* dV; int lddv;
 };
 
 constexpr int AT = 128;   // rows per image (max queries / keys)
 
 template <int DH> struct AImg { static constexpr int RS = DH * 2 + 16; static constexpr int BYTES = AT * RS; };
 
-// rows [0, len) of a (·, DH) fp32 matrix → bf16 image (zero rows beyond len), optionally scaled
-template <int DH>
-__device__ __forceinline__ void stage_rows(char* __restrict__ img, const float* __restrict__ src, int ld, int len, float scale) {
+// rows [0, len) of a (·, DH) matrix (fp32 or bf16 in HBM) → bf16 image (zero rows beyond len), optionally scaled
+template <int DH, typename T>
+__device__ __forceinline__ void stage_rows(char* __restrict__ img, const T* __restrict__ src, int ld, int len, float scale) {
     constexpr int UPR = DH / 4;
     for (int u = threadIdx.x; u < AT * UPR; u += 256) {
         const int row = u / UPR, c4 = u - row * UPR;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < len) v = *reinterpret_cast<const float4*>(src + (size_t)row * ld + 4 * c4);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row < len) {
+            if (sizeof(T) == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + 4 * c4);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(src) + (size_t)row * ld + 4 * c4);
+                v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+            }
+        }
         bf16x4 b;
-        b[0] = (__bf16)(v.x * scale); b[1] = (__bf16)(v.y * scale); b[2] = (__bf16)(v.z * scale); b[3] = (__bf16)(v.w * scale);
+        b[0] = (__bf16)(v[0] * scale); b[1] = (__bf16)(v[1] * scale); b[2] = (__bf16)(v[2] * scale); b[3] = (__bf16)(v[3] * scale);
         *reinterpret_cast<bf16x4*>(img + row * AImg<DH>::RS + c4 * 8) = b;
+    }
+}
+// one 32×32 accumulator tile → rows row0.. (valid below row_limit), columns col0..col0+31 of a row-major matrix.
+// bf16: sub-dword stores are slow, so lane pairs swap one value and each lane stores two adjacent columns as one dword.
+template <typename T>
+__device__ __forceinline__ void store_tile(T* __restrict__ base, int ld, int row0, int row_limit, int col0, const floatx16& acc,
+                                           float scale, int lane) {
+    const int l31 = lane & 31;
+    if (sizeof(T) == 4) {
+        float* p = reinterpret_cast<float*>(base);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = row0 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            if (r < row_limit) p[(size_t)r * ld + col0 + l31] = acc[e] * scale;
+        }
+    } else {
+        __bf16* p = reinterpret_cast<__bf16*>(base);
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const float y0 = acc[e] * scale, y1 = acc[e + 1] * scale;
+            const float py = __shfl_xor(odd ? y0 : y1, 1, 64);
+            const int ee = e + (odd ? 1 : 0);
+            const int r = row0 + (ee & 3) + 8 * (ee >> 2) + 4 * (lane >> 5);
+            union { __bf16 h[2]; uint32_t u; } pk;
+            pk.h[0] = (__bf16)(odd ? py : y0); pk.h[1] = (__bf16)(odd ? y1 : py);
+            if (r < row_limit) *reinterpret_cast<uint32_t*>(p + (size_t)r * ld + col0 + (l31 & ~1)) = pk.u;
+        }
     }
 }
 // MFMA operand fragment: 32 image rows starting at row0, 16 columns starting at 16·ds (lane = (row, half) → 8 columns)
@@ -72,7 +108,7 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
     return r;
 }
 
-template <int DH>
+template <int DH, typename T>
 __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(MAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int IB = AImg<DH>::BYTES;
@@ -81,9 +117,9 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(MAttnArgs a) {
     const int sh = blockIdx.x, s = sh / a.H, h = sh - s * a.H;
     const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
-    stage_rows<DH>(Qs, a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale);
-    stage_rows<DH>(Ks, a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f);
-    stage_rows<DH>(Vs, a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
+    stage_rows<DH, T>(Qs, (const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale);
+    stage_rows<DH, T>(Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f);
+    stage_rows<DH, T>(Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
     for (int j = threadIdx.x; j < AT; j += 256)
         mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
     __syncthreads();
@@ -156,14 +192,10 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(MAttnArgs a) {
     }
 #pragma unroll
     for (int dt = 0; dt < DH / 32; ++dt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int qr = q0 + acc_row(e, lane);
-            if (qr < q_len) a.O[(size_t)(q_off + qr) * a.ldo + h * DH + 32 * dt + l31] = acc[dt][e];
-        }
+        store_tile<T>((T*)a.O + (size_t)q_off * a.ldo + h * DH, a.ldo, q0, q_len, 32 * dt, acc[dt], 1.0f, lane);
 }
 
-template <int DH>
+template <int DH, typename T>
 __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int IB = AImg<DH>::BYTES;
@@ -174,10 +206,10 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MAttnArgs a) {
     const int sh = blockIdx.x, s = sh / a.H, h = sh - s * a.H;
     const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
-    stage_rows<DH>(Qs, a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale);
-    stage_rows<DH>(Ks, a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f);
-    stage_rows<DH>(Vs, a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
-    stage_rows<DH>(Ds, a.dO + (size_t)q_off * a.lddo + h * DH, a.lddo, q_len, 1.0f);
+    stage_rows<DH, T>(Qs, (const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale);
+    stage_rows<DH, T>(Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f);
+    stage_rows<DH, T>(Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
+    stage_rows<DH, T>(Ds, (const T*)a.dO + (size_t)q_off * a.lddo + h * DH, a.lddo, q_len, 1.0f);
     for (int j = threadIdx.x; j < AT; j += 256) {
         mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
         lse[j] = j < q_len ? a.LSE[((size_t)s * a.H + h) * a.max_q + j] : 0.f;
@@ -185,7 +217,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MAttnArgs a) {
     for (int r = wave; r < AT; r += 4) {          // delta = rowsum(dO ⊙ O)
         float d = 0.f;
         if (r < q_len && lane < DH)
-            d = a.dO[(size_t)(q_off + r) * a.lddo + h * DH + lane] * a.O[(size_t)(q_off + r) * a.ldo + h * DH + lane];
+            d = (float)((const T*)a.dO)[(size_t)(q_off + r) * a.lddo + h * DH + lane] *
+                (float)((const T*)a.O)[(size_t)(q_off + r) * a.ldo + h * DH + lane];
         d = wave_sum(d);
         if (lane == 0) delta[r] = d;
     }
@@ -236,15 +269,10 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MAttnArgs a) {
             }
         }
 #pragma unroll
-        for (int dt = 0; dt < DH / 32; ++dt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int kr = k0 + acc_row(e, lane);
-                if (kr < k_len) {
-                    a.dV[(size_t)(k_off + kr) * a.lddv + h * DH + 32 * dt + l31] = dv[dt][e];
-                    a.dK[(size_t)(k_off + kr) * a.lddk + h * DH + 32 * dt + l31] = dk[dt][e];   // Qs carries 1/sqrt(dh)
-                }
-            }
+        for (int dt = 0; dt < DH / 32; ++dt) {
+            store_tile<T>((T*)a.dV + (size_t)k_off * a.lddv + h * DH, a.lddv, k0, k_len, 32 * dt, dv[dt], 1.0f, lane);
+            store_tile<T>((T*)a.dK + (size_t)k_off * a.lddk + h * DH, a.lddk, k0, k_len, 32 * dt, dk[dt], 1.0f, lane);   // Qs carries 1/sqrt(dh)
+        }
     }
     // ---------------- pass 2: wave = query tile → dQ (transposed layout: query on lane, keys in registers)
     if (wave < nqt) {
@@ -285,11 +313,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MAttnArgs a) {
         }
 #pragma unroll
         for (int dt = 0; dt < DH / 32; ++dt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int qr = q0 + acc_row(e, lane);
-                if (qr < q_len) a.dQ[(size_t)(q_off + qr) * a.lddq + h * DH + 32 * dt + l31] = dq[dt][e] * a.scale;
-            }
+            store_tile<T>((T*)a.dQ + (size_t)q_off * a.lddq + h * DH, a.lddq, q0, q_len, 32 * dt, dq[dt], a.scale, lane);
     }
 }
 
@@ -305,64 +329,90 @@ static int mattn_set_lds(const void* fn, size_t bytes) {
     }
     return 0;
 }
-static bool mattn_ok(int dh, int max_q, int max_k, int ldq, int ldk, int ldv, const void* Q, const void* K, const void* V) {
+static bool mattn_ok(int dh, int max_q, int max_k, int ldq, int ldk, int ldv, const void* Q, const void* K, const void* V, int dt) {
+    const int al = dt ? 8 : 16;   // 4 elements per staging unit
     return (dh == 64 || dh == 32) && max_q <= AT && max_k <= AT && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 &&
-           (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0;
+           (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & (al - 1)) == 0;
+}
+
+template <typename T>
+static int mattn_fwd_launch(const MAttnArgs& a, int dh, int n_blocks, hipStream_t stream) {
+    int rc;
+    if (dh == 64) {
+        const size_t lds = 3 * AImg<64>::BYTES + AT * sizeof(float);
+        rc = mattn_set_lds((const void*)attn_mfma_fwd_kernel<64, T>, lds); if (rc) return rc;
+        hipLaunchKernelGGL((attn_mfma_fwd_kernel<64, T>), dim3(n_blocks), dim3(256), lds, stream, a);
+    } else {
+        const size_t lds = 3 * AImg<32>::BYTES + AT * sizeof(float);
+        rc = mattn_set_lds((const void*)attn_mfma_fwd_kernel<32, T>, lds); if (rc) return rc;
+        hipLaunchKernelGGL((attn_mfma_fwd_kernel<32, T>), dim3(n_blocks), dim3(256), lds, stream, a);
+    }
+    return svpc_check_launch("attn_mfma_fwd");
+}
+template <typename T>
+static int mattn_bwd_launch(const MAttnArgs& a, int dh, int n_blocks, hipStream_t stream) {
+    int rc;
+    if (dh == 64) {
+        const size_t lds = 4 * AImg<64>::BYTES + 3 * AT * sizeof(float);
+        rc = mattn_set_lds((const void*)attn_mfma_bwd_kernel<64, T>, lds); if (rc) return rc;
+        hipLaunchKernelGGL((attn_mfma_bwd_kernel<64, T>), dim3(n_blocks), dim3(256), lds, stream, a);
+    } else {
+        const size_t lds = 4 * AImg<32>::BYTES + 3 * AT * sizeof(float);
+        rc = mattn_set_lds((const void*)attn_mfma_bwd_kernel<32, T>, lds); if (rc) return rc;
+        hipLaunchKernelGGL((attn_mfma_bwd_kernel<32, T>), dim3(n_blocks), dim3(256), lds, stream, a);
+    }
+    return svpc_check_launch("attn_mfma_bwd");
 }
 
 extern "C" {
 
-// 1 if the MFMA path supports this problem (head dim 32/64, ≤128 rows per sequence, 16-byte aligned rows)
+// 1 if the MFMA path supports this problem (head dim 32/64, ≤128 rows per sequence, aligned rows)
 int svpc_attn_mfma_supported(int dh, int max_q, int max_k, int ldq, int ldk, int ldv) {
-    return mattn_ok(dh, max_q, max_k, ldq, ldk, ldv, nullptr, nullptr, nullptr) ? 1 : 0;
+    return mattn_ok(dh, max_q, max_k, ldq, ldk, ldv, nullptr, nullptr, nullptr, 0) ? 1 : 0;
 }
 
-int svpc_attn_mfma_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, float* LSE,
-                       const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,
-                       float scale, float p_drop, unsigned site, const u64* seed, hipStream_t stream) {
+// dt: element type of Q, K, V, O (0 = fp32, 1 = bf16); LSE and the softmax are fp32
+int svpc_attn_mfma_fwd_t(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int dt, float* LSE,
+                         const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,
+                         float scale, float p_drop, unsigned site, const u64* seed, hipStream_t stream) {
     if (n_seq == 0) return 0;
-    SVPC_REQUIRE(mattn_ok(dh, max_q, max_k, ldq, ldk, ldv, Q, K, V), "attn_mfma: unsupported shape/alignment");
+    SVPC_REQUIRE(mattn_ok(dh, max_q, max_k, ldq, ldk, ldv, Q, K, V, dt), "attn_mfma: unsupported shape/alignment");
     SVPC_REQUIRE(p_drop <= 0.f || seed != nullptr, "attn_mfma: dropout needs a seed pointer");
+    SVPC_REQUIRE(dt == 0 || (ldo % 2 == 0 && ((((uintptr_t)O) & 3) == 0)), "attn_mfma: bf16 output needs 4-byte aligned rows");
     MAttnArgs a{};
     a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.LSE = LSE; a.seq = seq; a.n_seq = n_seq;
     a.H = H; a.max_q = max_q; a.max_k = max_k; a.key_mask = key_mask; a.causal = causal; a.scale = scale; a.p_drop = p_drop;
     a.site = site; a.seed = seed;
-    int rc;
-    if (dh == 64) {
-        const size_t lds = 3 * AImg<64>::BYTES + AT * sizeof(float);
-        rc = mattn_set_lds((const void*)attn_mfma_fwd_kernel<64>, lds); if (rc) return rc;
-        hipLaunchKernelGGL(attn_mfma_fwd_kernel<64>, dim3(n_seq * H), dim3(256), lds, stream, a);
-    } else {
-        const size_t lds = 3 * AImg<32>::BYTES + AT * sizeof(float);
-        rc = mattn_set_lds((const void*)attn_mfma_fwd_kernel<32>, lds); if (rc) return rc;
-        hipLaunchKernelGGL(attn_mfma_fwd_kernel<32>, dim3(n_seq * H), dim3(256), lds, stream, a);
-    }
-    return svpc_check_launch("attn_mfma_fwd");
+    return dt ? mattn_fwd_launch<__bf16>(a, dh, n_seq * H, stream) : mattn_fwd_launch<float>(a, dh, n_seq * H, stream);
+}
+int svpc_attn_mfma_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, float* LSE,
+                       const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,
+                       float scale, float p_drop, unsigned site, const u64* seed, hipStream_t stream) {
+    return svpc_attn_mfma_fwd_t(Q, ldq, K, ldk, V, ldv, O, ldo, 0, LSE, seq, n_seq, H, dh, max_q, max_k, key_mask, causal, scale, p_drop,
+                                site, seed, stream);
 }
 
+int svpc_attn_mfma_bwd_t(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O, int ldo, int dt,
+                         const float* LSE, const void* dO, int lddo, void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv,
+                         const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal, float scale,
+                         float p_drop, unsigned site, const u64* seed, hipStream_t stream) {
+    if (n_seq == 0) return 0;
+    SVPC_REQUIRE(mattn_ok(dh, max_q, max_k, ldq, ldk, ldv, Q, K, V, dt) && lddo % 4 == 0 && ((((uintptr_t)dO) & (dt ? 7 : 15)) == 0),
+                 "attn_mfma: unsupported shape/alignment");
+    SVPC_REQUIRE(dt == 0 || (lddq % 2 == 0 && lddk % 2 == 0 && lddv % 2 == 0), "attn_mfma: bf16 gradients need even row strides");
+    MAttnArgs a{};
+    a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = const_cast<void*>(O); a.ldo = ldo;
+    a.LSE = const_cast<float*>(LSE); a.seq = seq; a.n_seq = n_seq; a.H = H; a.max_q = max_q; a.max_k = max_k; a.key_mask = key_mask;
+    a.causal = causal; a.scale = scale; a.p_drop = p_drop; a.site = site; a.seed = seed;
+    a.dO = dO; a.lddo = lddo; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
+    return dt ? mattn_bwd_launch<__bf16>(a, dh, n_seq * H, stream) : mattn_bwd_launch<float>(a, dh, n_seq * H, stream);
+}
 int svpc_attn_mfma_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                        const float* LSE, const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
                        const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal, float scale,
                        float p_drop, unsigned site, const u64* seed, hipStream_t stream) {
-    if (n_seq == 0) return 0;
-    SVPC_REQUIRE(mattn_ok(dh, max_q, max_k, ldq, ldk, ldv, Q, K, V) && lddo % 4 == 0 && ((((uintptr_t)dO) & 15) == 0),
-                 "attn_mfma: unsupported shape/alignment");
-    MAttnArgs a{};
-    a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = const_cast<float*>(O); a.ldo = ldo;
-    a.LSE = const_cast<float*>(LSE); a.seq = seq; a.n_seq = n_seq; a.H = H; a.max_q = max_q; a.max_k = max_k; a.key_mask = key_mask;
-    a.causal = causal; a.scale = scale; a.p_drop = p_drop; a.site = site; a.seed = seed;
-    a.dO = dO; a.lddo = lddo; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
-    int rc;
-    if (dh == 64) {
-        const size_t lds = 4 * AImg<64>::BYTES + 3 * AT * sizeof(float);
-        rc = mattn_set_lds((const void*)attn_mfma_bwd_kernel<64>, lds); if (rc) return rc;
-        hipLaunchKernelGGL(attn_mfma_bwd_kernel<64>, dim3(n_seq * H), dim3(256), lds, stream, a);
-    } else {
-        const size_t lds = 4 * AImg<32>::BYTES + 3 * AT * sizeof(float);
-        rc = mattn_set_lds((const void*)attn_mfma_bwd_kernel<32>, lds); if (rc) return rc;
-        hipLaunchKernelGGL(attn_mfma_bwd_kernel<32>, dim3(n_seq * H), dim3(256), lds, stream, a);
-    }
-    return svpc_check_launch("attn_mfma_bwd");
+    return svpc_attn_mfma_bwd_t(Q, ldq, K, ldk, V, ldv, O, ldo, 0, LSE, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, seq, n_seq, H, dh, max_q,
+                                max_k, key_mask, causal, scale, p_drop, site, seed, stream);
 }
 
 }  // extern "C"

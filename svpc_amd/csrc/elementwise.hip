@@ -10,19 +10,20 @@
 
 // ---- dz = dy * act'(.) * dropout ----------------------------------------------------------------------------
 // `aux` is the pre-activation z for GELU, the activated (pre-dropout) output y for ReLU / sigmoid.
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ aux,
-                                                      float* __restrict__ dz, size_t n, int act, float p, uint32_t site,
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ aux,
+                                                      T* __restrict__ dz, size_t n, int act, float p, uint32_t site,
                                                       const u64* __restrict__ seed_ptr) {
     const u64 seed = p > 0.f ? seed_ptr[0] : 0ull;
     const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float g = dy[i];
+        float g = (float)dy[i];
         if (p > 0.f) g *= drop_scale(seed, site, i, p, ik);
-        const float a = aux[i];
+        const float a = (float)aux[i];
         if (act == ACT_RELU) g = a > 0.f ? g : 0.f;
         else if (act == ACT_GELU) g *= gelu_erf_grad(a);
         else if (act == ACT_SIGMOID) g *= a * (1.0f - a);
-        dz[i] = g;
+        dz[i] = (T)g;
     }
 }
 
@@ -316,12 +317,19 @@ static inline unsigned grid1d(size_t n) { size_t g = (n + 255) / 256; return (un
 
 extern "C" {
 
-int svpc_act_bwd(const float* dy, const float* aux, float* dz, size_t n, int act, float p, unsigned site, const u64* seed,
-                 hipStream_t s) {
+int svpc_act_bwd_t(const void* dy, const void* aux, void* dz, int dt, size_t n, int act, float p, unsigned site, const u64* seed,
+                   hipStream_t s) {
     if (n == 0) return 0;
     SVPC_REQUIRE(p <= 0.f || seed != nullptr, "act_bwd: dropout needs a seed pointer");
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, s, dy, aux, dz, n, act, p, site, seed);
+    if (dt == 0) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid1d(n)), dim3(256), 0, s, (const float*)dy, (const float*)aux, (float*)dz, n,
+                                    act, p, site, seed);
+    else hipLaunchKernelGGL(act_bwd_kernel<__bf16>, dim3(grid1d(n)), dim3(256), 0, s, (const __bf16*)dy, (const __bf16*)aux, (__bf16*)dz, n,
+                            act, p, site, seed);
     return svpc_check_launch("act_bwd");
+}
+int svpc_act_bwd(const float* dy, const float* aux, float* dz, size_t n, int act, float p, unsigned site, const u64* seed,
+                 hipStream_t s) {
+    return svpc_act_bwd_t(dy, aux, dz, 0, n, act, p, site, seed, s);
 }
 int svpc_add(const float* a, const float* b, float* c, size_t n, hipStream_t s) {
     if (n == 0) return 0;

@@ -327,6 +327,10 @@ int svpc_gemm_mx(const void* A, int a_dt, int lda, int a_kc, const void* B, int 
         if (splitk < 1) splitk = 1;
     }
     int k_chunk = ceil_div(ceil_div(K, splitk), GBK) * GBK;
+    if (a_dt || b_dt || c_dt) {
+        // the bf16-storage variants only exist in the unguarded form: every K slice must be whole (K % 32 == 0 is required)
+        while (splitk > 1 && K % k_chunk != 0) { --splitk; k_chunk = ceil_div(ceil_div(K, splitk), GBK) * GBK; }
+    }
     splitk = ceil_div(K, k_chunk);
     if (K == 0) { splitk = 1; k_chunk = GBK; }
     const int a_el = a_dt ? 8 : 4, b_el = b_dt ? 8 : 4;   // elements per 16 bytes

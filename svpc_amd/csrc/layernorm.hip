@@ -10,10 +10,10 @@
 // per workgroup in registers → LDS → one partial row per workgroup, reduced by colsum_finalize (deterministic).
 #include "common.h"
 
-template <int W>
+template <int W, typename T>
 struct VecIO;
 template <>
-struct VecIO<4> {
+struct VecIO<4, float> {
     static __device__ __forceinline__ void load(const float* p, float* v) {
         float4 t = *reinterpret_cast<const float4*>(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -23,20 +23,42 @@ struct VecIO<4> {
     }
 };
 template <>
-struct VecIO<1> {
+struct VecIO<1, float> {
     static __device__ __forceinline__ void load(const float* p, float* v) { v[0] = p[0]; }
     static __device__ __forceinline__ void store(float* p, const float* v) { p[0] = v[0]; }
 };
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+template <>
+struct VecIO<4, __bf16> {
+    static __device__ __forceinline__ void load(const __bf16* p, float* v) {
+        bf16x4_t t = *reinterpret_cast<const bf16x4_t*>(p);
+        v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    }
+    static __device__ __forceinline__ void store(__bf16* p, const float* v) {
+        bf16x4_t t;
+        t[0] = (__bf16)v[0]; t[1] = (__bf16)v[1]; t[2] = (__bf16)v[2]; t[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4_t*>(p) = t;
+    }
+};
+template <>
+struct VecIO<1, __bf16> {
+    static __device__ __forceinline__ void load(const __bf16* p, float* v) { v[0] = (float)p[0]; }
+    static __device__ __forceinline__ void store(__bf16* p, const float* v) { p[0] = (__bf16)v[0]; }
+};
 
 struct LnArgs {
-    const float* x; const int* src_rows; const float* res; const float* gamma; const float* beta;
-    float* y; float* mean; float* rstd; int R; int D; float eps;
+    const void* x; const int* src_rows; const void* res; const float* gamma; const float* beta;
+    void* y; float* mean; float* rstd; int R; int D; float eps;
     float p_pre; uint32_t site_pre; float p_post; uint32_t site_post; const u64* seed;
     const float* add1; int mod1; const float* add2; const int* idx2;
 };
 
-template <int NPL, int W>
+// TX: element type of x; TY: element type of the residual and of y (float or __bf16; statistics are always fp32)
+template <int NPL, int W, typename TX, typename TY>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
+    const TX* __restrict__ xp = reinterpret_cast<const TX*>(a.x);
+    const TY* __restrict__ rp = reinterpret_cast<const TY*>(a.res);
+    TY* __restrict__ yp = reinterpret_cast<TY*>(a.y);
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= a.R) return;
@@ -54,14 +76,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
     for (int i = 0; i < NPL; ++i) {
         const int col = (lane + 64 * i) * W;
         if (col < D) {
-            VecIO<W>::load(a.x + xrow + col, &v[i * W]);
+            VecIO<W, TX>::load(xp + xrow + col, &v[i * W]);
             if (a.p_pre > 0.f) {
 #pragma unroll
                 for (int j = 0; j < W; ++j) v[i * W + j] *= drop_scale(seed, a.site_pre, orow + col + j, a.p_pre, ik_pre);
             }
             if (a.res) {
                 float t[W];
-                VecIO<W>::load(a.res + orow + col, t);
+                VecIO<W, TY>::load(rp + orow + col, t);
 #pragma unroll
                 for (int j = 0; j < W; ++j) v[i * W + j] += t[j];
             }
@@ -95,8 +117,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
         const int col = (lane + 64 * i) * W;
         if (col < D) {
             float g[W], b[W], o[W];
-            VecIO<W>::load(a.gamma + col, g);
-            VecIO<W>::load(a.beta + col, b);
+            VecIO<W, float>::load(a.gamma + col, g);
+            VecIO<W, float>::load(a.beta + col, b);
 #pragma unroll
             for (int j = 0; j < W; ++j) {
                 float t = (v[i * W + j] - mean) * rstd * g[j] + b[j];
@@ -105,34 +127,39 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
             }
             if (a.add1) {
                 float t[W];
-                VecIO<W>::load(a.add1 + a1row + col, t);
+                VecIO<W, float>::load(a.add1 + a1row + col, t);
 #pragma unroll
                 for (int j = 0; j < W; ++j) o[j] += t[j];
             }
             if (a.add2) {
                 float t[W];
-                VecIO<W>::load(a.add2 + a2row + col, t);
+                VecIO<W, float>::load(a.add2 + a2row + col, t);
 #pragma unroll
                 for (int j = 0; j < W; ++j) o[j] += t[j];
             }
-            VecIO<W>::store(a.y + orow + col, o);
+            VecIO<W, TY>::store(yp + orow + col, o);
         }
     }
 }
 
 struct LnBwdArgs {
-    const float* dy; const float* x; const int* src_rows; const float* res; const float* gamma;
+    const void* dy; const void* x; const int* src_rows; const void* res; const float* gamma;
     const float* mean; const float* rstd;
-    float* dh;      // (R, D) gradient w.r.t. the pre-LN sum (= residual gradient); may be null
-    float* dx;      // (R, D) gradient w.r.t. the gathered, pre-dropout x rows; may be null or == dh
+    void* dh;       // (R, D) gradient w.r.t. the pre-LN sum (= residual gradient), type TY; may be null
+    void* dx;       // (R, D) gradient w.r.t. the gathered, pre-dropout x rows, type TX; may be null or == dh
     float* partial; // (gridDim.x, 2, D) per-workgroup [dgamma; dbeta]
     int R; int D;
     float p_pre; uint32_t site_pre; float p_post; uint32_t site_post; const u64* seed;
 };
 
-template <int NPL, int W>
+template <int NPL, int W, typename TX, typename TY>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     extern __shared__ float smem[];  // 2*D floats
+    const TY* __restrict__ dyp = reinterpret_cast<const TY*>(a.dy);
+    const TX* __restrict__ xp = reinterpret_cast<const TX*>(a.x);
+    const TY* __restrict__ rp = reinterpret_cast<const TY*>(a.res);
+    TY* __restrict__ dhp = reinterpret_cast<TY*>(a.dh);
+    TX* __restrict__ dxp = reinterpret_cast<TX*>(a.dx);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int D = a.D;
@@ -150,7 +177,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
         const int col = (lane + 64 * i) * W;
 #pragma unroll
         for (int j = 0; j < W; ++j) { accg[i * W + j] = 0.f; accb[i * W + j] = 0.f; g[i * W + j] = 0.f; }
-        if (col < D) VecIO<W>::load(a.gamma + col, &g[i * W]);
+        if (col < D) VecIO<W, float>::load(a.gamma + col, &g[i * W]);
     }
     for (int r = blockIdx.x * 4 + wave; r < a.R; r += gridDim.x * 4) {
         const size_t xrow = (size_t)(a.src_rows ? a.src_rows[r] : r) * D;
@@ -163,18 +190,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
             const int col = (lane + 64 * i) * W;
             if (col < D) {
                 float h[W], d[W];
-                VecIO<W>::load(a.x + xrow + col, h);
+                VecIO<W, TX>::load(xp + xrow + col, h);
                 if (a.p_pre > 0.f) {
 #pragma unroll
                     for (int j = 0; j < W; ++j) h[j] *= drop_scale(seed, a.site_pre, orow + col + j, a.p_pre, ik_pre);
                 }
                 if (a.res) {
                     float t[W];
-                    VecIO<W>::load(a.res + orow + col, t);
+                    VecIO<W, TY>::load(rp + orow + col, t);
 #pragma unroll
                     for (int j = 0; j < W; ++j) h[j] += t[j];
                 }
-                VecIO<W>::load(a.dy + orow + col, d);
+                VecIO<W, TY>::load(dyp + orow + col, d);
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
                     float dy0 = d[j];
@@ -200,13 +227,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
                     float o[W];
 #pragma unroll
                     for (int j = 0; j < W; ++j) o[j] = rstd * (dxh[i * W + j] - s1 - xh[i * W + j] * s2);
-                    if (a.dh) VecIO<W>::store(a.dh + orow + col, o);
+                    if (a.dh) VecIO<W, TY>::store(dhp + orow + col, o);
                     if (a.dx && a.dx != a.dh) {
                         if (a.p_pre > 0.f) {
 #pragma unroll
                             for (int j = 0; j < W; ++j) o[j] *= drop_scale(seed, a.site_pre, orow + col + j, a.p_pre, ik_pre);
                         }
-                        VecIO<W>::store(a.dx + orow + col, o);
+                        VecIO<W, TX>::store(dxp + orow + col, o);
                     }
                 }
             }
@@ -269,8 +296,8 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
 }
 
 // partial[chunk][k][c] = sum over rows r of the chunk with idx[r]==k (idx null → k = 0) of x[r][c]
-template <int KMAX>
-__global__ __launch_bounds__(256) void bucket_colsum_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ idx,
+template <int KMAX, typename T>
+__global__ __launch_bounds__(256) void bucket_colsum_kernel(const T* __restrict__ x, int ldx, const int* __restrict__ idx,
                                                             int R, int C, int K, int rows_per_chunk, float* __restrict__ partial) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int chunk = blockIdx.y;
@@ -281,7 +308,7 @@ __global__ __launch_bounds__(256) void bucket_colsum_kernel(const float* __restr
     for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
     if (c < C) {
         for (int r = r0; r < r1; ++r) {
-            const float v = x[(size_t)r * ldx + c];
+            const float v = (float)x[(size_t)r * ldx + c];
             const int k = idx ? idx[r] : 0;
 #pragma unroll
             for (int kk = 0; kk < KMAX; ++kk) acc[kk] += (kk == k) ? v : 0.f;
@@ -293,13 +320,20 @@ __global__ __launch_bounds__(256) void bucket_colsum_kernel(const float* __restr
 }
 
 template <int NPL, int W>
-static int launch_ln_fwd(const LnArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((ln_fwd_kernel<NPL, W>), dim3(ceil_div(a.R, 4)), dim3(256), 0, s, a);
+static int launch_ln_fwd(const LnArgs& a, int x_dt, int y_dt, hipStream_t s) {
+    const dim3 g(ceil_div(a.R, 4)), b(256);
+    if (x_dt == 0 && y_dt == 0) hipLaunchKernelGGL((ln_fwd_kernel<NPL, W, float, float>), g, b, 0, s, a);
+    else if (x_dt == 0 && y_dt == 1) hipLaunchKernelGGL((ln_fwd_kernel<NPL, W, float, __bf16>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((ln_fwd_kernel<NPL, W, __bf16, __bf16>), g, b, 0, s, a);
     return svpc_check_launch("ln_fwd");
 }
 template <int NPL, int W>
-static int launch_ln_bwd(const LnBwdArgs& a, int G, hipStream_t s) {
-    hipLaunchKernelGGL((ln_bwd_kernel<NPL, W>), dim3(G), dim3(256), (size_t)2 * a.D * sizeof(float), s, a);
+static int launch_ln_bwd(const LnBwdArgs& a, int G, int x_dt, int y_dt, hipStream_t s) {
+    const dim3 g(G), b(256);
+    const size_t lds = (size_t)2 * a.D * sizeof(float);
+    if (x_dt == 0 && y_dt == 0) hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, float, float>), g, b, lds, s, a);
+    else if (x_dt == 0 && y_dt == 1) hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, float, __bf16>), g, b, lds, s, a);
+    else hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, __bf16, __bf16>), g, b, lds, s, a);
     return svpc_check_launch("ln_bwd");
 }
 
@@ -307,77 +341,106 @@ static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" {
 
-int svpc_ln_fwd(const float* x, const int* src_rows, const float* res, const float* gamma, const float* beta, float* y,
-                float* mean, float* rstd, int R, int D, float eps, float p_pre, unsigned site_pre, float p_post,
-                unsigned site_post, const u64* seed, const float* add1, int mod1, const float* add2, const int* idx2,
-                hipStream_t stream) {
+// dtype codes: 0 = fp32, 1 = bf16.  x_dt: x (and dx);  y_dt: residual, y, dy, dh.  Supported: (0,0), (0,1), (1,1).
+int svpc_ln_fwd_t(const void* x, int x_dt, const int* src_rows, const void* res, const float* gamma, const float* beta, void* y,
+                  int y_dt, float* mean, float* rstd, int R, int D, float eps, float p_pre, unsigned site_pre, float p_post,
+                  unsigned site_post, const u64* seed, const float* add1, int mod1, const float* add2, const int* idx2,
+                  hipStream_t stream) {
     if (R == 0) return 0;
+    SVPC_REQUIRE(!(x_dt == 1 && y_dt == 0), "ln_fwd: bf16 input with fp32 output is not instantiated");
     LnArgs a{x, src_rows, res, gamma, beta, y, mean, rstd, R, D, eps, p_pre, site_pre, p_post, site_post, seed,
              add1, mod1, add2, idx2};
     SVPC_REQUIRE((p_pre <= 0.f && p_post <= 0.f) || seed != nullptr, "ln_fwd: dropout needs a seed pointer");
     const bool vec = (D % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) &&
                      (!res || aligned16(res)) && (!add1 || aligned16(add1)) && (!add2 || aligned16(add2));
     if (vec) {
-        if (D <= 256) return launch_ln_fwd<1, 4>(a, stream);
-        if (D <= 1024) return launch_ln_fwd<4, 4>(a, stream);
-        if (D <= 3072) return launch_ln_fwd<12, 4>(a, stream);
-        if (D <= 8192) return launch_ln_fwd<32, 4>(a, stream);
+        if (D <= 256) return launch_ln_fwd<1, 4>(a, x_dt, y_dt, stream);
+        if (D <= 1024) return launch_ln_fwd<4, 4>(a, x_dt, y_dt, stream);
+        if (D <= 3072) return launch_ln_fwd<12, 4>(a, x_dt, y_dt, stream);
+        if (D <= 8192) return launch_ln_fwd<32, 4>(a, x_dt, y_dt, stream);
     } else {
-        if (D <= 256) return launch_ln_fwd<4, 1>(a, stream);
-        if (D <= 1024) return launch_ln_fwd<16, 1>(a, stream);
-        if (D <= 3072) return launch_ln_fwd<48, 1>(a, stream);
+        if (D <= 256) return launch_ln_fwd<4, 1>(a, x_dt, y_dt, stream);
+        if (D <= 1024) return launch_ln_fwd<16, 1>(a, x_dt, y_dt, stream);
+        if (D <= 3072) return launch_ln_fwd<48, 1>(a, x_dt, y_dt, stream);
     }
     svpc_set_error("ln_fwd: row width not supported");
     return -1;
+}
+int svpc_ln_fwd(const float* x, const int* src_rows, const float* res, const float* gamma, const float* beta, float* y,
+                float* mean, float* rstd, int R, int D, float eps, float p_pre, unsigned site_pre, float p_post,
+                unsigned site_post, const u64* seed, const float* add1, int mod1, const float* add2, const int* idx2,
+                hipStream_t stream) {
+    return svpc_ln_fwd_t(x, 0, src_rows, res, gamma, beta, y, 0, mean, rstd, R, D, eps, p_pre, site_pre, p_post, site_post, seed, add1,
+                         mod1, add2, idx2, stream);
 }
 
 // workspace: at least svpc_ln_bwd_groups(R) * 2 * D floats
 int svpc_ln_bwd_groups(int R) { int g = ceil_div(R, 4); return g < 1 ? 1 : (g > 512 ? 512 : g); }
 
-int svpc_ln_bwd(const float* dy, const float* x, const int* src_rows, const float* res, const float* gamma,
-                const float* mean, const float* rstd, float* dh, float* dx, float* dgamma, float* dbeta,
-                int accumulate, float* workspace, int R, int D, float p_pre, unsigned site_pre, float p_post,
-                unsigned site_post, const u64* seed, hipStream_t stream) {
+int svpc_ln_bwd_t(const void* dy, const void* x, int x_dt, int y_dt, const int* src_rows, const void* res, const float* gamma,
+                  const float* mean, const float* rstd, void* dh, void* dx, float* dgamma, float* dbeta,
+                  int accumulate, float* workspace, int R, int D, float p_pre, unsigned site_pre, float p_post,
+                  unsigned site_post, const u64* seed, hipStream_t stream) {
     if (R == 0) return 0;
+    SVPC_REQUIRE(!(x_dt == 1 && y_dt == 0), "ln_bwd: bf16 input with fp32 output is not instantiated");
     const int G = svpc_ln_bwd_groups(R);
     LnBwdArgs a{dy, x, src_rows, res, gamma, mean, rstd, dh, dx, workspace, R, D, p_pre, site_pre, p_post, site_post, seed};
     const bool vec = (D % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(gamma) && (!res || aligned16(res)) &&
                      (!dh || aligned16(dh)) && (!dx || aligned16(dx));
     int rc = -1;
     if (vec) {
-        if (D <= 256) rc = launch_ln_bwd<1, 4>(a, G, stream);
-        else if (D <= 1024) rc = launch_ln_bwd<4, 4>(a, G, stream);
-        else if (D <= 3072) rc = launch_ln_bwd<12, 4>(a, G, stream);
-        else if (D <= 8192) rc = launch_ln_bwd<32, 4>(a, G, stream);
+        if (D <= 256) rc = launch_ln_bwd<1, 4>(a, G, x_dt, y_dt, stream);
+        else if (D <= 1024) rc = launch_ln_bwd<4, 4>(a, G, x_dt, y_dt, stream);
+        else if (D <= 3072) rc = launch_ln_bwd<12, 4>(a, G, x_dt, y_dt, stream);
+        else if (D <= 8192) rc = launch_ln_bwd<32, 4>(a, G, x_dt, y_dt, stream);
     } else {
-        if (D <= 256) rc = launch_ln_bwd<4, 1>(a, G, stream);
-        else if (D <= 1024) rc = launch_ln_bwd<16, 1>(a, G, stream);
-        else if (D <= 3072) rc = launch_ln_bwd<48, 1>(a, G, stream);
+        if (D <= 256) rc = launch_ln_bwd<4, 1>(a, G, x_dt, y_dt, stream);
+        else if (D <= 1024) rc = launch_ln_bwd<16, 1>(a, G, x_dt, y_dt, stream);
+        else if (D <= 3072) rc = launch_ln_bwd<48, 1>(a, G, x_dt, y_dt, stream);
     }
     if (rc != 0) { if (rc == -1) svpc_set_error("ln_bwd: row width not supported"); return rc; }
     hipLaunchKernelGGL(ln_finalize_kernel, dim3(ceil_div(2 * D, 32)), dim3(256), 0, stream, workspace, G, D, dgamma, dbeta, accumulate);
     return svpc_check_launch("ln_bwd scatter");
+}
+int svpc_ln_bwd(const float* dy, const float* x, const int* src_rows, const float* res, const float* gamma,
+                const float* mean, const float* rstd, float* dh, float* dx, float* dgamma, float* dbeta,
+                int accumulate, float* workspace, int R, int D, float p_pre, unsigned site_pre, float p_post,
+                unsigned site_post, const u64* seed, hipStream_t stream) {
+    return svpc_ln_bwd_t(dy, x, 0, 0, src_rows, res, gamma, mean, rstd, dh, dx, dgamma, dbeta, accumulate, workspace, R, D, p_pre,
+                         site_pre, p_post, site_post, seed, stream);
 }
 
 // out[k][c] (+)= sum_{r : idx[r]==k} x[r][c]   (idx null → plain column sum, K must be 1).  K <= 8.
 // workspace: svpc_colsum_chunks(R) * K * C floats
 int svpc_colsum_chunks(int R) { int g = ceil_div(R, 32); return g < 1 ? 1 : (g > 600 ? 600 : g); }
 
-int svpc_bucket_colsum(const float* x, int ldx, const int* idx, int R, int C, int K, float* out, int accumulate,
-                       float* workspace, hipStream_t stream) {
+int svpc_bucket_colsum_t(const void* xv, int x_dt, int ldx, const int* idx, int R, int C, int K, float* out, int accumulate,
+                         float* workspace, hipStream_t stream) {
     SVPC_REQUIRE(K >= 1 && K <= 8, "bucket_colsum: K must be 1..8");
     if (R == 0 || C == 0) return 0;
     const int chunks = svpc_colsum_chunks(R);
     const int rpc = ceil_div(R, chunks);
     dim3 grid(ceil_div(C, 256), chunks);
-    if (K == 1) hipLaunchKernelGGL((bucket_colsum_kernel<1>), grid, dim3(256), 0, stream, x, ldx, idx, R, C, K, rpc, workspace);
-    else if (K <= 4) hipLaunchKernelGGL((bucket_colsum_kernel<4>), grid, dim3(256), 0, stream, x, ldx, idx, R, C, K, rpc, workspace);
-    else hipLaunchKernelGGL((bucket_colsum_kernel<8>), grid, dim3(256), 0, stream, x, ldx, idx, R, C, K, rpc, workspace);
+    if (x_dt == 0) {
+        const float* x = (const float*)xv;
+        if (K == 1) hipLaunchKernelGGL((bucket_colsum_kernel<1, float>), grid, dim3(256), 0, stream, x, ldx, idx, R, C, K, rpc, workspace);
+        else if (K <= 4) hipLaunchKernelGGL((bucket_colsum_kernel<4, float>), grid, dim3(256), 0, stream, x, ldx, idx, R, C, K, rpc, workspace);
+        else hipLaunchKernelGGL((bucket_colsum_kernel<8, float>), grid, dim3(256), 0, stream, x, ldx, idx, R, C, K, rpc, workspace);
+    } else {
+        const __bf16* x = (const __bf16*)xv;
+        if (K == 1) hipLaunchKernelGGL((bucket_colsum_kernel<1, __bf16>), grid, dim3(256), 0, stream, x, ldx, idx, R, C, K, rpc, workspace);
+        else if (K <= 4) hipLaunchKernelGGL((bucket_colsum_kernel<4, __bf16>), grid, dim3(256), 0, stream, x, ldx, idx, R, C, K, rpc, workspace);
+        else hipLaunchKernelGGL((bucket_colsum_kernel<8, __bf16>), grid, dim3(256), 0, stream, x, ldx, idx, R, C, K, rpc, workspace);
+    }
     int rc = svpc_check_launch("bucket_colsum");
     if (rc) return rc;
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(K * C, 32)), dim3(256), 0, stream, workspace, chunks, K * C,
                        out, accumulate);
     return svpc_check_launch("bucket_colsum finalize");
+}
+int svpc_bucket_colsum(const float* x, int ldx, const int* idx, int R, int C, int K, float* out, int accumulate,
+                       float* workspace, hipStream_t stream) {
+    return svpc_bucket_colsum_t(x, 0, ldx, idx, R, C, K, out, accumulate, workspace, stream);
 }
 
 }  // extern "C"

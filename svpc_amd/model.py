@@ -88,8 +88,9 @@ class _FcStack(nn.Module):
     def __getitem__(self, i):
         return getattr(self, str(i))
 
-    def run(self, x, eps, src_rows=None, pad_row=-1, drop=None, add1=None, add1_mod=0, add2=None, add2_idx=None):
-        xn = ops.layernorm(x, self[0].weight, self[0].bias, eps, src_rows=src_rows, pad_row=pad_row, post_drop=drop)
+    def run(self, x, eps, src_rows=None, pad_row=-1, drop=None, add1=None, add1_mod=0, add2=None, add2_idx=None, out_bf16=False):
+        xn = ops.layernorm(x, self[0].weight, self[0].bias, eps, src_rows=src_rows, pad_row=pad_row, post_drop=drop,
+                           out_bf16=out_bf16)
         h = ops.linear(xn, self[2].weight, self[2].bias, act=ACT_RELU)
         return ops.layernorm(h, self[4].weight, self[4].bias, eps, add1=add1, add1_mod=add1_mod,
                              add2=add2, add2_idx=add2_idx)
@@ -208,11 +209,12 @@ class BertLayerNoMemoryUntied(nn.Module):
         the selected rows are bit-for-bit what ``run`` produces for them (in eval mode)."""
         D = h.shape[1]
         att = self.attention.self
-        hq = ops.take_rows(h, sel_rows)
+        hq = ops.take_rows(h, sel_rows).float()      # the few selected rows leave the bf16 stream here (no-op in fp32 storage)
         q = ops.linear(hq, att.query.weight, att.query.bias)
         wkv, bkv, wg, bg = att.packed("kv")
         kv = ops.linear(h, wkv, bkv, wgrad=wg, bgrad=bg)
-        ctx = ops.attention(q, kv, (0, 0, D), D, cx.H, seq_sel, key_mask=key_mask, causal=False, drop=cx.drop(cx.p_a))
+        ctx = ops.attention(q.to(kv.dtype), kv, (0, 0, D), D, cx.H, seq_sel, key_mask=key_mask, causal=False,
+                            drop=cx.drop(cx.p_a)).float()
         so = self.attention.output
         ao = ops.linear(ctx, so.dense.weight, so.dense.bias)
         x1 = ops.layernorm(ao, so.LayerNorm.weight, so.LayerNorm.bias, cx.eps, residual=hq, pre_drop=cx.drop(cx.p_h))
@@ -674,9 +676,12 @@ class StateAwareRecursiveTransformer(nn.Module):
     def _encode_clips(self, feats_flat, video_rows, ids_v, key_mask_v, seq, cx, cls_only=None):
         Lv = self.config.max_v_len
         ve = self.video_embeddings
+        # training forward at interior-only shapes: the clip-encoder activation stream lives in HBM as bf16
+        stream_bf16 = cls_only is not None and ops.bf16_stream_ok(video_rows.numel(), self.config.hidden_size,
+                                                                   self.config.video_feature_size, self.config.intermediate_size)
         h = ve.video_embeddings.run(feats_flat, cx.eps, src_rows=video_rows, drop=cx.drop(cx.p_h),
                                     add1=ve.position_embeddings_video.pe[:Lv].contiguous(), add1_mod=Lv,
-                                    add2=self.token_type_embeddings.weight, add2_idx=ids_v)
+                                    add2=self.token_type_embeddings.weight, add2_idx=ids_v, out_bf16=stream_bf16)
         if cls_only is not None:      # (cls_rows, one-query segmentation): last layer only for the [CLS] rows
             return self.encoder.run(h, seq, key_mask_v, cx, last_rows=cls_only[0], last_seq=cls_only[1])
         return self.encoder.run(h, seq, key_mask_v, cx)

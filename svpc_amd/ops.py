@@ -141,6 +141,20 @@ def get_precision():
     return _PRECISION
 
 
+# bf16 activation stream: in "bf16" precision the clip encoder may keep its activations (and their gradients) in HBM as
+# bf16 — half the bytes for every LayerNorm / attention / GEMM operand; statistics, softmax, accumulation and all parameter
+# gradients stay fp32.  Only interior-only shapes qualify (rows % 128 == 0, feature dims % 128 == 0).
+BF16_STREAM = True
+
+
+def _dt(t):
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def bf16_stream_ok(rows, *dims):
+    return (_PRECISION == "bf16" and BF16_STREAM and rows % 128 == 0 and rows > 0 and all(d % 128 == 0 for d in dims))
+
+
 def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NONE, p=0.0, site=0, seed=None, accumulate=0):
     ws = _ws(C.device)
     ev = GEMM_TIMER.bracket(2.0 * M * N * K) if GEMM_TIMER is not None else None
@@ -166,7 +180,7 @@ def _colsum(x2d, idx=None, K=1, out=None, accumulate=0):
     if R == 0:
         return out
     ws = _ws(x2d.device)
-    _lib.call("bucket_colsum", _p(x2d), x2d.stride(0), _p(idx), R, Cc, K, _p(out), accumulate, _p(ws), _stream())
+    _lib.call("bucket_colsum_t", _p(x2d), _dt(x2d), x2d.stride(0), _p(idx), R, Cc, K, _p(out), accumulate, _p(ws), _stream())
     return out
 
 
@@ -197,7 +211,7 @@ class _Linear(Function):
         M, K = x.shape
         N = w.shape[1] if trans_w else w.shape[0]
         p, site, seed = _drop_args(drop)
-        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        y = torch.empty(M, N, dtype=x.dtype, device=x.device)
         z = torch.empty_like(y) if act == ACT_GELU else None
         _gemm(x, x.stride(0), 1, w, w.stride(0), 0 if trans_w else 1, y, M, N, K, Z=z, bias=b, act=act, p=p, site=site, seed=seed)
         ctx.save_for_backward(x, w, z if act == ACT_GELU else (y if act != ACT_NONE else None))
@@ -214,12 +228,13 @@ class _Linear(Function):
         dy = _c(dy)
         if act != ACT_NONE or p > 0.0:
             dz = torch.empty_like(dy)
-            _lib.call("act_bwd", _p(dy), _p(aux if aux is not None else dy), _p(dz), dy.numel(), act, p, site, _p(seed), _stream())
+            _lib.call("act_bwd_t", _p(dy), _p(aux if aux is not None else dy), _p(dz), _dt(dy), dy.numel(), act, p, site, _p(seed),
+                      _stream())
         else:
             dz = dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+            dx = torch.empty(M, K, dtype=x.dtype, device=dy.device)
             _gemm(dz, N, 1, w, w.stride(0), 1 if trans_w else 0, dx, M, K, N)
         wgrad, bgrad = ctx.direct
         if wgrad is not None or ctx.needs_input_grad[1]:
@@ -242,6 +257,10 @@ class _Linear(Function):
 
 
 def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgrad=None):
+    if x.dtype == torch.bfloat16:
+        n_out = w.shape[1] if trans_w else w.shape[0]
+        if trans_w or drop is not None or not bf16_stream_ok(x.shape[0], x.shape[1], n_out):
+            x = x.float()          # shapes outside the bf16-stream GEMM variants fall back to fp32 storage
     if wgrad is None:
         wgrad = _direct(w)
     if bgrad is None and b is not None:
@@ -252,7 +271,8 @@ def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgr
 # ------------------------------------------------------------------------------------------------ LayerNorm family
 class _LayerNorm(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, add2, eps, src_rows, pad_row, pre_drop, post_drop, add1, add1_mod, add2_idx):
+    def forward(ctx, x, gamma, beta, residual, add2, eps, src_rows, pad_row, pre_drop, post_drop, add1, add1_mod, add2_idx,
+                out_bf16=False):
         _need_gpu(x)
         ctx.direct = (_direct(gamma), _direct(beta), _direct(x) if src_rows is not None else None,
                       _direct(add2) if add2 is not None else None)
@@ -263,12 +283,15 @@ class _LayerNorm(Function):
         p_post, s_post, seed2 = _drop_args(post_drop)
         seed = seed1 if seed1 is not None else seed2
         residual = _c(residual) if residual is not None else None
-        y = torch.empty(R, D, dtype=torch.float32, device=x.device)
+        y_dtype = torch.bfloat16 if (out_bf16 or x.dtype == torch.bfloat16) else torch.float32
+        if residual is not None and residual.dtype != y_dtype:
+            residual = residual.to(y_dtype)
+        y = torch.empty(R, D, dtype=y_dtype, device=x.device)
         mean = torch.empty(R, dtype=torch.float32, device=x.device)
         rstd = torch.empty(R, dtype=torch.float32, device=x.device)
         add1 = _c(add1) if add1 is not None else None
-        _lib.call("ln_fwd", _p(x), _p(src_rows), _p(residual), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), R, D, float(eps),
-                  p_pre, s_pre, p_post, s_post, _p(seed), _p(add1), int(add1_mod), _p(add2), _p(add2_idx), _stream())
+        _lib.call("ln_fwd_t", _p(x), _dt(x), _p(src_rows), _p(residual), _p(gamma), _p(beta), _p(y), _dt(y), _p(mean), _p(rstd), R, D,
+                  float(eps), p_pre, s_pre, p_post, s_post, _p(seed), _p(add1), int(add1_mod), _p(add2), _p(add2_idx), _stream())
         ctx.save_for_backward(x, gamma, residual, mean, rstd, src_rows, add2_idx, seed)
         ctx.cfg = (R, D, p_pre, s_pre, p_post, s_post, pad_row, add2.shape[0] if add2 is not None else 0)
         return y
@@ -281,17 +304,19 @@ class _LayerNorm(Function):
         dev = dy.device
         need_x, need_res = ctx.needs_input_grad[0], (residual is not None and ctx.needs_input_grad[3])
         dh = dx_rows = None
-        if need_res or (need_x and p_pre <= 0.0):
-            dh = torch.empty(R, D, dtype=torch.float32, device=dev)
+        same_t = x.dtype == dy.dtype
+        if need_res or (need_x and p_pre <= 0.0 and same_t):
+            dh = torch.empty(R, D, dtype=dy.dtype, device=dev)
         if need_x:
-            dx_rows = dh if p_pre <= 0.0 else torch.empty(R, D, dtype=torch.float32, device=dev)
+            dx_rows = dh if (p_pre <= 0.0 and same_t) else torch.empty(R, D, dtype=x.dtype, device=dev)
         g_dir, b_dir, x_dir, a2_dir = ctx.direct
         direct_gb = g_dir is not None and b_dir is not None
         dgamma = g_dir if direct_gb else torch.empty(D, dtype=torch.float32, device=dev)
         dbeta = b_dir if direct_gb else torch.empty(D, dtype=torch.float32, device=dev)
         ws = _ws(dev)
-        _lib.call("ln_bwd", _p(dy), _p(x), _p(src_rows), _p(residual), _p(gamma), _p(mean), _p(rstd), _p(dh), _p(dx_rows),
-                  _p(dgamma), _p(dbeta), 1 if direct_gb else 0, _p(ws), R, D, p_pre, s_pre, p_post, s_post, _p(seed), _stream())
+        _lib.call("ln_bwd_t", _p(dy), _p(x), _dt(x), _dt(dy), _p(src_rows), _p(residual), _p(gamma), _p(mean), _p(rstd), _p(dh),
+                  _p(dx_rows), _p(dgamma), _p(dbeta), 1 if direct_gb else 0, _p(ws), R, D, p_pre, s_pre, p_post, s_post, _p(seed),
+                  _stream())
         if direct_gb:
             _ready(dgamma); _ready(dbeta)
             dgamma = dbeta = None
@@ -312,13 +337,13 @@ class _LayerNorm(Function):
                 _ready(a2_dir)
             else:
                 dadd2 = _colsum(dy, add2_idx, k_add2)
-        return dx, dgamma, dbeta, (dh if need_res else None), dadd2, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, (dh if need_res else None), dadd2, None, None, None, None, None, None, None, None, None
 
 
 def layernorm(x, gamma, beta, eps, residual=None, src_rows=None, pad_row=-1, pre_drop=None, post_drop=None,
-              add1=None, add1_mod=0, add2=None, add2_idx=None):
+              add1=None, add1_mod=0, add2=None, add2_idx=None, out_bf16=False):
     return _LayerNorm.apply(x, gamma, beta, residual, add2, eps, src_rows, pad_row, pre_drop, post_drop, add1, add1_mod,
-                            add2_idx)
+                            add2_idx, out_bf16)
 
 
 # ------------------------------------------------------------------------------------------------ attention
@@ -331,16 +356,24 @@ class _Attention(Function):
         kvt_c = qt if same else _rows2d(kvt)
         dh = D // H
         p, site, seed = _drop_args(drop)
-        out = torch.empty(seq.n_q_rows, D, dtype=torch.float32, device=qt.device)
+        if kvt_c.dtype != qt.dtype:
+            raise _lib.SvpcKernelError("attention: query and key/value tensors must have the same dtype")
+        out = torch.empty(seq.n_q_rows, D, dtype=qt.dtype, device=qt.device)
         lse = torch.empty(seq.n, H, seq.max_q, dtype=torch.float32, device=qt.device)
         tbl = seq.table if seq.table.device == qt.device else seq.table.to(qt.device)
-        es = 4
+        es = qt.element_size()
         qp, kp, vp = qt.data_ptr() + cols[0] * es, kvt_c.data_ptr() + cols[1] * es, kvt_c.data_ptr() + cols[2] * es
-        mfma = (_PRECISION == "bf16" and ((qp | kp | vp) & 15) == 0 and
+        mfma = (_PRECISION == "bf16" and ((qp | kp | vp) & (4 * es - 1)) == 0 and
                 _lib.load().svpc_attn_mfma_supported(dh, seq.max_q, seq.max_k, qt.stride(0), kvt_c.stride(0), kvt_c.stride(0)) == 1)
-        _lib.call("attn_mfma_fwd" if mfma else "attn_fwd", qp, qt.stride(0), kp, kvt_c.stride(0), vp, kvt_c.stride(0), _p(out), D,
-                  _p(lse), _p(tbl), seq.n, H, dh, seq.max_q, seq.max_k, _p(key_mask), 1 if causal else 0, 1.0 / math.sqrt(dh), p,
-                  site, _p(seed), _stream())
+        if mfma:
+            _lib.call("attn_mfma_fwd_t", qp, qt.stride(0), kp, kvt_c.stride(0), vp, kvt_c.stride(0), _p(out), D, _dt(qt), _p(lse),
+                      _p(tbl), seq.n, H, dh, seq.max_q, seq.max_k, _p(key_mask), 1 if causal else 0, 1.0 / math.sqrt(dh), p, site,
+                      _p(seed), _stream())
+        else:
+            if qt.dtype != torch.float32:
+                raise _lib.SvpcKernelError("attention: the bf16 stream needs the MFMA kernel (head dim 32/64, ≤128 rows)")
+            _lib.call("attn_fwd", qp, qt.stride(0), kp, kvt_c.stride(0), vp, kvt_c.stride(0), _p(out), D, _p(lse), _p(tbl), seq.n, H,
+                      dh, seq.max_q, seq.max_k, _p(key_mask), 1 if causal else 0, 1.0 / math.sqrt(dh), p, site, _p(seed), _stream())
         ctx.save_for_backward(qt, kvt_c, out, lse, key_mask, seed, tbl)
         ctx.cfg = (cols, D, H, seq.n, seq.max_q, seq.max_k, causal, p, site, same)
         ctx.mfma = mfma
@@ -365,10 +398,10 @@ class _Attention(Function):
         else:
             dq_t = covered(qt, D, n_q_rows)
             dkv_t = covered(kvt, 2 * D, n_k_rows)
-        es = 4
+        es = qt.element_size()
         if ctx.mfma:
-            _lib.call("attn_mfma_bwd", qt.data_ptr() + cols[0] * es, qt.stride(0), kvt.data_ptr() + cols[1] * es, kvt.stride(0),
-                      kvt.data_ptr() + cols[2] * es, kvt.stride(0), _p(out), D, _p(lse), _p(dO), D,
+            _lib.call("attn_mfma_bwd_t", qt.data_ptr() + cols[0] * es, qt.stride(0), kvt.data_ptr() + cols[1] * es, kvt.stride(0),
+                      kvt.data_ptr() + cols[2] * es, kvt.stride(0), _p(out), D, _dt(qt), _p(lse), _p(dO), D,
                       dq_t.data_ptr() + cols[0] * es, dq_t.stride(0), dkv_t.data_ptr() + cols[1] * es, dkv_t.stride(0),
                       dkv_t.data_ptr() + cols[2] * es, dkv_t.stride(0), _p(tbl), n, H, dh, max_q, max_k, _p(key_mask),
                       1 if causal else 0, 1.0 / math.sqrt(dh), p, site, _p(seed), _stream())

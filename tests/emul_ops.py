@@ -52,7 +52,7 @@ def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgr
 
 
 def layernorm(x, gamma, beta, eps, residual=None, src_rows=None, pad_row=-1, pre_drop=None, post_drop=None,
-              add1=None, add1_mod=0, add2=None, add2_idx=None):
+              add1=None, add1_mod=0, add2=None, add2_idx=None, out_bf16=False):
     h = x if src_rows is None else x[src_rows.long()]
     h = _apply_drop(h, pre_drop)
     if residual is not None:
@@ -325,3 +325,7 @@ def greedy_pick(scores, row_c, row_x, lt, pos, unk):
         mod.append(unk if i >= row_c[r] - row_x[r] else i)
     t = lambda v: torch.tensor(v, dtype=torch.int32, device=scores.device)
     return t(ext), t(mod)
+
+
+def bf16_stream_ok(rows, *dims):
+    return False

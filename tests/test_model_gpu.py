@@ -189,3 +189,52 @@ def test_graph_replay_equals_eager_training(golden_dir):
     assert all(np.isfinite(l_g)) and np.allclose(l_e, l_g, rtol=1e-4), (l_e, l_g)
     for n in p_e:
         assert torch.allclose(p_e[n], p_g[n], rtol=1e-4, atol=1e-6), n
+
+
+def test_bf16_activation_stream_close_to_fp32(golden_dir):
+    """Interior-only shape (clip rows % 128 == 0, dims % 128 == 0): the clip encoder keeps activations/gradients in bf16.
+    Stated tolerance vs the fp32 path on the same weights and inputs: loss ≤ 1e-2 relative, encoder weight gradients within
+    8 % of their max magnitude (bf16 rounding of operands; fp32 accumulation)."""
+    from svpc_amd import ops
+    from svpc_amd.model import StateAwareRecursiveTransformer
+    cfg = syn.make_config(model_type="vivt", hidden_size=128, num_hidden_layers=2, num_attention_heads=4, video_feature_size=128,
+                          vocab_size=50, word_vec_size=20, action_vocab_size=10, max_v_len=32, max_t_len=6, max_i_len=12)
+    torch.manual_seed(0)
+    model = StateAwareRecursiveTransformer(cfg)
+    g = torch.Generator().manual_seed(1)
+    for m in (model.ingredient_embeddings, model.text_embeddings):
+        m.set_pretrained_embedding(0.4 * torch.randn(50, 20, generator=g), freeze=False)
+    for m in (model.reasoner, model.recipe_reasoner):
+        m.set_pretrained_embedding(0.4 * torch.randn(10, 20, generator=g), freeze=False)
+    drawn = syn.draw_parameters(list(model.named_parameters()), seed=3)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(drawn[n])
+    model.to(DEV).eval()
+    batch = syn.make_batch(cfg, n_videos=2, max_steps=2, n_ingr=[3, 2], n_oov=[1, 0], seed=4, full_clips=False, device=DEV)
+    noise = [-torch.empty(2, 6, 50 + x).exponential_(generator=g).log().to(DEV) for x in (1, 0)]
+    model.gumbel_noise = noise
+    names = ["encoder.layer.0.attention.self.query.weight", "encoder.layer.0.output.dense.weight", "encoder.layer.1.attention.self.key.weight",
+             "video_embeddings.video_embeddings.2.weight", "video_embeddings.video_embeddings.0.weight", "token_type_embeddings.weight",
+             "encoder.layer.0.attention.output.LayerNorm.weight", "encoder.layer.0.hidden_intermediate.dense.bias"]
+    res = {}
+    for mode, stream in (("fp32", False), ("bf16", False), ("bf16", True)):
+        ops.set_precision(mode)
+        ops.BF16_STREAM = stream
+        try:
+            model.zero_grad()
+            loss = model(*syn.forward_args(batch))[0]
+            loss.backward()
+            res[(mode, stream)] = (loss.item(), {n: dict(model.named_parameters())[n].grad.clone() for n in names})
+        finally:
+            ops.set_precision("fp32")
+            ops.BF16_STREAM = True
+    ref_loss, ref_g = res[("fp32", False)]
+    for key in (("bf16", False), ("bf16", True)):
+        loss, gr = res[key]
+        assert abs(loss - ref_loss) <= 1e-2 * abs(ref_loss), (key, loss, ref_loss)
+        for n in names:
+            scale = ref_g[n].abs().max().item()
+            assert (gr[n] - ref_g[n]).abs().max().item() <= 0.08 * scale + 1e-4, (key, n)
+    # the stream really was bf16: results differ from the fp32-storage bf16-MFMA run
+    assert res[("bf16", True)][0] != res[("bf16", False)][0]
