@@ -32,26 +32,63 @@ constexpr int AT = 128;   // rows per image (max queries / keys)
 
 template <int DH> struct AImg { static constexpr int RS = DH * 2 + 16; static constexpr int BYTES = AT * RS; };
 
-// rows [0, len) of a (·, DH) matrix (fp32 or bf16 in HBM) → bf16 image (zero rows beyond len), optionally scaled
+// rows [0, len) of a (·, DH) matrix (fp32 or bf16 in HBM) → bf16 image (zero rows beyond len), optionally scaled.
+// All of a thread's loads are issued before the first conversion/LDS store (the staging is latency-, not bandwidth-bound);
+// ``stage_pair`` keeps two matrices in flight at once.
+template <int DH, typename T>
+struct RowStage {
+    static constexpr int UPR = DH / 4, NIT = AT * UPR / 256;
+    float4 raw[NIT];     // fp32: 4 values; bf16: 4 values in .x/.y (8 bytes)
+    __device__ __forceinline__ void load(const T* __restrict__ src, int ld, int len) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int u = threadIdx.x + 256 * it, row = u / UPR, c4 = u - row * UPR;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < len) {
+                if (sizeof(T) == 4) t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + 4 * c4);
+                else {
+                    const float2 h = *reinterpret_cast<const float2*>(reinterpret_cast<const __bf16*>(src) + (size_t)row * ld + 4 * c4);
+                    t.x = h.x; t.y = h.y;
+                }
+            }
+            raw[it] = t;
+        }
+    }
+    __device__ __forceinline__ void store(char* __restrict__ img, float scale) const {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int u = threadIdx.x + 256 * it, row = u / UPR, c4 = u - row * UPR;
+            bf16x4 b;
+            if (sizeof(T) == 4) {
+                b[0] = (__bf16)(raw[it].x * scale); b[1] = (__bf16)(raw[it].y * scale);
+                b[2] = (__bf16)(raw[it].z * scale); b[3] = (__bf16)(raw[it].w * scale);
+            } else {
+                union { float2 f; bf16x4 h; } cv;
+                cv.f = make_float2(raw[it].x, raw[it].y);
+                if (scale == 1.0f) b = cv.h;
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[j] = (__bf16)((float)cv.h[j] * scale);
+                }
+            }
+            *reinterpret_cast<bf16x4*>(img + row * AImg<DH>::RS + c4 * 8) = b;
+        }
+    }
+};
+template <int DH, typename T>
+__device__ __forceinline__ void stage_pair(char* imgA, const T* srcA, int ldA, int lenA, float scaleA,
+                                           char* imgB, const T* srcB, int ldB, int lenB, float scaleB) {
+    RowStage<DH, T> a, b;
+    a.load(srcA, ldA, lenA);
+    b.load(srcB, ldB, lenB);
+    a.store(imgA, scaleA);
+    b.store(imgB, scaleB);
+}
 template <int DH, typename T>
 __device__ __forceinline__ void stage_rows(char* __restrict__ img, const T* __restrict__ src, int ld, int len, float scale) {
-    constexpr int UPR = DH / 4;
-    for (int u = threadIdx.x; u < AT * UPR; u += 256) {
-        const int row = u / UPR, c4 = u - row * UPR;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (row < len) {
-            if (sizeof(T) == 4) {
-                const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + 4 * c4);
-                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            } else {
-                const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(src) + (size_t)row * ld + 4 * c4);
-                v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
-            }
-        }
-        bf16x4 b;
-        b[0] = (__bf16)(v[0] * scale); b[1] = (__bf16)(v[1] * scale); b[2] = (__bf16)(v[2] * scale); b[3] = (__bf16)(v[3] * scale);
-        *reinterpret_cast<bf16x4*>(img + row * AImg<DH>::RS + c4 * 8) = b;
-    }
+    RowStage<DH, T> a;
+    a.load(src, ld, len);
+    a.store(img, scale);
 }
 // one 32×32 accumulator tile → rows row0.. (valid below row_limit), columns col0..col0+31 of a row-major matrix.
 // bf16: sub-dword stores are slow, so lane pairs swap one value and each lane stores two adjacent columns as one dword.
@@ -109,7 +146,7 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 }
 
 template <int DH, typename T>
-__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(MAttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int IB = AImg<DH>::BYTES;
     char* Qs = smem; char* Ks = smem + IB; char* Vs = smem + 2 * IB;
@@ -117,9 +154,9 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(MAttnArgs a) {
     const int sh = blockIdx.x, s = sh / a.H, h = sh - s * a.H;
     const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
+    stage_pair<DH, T>(Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f,
+                      Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
     stage_rows<DH, T>(Qs, (const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale);
-    stage_rows<DH, T>(Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f);
-    stage_rows<DH, T>(Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
     for (int j = threadIdx.x; j < AT; j += 256)
         mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
     __syncthreads();
@@ -196,7 +233,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(MAttnArgs a) {
 }
 
 template <int DH, typename T>
-__global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MAttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   // 2 waves/SIMD: ≤ 256 registers, 2 workgroups per CU
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int IB = AImg<DH>::BYTES;
     char* Qs = smem; char* Ks = smem + IB; char* Vs = smem + 2 * IB; char* Ds = smem + 3 * IB;
@@ -206,10 +243,10 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(MAttnArgs a) {
     const int sh = blockIdx.x, s = sh / a.H, h = sh - s * a.H;
     const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
-    stage_rows<DH, T>(Qs, (const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale);
-    stage_rows<DH, T>(Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f);
-    stage_rows<DH, T>(Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
-    stage_rows<DH, T>(Ds, (const T*)a.dO + (size_t)q_off * a.lddo + h * DH, a.lddo, q_len, 1.0f);
+    stage_pair<DH, T>(Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f,
+                      Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
+    stage_pair<DH, T>(Qs, (const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale,
+                      Ds, (const T*)a.dO + (size_t)q_off * a.lddo + h * DH, a.lddo, q_len, 1.0f);
     for (int j = threadIdx.x; j < AT; j += 256) {
         mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
         lse[j] = j < q_len ? a.LSE[((size_t)s * a.H + h) * a.max_q + j] : 0.f;

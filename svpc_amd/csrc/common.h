@@ -55,18 +55,24 @@ __device__ __forceinline__ float block_max_256(float v, float* red) {
 }
 
 // ---- counter-based RNG (dropout masks, Gumbel noise) ---------------------------------------------
-// One 32-bit uniform per (seed, site, element index); recomputed in backward, never stored.
-__device__ __host__ __forceinline__ uint32_t svpc_hash32(u64 seed, uint32_t site, u64 idx) {
-    u64 z = seed + 0x9E3779B97F4A7C15ull * (u64)(site + 1) + idx * 0xD1B54A32D192ED03ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 32);
+// One uniform per (seed, site, element index); recomputed in backward, never stored.  The generator is a 32-bit
+// integer hash (lowbias32: 2 multiplies + 3 xor-shifts ≈ 8 VALU ops) — the dropout masks of the LayerNorm / attention kernels
+// are drawn per element inside HBM-bound kernels, so a 64-bit mixer would make them VALU-bound.
+__device__ __host__ __forceinline__ uint32_t svpc_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
 }
-// keep-probability 1-p; returns the multiplier (0 or 1/(1-p))
+__device__ __host__ __forceinline__ uint32_t svpc_hash32(u64 seed, uint32_t site, u64 idx) {
+    const uint32_t key = (uint32_t)(seed ^ (seed >> 32)) + (site + 1u) * 0x9E3779B9u;
+    const uint32_t hi = (uint32_t)(idx >> 32);
+    return svpc_mix32(((uint32_t)idx ^ key) + hi * 0x85EBCA6Bu);
+}
+// keep-probability 1-p (16-bit resolution); returns the multiplier (0 or 1/(1-p))
 __device__ __forceinline__ float drop_scale(u64 seed, uint32_t site, u64 idx, float p, float inv_keep) {
-    uint32_t thr = (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f);
-    return svpc_hash32(seed, site, idx) >= thr ? inv_keep : 0.0f;
+    const uint32_t thr = (uint32_t)(p * 65536.0f);
+    return (svpc_hash32(seed, site, idx) >> 16) >= thr ? inv_keep : 0.0f;
 }
 __device__ __forceinline__ float gumbel_noise(u64 seed, uint32_t site, u64 idx) {
     float u = ((float)svpc_hash32(seed, site, idx) + 0.5f) * (1.0f / 4294967296.0f);
