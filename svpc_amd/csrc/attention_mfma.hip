@@ -28,14 +28,14 @@ struct MAttnArgs {
     const void* dO; int lddo; void* dQ; int lddq; void* dK; int lddk; void* dV; int lddv;
 };
 
-constexpr int AT = 128;   // rows per image (max queries / keys)
+constexpr int AT_MAX = 128;   // rows per image: 128 (clip encoder) or 32 (22-token decoder, ≤12-step sequences, ≤3-slot memory)
 
-template <int DH> struct AImg { static constexpr int RS = DH * 2 + 16; static constexpr int BYTES = AT * RS; };
+template <int DH> struct AImg { static constexpr int RS = DH * 2 + 16; };
 
 // rows [0, len) of a (·, DH) matrix (fp32 or bf16 in HBM) → bf16 image (zero rows beyond len), optionally scaled.
 // All of a thread's loads are issued before the first conversion/LDS store (the staging is latency-, not bandwidth-bound);
 // ``stage_pair`` keeps two matrices in flight at once.
-template <int DH, typename T>
+template <int DH, typename T, int AT>
 struct RowStage {
     static constexpr int UPR = DH / 4, NIT = AT * UPR / 256;
     float4 raw[NIT];     // fp32: 4 values; bf16: 4 values in .x/.y (8 bytes)
@@ -75,18 +75,18 @@ struct RowStage {
         }
     }
 };
-template <int DH, typename T>
+template <int DH, typename T, int AT>
 __device__ __forceinline__ void stage_pair(char* imgA, const T* srcA, int ldA, int lenA, float scaleA,
                                            char* imgB, const T* srcB, int ldB, int lenB, float scaleB) {
-    RowStage<DH, T> a, b;
+    RowStage<DH, T, AT> a, b;
     a.load(srcA, ldA, lenA);
     b.load(srcB, ldB, lenB);
     a.store(imgA, scaleA);
     b.store(imgB, scaleB);
 }
-template <int DH, typename T>
+template <int DH, typename T, int AT>
 __device__ __forceinline__ void stage_rows(char* __restrict__ img, const T* __restrict__ src, int ld, int len, float scale) {
-    RowStage<DH, T> a;
+    RowStage<DH, T, AT> a;
     a.load(src, ld, len);
     a.store(img, scale);
 }
@@ -145,28 +145,28 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
     return r;
 }
 
-template <int DH, typename T>
+template <int DH, typename T, int AT>
 __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int IB = AImg<DH>::BYTES;
+    constexpr int IB = AT * AImg<DH>::RS, NTL = AT / 32;
     char* Qs = smem; char* Ks = smem + IB; char* Vs = smem + 2 * IB;
     float* mterm = reinterpret_cast<float*>(smem + 3 * IB);
     const int sh = blockIdx.x, s = sh / a.H, h = sh - s * a.H;
     const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
-    stage_pair<DH, T>(Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f,
-                      Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
-    stage_rows<DH, T>(Qs, (const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale);
+    stage_pair<DH, T, AT>(Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f,
+                          Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
+    stage_rows<DH, T, AT>(Qs, (const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale);
     for (int j = threadIdx.x; j < AT; j += 256)
         mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
     __syncthreads();
     const int q0 = 32 * wave;
-    if (q0 >= q_len) return;
+    if (q0 >= q_len || wave >= NTL) return;
     const int nkt = (k_len + 31) >> 5;
 
-    floatx16 st[4];
+    floatx16 st[NTL];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
+    for (int jt = 0; jt < NTL; ++jt) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) st[jt][e] = 0.f;
         if (jt < nkt) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
     const int q = q0 + l31;                 // this lane's query
     float mx = -INFINITY;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+    for (int jt = 0; jt < NTL; ++jt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int key = 32 * jt + acc_row(e, lane);
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+    for (int jt = 0; jt < NTL; ++jt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { const float p = expf(st[jt][e] - mx); st[jt][e] = p; sum += p; }
     sum += __shfl_xor(sum, 32, 64);
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[dt][e] = 0.f;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
+    for (int jt = 0; jt < NTL; ++jt) {
         if (jt < nkt) {
             float pv[16];
 #pragma unroll
@@ -232,10 +232,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
         store_tile<T>((T*)a.O + (size_t)q_off * a.ldo + h * DH, a.ldo, q0, q_len, 32 * dt, acc[dt], 1.0f, lane);
 }
 
-template <int DH, typename T>
+template <int DH, typename T, int AT>
 __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   // 2 waves/SIMD: ≤ 256 registers, 2 workgroups per CU
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int IB = AImg<DH>::BYTES;
+    constexpr int IB = AT * AImg<DH>::RS;
     char* Qs = smem; char* Ks = smem + IB; char* Vs = smem + 2 * IB; char* Ds = smem + 3 * IB;
     float* mterm = reinterpret_cast<float*>(smem + 4 * IB);
     float* lse = mterm + AT;
@@ -243,9 +243,9 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
     const int sh = blockIdx.x, s = sh / a.H, h = sh - s * a.H;
     const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
-    stage_pair<DH, T>(Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f,
-                      Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
-    stage_pair<DH, T>(Qs, (const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale,
+    stage_pair<DH, T, AT>(Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f,
+                          Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
+    stage_pair<DH, T, AT>(Qs, (const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale,
                       Ds, (const T*)a.dO + (size_t)q_off * a.lddo + h * DH, a.lddo, q_len, 1.0f);
     for (int j = threadIdx.x; j < AT; j += 256) {
         mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
@@ -368,37 +368,38 @@ static int mattn_set_lds(const void* fn, size_t bytes) {
 }
 static bool mattn_ok(int dh, int max_q, int max_k, int ldq, int ldk, int ldv, const void* Q, const void* K, const void* V, int dt) {
     const int al = dt ? 8 : 16;   // 4 elements per staging unit
-    return (dh == 64 || dh == 32) && max_q <= AT && max_k <= AT && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 &&
+    return (dh == 64 || dh == 32) && max_q <= AT_MAX && max_k <= AT_MAX && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 &&
            (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & (al - 1)) == 0;
 }
 
+template <typename T, int DH, int AT>
+static int mattn_fwd_go(const MAttnArgs& a, int n_blocks, hipStream_t stream) {
+    const size_t lds = 3 * (size_t)AT * AImg<DH>::RS + AT * sizeof(float);
+    int rc = mattn_set_lds((const void*)attn_mfma_fwd_kernel<DH, T, AT>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_mfma_fwd_kernel<DH, T, AT>), dim3(n_blocks), dim3(256), lds, stream, a);
+    return svpc_check_launch("attn_mfma_fwd");
+}
+template <typename T, int DH, int AT>
+static int mattn_bwd_go(const MAttnArgs& a, int n_blocks, hipStream_t stream) {
+    const size_t lds = 4 * (size_t)AT * AImg<DH>::RS + 3 * AT * sizeof(float);
+    int rc = mattn_set_lds((const void*)attn_mfma_bwd_kernel<DH, T, AT>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_mfma_bwd_kernel<DH, T, AT>), dim3(n_blocks), dim3(256), lds, stream, a);
+    return svpc_check_launch("attn_mfma_bwd");
+}
+// image height: 32 rows when every sequence has ≤ 32 queries and keys (decoder, step encoder, memory slots), else 128
 template <typename T>
 static int mattn_fwd_launch(const MAttnArgs& a, int dh, int n_blocks, hipStream_t stream) {
-    int rc;
-    if (dh == 64) {
-        const size_t lds = 3 * AImg<64>::BYTES + AT * sizeof(float);
-        rc = mattn_set_lds((const void*)attn_mfma_fwd_kernel<64, T>, lds); if (rc) return rc;
-        hipLaunchKernelGGL((attn_mfma_fwd_kernel<64, T>), dim3(n_blocks), dim3(256), lds, stream, a);
-    } else {
-        const size_t lds = 3 * AImg<32>::BYTES + AT * sizeof(float);
-        rc = mattn_set_lds((const void*)attn_mfma_fwd_kernel<32, T>, lds); if (rc) return rc;
-        hipLaunchKernelGGL((attn_mfma_fwd_kernel<32, T>), dim3(n_blocks), dim3(256), lds, stream, a);
-    }
-    return svpc_check_launch("attn_mfma_fwd");
+    const bool small = a.max_q <= 32 && a.max_k <= 32;
+    if (dh == 64) return small ? mattn_fwd_go<T, 64, 32>(a, n_blocks, stream) : mattn_fwd_go<T, 64, 128>(a, n_blocks, stream);
+    return small ? mattn_fwd_go<T, 32, 32>(a, n_blocks, stream) : mattn_fwd_go<T, 32, 128>(a, n_blocks, stream);
 }
 template <typename T>
 static int mattn_bwd_launch(const MAttnArgs& a, int dh, int n_blocks, hipStream_t stream) {
-    int rc;
-    if (dh == 64) {
-        const size_t lds = 4 * AImg<64>::BYTES + 3 * AT * sizeof(float);
-        rc = mattn_set_lds((const void*)attn_mfma_bwd_kernel<64, T>, lds); if (rc) return rc;
-        hipLaunchKernelGGL((attn_mfma_bwd_kernel<64, T>), dim3(n_blocks), dim3(256), lds, stream, a);
-    } else {
-        const size_t lds = 4 * AImg<32>::BYTES + 3 * AT * sizeof(float);
-        rc = mattn_set_lds((const void*)attn_mfma_bwd_kernel<32, T>, lds); if (rc) return rc;
-        hipLaunchKernelGGL((attn_mfma_bwd_kernel<32, T>), dim3(n_blocks), dim3(256), lds, stream, a);
-    }
-    return svpc_check_launch("attn_mfma_bwd");
+    const bool small = a.max_q <= 32 && a.max_k <= 32;
+    if (dh == 64) return small ? mattn_bwd_go<T, 64, 32>(a, n_blocks, stream) : mattn_bwd_go<T, 64, 128>(a, n_blocks, stream);
+    return small ? mattn_bwd_go<T, 32, 32>(a, n_blocks, stream) : mattn_bwd_go<T, 32, 128>(a, n_blocks, stream);
 }
 
 extern "C" {
