@@ -233,9 +233,11 @@ def main():
     torch.cuda.synchronize()
     # roofline leg: HIP events around the encoder-sized GEMM launches.  Eager mode: inside the timed region.  Graph mode: events
     # cannot be recorded inside a replay, so the same kernels are bracketed in instrumented eager steps right after it.
-    big = 2.0 * (args.batch * args.clips * cfg.max_v_len) * cfg.hidden_size * cfg.hidden_size * 0.99
+    # Dominant kernel = the encoder projection GEMM: (T·Lv) × D × D, NT layout (attention output / FFN-in / FFN-out forward).
+    rows_enc = args.batch * args.clips * cfg.max_v_len
+    dom_shape = (rows_enc, cfg.hidden_size, cfg.hidden_size, 1, 1)
     if graph is None:
-        ops.GEMM_TIMER = ops.KernelTimer(min_flops=big)
+        ops.GEMM_TIMER = ops.KernelTimer(shape=dom_shape)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -247,7 +249,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if graph is not None:
-        ops.GEMM_TIMER = ops.KernelTimer(min_flops=big)
+        ops.GEMM_TIMER = ops.KernelTimer(shape=dom_shape)
         for _ in range(3):
             eager_step()
         torch.cuda.synchronize()
@@ -262,6 +264,12 @@ def main():
     if rank == 0:
         ms = 1000.0 * elapsed / args.steps
         achieved = gsum["work"] / (gsum["ms"] * 1e-3) / 1e12 if gsum["ms"] > 0 else 0.0
+        bf16_stream = args.precision == "bf16" and ops.bf16_stream_ok(rows_enc, cfg.hidden_size, cfg.video_feature_size)
+        el = 2 if bf16_stream else 4
+        alg_bytes = rows_enc * cfg.hidden_size * el * 2 + cfg.hidden_size * cfg.hidden_size * 4     # A + C (+ fp32 W)
+        # HBM traffic per launch from rocprofv3 PMC passes on this exact launch (profiles/r01_c_pmc_gemm_19200x768x768_bf16.csv):
+        # FETCH_SIZE 34,187 KB × 2 (gfx950 reports half of a 16-B/lane stream) + WRITE_SIZE 28,800 KB.  Only valid for that shape.
+        traffic = (2 * 34187 + 28800) * 1024 if (dom_shape == (19200, 768, 768, 1, 1) and bf16_stream) else None
         out = {
             "metric": "train steps/sec (vivt, batch=16, clip_seq=12)", "value": world * args.steps / elapsed,
             "unit": "steps/s (one step = 16 clip-sequences per GPU; whole-job aggregate)", "n_gpus": world, "steps": args.steps,
@@ -274,10 +282,13 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
                        "host_enqueue_ms_per_step": host_enqueue_ms,
                        "launch": "hipGraph replay" if graph is not None else "eager"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_%s_kernel<128,128> (encoder-sized GEMMs: M>=%d)" % (args.precision, args.batch * args.clips * cfg.max_v_len),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<128,128,NT> C[%d,%d] = A[%d,%d]·W[%d,%d]^T (encoder projection / FFN forward)"
+                                   % (rows_enc, cfg.hidden_size, rows_enc, cfg.hidden_size, cfg.hidden_size, cfg.hidden_size),
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS[args.precision],
-                         "traffic": None, "launches": gsum["launches"], "avg_launch_ms": gsum["ms"] / max(1, gsum["launches"]),
+                         "traffic": traffic, "algorithmic_flop_per_launch": 2.0 * rows_enc * cfg.hidden_size * cfg.hidden_size,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "launches": gsum["launches"], "avg_launch_ms": gsum["ms"] / max(1, gsum["launches"]),
                          "measured": "HIP events on the launch stream, " + ("3 instrumented eager steps after the timed graph replays"
                                                                             if graph is not None else "inside the timed region")},
         }
