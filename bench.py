@@ -25,6 +25,7 @@ from svpc_amd import StateAwareRecursiveTransformer, make_batch, make_config  # 
 from svpc_amd import ops, synthetic as syn  # noqa: E402
 from svpc_amd.optim import FusedBertAdam, GradReducer  # noqa: E402
 
+PMC_TRAFFIC_BYTES = 205654105   # (2·FETCH_SIZE + WRITE_SIZE)·1024, means per launch of the dominant symbol: profiles/r01_c_pmc_bench_dominant_gemm.csv
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense peaks (f32-in MFMA; bf16 MFMA)
 
 
@@ -233,11 +234,18 @@ def main():
     torch.cuda.synchronize()
     # roofline leg: HIP events around the encoder-sized GEMM launches.  Eager mode: inside the timed region.  Graph mode: events
     # cannot be recorded inside a replay, so the same kernels are bracketed in instrumented eager steps right after it.
-    # Dominant kernel = the encoder projection GEMM: (T·Lv) × D × D, NT layout (attention output / FFN-in / FFN-out forward).
+    # Dominant kernel = the forward GEMM of the clip encoder: ONE kernel symbol (gemm_bf16_kernel<128,128,NT,interior,8 waves,
+    # bf16 A, fp32 W, bf16 C>) covering Q/K/V, attention-output, FFN-in/out projections and the video embedding — every launch
+    # of that symbol is bracketed, so the average can be checked against rocprofv3's per-kernel average.
     rows_enc = args.batch * args.clips * cfg.max_v_len
-    dom_shape = (rows_enc, cfg.hidden_size, cfg.hidden_size, 1, 1)
+    bf16_stream = args.precision == "bf16" and ops.bf16_stream_ok(rows_enc, cfg.hidden_size, cfg.video_feature_size)
+    want_dt = (1, 0, 1) if bf16_stream else (0, 0, 0)
+
+    def dom_select(d):
+        M_, N_, K_, akc, bkc, adt, bdt, cdt = d
+        return M_ == rows_enc and akc == 1 and bkc == 1 and (adt, bdt, cdt) == want_dt
     if graph is None:
-        ops.GEMM_TIMER = ops.KernelTimer(shape=dom_shape)
+        ops.GEMM_TIMER = ops.KernelTimer(select=dom_select)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -249,7 +257,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if graph is not None:
-        ops.GEMM_TIMER = ops.KernelTimer(shape=dom_shape)
+        ops.GEMM_TIMER = ops.KernelTimer(select=dom_select)
         for _ in range(3):
             eager_step()
         torch.cuda.synchronize()
@@ -264,12 +272,16 @@ def main():
     if rank == 0:
         ms = 1000.0 * elapsed / args.steps
         achieved = gsum["work"] / (gsum["ms"] * 1e-3) / 1e12 if gsum["ms"] > 0 else 0.0
-        bf16_stream = args.precision == "bf16" and ops.bf16_stream_ok(rows_enc, cfg.hidden_size, cfg.video_feature_size)
         el = 2 if bf16_stream else 4
-        alg_bytes = rows_enc * cfg.hidden_size * el * 2 + cfg.hidden_size * cfg.hidden_size * 4     # A + C (+ fp32 W)
-        # HBM traffic per launch from rocprofv3 PMC passes on this exact launch (profiles/r01_c_pmc_gemm_19200x768x768_bf16.csv):
-        # FETCH_SIZE 34,187 KB × 2 (gfx950 reports half of a 16-B/lane stream) + WRITE_SIZE 28,800 KB.  Only valid for that shape.
-        traffic = (2 * 34187 + 28800) * 1024 if (dom_shape == (19200, 768, 768, 1, 1) and bf16_stream) else None
+        D_, F_, L_ = cfg.hidden_size, cfg.video_feature_size, cfg.num_hidden_layers
+        # launches of the symbol per step: per full layer Q/K/V (N=3D), attention-out, FFN-in, FFN-out; last layer K/V only; video embed
+        shapes = [(3 * D_, D_), (D_, D_), (D_, D_), (D_, D_)] * (L_ - 1) + [(2 * D_, D_), (D_, F_)]
+        alg_bytes = sum(rows_enc * (k + n) * el + n * k * 4 for n, k in shapes) / len(shapes)
+        alg_flop = sum(2.0 * rows_enc * n * k for n, k in shapes) / len(shapes)
+        # mean HBM traffic per launch of this symbol from rocprofv3 PMC passes over this very command (profiles/r01_c_pmc_bench_*.csv):
+        # FETCH_SIZE × 2 (gfx950 reports half of a 16-B/lane stream) + WRITE_SIZE, in KB.  Only valid for the default workload.
+        default_cfg = (args.batch, args.clips, L_, D_, F_, args.model_type) == (16, 12, 6, 768, 3072, "vivt") and bf16_stream
+        traffic = PMC_TRAFFIC_BYTES if default_cfg else None
         out = {
             "metric": "train steps/sec (vivt, batch=16, clip_seq=12)", "value": world * args.steps / elapsed,
             "unit": "steps/s (one step = 16 clip-sequences per GPU; whole-job aggregate)", "n_gpus": world, "steps": args.steps,
@@ -282,12 +294,11 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
                        "host_enqueue_ms_per_step": host_enqueue_ms,
                        "launch": "hipGraph replay" if graph is not None else "eager"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<128,128,NT> C[%d,%d] = A[%d,%d]·W[%d,%d]^T (encoder projection / FFN forward)"
-                                   % (rows_enc, cfg.hidden_size, rows_enc, cfg.hidden_size, cfg.hidden_size, cfg.hidden_size),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<128,128,NT,interior,8 waves,%s> — all clip-encoder forward GEMMs "
+                                   "(M=%d rows; Q/K/V, attention-out, FFN, video embedding)" % ("bf16·f32→bf16" if bf16_stream else "f32", rows_enc),
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS[args.precision],
-                         "traffic": traffic, "algorithmic_flop_per_launch": 2.0 * rows_enc * cfg.hidden_size * cfg.hidden_size,
-                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic": traffic, "algorithmic_flop_per_launch": alg_flop, "algorithmic_bytes_per_launch": alg_bytes,
                          "launches": gsum["launches"], "avg_launch_ms": gsum["ms"] / max(1, gsum["launches"]),
                          "measured": "HIP events on the launch stream, " + ("3 instrumented eager steps after the timed graph replays"
                                                                             if graph is not None else "inside the timed region")},

@@ -106,13 +106,13 @@ class KernelTimer:
     """Optional HIP-event bracket around launches of one kernel class (bench.py's roofline leg).  Events are
     recorded on the stream the kernel is launched on (PyTorch's current stream)."""
 
-    def __init__(self, min_flops=0.0, shape=None):
+    def __init__(self, min_flops=0.0, select=None):
         self.min_flops = min_flops
-        self.shape = shape  # optional exact (M, N, K, a_kc, b_kc) filter
-        self.records = []   # (work, start_event, end_event)
+        self.select = select  # optional predicate on (M, N, K, a_kc, b_kc, a_dt, b_dt, c_dt)
+        self.records = []     # (work, start_event, end_event)
 
-    def bracket(self, work, shape=None):
-        if work < self.min_flops or (self.shape is not None and shape != self.shape):
+    def bracket(self, work, desc=None):
+        if work < self.min_flops or (self.select is not None and not self.select(desc)):
             return None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.records.append((work, e0, e1))
@@ -158,7 +158,8 @@ def bf16_stream_ok(rows, *dims):
 
 def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NONE, p=0.0, site=0, seed=None, accumulate=0):
     ws = _ws(C.device)
-    ev = GEMM_TIMER.bracket(2.0 * M * N * K, (M, N, K, a_kc, b_kc)) if GEMM_TIMER is not None else None
+    ev = (GEMM_TIMER.bracket(2.0 * M * N * K, (M, N, K, a_kc, b_kc, _dt(A), _dt(B), _dt(C)))
+          if GEMM_TIMER is not None else None)
     if ev:
         ev[0].record()
     if _PRECISION == "bf16":
