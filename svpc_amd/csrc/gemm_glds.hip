@@ -1,0 +1,240 @@
+// bf16 × bf16 GEMM for the clip-encoder activation stream with DIRECT-TO-LDS operand staging (global_load_lds_dwordx4):
+// no staging registers, no conversion, no ds_write — the loads of three k-tiles stay in flight behind a counted vmcnt while the
+// matrix cores work on the current one (4-deep LDS ring, one raw s_barrier per k-tile).
+//
+//   C[M,N] = epi( sum_k A(m,k) · B(n,k) ),  A: a_kc ? [M][lda] : [K][lda],  B: b_kc ? [N][ldb] : [K][ldb]   (bf16, interior shapes)
+//
+// Tile 128×128×32, 512 threads = 8 waves (2×4), each wave 64×32 as two 32×32 v_mfma_f32_32x32x16_bf16 tiles.
+// One k-tile of one operand is 8 KiB = 8 wave-instructions of 1 KiB (64 lanes × 16 B, LDS destination = wave-uniform base
+// + lane·16); wave w issues instruction w of A and of B.  The LDS image is linear in that order; bank conflicts are removed by
+// permuting the 16-byte chunks on the SOURCE side (per-lane global address) and applying the same XOR on the read side:
+//   k-contiguous operand: [128 rows][64 B], chunk c of row r stored at c ^ ((r>>2)&3)      → ds_read_b128 fragments, conflict-free
+//   k-strided operand:    [32 k-rows][256 B], chunk c of k-row q stored at c ^ ((q&3)<<2)  → ds_read_b64_tr_b16 fragments
+// Weights come from the bf16 shadow arena the fused optimizer maintains next to the fp32 masters.
+#include "gemm_common.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+constexpr int GL_BM = 128, GL_BN = 128, GL_BK = 32;
+constexpr int GL_OP = 8192;                 // bytes of one operand tile
+constexpr int GL_STAGE = 2 * GL_OP;
+
+typedef const void __attribute__((address_space(1))) * gl_gptr;
+typedef void __attribute__((address_space(3))) * gl_lptr;
+
+template <bool KC>
+__device__ __forceinline__ const __bf16* glds_src(const __bf16* P, int ld, int m0, int k0, int wave, int lane, size_t& step) {
+    if (KC) {
+        const int row = 16 * wave + (lane >> 2), pos = lane & 3;
+        const int c = pos ^ ((row >> 2) & 3);
+        step = GL_BK;
+        return P + (size_t)(m0 + row) * ld + k0 + 8 * c;
+    } else {
+        const int krow = 4 * wave + (lane >> 4), pos = lane & 15;
+        const int c = pos ^ ((krow & 3) << 2);
+        step = (size_t)GL_BK * ld;
+        return P + (size_t)(k0 + krow) * ld + m0 + 8 * c;
+    }
+}
+
+// MFMA 32x32x16 operand fragment (rows row0..row0+31 of the tile, k-step ks) from a staged image
+template <bool KC>
+__device__ __forceinline__ bf16x8 glds_fragment(const char* __restrict__ img, int row0, int ks, int lane) {
+    if (KC) {
+        const int row = row0 + (lane & 31);
+        const int c = (2 * ks + (lane >> 5)) ^ ((row >> 2) & 3);
+        return *reinterpret_cast<const bf16x8*>(img + row * 64 + c * 16);
+    } else {
+        const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, h = g >> 1;
+        const int krow = ks * 16 + 8 * h + q;                       // (krow & 3) == q for both halves
+        const int col = row0 + 16 * (g & 1) + 4 * p;
+        const int off = (((col >> 3) ^ (q << 2)) << 4) + (col & 7) * 2;
+        typedef short4v __attribute__((address_space(3))) * lds_ptr;
+        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + krow * 256 + off));
+        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + (krow + 4) * 256 + off));
+        union { short s[8]; bf16x8 v; } u;
+        u.s[0] = lo[0]; u.s[1] = lo[1]; u.s[2] = lo[2]; u.s[3] = lo[3];
+        u.s[4] = hi[0]; u.s[5] = hi[1]; u.s[6] = hi[2]; u.s[7] = hi[3];
+        return u.v;
+    }
+}
+
+template <bool A_KC, bool B_KC, typename TC, int NS>
+__global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B, int ldb,
+                                                        TC* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_m,
+                                                        int tiles_n, int splitk, int k_chunk, float* __restrict__ slabs, int remap) {
+    __shared__ __attribute__((aligned(1024))) char smem[NS * GL_STAGE];
+    const int wg = remap ? xcd_remap(blockIdx.x, tiles_m * tiles_n * splitk) : (int)blockIdx.x;
+    const int ks_id = wg / (tiles_m * tiles_n);
+    const int tile = wg - ks_id * (tiles_m * tiles_n);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * GL_BM, n0 = tn * GL_BN;
+    const int k_begin = ks_id * k_chunk;
+    const int k_end = min(K, k_begin + k_chunk);
+    const int nk = (k_end - k_begin) / GL_BK;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+
+    size_t stepA, stepB;
+    const __bf16* ga = glds_src<A_KC>(A, lda, m0, k_begin, wave, lane, stepA);
+    const __bf16* gb = glds_src<B_KC>(B, ldb, n0, k_begin, wave, lane, stepB);
+    char* const my = smem + wave * 1024;        // this wave's 1-KiB slice inside an operand tile
+
+    floatx16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+#define GL_ISSUE(t)                                                                                                       \
+    do {                                                                                                                  \
+        char* st = my + ((t) % NS) * GL_STAGE;                                                                            \
+        __builtin_amdgcn_global_load_lds((gl_gptr)ga, (gl_lptr)st, 16, 0, 0);                                             \
+        __builtin_amdgcn_global_load_lds((gl_gptr)gb, (gl_lptr)(st + GL_OP), 16, 0, 0);                                   \
+        ga += stepA; gb += stepB;                                                                                         \
+    } while (0)
+
+    for (int t = 0; t < NS - 1 && t < nk; ++t) GL_ISSUE(t);
+
+    for (int t = 0; t < nk; ++t) {
+        // this wave's two loads of tile t have landed once at most 2·(tiles issued after t) remain outstanding
+        const int rem = nk - 1 - t;
+        if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();               // every wave's slice of tile t is in LDS; every wave is done with tile t-1
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + NS - 1 < nk) GL_ISSUE(t + NS - 1);  // refills the stage tile t-1 used
+        const char* sa = smem + (t % NS) * GL_STAGE;
+        const char* sb = sa + GL_OP;
+#pragma unroll
+        for (int ks = 0; ks < GL_BK / 16; ++ks) {
+            const bf16x8 b = glds_fragment<B_KC>(sb, wc * 32, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(glds_fragment<A_KC>(sa, wr * 64 + i * 32, ks, lane), b, acc[i], 0, 0, 0);
+        }
+    }
+#undef GL_ISSUE
+
+    const u64 seed = (epi.p_drop > 0.f && splitk == 1) ? epi.seed[0] : 0ull;
+    const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int col = n0 + wc * 32 + l31;
+    if (sizeof(TC) == 2 && splitk == 1 && epi.p_drop <= 0.f && !epi.accumulate) {
+        const bool odd = lane & 1;
+        const float bias = epi.bias ? epi.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const float z0 = acc[i][e] + bias, z1 = acc[i][e + 1] + bias;
+                const float y0 = apply_act(z0, epi.act), y1 = apply_act(z1, epi.act);
+                const float py = __shfl_xor(odd ? y0 : y1, 1, 64);
+                const float pz = __shfl_xor(odd ? z0 : z1, 1, 64);
+                const int row = m0 + wr * 64 + i * 32 + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2) + 4 * lhi;
+                const size_t o = (size_t)row * ldc + (col & ~1);
+                union { __bf16 h[2]; uint32_t u; } pk;
+                pk.h[0] = (__bf16)(odd ? py : y0); pk.h[1] = (__bf16)(odd ? y1 : py);
+                *reinterpret_cast<uint32_t*>(reinterpret_cast<__bf16*>(C) + o) = pk.u;
+                if (epi.Z) {
+                    pk.h[0] = (__bf16)(odd ? pz : z0); pk.h[1] = (__bf16)(odd ? z1 : pz);
+                    *reinterpret_cast<uint32_t*>(reinterpret_cast<__bf16*>(epi.Z) + o) = pk.u;
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+            if (splitk == 1) epilogue_store_t<TC>(acc[i][e], row, col, C, ldc, epi, seed, inv_keep);
+            else slabs[((size_t)ks_id * M + row) * N + col] = acc[i][e];
+        }
+}
+
+template <typename TC>
+__global__ __launch_bounds__(256) void glds_splitk_reduce_kernel(const float* __restrict__ slabs, int splitk, TC* __restrict__ C, int ldc,
+                                                                 int M, int N, Epi epi) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    const int row = (int)(i / N), col = (int)(i - (size_t)row * N);
+    float s = 0.f;
+    for (int k = 0; k < splitk; ++k) s += slabs[(size_t)k * M * N + i];
+    const u64 seed = epi.p_drop > 0.f ? epi.seed[0] : 0ull;
+    const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
+    epilogue_store_t<TC>(s, row, col, C, ldc, epi, seed, inv_keep);
+}
+
+extern "C" {
+
+// 1 if (shape, layout) can run on the direct-to-LDS kernel: bf16 A and B, interior-only, 16-byte aligned rows
+int svpc_gemm_glds_supported(int a_kc, int b_kc, int lda, int ldb, int M, int N, int K) {
+    return (M % GL_BM == 0 && N % GL_BN == 0 && K % GL_BK == 0 && M > 0 && N > 0 && K > 0 && lda % 8 == 0 && ldb % 8 == 0) ? 1 : 0;
+}
+
+// A, B bf16; C bf16 (c_dt = 1) or fp32 (c_dt = 0); Z (optional pre-activation copy) has C's type.
+int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int b_kc, void* C, int c_dt, int ldc, void* Z, int M, int N,
+                   int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate, float* workspace,
+                   size_t workspace_bytes, hipStream_t stream) {
+    if (M == 0 || N == 0) return 0;
+    SVPC_REQUIRE(svpc_gemm_glds_supported(a_kc, b_kc, lda, ldb, M, N, K) && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0,
+                 "gemm_glds: needs interior-only shapes (128 × 128 × 32) and 16-byte aligned bf16 rows");
+    SVPC_REQUIRE(p_drop <= 0.f || seed != nullptr, "gemm: dropout needs a seed pointer");
+    Epi epi{bias, act, p_drop, site, seed, accumulate, (float*)Z};
+    const int tiles_m = M / GL_BM, tiles_n = N / GL_BN, tiles = tiles_m * tiles_n;
+    int splitk = 1;
+    if (K >= 512 && tiles < 256) {
+        splitk = ceil_div(512, tiles);
+        const int max_by_k = K / 256;
+        if (splitk > max_by_k) splitk = max_by_k;
+        if (splitk > 64) splitk = 64;
+        while (splitk > 1 && (size_t)splitk * M * N * sizeof(float) > workspace_bytes) --splitk;
+        if (splitk < 1) splitk = 1;
+    }
+    int k_chunk = ceil_div(ceil_div(K, splitk), GL_BK) * GL_BK;
+    while (splitk > 1 && K % k_chunk != 0) { --splitk; k_chunk = ceil_div(ceil_div(K, splitk), GL_BK) * GL_BK; }
+    splitk = ceil_div(K, k_chunk);
+    static int remap = -1;
+    if (remap < 0) { const char* e = getenv("SVPC_GEMM_REMAP"); remap = e ? atoi(e) : 1; }
+    dim3 grid(tiles * splitk), block(512);
+    static int ns = -1;
+    if (ns < 0) { const char* e = getenv("SVPC_GLDS_NS"); ns = e ? atoi(e) : 3;   // 3 stages = 48 KiB → 3 workgroups per CU (measured best) }
+#define GL_LAUNCH(AK, BKC, TC)                                                                                                       \
+    do {                                                                                                                             \
+        if (ns == 3)                                                                                                                 \
+            hipLaunchKernelGGL((gemm_glds_kernel<AK, BKC, TC, 3>), grid, block, 0, stream, (const __bf16*)A, lda, (const __bf16*)B, ldb, \
+                               (TC*)C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, workspace, remap);                      \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((gemm_glds_kernel<AK, BKC, TC, 4>), grid, block, 0, stream, (const __bf16*)A, lda, (const __bf16*)B, ldb, \
+                               (TC*)C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, workspace, remap);                      \
+    } while (0)
+    if (c_dt == 1) {
+        if (a_kc && b_kc) GL_LAUNCH(true, true, __bf16);
+        else if (a_kc && !b_kc) GL_LAUNCH(true, false, __bf16);
+        else if (!a_kc && b_kc) GL_LAUNCH(false, true, __bf16);
+        else GL_LAUNCH(false, false, __bf16);
+    } else {
+        if (a_kc && b_kc) GL_LAUNCH(true, true, float);
+        else if (a_kc && !b_kc) GL_LAUNCH(true, false, float);
+        else if (!a_kc && b_kc) GL_LAUNCH(false, true, float);
+        else GL_LAUNCH(false, false, float);
+    }
+#undef GL_LAUNCH
+    int rc = svpc_check_launch("gemm_glds");
+    if (rc) return rc;
+    if (splitk > 1) {
+        const size_t n = (size_t)M * N;
+        const dim3 g((unsigned)((n + 255) / 256));
+        if (c_dt == 0) hipLaunchKernelGGL(glds_splitk_reduce_kernel<float>, g, dim3(256), 0, stream, workspace, splitk, (float*)C, ldc, M, N, epi);
+        else hipLaunchKernelGGL(glds_splitk_reduce_kernel<__bf16>, g, dim3(256), 0, stream, workspace, splitk, (__bf16*)C, ldc, M, N, epi);
+        rc = svpc_check_launch("gemm_glds splitk reduce");
+    }
+    return rc;
+}
+
+}  // extern "C"

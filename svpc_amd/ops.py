@@ -146,6 +146,7 @@ def get_precision():
 # bf16 — half the bytes for every LayerNorm / attention / GEMM operand; statistics, softmax, accumulation and all parameter
 # gradients stay fp32.  Only interior-only shapes qualify (rows % 128 == 0, feature dims % 128 == 0).
 BF16_STREAM = True
+USE_GLDS = True        # direct-to-LDS GEMM for bf16 × bf16 interior shapes
 
 
 def _dt(t):
@@ -162,7 +163,11 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NON
           if GEMM_TIMER is not None else None)
     if ev:
         ev[0].record()
-    if _PRECISION == "bf16":
+    if _PRECISION == "bf16" and USE_GLDS and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and \
+            _lib.load().svpc_gemm_glds_supported(a_kc, b_kc, lda, ldb, M, N, K) == 1:
+        _lib.call("gemm_glds", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), _dt(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
+                  _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+    elif _PRECISION == "bf16":
         dt = lambda t: 1 if t.dtype == torch.bfloat16 else 0
         _lib.call("gemm_mx", _p(A), dt(A), lda, a_kc, _p(B), dt(B), ldb, b_kc, _p(C), dt(C), C.stride(0), _p(Z), M, N, K, _p(bias),
                   act, p, site, _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())

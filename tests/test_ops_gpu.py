@@ -359,3 +359,21 @@ def test_gemm_mx_bf16_storage(bf16_mode, M, N, K, a_kc, b_kc, dts):
     O._gemm(Am, Am.stride(0), a_kc, Bm, Bm.stride(0), b_kc, C, M, N, K)
     tol = (1e-2 if dts[2] == "bf16" else 2e-6 * math.sqrt(K)) * max(1.0, ref.abs().max().item())
     assert (C.double() - ref).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("M,N,K,a_kc,b_kc,c_bf16", [
+    (128, 128, 32, 1, 1, False), (256, 768, 768, 1, 1, True), (19200, 768, 768, 1, 1, True), (256, 2304, 768, 1, 0, True),
+    (768, 2304, 19200, 0, 0, False), (128, 256, 4096, 0, 0, False), (256, 128, 1024, 0, 1, False), (384, 3072, 768, 1, 1, False)])
+def test_gemm_glds_direct_to_lds(bf16_mode, M, N, K, a_kc, b_kc, c_bf16):
+    """Direct-to-LDS bf16×bf16 GEMM (global_load_lds ring, source-side chunk swizzle, row and transposed fragments):
+    exact up to accumulation order for fp32 output, bf16 rounding for bf16 output; all four layouts, split-K."""
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    B = torch.randn(N, K, generator=g).bfloat16().to(DEV)
+    ref = A.double() @ B.double().t()
+    Am = A if a_kc else A.t().contiguous()
+    Bm = B if b_kc else B.t().contiguous()
+    C = torch.empty(M, N, device=DEV, dtype=torch.bfloat16 if c_bf16 else torch.float32)
+    O._gemm(Am, Am.stride(0), a_kc, Bm, Bm.stride(0), b_kc, C, M, N, K)
+    tol = (1e-2 if c_bf16 else 2e-6 * math.sqrt(K)) * max(1.0, ref.abs().max().item())
+    assert (C.double() - ref).abs().max().item() <= tol

@@ -33,4 +33,7 @@ if __name__ == "__main__":
             dts = (bf, bf, f) if (not a and not b) else (bf, f, bf)
             us2, tf2 = bench(M, N, K, a, b, prec, dts=dts)
             line += "   | bf16 storage: %8.1f us  %7.1f TFLOP/s" % (us2, tf2)
+            dts3 = (bf, bf, f) if (not a and not b) else (bf, bf, bf)
+            us3, tf3 = bench(M, N, K, a, b, prec, dts=dts3)
+            line += "   | glds (bf16 W): %8.1f us  %7.1f TFLOP/s" % (us3, tf3)
         print(line, flush=True)
