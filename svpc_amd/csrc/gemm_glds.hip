@@ -203,7 +203,7 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
     if (remap < 0) { const char* e = getenv("SVPC_GEMM_REMAP"); remap = e ? atoi(e) : 1; }
     dim3 grid(tiles * splitk), block(512);
     static int ns = -1;
-    if (ns < 0) { const char* e = getenv("SVPC_GLDS_NS"); ns = e ? atoi(e) : 3;   // 3 stages = 48 KiB → 3 workgroups per CU (measured best) }
+    if (ns < 0) { const char* e = getenv("SVPC_GLDS_NS"); ns = e ? atoi(e) : 3; }   // 3 stages = 48 KiB → 3 workgroups per CU (measured best)
 #define GL_LAUNCH(AK, BKC, TC)                                                                                                       \
     do {                                                                                                                             \
         if (ns == 3)                                                                                                                 \
