@@ -234,12 +234,14 @@ def main():
     torch.cuda.synchronize()
     # roofline leg: HIP events around the encoder-sized GEMM launches.  Eager mode: inside the timed region.  Graph mode: events
     # cannot be recorded inside a replay, so the same kernels are bracketed in instrumented eager steps right after it.
-    # Dominant kernel = the forward GEMM of the clip encoder: ONE kernel symbol (gemm_bf16_kernel<128,128,NT,interior,8 waves,
-    # bf16 A, fp32 W, bf16 C>) covering Q/K/V, attention-output, FFN-in/out projections and the video embedding — every launch
-    # of that symbol is bracketed, so the average can be checked against rocprofv3's per-kernel average.
+    # Dominant kernel = the forward GEMM of the clip encoder: ONE kernel symbol (gemm_glds_kernel<true,true,__bf16,3>: bf16
+    # activations × bf16 weight shadow → bf16, both operands direct-to-LDS) covering Q/K/V, attention-output, FFN-in/out
+    # projections and the video embedding — every launch of that symbol is bracketed, so the average can be checked against
+    # rocprofv3's per-kernel average.
     rows_enc = args.batch * args.clips * cfg.max_v_len
     bf16_stream = args.precision == "bf16" and ops.bf16_stream_ok(rows_enc, cfg.hidden_size, cfg.video_feature_size)
-    want_dt = (1, 0, 1) if bf16_stream else (0, 0, 0)
+    glds = bf16_stream and ops.USE_GLDS      # weights come from the optimizer's bf16 shadow → direct-to-LDS kernel
+    want_dt = ((1, 1, 1) if glds else (1, 0, 1)) if bf16_stream else (0, 0, 0)
 
     def dom_select(d):
         M_, N_, K_, akc, bkc, adt, bdt, cdt = d
@@ -276,12 +278,12 @@ def main():
         D_, F_, L_ = cfg.hidden_size, cfg.video_feature_size, cfg.num_hidden_layers
         # launches of the symbol per step: per full layer Q/K/V (N=3D), attention-out, FFN-in, FFN-out; last layer K/V only; video embed
         shapes = [(3 * D_, D_), (D_, D_), (D_, D_), (D_, D_)] * (L_ - 1) + [(2 * D_, D_), (D_, F_)]
-        alg_bytes = sum(rows_enc * (k + n) * el + n * k * 4 for n, k in shapes) / len(shapes)
+        alg_bytes = sum(rows_enc * (k + n) * el + n * k * (2 if glds else 4) for n, k in shapes) / len(shapes)
         alg_flop = sum(2.0 * rows_enc * n * k for n, k in shapes) / len(shapes)
         # mean HBM traffic per launch of this symbol from rocprofv3 PMC passes over this very command (profiles/r01_c_pmc_bench_*.csv):
         # FETCH_SIZE × 2 (gfx950 reports half of a 16-B/lane stream) + WRITE_SIZE, in KB.  Only valid for the default workload.
         default_cfg = (args.batch, args.clips, L_, D_, F_, args.model_type) == (16, 12, 6, 768, 3072, "vivt") and bf16_stream
-        traffic = PMC_TRAFFIC_BYTES if default_cfg else None
+        traffic = PMC_TRAFFIC_BYTES if (default_cfg and glds) else None
         out = {
             "metric": "train steps/sec (vivt, batch=16, clip_seq=12)", "value": world * args.steps / elapsed,
             "unit": "steps/s (one step = 16 clip-sequences per GPU; whole-job aggregate)", "n_gpus": world, "steps": args.steps,
@@ -294,8 +296,10 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
                        "host_enqueue_ms_per_step": host_enqueue_ms,
                        "launch": "hipGraph replay" if graph is not None else "eager"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<128,128,NT,interior,8 waves,%s> — all clip-encoder forward GEMMs "
-                                   "(M=%d rows; Q/K/V, attention-out, FFN, video embedding)" % ("bf16·f32→bf16" if bf16_stream else "f32", rows_enc),
+            "roofline": {"bound": "mfma", "kernel": "%s — all clip-encoder forward GEMMs (M=%d rows; Q/K/V, attention-out, FFN, "
+                                   "video embedding)" % ("gemm_glds_kernel<true,true,__bf16,3> (bf16·bf16→bf16, direct-to-LDS)" if glds else
+                                                         "gemm_bf16_kernel<128,128,NT,interior,8 waves,%s>" % ("bf16·f32→bf16" if bf16_stream else "f32"),
+                                                         rows_enc),
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS[args.precision],
                          "traffic": traffic, "algorithmic_flop_per_launch": alg_flop, "algorithmic_bytes_per_launch": alg_bytes,

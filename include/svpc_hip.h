@@ -176,7 +176,8 @@ int svpc_dropout_mask(float* out, size_t n, float p, unsigned site, const svpc_u
 int svpc_bump_seed(svpc_u64* seed, svpc_stream_t stream);
 
 /* ---- fused training-step tail: clip_grad_norm_ train.py:141-142, BertAdam optimization.py:284-331, EMA :196-203.
- *      meta = device array of {float* p,g,m,v,ema; long long n; float wd; int pad}; chunk tables built by the host. */
+ *      meta = device array of {float* p,g,m,v,ema; long long n; float wd; int pad; bf16* shadow (or NULL)}; chunk tables built by
+ *      the host.  shadow[i] = bf16(p[i]) is refreshed by the Adam kernel (operand storage of svpc_gemm_glds). */
 int svpc_opt_chunk(void);
 int svpc_opt_meta_bytes(void);
 int svpc_opt_step(const void* meta, const int* chunk_tid, const long long* chunk_start, const int* tensor_chunk_off, int n_tensors,

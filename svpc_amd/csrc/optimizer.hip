@@ -2,10 +2,11 @@
 // per-tensor clip to 1.0, m/v update without bias correction, decay added to the update, scheduled lr) → EMA
 // (optimization.py:196-203).  The ≈190 parameter tensors are walked through a chunk table (tensor id, offset) so the
 // whole step is 3 launches instead of ≈10³ eager ops; per-tensor and global norms are reduced in a fixed order.
-// HBM-bound: 4 reads + 3 writes of the parameter bytes (+2 with EMA).
+// HBM-bound: 4 reads + 3 writes of the parameter bytes (+2 with EMA, +½ for the bf16 weight shadow).
 #include "common.h"
 
-struct TensorMeta { float* p; float* g; float* m; float* v; float* ema; long long n; float wd; int pad; };
+// shadow: optional bf16 copy of the parameter (operand of the direct-to-LDS GEMMs), rewritten by the Adam kernel
+struct TensorMeta { float* p; float* g; float* m; float* v; float* ema; long long n; float wd; int pad; __bf16* shadow; };
 
 constexpr int OPT_CHUNK = 16384;
 
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(const TensorMeta* __restr
         if (t.wd > 0.f) upd += t.wd * p;
         p -= lr * upd;
         t.m[i] = m; t.v[i] = v; t.p[i] = p;
+        if (t.shadow) t.shadow[i] = (__bf16)p;
         if (t.ema && ema_decay >= 0.f) t.ema[i] = (1.f - ema_decay) * p + ema_decay * t.ema[i];
     }
 }

@@ -33,6 +33,7 @@ class GraphedTrainStep:
             self.loss = model(*forward_args)[0]
             self.loss.backward()
             optimizer.launch()
+        self._versions = optimizer.weights.versions()
 
     def _eager(self):
         self.opt.zero_grad()
@@ -42,6 +43,10 @@ class GraphedTrainStep:
         return loss
 
     def __call__(self):
+        v = self.opt.weights.versions()
+        if v != self._versions:          # parameters were edited from Python (load_state_dict …): re-cast the bf16 shadow
+            self.opt.weights.refresh()
+            self._versions = self.opt.weights.versions()
         self.opt.set_hyper()
         self.graph.replay()
         self.opt.step_count += 1

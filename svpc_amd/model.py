@@ -125,13 +125,24 @@ class BertSelfAttention(nn.Module):
         self.query, self.key, self.value = nn.Linear(D, D), nn.Linear(D, D), nn.Linear(D, D)
 
     def packed(self, which="qkv"):
-        """Packed projection weight/bias (+ the packed views of their gradients inside the optimizer's arena, when built)."""
+        """Packed projection → (weight, bias, weight-grad view, bias-grad view, bf16 weight shadow).
+
+        Once the parameters live in a ``WeightStore`` (built by the fused optimizer, or ``WeightStore.for_model`` for
+        inference) weight / bias / shadow are views of its contiguous [Wq Wk Wv | bq bk bv] block; the gradient views come
+        from the optimizer's arena.  Before that the weights are concatenated and autograd splits the gradient."""
+        qw = self.query.weight
+        pg = getattr(qw, "_svpc_packed", None)
+        wg, bg = pg[which] if pg is not None and which in pg else (None, None)
+        pw = getattr(qw, "_svpc_packed_w", None)
+        if pw is not None and which in pw and (wg is not None or not torch.is_grad_enabled()):
+            for p in qw._svpc_packed_w_members[:3]:
+                ops._shadow(p)
+            w, b, w16 = pw[which]
+            return w, b, wg, bg, w16
         mods = {"q": self.query, "k": self.key, "v": self.value}
         w = torch.cat([mods[c].weight for c in which], 0)
         b = torch.cat([mods[c].bias for c in which], 0)
-        pg = getattr(self.query.weight, "_svpc_packed", None)
-        wg, bg = pg[which] if pg is not None and which in pg else (None, None)
-        return w, b, wg, bg
+        return w, b, wg, bg, None
 
 
 class BertSelfOutput(nn.Module):
@@ -190,8 +201,8 @@ class BertLayerNoMemoryUntied(nn.Module):
 
     def run(self, h, seq, key_mask, cx):
         D = h.shape[1]
-        w, b, wg, bg = self.attention.self.packed()
-        qkv = ops.linear(h, w, b, wgrad=wg, bgrad=bg)
+        w, b, wg, bg, w16 = self.attention.self.packed()
+        qkv = ops.linear(h, w, b, wgrad=wg, bgrad=bg, w16=w16)
         ctx = ops.attention(qkv, qkv, (0, D, 2 * D), D, cx.H, seq, key_mask=key_mask, causal=False, drop=cx.drop(cx.p_a))
         so = self.attention.output
         ao = ops.linear(ctx, so.dense.weight, so.dense.bias)
@@ -211,8 +222,8 @@ class BertLayerNoMemoryUntied(nn.Module):
         att = self.attention.self
         hq = ops.take_rows(h, sel_rows).float()      # the few selected rows leave the bf16 stream here (no-op in fp32 storage)
         q = ops.linear(hq, att.query.weight, att.query.bias)
-        wkv, bkv, wg, bg = att.packed("kv")
-        kv = ops.linear(h, wkv, bkv, wgrad=wg, bgrad=bg)
+        wkv, bkv, wg, bg, w16 = att.packed("kv")
+        kv = ops.linear(h, wkv, bkv, wgrad=wg, bgrad=bg, w16=w16)
         ctx = ops.attention(q.to(kv.dtype), kv, (0, 0, D), D, cx.H, seq_sel, key_mask=key_mask, causal=False,
                             drop=cx.drop(cx.p_a)).float()
         so = self.attention.output
@@ -264,15 +275,15 @@ class BertDecoderLayerNoMemoryUntied(nn.Module):
 
     def run(self, x, text_mask, mem, seq_self, seq_cross, mem_mask, cx):
         D = x.shape[1]
-        w, b, wg, bg = self.self_attention.packed()
-        qkv = ops.linear(x, w, b, wgrad=wg, bgrad=bg)
+        w, b, wg, bg, w16 = self.self_attention.packed()
+        qkv = ops.linear(x, w, b, wgrad=wg, bgrad=bg, w16=w16)
         sa = ops.attention(qkv, qkv, (0, D, 2 * D), D, cx.H, seq_self, key_mask=text_mask, causal=True,
                            drop=cx.drop(cx.p_a))
         x1 = ops.layernorm(sa, self.norm1.weight, self.norm1.bias, cx.eps, residual=x)
         ca_m = self.dec_enc_attention
         qc = ops.linear(x1, ca_m.query.weight, ca_m.query.bias)
-        wkv, bkv, wg, bg = ca_m.packed("kv")
-        kvc = ops.linear(mem, wkv, bkv, wgrad=wg, bgrad=bg)
+        wkv, bkv, wg, bg, w16 = ca_m.packed("kv")
+        kvc = ops.linear(mem, wkv, bkv, wgrad=wg, bgrad=bg, w16=w16)
         ca = ops.attention(qc, kvc, (0, 0, D), D, cx.H, seq_cross, key_mask=mem_mask, causal=False, drop=cx.drop(cx.p_a))
         x2 = ops.layernorm(ca, self.norm2.weight, self.norm2.bias, cx.eps, residual=x1)
         o = ops.linear(x2, self.output.dense.weight, self.output.dense.bias)

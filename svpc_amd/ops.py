@@ -164,7 +164,7 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NON
     if ev:
         ev[0].record()
     if _PRECISION == "bf16" and USE_GLDS and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and \
-            _lib.load().svpc_gemm_glds_supported(a_kc, b_kc, lda, ldb, M, N, K) == 1:
+            (A.data_ptr() | B.data_ptr()) % 16 == 0 and _lib.load().svpc_gemm_glds_supported(a_kc, b_kc, lda, ldb, M, N, K) == 1:
         _lib.call("gemm_glds", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), _dt(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
                   _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
     elif _PRECISION == "bf16":
@@ -209,12 +209,24 @@ def _ready(t, kind=None):
         GRAD_READY_HOOK(t.data_ptr(), t.numel(), kind)
 
 
+def _shadow(w):
+    """bf16 shadow of parameter ``w`` (svpc_amd.optim.WeightStore), re-cast first if ``w`` changed behind the store's back."""
+    s = getattr(w, "_svpc_bf16", None)
+    if s is None:
+        return None
+    if w._version != w._svpc_bf16_ver:
+        with torch.no_grad():
+            s.copy_(w.detach())
+        w._svpc_bf16_ver = w._version
+    return s
+
+
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, w, b, act, trans_w, drop, wgrad, bgrad):
+    def forward(ctx, x, w, b, act, trans_w, drop, wgrad, bgrad, w16):
         _need_gpu(x)
         x = _rows2d(x)
-        w = _c(w)
+        w = _c(w if w16 is None else w16)      # bf16 shadow: both GEMM operands stream straight into LDS
         M, K = x.shape
         N = w.shape[1] if trans_w else w.shape[0]
         p, site, seed = _drop_args(drop)
@@ -260,10 +272,10 @@ class _Linear(Function):
                 _ready(bgrad, "b")
             else:
                 db = _colsum(dz).view(-1)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgrad=None):
+def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgrad=None, w16=None):
     if x.dtype == torch.bfloat16:
         n_out = w.shape[1] if trans_w else w.shape[0]
         if trans_w or drop is not None or not bf16_stream_ok(x.shape[0], x.shape[1], n_out):
@@ -272,7 +284,12 @@ def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgr
         wgrad = _direct(w)
     if bgrad is None and b is not None:
         bgrad = _direct(b)
-    return _Linear.apply(x, w, b, act, trans_w, drop, wgrad, bgrad)
+    if x.dtype == torch.bfloat16 and USE_GLDS:
+        if w16 is None:
+            w16 = _shadow(w)
+    else:
+        w16 = None
+    return _Linear.apply(x, w, b, act, trans_w, drop, wgrad, bgrad, w16)
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm family

@@ -29,42 +29,129 @@ def warmup_linear(progress, warmup):
 
 class _Meta(ctypes.Structure):
     _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
-                ("ema", ctypes.c_void_p), ("n", ctypes.c_longlong), ("wd", ctypes.c_float), ("pad", ctypes.c_int)]
+                ("ema", ctypes.c_void_p), ("n", ctypes.c_longlong), ("wd", ctypes.c_float), ("pad", ctypes.c_int),
+                ("shadow", ctypes.c_void_p)]
+
+
+_QKV = {"query.weight": 0, "key.weight": 1, "value.weight": 2, "query.bias": 3, "key.bias": 4, "value.bias": 5}
+
+
+def _ordered(named_params):
+    """Keep registration order, but lay each attention block out as [Wq Wk Wv | bq bk bv] so the packed projection
+    ((3D, D) / (2D, D)) — weight, bf16 shadow and gradient alike — is one contiguous region a GEMM can use in place."""
+    first, keyed = {}, []
+    for i, (n, p) in enumerate(named_params):
+        for suf, k in _QKV.items():
+            if n.endswith("." + suf):
+                pre = n[:-len(suf)]
+                first.setdefault(pre, i)
+                keyed.append(((first[pre], k), n, p))
+                break
+        else:
+            keyed.append(((i, -1), n, p))
+    keyed.sort(key=lambda t: t[0])
+    return [(n, p) for _, n, p in keyed]
+
+
+def _layout(named_params):
+    named_params = _ordered(list(named_params))
+    names = [n for n, _ in named_params]
+    params = [p for _, p in named_params]
+    offsets, off = [], 0
+    for p in params:
+        offsets.append(off)
+        off += (p.numel() + 7) // 8 * 8          # keep every tensor 16-byte aligned, in the bf16 shadow too
+    return names, params, offsets, off
+
+
+def _packed_groups(names, params, offsets):
+    """→ [(query weight parameter, [6 member indices])] for every attention block laid out contiguously."""
+    idx = {n: i for i, n in enumerate(names)}
+    out = []
+    for n in names:
+        if not n.endswith(".query.weight"):
+            continue
+        pre = n[:-len("query.weight")]
+        need = [pre + s for s in ("query.weight", "key.weight", "value.weight", "query.bias", "key.bias", "value.bias")]
+        if not all(k in idx for k in need):
+            continue
+        ids = [idx[k] for k in need]
+        if ids != list(range(ids[0], ids[0] + 6)):
+            continue
+        D_out, D_in = params[ids[0]].shape
+        if (D_out * D_in) % 8 or D_out % 8:
+            continue
+        out.append((params[ids[0]], ids))
+    return out
+
+
+def _packed_views(flat, offsets, ids, D_out, D_in):
+    ow, ob = offsets[ids[0]], offsets[ids[3]]
+    return {
+        "qkv": (flat[ow:ow + 3 * D_out * D_in].view(3 * D_out, D_in), flat[ob:ob + 3 * D_out]),
+        "kv": (flat[offsets[ids[1]]:offsets[ids[1]] + 2 * D_out * D_in].view(2 * D_out, D_in),
+               flat[offsets[ids[4]]:offsets[ids[4]] + 2 * D_out]),
+        "q": (flat[ow:ow + D_out * D_in].view(D_out, D_in), flat[ob:ob + D_out]),
+    }
+
+
+class WeightStore:
+    """All parameters of a model in ONE contiguous fp32 buffer (``p.data`` re-pointed into it, attention blocks laid out
+    [Wq Wk Wv | bq bk bv]) plus a bf16 shadow of the same layout.
+
+    * the packed Q/K/V (and K/V) projection weights/biases are plain views — no concatenation per forward;
+    * the shadow is the B operand of the direct-to-LDS bf16 GEMMs (svpc_gemm_glds) in the bf16 activation stream; the
+      fused optimizer rewrites it in the Adam kernel, anything else that changes a parameter is caught through the
+      tensor version counter (``ops._shadow``) or refreshed wholesale with ``refresh()``.
+    """
+
+    def __init__(self, named_params, layout=None):
+        self.names, self.params, self.offsets, self.numel = layout if layout is not None else _layout(named_params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.shadow = torch.zeros(self.numel, dtype=torch.bfloat16, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                n = p.numel()
+                view = self.flat[o:o + n].view_as(p)
+                view.copy_(p.detach())
+                p.data = view
+                p._svpc_bf16 = self.shadow[o:o + n].view_as(p)
+        for q, ids in _packed_groups(self.names, self.params, self.offsets):
+            D_out, D_in = q.shape
+            fw = _packed_views(self.flat, self.offsets, ids, D_out, D_in)
+            sw = _packed_views(self.shadow, self.offsets, ids, D_out, D_in)
+            q._svpc_packed_w = {k: (fw[k][0], fw[k][1], sw[k][0]) for k in fw}
+            q._svpc_packed_w_members = [self.params[i] for i in ids]
+        self.refresh()
+
+    @classmethod
+    def for_model(cls, model):
+        """Inference-time use (no optimizer): adopt every parameter of ``model``."""
+        store = getattr(model, "_svpc_weight_store", None)
+        if store is None:
+            store = cls(list(model.named_parameters()))
+            model._svpc_weight_store = store
+        return store
+
+    def refresh(self):
+        """shadow ← bf16(weights) for the whole store (after load_state_dict, EMA swap, manual edits …)."""
+        with torch.no_grad():
+            self.shadow.copy_(self.flat)
+        for p in self.params:
+            p._svpc_bf16_ver = p._version
+
+    def versions(self):
+        return sum(p._version for p in self.params)
 
 
 class GradArena:
     """Contiguous fp32 gradient storage; ``p.grad`` of every member is a view into it."""
 
-    _QKV = {"query.weight": 0, "key.weight": 1, "value.weight": 2, "query.bias": 3, "key.bias": 4, "value.bias": 5}
-
-    @classmethod
-    def _ordered(cls, named_params):
-        """Keep registration order, but lay each attention block out as [Wq Wk Wv | bq bk bv] so the packed projection
-        gradient ((3D, D) / (2D, D)) is one contiguous arena region the wgrad GEMM can write in place."""
-        first, keyed = {}, []
-        for i, (n, p) in enumerate(named_params):
-            for suf, k in cls._QKV.items():
-                if n.endswith("." + suf):
-                    pre = n[:-len(suf)]
-                    first.setdefault(pre, i)
-                    keyed.append(((first[pre], k), n, p))
-                    break
-            else:
-                keyed.append(((i, -1), n, p))
-        keyed.sort(key=lambda t: t[0])
-        return [(n, p) for _, n, p in keyed]
-
     def __init__(self, named_params):
-        named_params = self._ordered(list(named_params))
-        self.names = [n for n, _ in named_params]
-        self.params = [p for _, p in named_params]
+        self.names, self.params, self.offsets, self.numel = _layout(named_params)
         dev = self.params[0].device
-        self.offsets, off = [], 0
-        for p in self.params:
-            self.offsets.append(off)
-            off += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
-        self.numel = off
-        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         for p, o in zip(self.params, self.offsets):
             view = self.flat[o:o + p.numel()].view_as(p)
             if p.grad is not None:
@@ -72,29 +159,13 @@ class GradArena:
             p.grad = view
             p._svpc_direct = True       # ops write this parameter's gradient in place from now on
         # packed views for the fused Q/K/V (and K/V) projections
-        idx = {n: i for i, n in enumerate(self.names)}
-        for n, i in idx.items():
-            if not n.endswith(".query.weight"):
-                continue
-            pre = n[:-len("query.weight")]
-            need = [pre + s for s in ("query.weight", "key.weight", "value.weight", "query.bias", "key.bias", "value.bias")]
-            if not all(k in idx for k in need):
-                continue
-            ids = [idx[k] for k in need]
-            if ids != list(range(ids[0], ids[0] + 6)):
-                continue
-            q = self.params[ids[0]]
+        for q, ids in _packed_groups(self.names, self.params, self.offsets):
             D_out, D_in = q.shape
-            if (D_out * D_in) % 4 or D_out % 4:
-                continue
-            ow, ob = self.offsets[ids[0]], self.offsets[ids[3]]
-            q._svpc_packed = {
-                "qkv": (self.flat[ow:ow + 3 * D_out * D_in].view(3 * D_out, D_in), self.flat[ob:ob + 3 * D_out]),
-                "kv": (self.flat[self.offsets[ids[1]]:self.offsets[ids[1]] + 2 * D_out * D_in].view(2 * D_out, D_in),
-                       self.flat[self.offsets[ids[4]]:self.offsets[ids[4]] + 2 * D_out]),
-                "q": (self.flat[ow:ow + D_out * D_in].view(D_out, D_in), self.flat[ob:ob + D_out]),
-            }
+            q._svpc_packed = _packed_views(self.flat, self.offsets, ids, D_out, D_in)
             q._svpc_packed_members = {"qkv": ids, "kv": [ids[1], ids[2], ids[4], ids[5]], "q": [ids[0], ids[3]]}
+
+    def layout(self):
+        return self.names, self.params, self.offsets, self.numel
 
     def zero(self):
         self.flat.zero_()
@@ -122,6 +193,8 @@ class FusedBertAdam:
         assert live, "no parameter received a gradient"
         self.arena = GradArena(live)
         dev = self.arena.flat.device
+        # parameters move into one contiguous buffer with the arena's layout, next to their bf16 shadow
+        self.weights = WeightStore(None, layout=self.arena.layout())
         self.m = torch.zeros_like(self.arena.flat)
         self.v = torch.zeros_like(self.arena.flat)
         self.ema = None
@@ -142,7 +215,7 @@ class FusedBertAdam:
             es = 4
             metas[i] = _Meta(p.data_ptr(), self.arena.flat.data_ptr() + o * es, self.m.data_ptr() + o * es,
                              self.v.data_ptr() + o * es, (self.ema.data_ptr() + o * es) if self.ema is not None else None,
-                             n, wd, 0)
+                             n, wd, 0, self.weights.shadow.data_ptr() + o * 2)
             for s in range(0, n, chunk):
                 chunk_tid.append(i)
                 chunk_start.append(s)
@@ -197,6 +270,20 @@ class FusedBertAdam:
         self.set_hyper()
         self.launch()
         self.step_count += 1
+
+    # -- EMA evaluation swap (optimization.py:205-216: assign the shadow weights for validation, resume afterwards)
+    def ema_assign(self):
+        assert self.ema is not None and self.arena is not None
+        self._backup = self.weights.flat.clone()
+        with torch.no_grad():
+            self.weights.flat.copy_(self.ema)
+        self.weights.refresh()
+
+    def ema_resume(self):
+        with torch.no_grad():
+            self.weights.flat.copy_(self._backup)
+        self._backup = None
+        self.weights.refresh()
 
     def grad_norm(self):
         """global gradient norm seen by the last step (device scalar, no sync)."""
@@ -257,7 +344,7 @@ class GradReducer:
 
     def _close(self, members):
         lo = min(self.arena.offsets[i] for i in members)
-        hi = max(self.arena.offsets[i] + (self.arena.params[i].numel() + 3) // 4 * 4 for i in members)
+        hi = max(self.arena.offsets[i] + (self.arena.params[i].numel() + 7) // 8 * 8 for i in members)
         self.buckets.append((lo, hi, list(members)))
 
     def reset(self):

@@ -44,7 +44,11 @@ def _act(z, act):
     return z
 
 
-def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgrad=None):
+def _shadow(w):
+    return None
+
+
+def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgrad=None, w16=None):
     z = x @ (w if trans_w else w.t())
     if b is not None:
         z = z + b

@@ -191,11 +191,8 @@ def test_graph_replay_equals_eager_training(golden_dir):
         assert torch.allclose(p_e[n], p_g[n], rtol=1e-4, atol=1e-6), n
 
 
-def test_bf16_activation_stream_close_to_fp32(golden_dir):
-    """Interior-only shape (clip rows % 128 == 0, dims % 128 == 0): the clip encoder keeps activations/gradients in bf16.
-    Stated tolerance vs the fp32 path on the same weights and inputs: loss ≤ 1e-2 relative, encoder weight gradients within
-    8 % of their max magnitude (bf16 rounding of operands; fp32 accumulation)."""
-    from svpc_amd import ops
+def _stream_model():
+    """small interior-only shape: clip rows % 128 == 0 and every feature dim % 128 == 0, so the bf16 stream engages"""
     from svpc_amd.model import StateAwareRecursiveTransformer
     cfg = syn.make_config(model_type="vivt", hidden_size=128, num_hidden_layers=2, num_attention_heads=4, video_feature_size=128,
                           vocab_size=50, word_vec_size=20, action_vocab_size=10, max_v_len=32, max_t_len=6, max_i_len=12)
@@ -214,6 +211,15 @@ def test_bf16_activation_stream_close_to_fp32(golden_dir):
     batch = syn.make_batch(cfg, n_videos=2, max_steps=2, n_ingr=[3, 2], n_oov=[1, 0], seed=4, full_clips=False, device=DEV)
     noise = [-torch.empty(2, 6, 50 + x).exponential_(generator=g).log().to(DEV) for x in (1, 0)]
     model.gumbel_noise = noise
+    return cfg, model, batch
+
+
+def test_bf16_activation_stream_close_to_fp32(golden_dir):
+    """Interior-only shape (clip rows % 128 == 0, dims % 128 == 0): the clip encoder keeps activations/gradients in bf16.
+    Stated tolerance vs the fp32 path on the same weights and inputs: loss ≤ 1e-2 relative, encoder weight gradients within
+    8 % of their max magnitude (bf16 rounding of operands; fp32 accumulation)."""
+    from svpc_amd import ops
+    cfg, model, batch = _stream_model()
     names = ["encoder.layer.0.attention.self.query.weight", "encoder.layer.0.output.dense.weight", "encoder.layer.1.attention.self.key.weight",
              "video_embeddings.video_embeddings.2.weight", "video_embeddings.video_embeddings.0.weight", "token_type_embeddings.weight",
              "encoder.layer.0.attention.output.LayerNorm.weight", "encoder.layer.0.hidden_intermediate.dense.bias"]
@@ -238,3 +244,56 @@ def test_bf16_activation_stream_close_to_fp32(golden_dir):
             assert (gr[n] - ref_g[n]).abs().max().item() <= 0.08 * scale + 1e-4, (key, n)
     # the stream really was bf16: results differ from the fp32-storage bf16-MFMA run
     assert res[("bf16", True)][0] != res[("bf16", False)][0]
+
+
+def test_weight_store_and_bf16_shadow():
+    """The fused optimizer moves the parameters into one contiguous buffer and keeps a bf16 shadow next to it (the B operand
+    of the direct-to-LDS GEMMs): packed Q/K/V views must equal the concatenation, the shadow must be bf16(p) bit-for-bit after
+    every Adam step, a Python-side edit must be caught by the version counter, the EMA swap must round-trip, and the training
+    step through the shadow must equal the one that converts the fp32 weights on the fly (same rounding, other kernel)."""
+    from svpc_amd import ops
+    from svpc_amd.optim import FusedBertAdam
+    losses = {}
+    for glds in (True, False):
+        cfg, model, batch = _stream_model()
+        opt = FusedBertAdam(list(model.named_parameters()), lr=1e-3, warmup=0.1, t_total=50, grad_clip=1.0, ema_decay=0.999)
+        ops.set_precision("bf16")
+        ops.USE_GLDS = glds
+        try:
+            ls = []
+            for it in range(3):
+                opt.zero_grad()
+                loss = model(*syn.forward_args(batch))[0]
+                loss.backward()
+                opt.step()
+                ls.append(loss.item())
+            losses[glds] = ls
+        finally:
+            ops.set_precision("fp32")
+            ops.USE_GLDS = True
+        st = opt.weights
+        assert torch.equal(st.shadow, st.flat.bfloat16())
+        att = model.encoder.layer[0].attention.self
+        w, b, wg, bg, w16 = att.packed("qkv")
+        assert torch.equal(w, torch.cat([att.query.weight, att.key.weight, att.value.weight], 0))
+        assert torch.equal(b, torch.cat([att.query.bias, att.key.bias, att.value.bias], 0))
+        assert torch.equal(w16, w.bfloat16()) and wg.shape == w.shape
+        wkv = att.packed("kv")[0]
+        assert torch.equal(wkv, torch.cat([att.key.weight, att.value.weight], 0))
+        for p in model.parameters():                 # every trained parameter now lives in the store
+            if p.grad is not None:
+                assert st.flat.data_ptr() <= p.data_ptr() < st.flat.data_ptr() + st.flat.numel() * 4
+        # Python-side edit → version counter → shadow re-cast on next use
+        with torch.no_grad():
+            att.key.weight.mul_(1.5)
+        assert not torch.equal(att.key.weight._svpc_bf16, att.key.weight.bfloat16())
+        w16 = att.packed("qkv")[4]
+        assert torch.equal(w16, torch.cat([att.query.weight, att.key.weight, att.value.weight], 0).bfloat16())
+        # EMA swap (optimization.py:205-216)
+        before = st.flat.clone()
+        opt.ema_assign()
+        assert torch.equal(st.flat, opt.ema) and torch.equal(st.shadow, opt.ema.bfloat16())
+        opt.ema_resume()
+        assert torch.equal(st.flat, before) and torch.equal(st.shadow, before.bfloat16())
+    for a, b in zip(losses[True], losses[False]):
+        assert abs(a - b) <= 2e-4 * abs(b), (losses)
