@@ -1,0 +1,280 @@
+// fp32-operand GEMM on the bf16 matrix cores with DIRECT-TO-LDS staging, for the latency-bound half of the train step
+// (decoder / text rows, step-level rows, simulator and LSTM projections, their dgrad and wgrad): these launches have
+// 12–800 tiles and 6–130 k-tiles, so what bounds them is the memory round trip per k-tile, not bandwidth or MFMA rate.
+//
+//   C[M,N] = epi( sum_k A(m,k) · B(n,k) ),  A: a_kc ? [M][lda] : [K][lda],  B: b_kc ? [N][ldb] : [K][ldb]   (fp32 in HBM)
+//
+// The fp32 tiles go global → LDS with global_load_lds_dwordx4 into a ring of NS stages, NS-1 k-tiles in flight behind a counted
+// vmcnt (no staging registers); they are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) when a wave builds its MFMA fragments, which
+// is the same rounding the register-staged kernel (gemm_bf16.hip) applies on its way into LDS — results are bit-identical.
+// Edges: rows past M / N are clamped to the last row (their products are never stored); K must be a multiple of 32.
+//
+// LDS images of one operand tile (R rows × 32 k, fp32):
+//   k-contiguous: [R][128 B], 16-byte chunk c of row r stored at c ^ ((r>>1)&7)   → 2 × ds_read_b128 per fragment, conflict-free
+//   k-strided:    [32 k-rows][R·4 B], linear                                     → 8 × ds_read_b32 per fragment, conflict-free
+#include "gemm_common.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef const void __attribute__((address_space(1))) * l32_gptr;
+typedef void __attribute__((address_space(3))) * l32_lptr;
+
+constexpr int L32_BK = 32;
+
+template <int N> __device__ __forceinline__ void l32_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Per-lane source pointer of wave-instruction `j` (1 KiB) of an operand tile whose first row is m0 and first k is k0.
+template <int R, bool KC>
+__device__ __forceinline__ const float* l32_src(const float* P, int ld, int m0, int rows, int k0, int j, int lane) {
+    if (KC) {
+        const int row = 8 * j + (lane >> 3), pos = lane & 7;
+        const int c = pos ^ ((row >> 1) & 7);
+        const int gr = min(m0 + row, rows - 1);
+        return P + (size_t)gr * ld + k0 + 4 * c;
+    } else {
+        constexpr int CPR = R / 4;                      // 16-byte chunks per k-row
+        const int krow = j * (64 / CPR) + lane / CPR, c = lane % CPR;
+        const int gm = min(m0 + 4 * c, rows - 4);       // rows % 4 == 0 (checked on the host)
+        return P + (size_t)(k0 + krow) * ld + gm;
+    }
+}
+
+// MFMA 32x32x16 operand fragment: row (row0 + lane&31), k = 16·ks + 8·(lane>>5) + 0..7, rounded to bf16
+template <int R, bool KC>
+__device__ __forceinline__ bf16x8 l32_fragment(const char* __restrict__ img, int row0, int ks, int lane) {
+    float f[8];
+    if (KC) {
+        const int row = row0 + (lane & 31), sw = (row >> 1) & 7;
+        const int c0 = 4 * ks + 2 * (lane >> 5);
+        const float4 lo = *reinterpret_cast<const float4*>(img + row * 128 + ((c0 ^ sw) << 4));
+        const float4 hi = *reinterpret_cast<const float4*>(img + row * 128 + (((c0 + 1) ^ sw) << 4));
+        f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+    } else {
+        const float* p = reinterpret_cast<const float*>(img) + (16 * ks + 8 * (lane >> 5)) * R + row0 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = p[j * R];
+    }
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)f[j];
+    return v;
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int NS>
+__global__ __launch_bounds__(256) void gemm_l32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                       float* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_m,
+                                                       int tiles_n, int splitk, int k_chunk, float* __restrict__ slabs, int remap) {
+    extern __shared__ __attribute__((aligned(1024))) char l32_smem[];
+    constexpr int A_BYTES = BM * L32_BK * 4, B_BYTES = BN * L32_BK * 4, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_PER_WAVE = BM / 32, B_PER_WAVE = BN / 32;          // wave-instructions per wave and k-tile (4 waves)
+    constexpr int P = A_PER_WAVE + B_PER_WAVE;
+    constexpr int TM = BM / 64, TN = BN / 64;                          // 32×32 MFMA tiles per wave (waves 2 × 2)
+    const int wg = remap ? xcd_remap(blockIdx.x, tiles_m * tiles_n * splitk) : (int)blockIdx.x;
+    const int ks_id = wg / (tiles_m * tiles_n);
+    const int tile = wg - ks_id * (tiles_m * tiles_n);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int k_begin = ks_id * k_chunk;
+    const int k_end = min(K, k_begin + k_chunk);
+    const int nk = (k_end - k_begin) / L32_BK;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const float* ga[A_PER_WAVE];
+    const float* gb[B_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) ga[i] = l32_src<BM, A_KC>(A, lda, m0, M, k_begin, wave * A_PER_WAVE + i, lane);
+#pragma unroll
+    for (int i = 0; i < B_PER_WAVE; ++i) gb[i] = l32_src<BN, B_KC>(B, ldb, n0, N, k_begin, wave * B_PER_WAVE + i, lane);
+    const size_t stepA = A_KC ? (size_t)L32_BK : (size_t)L32_BK * lda;
+    const size_t stepB = B_KC ? (size_t)L32_BK : (size_t)L32_BK * ldb;
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#define L32_ISSUE(t)                                                                                                              \
+    do {                                                                                                                          \
+        char* st = l32_smem + ((t) % NS) * STAGE;                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < A_PER_WAVE; ++i) {                                                                  \
+            __builtin_amdgcn_global_load_lds((l32_gptr)ga[i], (l32_lptr)(st + (wave * A_PER_WAVE + i) * 1024), 16, 0, 0);        \
+            ga[i] += stepA;                                                                                                       \
+        }                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < B_PER_WAVE; ++i) {                                                                  \
+            __builtin_amdgcn_global_load_lds((l32_gptr)gb[i], (l32_lptr)(st + A_BYTES + (wave * B_PER_WAVE + i) * 1024), 16, 0, 0); \
+            gb[i] += stepB;                                                                                                       \
+        }                                                                                                                         \
+    } while (0)
+
+    for (int t = 0; t < NS - 1 && t < nk; ++t) L32_ISSUE(t);
+
+    for (int t = 0; t < nk; ++t) {
+        // tile t has landed once at most P·(tiles issued after t) of this wave's loads are still outstanding
+        const int after = min(NS - 2, nk - 1 - t);
+        switch (after) {
+            case 0: l32_wait_vmcnt<0>(); break;
+            case 1: l32_wait_vmcnt<P>(); break;
+            case 2: l32_wait_vmcnt<2 * P>(); break;
+            case 3: l32_wait_vmcnt<(NS > 4 ? 3 * P : 0)>(); break;
+            case 4: l32_wait_vmcnt<(NS > 5 ? 4 * P : 0)>(); break;
+            case 5: l32_wait_vmcnt<(NS > 6 ? 5 * P : 0)>(); break;
+            default: l32_wait_vmcnt<(NS > 7 ? 6 * P : 0)>(); break;
+        }
+        __builtin_amdgcn_s_barrier();               // every wave's part of tile t is in LDS; every wave is done with tile t-1
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + NS - 1 < nk) L32_ISSUE(t + NS - 1); // refills the stage tile t-1 used
+        const char* sa = l32_smem + (t % NS) * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < L32_BK / 16; ++ks) {
+            bf16x8 bf[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = l32_fragment<BN, B_KC>(sb, wc * (BN / 2) + j * 32, ks, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const bf16x8 af = l32_fragment<BM, A_KC>(sa, wr * (BM / 2) + i * 32, ks, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+#undef L32_ISSUE
+
+    const u64 seed = (epi.p_drop > 0.f && splitk == 1) ? epi.seed[0] : 0ull;
+    const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
+    const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wc * (BN / 2) + j * 32 + l31;
+            if (col >= N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                if (row >= M) continue;
+                if (splitk == 1) epilogue_store(acc[i][j][e], row, col, C, ldc, epi, seed, inv_keep);
+                else slabs[((size_t)ks_id * M + row) * N + col] = acc[i][j][e];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void l32_splitk_reduce_kernel(const float* __restrict__ slabs, int splitk, float* __restrict__ C, int ldc,
+                                                                int M, int N, Epi epi) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    const int row = (int)(i / N), col = (int)(i - (size_t)row * N);
+    float s = 0.f;
+    for (int k = 0; k < splitk; ++k) s += slabs[(size_t)k * M * N + i];
+    const u64 seed = epi.p_drop > 0.f ? epi.seed[0] : 0ull;
+    const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
+    epilogue_store(s, row, col, C, ldc, epi, seed, inv_keep);
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int NS>
+static int l32_launch_one(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
+                          int K, Epi epi, int tiles_m, int tiles_n, int splitk, int k_chunk, float* slabs, int remap) {
+    constexpr int LDS = NS * (BM + BN) * L32_BK * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_l32_kernel<BM, BN, A_KC, B_KC, NS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { svpc_set_error("gemm_l32: cannot raise the dynamic LDS limit"); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_l32_kernel<BM, BN, A_KC, B_KC, NS>), grid, dim3(256), LDS, stream, A, lda, B, ldb, C, ldc, M, N, K, epi,
+                       tiles_m, tiles_n, splitk, k_chunk, slabs, remap);
+    return 0;
+}
+template <int BM, int BN, int NS>
+static int l32_launch(int a_kc, int b_kc, dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                      int M, int N, int K, Epi epi, int tiles_m, int tiles_n, int splitk, int k_chunk, float* slabs, int remap) {
+#define L32_ARGS grid, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, slabs, remap
+    if (a_kc && b_kc) return l32_launch_one<BM, BN, true, true, NS>(L32_ARGS);
+    if (a_kc) return l32_launch_one<BM, BN, true, false, NS>(L32_ARGS);
+    if (b_kc) return l32_launch_one<BM, BN, false, true, NS>(L32_ARGS);
+    return l32_launch_one<BM, BN, false, false, NS>(L32_ARGS);
+#undef L32_ARGS
+}
+
+extern "C" {
+
+// 1 if the fp32 direct-to-LDS kernel can run this (shape, layout): whole k-tiles, 16-byte aligned chunks, and for a k-strided
+// operand a row count that is a multiple of 4 (its 16-byte chunks run along the rows)
+int svpc_gemm_l32_supported(int a_kc, int b_kc, int lda, int ldb, int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % L32_BK != 0 || lda % 4 != 0 || ldb % 4 != 0) return 0;
+    if (!a_kc && (M % 4 != 0)) return 0;
+    if (!b_kc && (N % 4 != 0)) return 0;
+    return 1;
+}
+
+// 1 if this kernel is also the FASTER choice (measured on MI355X, tools/small_gemms.py sweep): grids below ≈300 128²-tiles
+// with a short k-loop.  Larger grids are bandwidth-bound, where the 8-wave register-staged kernel moves more bytes per CU;
+// long k-loops on few tiles want split-K slabs, which that kernel already does.
+int svpc_gemm_l32_preferred(int a_kc, int b_kc, int lda, int ldb, int M, int N, int K) {
+    if (!svpc_gemm_l32_supported(a_kc, b_kc, lda, ldb, M, N, K)) return 0;
+    const int t128 = ceil_div(M, 128) * ceil_div(N, 128);
+    return (t128 <= 300 && K < 2048) ? 1 : 0;
+}
+
+// Same contract as svpc_gemm_mx with fp32 A, B, C (reference: every nn.Linear / matmul of model.py that is not on the
+// clip-encoder bf16 stream — e.g. :620-663 decoder, :594-617 step-wise encoder, :742-823 simulator, :1017-1025 BiLSTM).
+int svpc_gemm_l32(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, int M, int N, int K,
+                  const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate, float* workspace,
+                  size_t workspace_bytes, hipStream_t stream) {
+    if (M == 0 || N == 0) return 0;
+    SVPC_REQUIRE(svpc_gemm_l32_supported(a_kc, b_kc, lda, ldb, M, N, K) && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0,
+                 "gemm_l32: needs K % 32 == 0 and 16-byte aligned fp32 rows");
+    SVPC_REQUIRE(p_drop <= 0.f || seed != nullptr, "gemm: dropout needs a seed pointer");
+    Epi epi{bias, act, p_drop, site, seed, accumulate, Z};
+    static int env_tile = -1, env_split = -1, remap = -1;
+    if (env_tile < 0) { const char* e = getenv("SVPC_L32_TILE"); env_tile = e ? atoi(e) : 0; }      // 128 | 64 (deep ring) | 65 (64, 4 stages)
+    if (env_split < 0) { const char* e = getenv("SVPC_L32_SPLITK"); env_split = e ? atoi(e) : 0; }
+    if (remap < 0) { const char* e = getenv("SVPC_GEMM_REMAP"); remap = e ? atoi(e) : 1; }
+    const int t128 = ceil_div(M, 128) * ceil_div(N, 128), t64 = ceil_div(M, 64) * ceil_div(N, 64);
+    // 64² tiles with a 4-stage ring (two workgroups per CU) were the fastest form for every small grid in the sweep; 128² tiles
+    // (one workgroup per CU) and the 8-stage ring stay selectable through SVPC_L32_TILE for experiments
+    int mode = (M >= 96 && N >= 96 && t128 > 300) ? 128 : 65;
+    (void)t64;
+    if (env_tile == 128 || env_tile == 64 || env_tile == 65) mode = env_tile;
+    const int BMN = mode == 128 ? 128 : 64;
+    const int tiles_m = ceil_div(M, BMN), tiles_n = ceil_div(N, BMN), tiles = tiles_m * tiles_n;
+    // split K only when the grid would leave most CUs idle AND every slice still has a long k-loop (a short loop is already
+    // covered by the ring: all of its tiles are in flight at once, so splitting only adds the reduce launch)
+    int splitk = 1;
+    if (tiles <= 128 && K >= 2048) {
+        splitk = 256 / tiles;
+        const int max_by_k = K / 512;
+        if (splitk > max_by_k) splitk = max_by_k;
+        if (splitk > 32) splitk = 32;
+    }
+    if (env_split > 0) splitk = env_split;
+    while (splitk > 1 && (size_t)splitk * M * N * sizeof(float) > workspace_bytes) --splitk;
+    if (splitk < 1) splitk = 1;
+    int k_chunk = ceil_div(ceil_div(K, splitk), L32_BK) * L32_BK;
+    splitk = ceil_div(K, k_chunk);
+    dim3 grid(tiles * splitk);
+    int rc;
+#define L32_ARGS a_kc, b_kc, grid, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, workspace, remap
+    if (mode == 128) rc = l32_launch<128, 128, 4>(L32_ARGS);
+    else if (mode == 64) rc = l32_launch<64, 64, 8>(L32_ARGS);
+    else rc = l32_launch<64, 64, 4>(L32_ARGS);
+#undef L32_ARGS
+    if (rc) return rc;
+    rc = svpc_check_launch("gemm_l32");
+    if (rc) return rc;
+    if (splitk > 1) {
+        const size_t n = (size_t)M * N;
+        hipLaunchKernelGGL(l32_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, workspace, splitk, C, ldc, M, N,
+                           epi);
+        rc = svpc_check_launch("gemm_l32 splitk reduce");
+    }
+    return rc;
+}
+
+}  // extern "C"

@@ -28,13 +28,75 @@ def _p(t):
 
 
 def _ws(device):
-    """One scratch arena per device (split-K slabs, reduction partials); ops on a stream use it one at a time."""
-    key = str(device)
+    """One scratch arena per (device, stream) (split-K slabs, reduction partials); ops on a stream use it one at a time."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
     w = _WS.get(key)
     if w is None:
         w = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
         _WS[key] = w
     return w
+
+
+# Side streams for parameter gradients: a weight / bias gradient written straight into the optimizer's arena has no consumer
+# until the optimizer (or the gradient all-reduce) runs, so its kernels are forked onto a side stream and run beside the
+# dgrad chain — the text-side and step-level launches occupy a fraction of the 256 CUs each.  A gradient always uses the same
+# side stream (accumulating launches stay ordered); the streams are joined at the end of backward (autograd callback), before a
+# gradient bucket is all-reduced, and before the optimizer kernels.  Inside a hipGraph capture the forks/joins become edges.
+SIDE_WGRAD = True
+_N_SIDE = 2
+_SIDE = {}
+_SIDE_DIRTY = []
+_JOIN_QUEUED = [False]
+
+
+def join_side():
+    """Make the current stream wait for every side stream that has gradient work in flight."""
+    _JOIN_QUEUED[0] = False
+    if _SIDE_DIRTY:
+        cur = torch.cuda.current_stream()
+        for st in _SIDE_DIRTY:
+            cur.wait_stream(st)
+        del _SIDE_DIRTY[:]
+
+
+class _side_of:
+    """``with _side_of(grad, dz, x):`` — launches inside run on the side stream that owns arena gradient ``grad``; the listed
+    tensors are produced on the current stream and read there."""
+
+    def __init__(self, grad, *tensors):
+        self.on = SIDE_WGRAD and grad is not None and grad.is_cuda
+        if not self.on:
+            return
+        dev = grad.device
+        pool = _SIDE.get(dev)
+        if pool is None:
+            pool = _SIDE[dev] = [torch.cuda.Stream(device=dev) for _ in range(_N_SIDE)]
+        self.stream = pool[(grad.data_ptr() >> 9) % len(pool)]
+        self.tensors = tensors
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        self.stream.wait_stream(torch.cuda.current_stream())
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(self.stream)
+        if self.stream not in _SIDE_DIRTY:
+            _SIDE_DIRTY.append(self.stream)
+        if not _JOIN_QUEUED[0]:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(join_side)
+                _JOIN_QUEUED[0] = True
+            except RuntimeError:      # not inside a backward pass: the caller joins (optimizer / reducer do)
+                pass
+        self.cm = torch.cuda.stream(self.stream)
+        self.cm.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.cm.__exit__(*exc)
+        return False
 
 
 def _need_gpu(t):
@@ -147,6 +209,7 @@ def get_precision():
 # gradients stay fp32.  Only interior-only shapes qualify (rows % 128 == 0, feature dims % 128 == 0).
 BF16_STREAM = True
 USE_GLDS = True        # direct-to-LDS GEMM for bf16 × bf16 interior shapes
+USE_L32 = True         # direct-to-LDS GEMM for fp32 × fp32 operands (latency-bound text / step-level side)
 
 
 def _dt(t):
@@ -166,6 +229,10 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NON
     if _PRECISION == "bf16" and USE_GLDS and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and \
             (A.data_ptr() | B.data_ptr()) % 16 == 0 and _lib.load().svpc_gemm_glds_supported(a_kc, b_kc, lda, ldb, M, N, K) == 1:
         _lib.call("gemm_glds", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), _dt(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
+                  _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+    elif _PRECISION == "bf16" and USE_L32 and A.dtype == B.dtype == C.dtype == torch.float32 and \
+            (A.data_ptr() | B.data_ptr()) % 16 == 0 and _lib.load().svpc_gemm_l32_preferred(a_kc, b_kc, lda, ldb, M, N, K) == 1:
+        _lib.call("gemm_l32", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
                   _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
     elif _PRECISION == "bf16":
         dt = lambda t: 1 if t.dtype == torch.bfloat16 else 0
@@ -259,16 +326,18 @@ class _Linear(Function):
         if wgrad is not None or ctx.needs_input_grad[1]:
             acc = 1 if wgrad is not None else 0
             dw = wgrad if wgrad is not None else torch.empty_like(w)
-            if trans_w:   # w (K, N): dw = xᵀ dz
-                _gemm(x, x.stride(0), 0, dz, N, 0, dw, K, N, M, accumulate=acc)
-            else:         # w (N, K): dw = dzᵀ x
-                _gemm(dz, N, 0, x, x.stride(0), 0, dw, N, K, M, accumulate=acc)
+            with _side_of(wgrad, dz, x):
+                if trans_w:   # w (K, N): dw = xᵀ dz
+                    _gemm(x, x.stride(0), 0, dz, N, 0, dw, K, N, M, accumulate=acc)
+                else:         # w (N, K): dw = dzᵀ x
+                    _gemm(dz, N, 0, x, x.stride(0), 0, dw, N, K, M, accumulate=acc)
             if wgrad is not None:
                 _ready(wgrad, "w")
                 dw = None
         if has_b and (bgrad is not None or ctx.needs_input_grad[2]):
             if bgrad is not None:
-                _colsum(dz, out=bgrad.view(1, -1), accumulate=1)
+                with _side_of(bgrad, dz):
+                    _colsum(dz, out=bgrad.view(1, -1), accumulate=1)
                 _ready(bgrad, "b")
             else:
                 db = _colsum(dz).view(-1)

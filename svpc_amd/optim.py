@@ -260,6 +260,8 @@ class FusedBertAdam:
 
     def launch(self):
         """The three kernels only (graph-capturable)."""
+        from . import ops
+        ops.join_side()        # parameter-gradient kernels forked onto side streams
         stream = torch.cuda.current_stream().cuda_stream
         _lib.call("opt_step", self.meta.data_ptr(), self.chunk_tid.data_ptr(), self.chunk_start.data_ptr(),
                   self.tensor_chunk_off.data_ptr(), self.n_tensors, self.n_chunks, self.partial.data_ptr(),
@@ -354,6 +356,8 @@ class GradReducer:
         self._count = {}
 
     def _launch(self, bi):
+        from . import ops
+        ops.join_side()        # the bucket's gradients may still be in flight on a side stream
         s, e, _ = self.buckets[bi]
         self.launched[bi] = True
         self.works.append(self.dist.all_reduce(self.arena.flat[s:e], op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True))

@@ -377,3 +377,49 @@ def test_gemm_glds_direct_to_lds(bf16_mode, M, N, K, a_kc, b_kc, c_bf16):
     O._gemm(Am, Am.stride(0), a_kc, Bm, Bm.stride(0), b_kc, C, M, N, K)
     tol = (1e-2 if c_bf16 else 2e-6 * math.sqrt(K)) * max(1.0, ref.abs().max().item())
     assert (C.double() - ref).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("M,N,K,a_kc,b_kc,acc,bias_act", [
+    (192, 768, 768, 1, 1, 0, True), (200, 951, 768, 1, 1, 0, True), (4224, 768, 768, 1, 0, 0, False), (768, 768, 192, 0, 0, 1, False),
+    (16, 3072, 768, 1, 1, 0, True), (3072, 768, 32, 0, 0, 1, False), (100, 60, 64, 1, 1, 0, False), (64, 64, 4224, 0, 0, 0, False),
+    (768, 768, 4224, 0, 0, 1, False), (4224, 2304, 768, 1, 1, 0, True), (12, 20, 96, 0, 1, 0, False), (36, 8, 160, 1, 0, 0, False),
+    (2304, 768, 4224, 0, 0, 0, False), (132, 136, 2048, 0, 0, 0, False)])
+def test_gemm_l32_fp32_direct_to_lds(bf16_mode, M, N, K, a_kc, b_kc, acc, bias_act):
+    """fp32-operand direct-to-LDS GEMM (deep ring, bf16 rounding at fragment build): all four layouts, clamped M/N edges,
+    128² / 64² tiles, split-K, accumulate and bias+activation epilogues — against fp64 on the bf16-rounded operands."""
+    assert O._lib.load().svpc_gemm_l32_supported(a_kc, b_kc, K if a_kc else M, K if b_kc else N, M, N, K) == 1
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    B = torch.randn(N, K, generator=g).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV) if bias_act else None
+    C0 = torch.randn(M, N, generator=g).to(DEV)
+    ref = A.bfloat16().double() @ B.bfloat16().double().t()
+    if bias_act:
+        ref = torch.relu(ref + bias.double())
+    if acc:
+        ref = ref + C0.double()
+    Am = A if a_kc else A.t().contiguous()
+    Bm = B if b_kc else B.t().contiguous()
+    C = C0.clone()
+    ws = O._ws(C.device)
+    O._lib.call("gemm_l32", A_ := Am.data_ptr(), Am.stride(0), a_kc, Bm.data_ptr(), Bm.stride(0), b_kc, C.data_ptr(), C.stride(0), None,
+                M, N, K, None if bias is None else bias.data_ptr(), O.ACT_RELU if bias_act else O.ACT_NONE, 0.0, 0, None, acc,
+                ws.data_ptr(), ws.numel() * 4, O._stream())
+    tol = 2e-6 * math.sqrt(K) * max(1.0, ref.abs().max().item())
+    assert (C.double() - ref).abs().max().item() <= tol
+
+
+def test_gemm_l32_unsupported_shapes_fall_back(bf16_mode):
+    """K % 32 != 0 (word vectors W=300, vocabulary as K) or a k-strided operand whose row count is not a multiple of 4 stay
+    on the register-staged kernel."""
+    lib = O._lib.load()
+    assert lib.svpc_gemm_l32_supported(1, 1, 300, 300, 64, 64, 300) == 0
+    assert lib.svpc_gemm_l32_supported(0, 1, 951, 768, 951, 768, 4224) == 0
+    assert lib.svpc_gemm_l32_supported(1, 0, 960, 768, 64, 768, 951) == 0
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(70, 300, generator=g).to(DEV)
+    B = torch.randn(50, 300, generator=g).to(DEV)
+    C = torch.empty(70, 50, device=DEV)
+    O._gemm(A, 300, 1, B, 300, 1, C, 70, 50, 300)
+    ref = A.bfloat16().double() @ B.bfloat16().double().t()
+    assert (C.double() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
