@@ -43,6 +43,11 @@ int svpc_ln_bwd_t(const void* dy, const void* x, int x_dt, int y_dt, const int* 
                   const float* mean, const float* rstd, void* dh, void* dx, float* dgamma, float* dbeta, int accumulate,
                   float* workspace, int R, int D, float p_pre, unsigned site_pre, float p_post, unsigned site_post,
                   const svpc_u64* seed, svpc_stream_t stream);
+/* the same in two calls, so that the parameter-gradient tail can run on another stream: partial = svpc_ln_bwd_groups(R)·2D floats */
+int svpc_ln_bwd_rows_t(const void* dy, const void* x, int x_dt, int y_dt, const int* src_rows, const void* res, const float* gamma,
+                       const float* mean, const float* rstd, void* dh, void* dx, float* partial, int R, int D, float p_pre,
+                       unsigned site_pre, float p_post, unsigned site_post, const svpc_u64* seed, svpc_stream_t stream);
+int svpc_ln_param_grads(const float* partial, int R, int D, float* dgamma, float* dbeta, int accumulate, svpc_stream_t stream);
 int svpc_bucket_colsum_t(const void* x, int x_dt, int ldx, const int* idx, int R, int C, int K, float* out, int accumulate,
                          float* workspace, svpc_stream_t stream);
 int svpc_ln_bwd_groups(int R); /* workspace floats needed by svpc_ln_bwd = (groups + 1) * 2 * D */

@@ -152,7 +152,11 @@ struct LnBwdArgs {
     float p_pre; uint32_t site_pre; float p_post; uint32_t site_post; const u64* seed;
 };
 
-template <int NPL, int W, typename TX, typename TY>
+// One wave per row, RU rows per wave in flight (all loads of the RU rows are issued before the first reduction: with ≤2
+// workgroups resident per CU the kernel is bound by bytes in flight, not by bandwidth).  dgamma / dbeta partials stay in
+// registers across the wave's rows, are combined over the 4 waves in a fixed order through LDS, and leave as one row of
+// `partial` per workgroup (summed by ln_finalize_kernel) — deterministic, no atomics.
+template <int NPL, int W, typename TX, typename TY, int RU>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     extern __shared__ float smem[];  // 2*D floats
     const TY* __restrict__ dyp = reinterpret_cast<const TY*>(a.dy);
@@ -163,8 +167,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int D = a.D;
-    for (int c = threadIdx.x; c < 2 * D; c += 256) smem[c] = 0.f;
-    __syncthreads();
     const bool any_drop = (a.p_pre > 0.f) || (a.p_post > 0.f);
     const u64 seed = any_drop ? a.seed[0] : 0ull;
     const float ik_pre = a.p_pre > 0.f ? 1.0f / (1.0f - a.p_pre) : 1.0f;
@@ -179,79 +181,109 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
         for (int j = 0; j < W; ++j) { accg[i * W + j] = 0.f; accb[i * W + j] = 0.f; g[i * W + j] = 0.f; }
         if (col < D) VecIO<W, float>::load(a.gamma + col, &g[i * W]);
     }
-    for (int r = blockIdx.x * 4 + wave; r < a.R; r += gridDim.x * 4) {
-        const size_t xrow = (size_t)(a.src_rows ? a.src_rows[r] : r) * D;
-        const size_t orow = (size_t)r * D;
-        const float mean = a.mean[r], rstd = a.rstd[r];
-        float xh[NPL * W], dxh[NPL * W];
-        float s1 = 0.f, s2 = 0.f;
+    const int stride = gridDim.x * 4;
+    for (int r0 = blockIdx.x * 4 + wave; r0 < a.R; r0 += stride * RU) {
+        float h[RU][NPL * W], d[RU][NPL * W];
+        float mean[RU], rstd[RU];
+        // ---- load phase: every row's bytes are requested before anything is consumed
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) {
-            const int col = (lane + 64 * i) * W;
-            if (col < D) {
-                float h[W], d[W];
-                VecIO<W, TX>::load(xp + xrow + col, h);
-                if (a.p_pre > 0.f) {
+        for (int u = 0; u < RU; ++u) {
+            const int r = r0 + u * stride;
+            if (r < a.R) {
+                const size_t xrow = (size_t)(a.src_rows ? a.src_rows[r] : r) * D;
+                const size_t orow = (size_t)r * D;
+                mean[u] = a.mean[r]; rstd[u] = a.rstd[r];
 #pragma unroll
-                    for (int j = 0; j < W; ++j) h[j] *= drop_scale(seed, a.site_pre, orow + col + j, a.p_pre, ik_pre);
-                }
-                if (a.res) {
-                    float t[W];
-                    VecIO<W, TY>::load(rp + orow + col, t);
+                for (int i = 0; i < NPL; ++i) {
+                    const int col = (lane + 64 * i) * W;
+                    if (col < D) {
+                        VecIO<W, TX>::load(xp + xrow + col, &h[u][i * W]);
+                        VecIO<W, TY>::load(dyp + orow + col, &d[u][i * W]);
+                        if (a.res) {
+                            float t[W];
+                            VecIO<W, TY>::load(rp + orow + col, t);
+                            if (a.p_pre > 0.f) {
 #pragma unroll
-                    for (int j = 0; j < W; ++j) h[j] += t[j];
-                }
-                VecIO<W, TY>::load(dyp + orow + col, d);
+                                for (int j = 0; j < W; ++j)
+                                    h[u][i * W + j] *= drop_scale(seed, a.site_pre, orow + col + j, a.p_pre, ik_pre);
+                            }
 #pragma unroll
-                for (int j = 0; j < W; ++j) {
-                    float dy0 = d[j];
-                    if (a.p_post > 0.f) dy0 *= drop_scale(seed, a.site_post, orow + col + j, a.p_post, ik_post);
-                    const float xhat = (h[j] - mean) * rstd;
-                    accg[i * W + j] += dy0 * xhat;
-                    accb[i * W + j] += dy0;
-                    const float t = dy0 * g[i * W + j];
-                    xh[i * W + j] = xhat;
-                    dxh[i * W + j] = t;
-                    s1 += t;
-                    s2 += t * xhat;
+                            for (int j = 0; j < W; ++j) h[u][i * W + j] += t[j];
+                        } else if (a.p_pre > 0.f) {
+#pragma unroll
+                            for (int j = 0; j < W; ++j) h[u][i * W + j] *= drop_scale(seed, a.site_pre, orow + col + j, a.p_pre, ik_pre);
+                        }
+                    }
                 }
             }
         }
-        if (a.dh || a.dx) {
-            s1 = wave_sum(s1) * invD;
-            s2 = wave_sum(s2) * invD;
+        // ---- compute phase
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int r = r0 + u * stride;
+            if (r >= a.R) continue;
+            const size_t orow = (size_t)r * D;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
                 const int col = (lane + 64 * i) * W;
                 if (col < D) {
-                    float o[W];
 #pragma unroll
-                    for (int j = 0; j < W; ++j) o[j] = rstd * (dxh[i * W + j] - s1 - xh[i * W + j] * s2);
-                    if (a.dh) VecIO<W, TY>::store(dhp + orow + col, o);
-                    if (a.dx && a.dx != a.dh) {
-                        if (a.p_pre > 0.f) {
+                    for (int j = 0; j < W; ++j) {
+                        float dy0 = d[u][i * W + j];
+                        if (a.p_post > 0.f) dy0 *= drop_scale(seed, a.site_post, orow + col + j, a.p_post, ik_post);
+                        const float xhat = (h[u][i * W + j] - mean[u]) * rstd[u];
+                        accg[i * W + j] += dy0 * xhat;
+                        accb[i * W + j] += dy0;
+                        const float t = dy0 * g[i * W + j];
+                        h[u][i * W + j] = xhat;
+                        d[u][i * W + j] = t;
+                        s1 += t;
+                        s2 += t * xhat;
+                    }
+                }
+            }
+            if (a.dh || a.dx) {
+                s1 = wave_sum(s1) * invD;
+                s2 = wave_sum(s2) * invD;
 #pragma unroll
-                            for (int j = 0; j < W; ++j) o[j] *= drop_scale(seed, a.site_pre, orow + col + j, a.p_pre, ik_pre);
+                for (int i = 0; i < NPL; ++i) {
+                    const int col = (lane + 64 * i) * W;
+                    if (col < D) {
+                        float o[W];
+#pragma unroll
+                        for (int j = 0; j < W; ++j) o[j] = rstd[u] * (d[u][i * W + j] - s1 - h[u][i * W + j] * s2);
+                        if (a.dh) VecIO<W, TY>::store(dhp + orow + col, o);
+                        if (a.dx && a.dx != a.dh) {
+                            if (a.p_pre > 0.f) {
+#pragma unroll
+                                for (int j = 0; j < W; ++j) o[j] *= drop_scale(seed, a.site_pre, orow + col + j, a.p_pre, ik_pre);
+                            }
+                            VecIO<W, TX>::store(dxp + orow + col, o);
                         }
-                        VecIO<W, TX>::store(dxp + orow + col, o);
                     }
                 }
             }
         }
     }
-    // workgroup reduce of the gamma/beta partials through LDS (float adds on LDS)
+    // workgroup reduce of the gamma/beta partials through LDS: wave 0 stores, waves 1..3 add in order (each lane owns its columns)
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-        const int col = (lane + 64 * i) * W;
-        if (col < D) {
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
 #pragma unroll
-            for (int j = 0; j < W; ++j) {
-                atomicAdd(&smem[col + j], accg[i * W + j]);
-                atomicAdd(&smem[D + col + j], accb[i * W + j]);
+            for (int i = 0; i < NPL; ++i) {
+                const int col = (lane + 64 * i) * W;
+                if (col < D) {
+#pragma unroll
+                    for (int j = 0; j < W; ++j) {
+                        if (w == 0) { smem[col + j] = accg[i * W + j]; smem[D + col + j] = accb[i * W + j]; }
+                        else { smem[col + j] += accg[i * W + j]; smem[D + col + j] += accb[i * W + j]; }
+                    }
+                }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
     float* out = a.partial + (size_t)blockIdx.x * 2 * D;
     for (int c = threadIdx.x; c < 2 * D; c += 256) out[c] = smem[c];
 }
@@ -331,9 +363,10 @@ template <int NPL, int W>
 static int launch_ln_bwd(const LnBwdArgs& a, int G, int x_dt, int y_dt, hipStream_t s) {
     const dim3 g(G), b(256);
     const size_t lds = (size_t)2 * a.D * sizeof(float);
-    if (x_dt == 0 && y_dt == 0) hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, float, float>), g, b, lds, s, a);
-    else if (x_dt == 0 && y_dt == 1) hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, float, __bf16>), g, b, lds, s, a);
-    else hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, __bf16, __bf16>), g, b, lds, s, a);
+    constexpr int RU = (NPL * W <= 16) ? 2 : 1;      // two rows in flight per wave while the registers allow it
+    if (x_dt == 0 && y_dt == 0) hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, float, float, RU>), g, b, lds, s, a);
+    else if (x_dt == 0 && y_dt == 1) hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, float, __bf16, RU>), g, b, lds, s, a);
+    else hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, __bf16, __bf16, RU>), g, b, lds, s, a);
     return svpc_check_launch("ln_bwd");
 }
 
@@ -377,14 +410,14 @@ int svpc_ln_fwd(const float* x, const int* src_rows, const float* res, const flo
 // workspace: at least svpc_ln_bwd_groups(R) * 2 * D floats
 int svpc_ln_bwd_groups(int R) { int g = ceil_div(R, 4); return g < 1 ? 1 : (g > 512 ? 512 : g); }
 
-int svpc_ln_bwd_t(const void* dy, const void* x, int x_dt, int y_dt, const int* src_rows, const void* res, const float* gamma,
-                  const float* mean, const float* rstd, void* dh, void* dx, float* dgamma, float* dbeta,
-                  int accumulate, float* workspace, int R, int D, float p_pre, unsigned site_pre, float p_post,
-                  unsigned site_post, const u64* seed, hipStream_t stream) {
+// rows part only: dh / dx and the per-workgroup [dgamma ; dbeta] partials (svpc_ln_bwd_groups(R) × 2D floats)
+int svpc_ln_bwd_rows_t(const void* dy, const void* x, int x_dt, int y_dt, const int* src_rows, const void* res, const float* gamma,
+                       const float* mean, const float* rstd, void* dh, void* dx, float* partial, int R, int D, float p_pre,
+                       unsigned site_pre, float p_post, unsigned site_post, const u64* seed, hipStream_t stream) {
     if (R == 0) return 0;
     SVPC_REQUIRE(!(x_dt == 1 && y_dt == 0), "ln_bwd: bf16 input with fp32 output is not instantiated");
     const int G = svpc_ln_bwd_groups(R);
-    LnBwdArgs a{dy, x, src_rows, res, gamma, mean, rstd, dh, dx, workspace, R, D, p_pre, site_pre, p_post, site_post, seed};
+    LnBwdArgs a{dy, x, src_rows, res, gamma, mean, rstd, dh, dx, partial, R, D, p_pre, site_pre, p_post, site_post, seed};
     const bool vec = (D % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(gamma) && (!res || aligned16(res)) &&
                      (!dh || aligned16(dh)) && (!dx || aligned16(dx));
     int rc = -1;
@@ -398,9 +431,24 @@ int svpc_ln_bwd_t(const void* dy, const void* x, int x_dt, int y_dt, const int* 
         else if (D <= 1024) rc = launch_ln_bwd<16, 1>(a, G, x_dt, y_dt, stream);
         else if (D <= 3072) rc = launch_ln_bwd<48, 1>(a, G, x_dt, y_dt, stream);
     }
-    if (rc != 0) { if (rc == -1) svpc_set_error("ln_bwd: row width not supported"); return rc; }
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3(ceil_div(2 * D, 32)), dim3(256), 0, stream, workspace, G, D, dgamma, dbeta, accumulate);
-    return svpc_check_launch("ln_bwd scatter");
+    if (rc == -1) svpc_set_error("ln_bwd: row width not supported");
+    return rc;
+}
+// parameter-gradient part: dgamma / dbeta (+)= column sums of the partials (may run on another stream than the rows part)
+int svpc_ln_param_grads(const float* partial, int R, int D, float* dgamma, float* dbeta, int accumulate, hipStream_t stream) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(ceil_div(2 * D, 32)), dim3(256), 0, stream, partial, svpc_ln_bwd_groups(R), D, dgamma, dbeta,
+                       accumulate);
+    return svpc_check_launch("ln_param_grads");
+}
+int svpc_ln_bwd_t(const void* dy, const void* x, int x_dt, int y_dt, const int* src_rows, const void* res, const float* gamma,
+                  const float* mean, const float* rstd, void* dh, void* dx, float* dgamma, float* dbeta,
+                  int accumulate, float* workspace, int R, int D, float p_pre, unsigned site_pre, float p_post,
+                  unsigned site_post, const u64* seed, hipStream_t stream) {
+    int rc = svpc_ln_bwd_rows_t(dy, x, x_dt, y_dt, src_rows, res, gamma, mean, rstd, dh, dx, workspace, R, D, p_pre, site_pre, p_post,
+                                site_post, seed, stream);
+    if (rc) return rc;
+    return svpc_ln_param_grads(workspace, R, D, dgamma, dbeta, accumulate, stream);
 }
 int svpc_ln_bwd(const float* dy, const float* x, const int* src_rows, const float* res, const float* gamma,
                 const float* mean, const float* rstd, float* dh, float* dx, float* dgamma, float* dbeta,

@@ -406,10 +406,12 @@ class _LayerNorm(Function):
         direct_gb = g_dir is not None and b_dir is not None
         dgamma = g_dir if direct_gb else torch.empty(D, dtype=torch.float32, device=dev)
         dbeta = b_dir if direct_gb else torch.empty(D, dtype=torch.float32, device=dev)
-        ws = _ws(dev)
-        _lib.call("ln_bwd_t", _p(dy), _p(x), _dt(x), _dt(dy), _p(src_rows), _p(residual), _p(gamma), _p(mean), _p(rstd), _p(dh),
-                  _p(dx_rows), _p(dgamma), _p(dbeta), 1 if direct_gb else 0, _p(ws), R, D, p_pre, s_pre, p_post, s_post, _p(seed),
-                  _stream())
+        # rows part on this stream; the dgamma/dbeta tail only feeds the optimizer, so it is forked off (own partial buffer)
+        partial = torch.empty(_lib.load().svpc_ln_bwd_groups(R) * 2 * D, dtype=torch.float32, device=dev)
+        _lib.call("ln_bwd_rows_t", _p(dy), _p(x), _dt(x), _dt(dy), _p(src_rows), _p(residual), _p(gamma), _p(mean), _p(rstd), _p(dh),
+                  _p(dx_rows), _p(partial), R, D, p_pre, s_pre, p_post, s_post, _p(seed), _stream())
+        with _side_of(g_dir if direct_gb else None, partial):
+            _lib.call("ln_param_grads", _p(partial), R, D, _p(dgamma), _p(dbeta), 1 if direct_gb else 0, _stream())
         if direct_gb:
             _ready(dgamma); _ready(dbeta)
             dgamma = dbeta = None
