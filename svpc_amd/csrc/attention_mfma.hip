@@ -35,14 +35,16 @@ template <int DH> struct AImg { static constexpr int RS = DH * 2 + 16; };
 // rows [0, len) of a (·, DH) matrix (fp32 or bf16 in HBM) → bf16 image (zero rows beyond len), optionally scaled.
 // All of a thread's loads are issued before the first conversion/LDS store (the staging is latency-, not bandwidth-bound);
 // ``stage_pair`` keeps two matrices in flight at once.
-template <int DH, typename T, int AT>
+template <int DH, typename T, int AT, int NT = 256>
 struct RowStage {
-    static constexpr int UPR = DH / 4, NIT = AT * UPR / 256;
+    static constexpr int UPR = DH / 4, NIT = AT * UPR / NT;
     float4 raw[NIT];     // fp32: 4 values; bf16: 4 values in .x/.y (8 bytes)
+    int tid;
+    __device__ __forceinline__ RowStage(int t) : tid(t) {}
     __device__ __forceinline__ void load(const T* __restrict__ src, int ld, int len) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int u = threadIdx.x + 256 * it, row = u / UPR, c4 = u - row * UPR;
+            const int u = tid + NT * it, row = u / UPR, c4 = u - row * UPR;
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < len) {
                 if (sizeof(T) == 4) t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + 4 * c4);
@@ -57,7 +59,7 @@ struct RowStage {
     __device__ __forceinline__ void store(char* __restrict__ img, float scale) const {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int u = threadIdx.x + 256 * it, row = u / UPR, c4 = u - row * UPR;
+            const int u = tid + NT * it, row = u / UPR, c4 = u - row * UPR;
             bf16x4 b;
             if (sizeof(T) == 4) {
                 b[0] = (__bf16)(raw[it].x * scale); b[1] = (__bf16)(raw[it].y * scale);
@@ -75,18 +77,18 @@ struct RowStage {
         }
     }
 };
-template <int DH, typename T, int AT>
-__device__ __forceinline__ void stage_pair(char* imgA, const T* srcA, int ldA, int lenA, float scaleA,
+template <int DH, typename T, int AT, int NT = 256>
+__device__ __forceinline__ void stage_pair(int tid, char* imgA, const T* srcA, int ldA, int lenA, float scaleA,
                                            char* imgB, const T* srcB, int ldB, int lenB, float scaleB) {
-    RowStage<DH, T, AT> a, b;
+    RowStage<DH, T, AT, NT> a(tid), b(tid);
     a.load(srcA, ldA, lenA);
     b.load(srcB, ldB, lenB);
     a.store(imgA, scaleA);
     b.store(imgB, scaleB);
 }
-template <int DH, typename T, int AT>
-__device__ __forceinline__ void stage_rows(char* __restrict__ img, const T* __restrict__ src, int ld, int len, float scale) {
-    RowStage<DH, T, AT> a;
+template <int DH, typename T, int AT, int NT = 256>
+__device__ __forceinline__ void stage_rows(int tid, char* __restrict__ img, const T* __restrict__ src, int ld, int len, float scale) {
+    RowStage<DH, T, AT, NT> a(tid);
     a.load(src, ld, len);
     a.store(img, scale);
 }
@@ -145,21 +147,36 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
     return r;
 }
 
-template <int DH, typename T, int AT>
+// group-wide sync: the 4 waves of a workgroup, or — PERWAVE — one wave with itself (LDS is in-order per wave; the fence keeps
+// the compiler from moving the reads above the writes)
+template <bool PERWAVE> __device__ __forceinline__ void group_sync() {
+    if (PERWAVE) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+}
+
+// PERWAVE (AT = 32 only): every wave owns a whole (sequence, head) — staging, softmax and both products — with its own LDS
+// images and no workgroup barrier; 4 (sequence, head) pairs per workgroup.  For the 22-token decoder, ≤12-step and ≤3-slot
+// sequences this puts 4× more problems in flight than one workgroup per pair (whose waves 1..3 idle after the staging).
+template <int DH, typename T, int AT, bool PERWAVE>
 __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
     constexpr int IB = AT * AImg<DH>::RS, NTL = AT / 32;
+    constexpr int GROUP_BYTES = 3 * IB + AT * (int)sizeof(float), NT = PERWAVE ? 64 : 256;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31;
+    const int wave = PERWAVE ? 0 : wv, tid = PERWAVE ? lane : (int)threadIdx.x;
+    char* smem = smem_all + (PERWAVE ? wv * GROUP_BYTES : 0);
     char* Qs = smem; char* Ks = smem + IB; char* Vs = smem + 2 * IB;
     float* mterm = reinterpret_cast<float*>(smem + 3 * IB);
-    const int sh = blockIdx.x, s = sh / a.H, h = sh - s * a.H;
+    const int sh = PERWAVE ? (int)blockIdx.x * 4 + wv : (int)blockIdx.x;
+    if (PERWAVE && sh >= a.n_seq * a.H) return;
+    const int s = sh / a.H, h = sh - s * a.H;
     const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
-    stage_pair<DH, T, AT>(Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f,
-                          Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
-    stage_rows<DH, T, AT>(Qs, (const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale);
-    for (int j = threadIdx.x; j < AT; j += 256)
+    stage_pair<DH, T, AT, NT>(tid, Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f,
+                              Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
+    stage_rows<DH, T, AT, NT>(tid, Qs, (const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale);
+    for (int j = tid; j < AT; j += NT)
         mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
-    __syncthreads();
+    group_sync<PERWAVE>();
     const int q0 = 32 * wave;
     if (q0 >= q_len || wave >= NTL) return;
     const int nkt = (k_len + 31) >> 5;
@@ -232,34 +249,71 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
         store_tile<T>((T*)a.O + (size_t)q_off * a.ldo + h * DH, a.ldo, q0, q_len, 32 * dt, acc[dt], 1.0f, lane);
 }
 
-template <int DH, typename T, int AT>
+template <int DH, typename T, int AT, bool PERWAVE>
 __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   // 2 waves/SIMD: ≤ 256 registers, 2 workgroups per CU
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
     constexpr int IB = AT * AImg<DH>::RS;
+    constexpr int GROUP_BYTES = 4 * IB + 3 * AT * (int)sizeof(float), NT = PERWAVE ? 64 : 256;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31;
+    const int wave = PERWAVE ? 0 : wv, tid = PERWAVE ? lane : (int)threadIdx.x;
+    char* smem = smem_all + (PERWAVE ? wv * GROUP_BYTES : 0);
     char* Qs = smem; char* Ks = smem + IB; char* Vs = smem + 2 * IB; char* Ds = smem + 3 * IB;
     float* mterm = reinterpret_cast<float*>(smem + 4 * IB);
     float* lse = mterm + AT;
     float* delta = lse + AT;
-    const int sh = blockIdx.x, s = sh / a.H, h = sh - s * a.H;
+    const int sh = PERWAVE ? (int)blockIdx.x * 4 + wv : (int)blockIdx.x;
+    if (PERWAVE && sh >= a.n_seq * a.H) return;
+    const int s = sh / a.H, h = sh - s * a.H;
     const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
-    stage_pair<DH, T, AT>(Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f,
-                          Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
-    stage_pair<DH, T, AT>(Qs, (const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale,
-                      Ds, (const T*)a.dO + (size_t)q_off * a.lddo + h * DH, a.lddo, q_len, 1.0f);
-    for (int j = threadIdx.x; j < AT; j += 256) {
+    stage_pair<DH, T, AT, NT>(tid, Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f,
+                              Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
+    stage_pair<DH, T, AT, NT>(tid, Qs, (const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale,
+                              Ds, (const T*)a.dO + (size_t)q_off * a.lddo + h * DH, a.lddo, q_len, 1.0f);
+    for (int j = tid; j < AT; j += NT) {
         mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
         lse[j] = j < q_len ? a.LSE[((size_t)s * a.H + h) * a.max_q + j] : 0.f;
     }
-    for (int r = wave; r < AT; r += 4) {          // delta = rowsum(dO ⊙ O)
+    if (PERWAVE) {                                // delta = rowsum(dO ⊙ O): lane pair per row (AT = 32), all loads independent
+        const int r = lane >> 1, c0 = (lane & 1) * (DH / 2);
         float d = 0.f;
-        if (r < q_len && lane < DH)
-            d = (float)((const T*)a.dO)[(size_t)(q_off + r) * a.lddo + h * DH + lane] *
-                (float)((const T*)a.O)[(size_t)(q_off + r) * a.ldo + h * DH + lane];
-        d = wave_sum(d);
-        if (lane == 0) delta[r] = d;
+        if (r < q_len) {
+            const T* po = (const T*)a.dO + (size_t)(q_off + r) * a.lddo + h * DH + c0;
+            const T* oo = (const T*)a.O + (size_t)(q_off + r) * a.ldo + h * DH + c0;
+            if (sizeof(T) == 4) {
+                float4 x[DH / 8], y[DH / 8];
+#pragma unroll
+                for (int c = 0; c < DH / 8; ++c) {
+                    x[c] = reinterpret_cast<const float4*>(po)[c];
+                    y[c] = reinterpret_cast<const float4*>(oo)[c];
+                }
+#pragma unroll
+                for (int c = 0; c < DH / 8; ++c) d += x[c].x * y[c].x + x[c].y * y[c].y + x[c].z * y[c].z + x[c].w * y[c].w;
+            } else {
+                bf16x8 x[DH / 16], y[DH / 16];
+#pragma unroll
+                for (int c = 0; c < DH / 16; ++c) {
+                    x[c] = reinterpret_cast<const bf16x8*>(po)[c];
+                    y[c] = reinterpret_cast<const bf16x8*>(oo)[c];
+                }
+#pragma unroll
+                for (int c = 0; c < DH / 16; ++c)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d += (float)x[c][j] * (float)y[c][j];
+            }
+        }
+        d += __shfl_xor(d, 1, 64);
+        if ((lane & 1) == 0) delta[r] = d;
+    } else {
+        for (int r = wave; r < AT; r += 4) {
+            float d = 0.f;
+            if (r < q_len && lane < DH)
+                d = (float)((const T*)a.dO)[(size_t)(q_off + r) * a.lddo + h * DH + lane] *
+                    (float)((const T*)a.O)[(size_t)(q_off + r) * a.ldo + h * DH + lane];
+            d = wave_sum(d);
+            if (lane == 0) delta[r] = d;
+        }
     }
-    __syncthreads();
+    group_sync<PERWAVE>();
     const u64 seed = a.p_drop > 0.f ? a.seed[0] : 0ull;
     const float ik = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
     const u64 dbase = (u64)(s * a.H + h) * a.max_q;
@@ -373,19 +427,21 @@ static bool mattn_ok(int dh, int max_q, int max_k, int ldq, int ldk, int ldv, co
 }
 
 template <typename T, int DH, int AT>
-static int mattn_fwd_go(const MAttnArgs& a, int n_blocks, hipStream_t stream) {
-    const size_t lds = 3 * (size_t)AT * AImg<DH>::RS + AT * sizeof(float);
-    int rc = mattn_set_lds((const void*)attn_mfma_fwd_kernel<DH, T, AT>, lds);
+static int mattn_fwd_go(const MAttnArgs& a, int n_pairs, hipStream_t stream) {
+    constexpr bool PW = (AT == 32);
+    const size_t lds = (3 * (size_t)AT * AImg<DH>::RS + AT * sizeof(float)) * (PW ? 4 : 1);
+    int rc = mattn_set_lds((const void*)attn_mfma_fwd_kernel<DH, T, AT, PW>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((attn_mfma_fwd_kernel<DH, T, AT>), dim3(n_blocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((attn_mfma_fwd_kernel<DH, T, AT, PW>), dim3(PW ? ceil_div(n_pairs, 4) : n_pairs), dim3(256), lds, stream, a);
     return svpc_check_launch("attn_mfma_fwd");
 }
 template <typename T, int DH, int AT>
-static int mattn_bwd_go(const MAttnArgs& a, int n_blocks, hipStream_t stream) {
-    const size_t lds = 4 * (size_t)AT * AImg<DH>::RS + 3 * AT * sizeof(float);
-    int rc = mattn_set_lds((const void*)attn_mfma_bwd_kernel<DH, T, AT>, lds);
+static int mattn_bwd_go(const MAttnArgs& a, int n_pairs, hipStream_t stream) {
+    constexpr bool PW = (AT == 32);
+    const size_t lds = (4 * (size_t)AT * AImg<DH>::RS + 3 * AT * sizeof(float)) * (PW ? 4 : 1);
+    int rc = mattn_set_lds((const void*)attn_mfma_bwd_kernel<DH, T, AT, PW>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((attn_mfma_bwd_kernel<DH, T, AT>), dim3(n_blocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((attn_mfma_bwd_kernel<DH, T, AT, PW>), dim3(PW ? ceil_div(n_pairs, 4) : n_pairs), dim3(256), lds, stream, a);
     return svpc_check_launch("attn_mfma_bwd");
 }
 // image height: 32 rows when every sequence has ≤ 32 queries and keys (decoder, step encoder, memory slots), else 128
@@ -437,6 +493,8 @@ int svpc_attn_mfma_bwd_t(const void* Q, int ldq, const void* K, int ldk, const v
     if (n_seq == 0) return 0;
     SVPC_REQUIRE(mattn_ok(dh, max_q, max_k, ldq, ldk, ldv, Q, K, V, dt) && lddo % 4 == 0 && ((((uintptr_t)dO) & (dt ? 7 : 15)) == 0),
                  "attn_mfma: unsupported shape/alignment");
+    SVPC_REQUIRE(ldo % (dt ? 8 : 4) == 0 && lddo % (dt ? 8 : 4) == 0 && (((uintptr_t)O | (uintptr_t)dO) & 15) == 0,
+                 "attn_mfma: O and dO rows must be 16-byte aligned");
     SVPC_REQUIRE(dt == 0 || (lddq % 2 == 0 && lddk % 2 == 0 && lddv % 2 == 0), "attn_mfma: bf16 gradients need even row strides");
     MAttnArgs a{};
     a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = const_cast<void*>(O); a.ldo = ldo;
