@@ -179,6 +179,12 @@ int svpc_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, co
                        float* c, float* gates_act, int N, int D, svpc_stream_t stream);
 int svpc_lstm_cell_bwd(const float* dh, const float* dc, const float* gates_act, const float* c_prev, const float* active,
                        float* dgates, float* dc_prev, float* dh_prev, int N, int D, svpc_stream_t stream);
+/* sequence forms for the fused recurrence (nn.LSTM model.py:859-860, used at :1022-1024): gx rows gathered in place; the
+ * backward adds the gradient from the layer above (dh_out) to the recurrent one (dh_rec) */
+int svpc_lstm_cell_fwd_idx(const float* gx_all, const int* rows, const float* gh, const float* c_prev, const float* h_prev,
+                           const float* active, float* h, float* c, float* gates_act, int N, int D, svpc_stream_t stream);
+int svpc_lstm_cell_bwd_seq(const float* dh_out, const float* dh_rec, const float* dc, const float* gates_act, const float* c_prev,
+                           const float* active, float* dgates, float* dc_prev, float* dh_prev, int N, int D, svpc_stream_t stream);
 /* greedy decoding step: argmax with the UNK column suppressed + OOV→UNK remap, src/translator.py:104-112 */
 int svpc_greedy_pick(const float* scores, int ld, const int* row_c, const int* row_x, int n_sent, int lt, int pos, int unk,
                      int* next_ext, int* next_model, svpc_stream_t stream);

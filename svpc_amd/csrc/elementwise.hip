@@ -281,6 +281,53 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
     dh_prev[i] = (1.f - a) * dh[i];
 }
 
+// Sequence forms used by the fused BiLSTM recurrence: the step's input-projection rows are gathered in place
+// (gx_all[rows[n]]), and the backward adds the gradient arriving from the layer above (dh_out) to the recurrent one.
+__global__ __launch_bounds__(256) void lstm_cell_fwd_idx_kernel(const float* __restrict__ gx_all, const int* __restrict__ rows,
+                                                                const float* __restrict__ gh, const float* __restrict__ c_prev,
+                                                                const float* __restrict__ h_prev, const float* __restrict__ active,
+                                                                float* __restrict__ h, float* __restrict__ c,
+                                                                float* __restrict__ gates_act, int N, int D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * D) return;
+    const int n = i / D, d = i - n * D;
+    const size_t g0 = (size_t)n * 4 * D + d;
+    const float* gx = gx_all + (size_t)rows[n] * 4 * D + d;
+    const float gi = sigmoidf_(gx[0] + gh[g0]);
+    const float gf = sigmoidf_(gx[D] + gh[g0 + D]);
+    const float gg = tanhf(gx[2 * D] + gh[g0 + 2 * D]);
+    const float go = sigmoidf_(gx[3 * D] + gh[g0 + 3 * D]);
+    gates_act[g0] = gi; gates_act[g0 + D] = gf; gates_act[g0 + 2 * D] = gg; gates_act[g0 + 3 * D] = go;
+    const float cn = gf * c_prev[i] + gi * gg;
+    const float hn = go * tanhf(cn);
+    const float a = active[n];
+    c[i] = a * cn + (1.f - a) * c_prev[i];
+    h[i] = a * hn + (1.f - a) * h_prev[i];
+}
+__global__ __launch_bounds__(256) void lstm_cell_bwd_seq_kernel(const float* __restrict__ dh_out, const float* __restrict__ dh_rec,
+                                                                const float* __restrict__ dc, const float* __restrict__ gates_act,
+                                                                const float* __restrict__ c_prev, const float* __restrict__ active,
+                                                                float* __restrict__ dgates, float* __restrict__ dc_prev,
+                                                                float* __restrict__ dh_prev, int N, int D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * D) return;
+    const int n = i / D, d = i - n * D;
+    const size_t g0 = (size_t)n * 4 * D + d;
+    const float gi = gates_act[g0], gf = gates_act[g0 + D], gg = gates_act[g0 + 2 * D], go = gates_act[g0 + 3 * D];
+    const float a = active[n];
+    const float dht = dh_out[i] + dh_rec[i];
+    const float dhn = a * dht, dcn_in = a * dc[i];
+    const float cn = gf * c_prev[i] + gi * gg;
+    const float tc = tanhf(cn);
+    const float dcn = dcn_in + dhn * go * (1.f - tc * tc);
+    dgates[g0] = dcn * gg * gi * (1.f - gi);
+    dgates[g0 + D] = dcn * c_prev[i] * gf * (1.f - gf);
+    dgates[g0 + 2 * D] = dcn * gi * (1.f - gg * gg);
+    dgates[g0 + 3 * D] = dhn * tc * go * (1.f - go);
+    dc_prev[i] = dcn * gf + (1.f - a) * dc[i];
+    dh_prev[i] = (1.f - a) * dht;
+}
+
 // ---- greedy pick (src/translator.py:104-112): per sentence j take row j*lt+pos of the score matrix, suppress the UNK
 // column (-1e10), first-index argmax over the row's C_j classes; the emitted stream keeps the extended id, the model
 // side sees UNK for copied out-of-vocabulary words (id >= C_j - X_j).
@@ -430,6 +477,20 @@ int svpc_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, co
     hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ceil_div(N * D, 256)), dim3(256), 0, s, gx, gh, c_prev, h_prev, active, h, c,
                        gates_act, N, D);
     return svpc_check_launch("lstm_cell_fwd");
+}
+int svpc_lstm_cell_fwd_idx(const float* gx_all, const int* rows, const float* gh, const float* c_prev, const float* h_prev,
+                           const float* active, float* h, float* c, float* gates_act, int N, int D, hipStream_t s) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(lstm_cell_fwd_idx_kernel, dim3(ceil_div(N * D, 256)), dim3(256), 0, s, gx_all, rows, gh, c_prev, h_prev, active, h,
+                       c, gates_act, N, D);
+    return svpc_check_launch("lstm_cell_fwd_idx");
+}
+int svpc_lstm_cell_bwd_seq(const float* dh_out, const float* dh_rec, const float* dc, const float* gates_act, const float* c_prev,
+                           const float* active, float* dgates, float* dc_prev, float* dh_prev, int N, int D, hipStream_t s) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(lstm_cell_bwd_seq_kernel, dim3(ceil_div(N * D, 256)), dim3(256), 0, s, dh_out, dh_rec, dc, gates_act, c_prev, active,
+                       dgates, dc_prev, dh_prev, N, D);
+    return svpc_check_launch("lstm_cell_bwd_seq");
 }
 int svpc_lstm_cell_bwd(const float* dh, const float* dc, const float* gates_act, const float* c_prev, const float* active,
                        float* dgates, float* dc_prev, float* dh_prev, int N, int D, hipStream_t s) {

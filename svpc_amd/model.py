@@ -883,28 +883,29 @@ class StateAwareRecursiveTransformer(nn.Module):
 
     def _bilstm(self, x, plan):
         """Bidirectional LSTM over each video's step sequence, directions summed (model.py:1022-1024).
-        Input projections for all steps are one GEMM per direction; the recurrence advances all videos
-        together, one (N, D)×(D, 4D) GEMM + one fused cell kernel per time step."""
+        Input projections for all steps are one GEMM per direction; each direction's recurrence is one fused autograd node
+        (ops.lstm_sequence) that advances all videos together.  The two directions are independent chains of small launches,
+        so the reverse one runs on a side stream beside the forward one (its backward follows it there)."""
         rnn = self.recipe_encoder
-        D = self.config.hidden_size
-        N = plan.N
-        out = None
+        outs = []
+        main = torch.cuda.current_stream() if x.is_cuda else None
         for sfx, rows_t in (("", plan.lstm_fwd_rows), ("_reverse", plan.lstm_bwd_rows)):
             w_ih, w_hh = getattr(rnn, "weight_ih_l0" + sfx), getattr(rnn, "weight_hh_l0" + sfx)
             bias = getattr(rnn, "bias_ih_l0" + sfx) + getattr(rnn, "bias_hh_l0" + sfx)
-            gx_all = ops.linear(x, w_ih, bias)                                               # (T, 4D)
-            h = x.new_zeros(N, D)
-            c = x.new_zeros(N, D)
-            hs = []
-            for t, rows in enumerate(rows_t):
-                gh = ops.linear(h, w_hh, None)
-                h, c = ops.lstm_cell(ops.take_rows(gx_all, rows), gh, c, h, plan.lstm_active[t])
-                hs.append(h)
-            # gather each valid (video, time) output back into step-row order
-            hs = torch.stack(hs, 0)                                                          # (S, N, D)
-            d = ops.take_rows(hs.reshape(-1, D), plan.lstm_pick[sfx])
-            out = d if out is None else ops.add(out, d)
-        return out
+            side = ops.branch_stream(x.device) if (sfx and main is not None) else None
+            if side is None:
+                gx_all = ops.linear(x, w_ih, bias)                                           # (T, 4D)
+                outs.append(ops.lstm_sequence(gx_all, w_hh, rows_t, plan.lstm_active, plan.lstm_pick[sfx]))
+            else:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    gx_all = ops.linear(x, w_ih, bias)
+                    d = ops.lstm_sequence(gx_all, w_hh, rows_t, plan.lstm_active, plan.lstm_pick[sfx])
+                x.record_stream(side)
+                d.record_stream(main)
+                main.wait_stream(side)
+                outs.append(d)
+        return ops.add(outs[0], outs[1])
 
     def reconstruct(self, prediction_scores, text_mask, ga_ingr_vectors):
         """reference-shaped wrapper (model.py:1017-1025) for one video."""

@@ -49,6 +49,19 @@ _SIDE_DIRTY = []
 _JOIN_QUEUED = [False]
 
 
+_BRANCH = {}
+
+
+def branch_stream(device):
+    """Stream for an independent forward branch (its autograd nodes run their backward there too); None when disabled."""
+    if not SIDE_WGRAD:
+        return None
+    st = _BRANCH.get(device)
+    if st is None:
+        st = _BRANCH[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 def join_side():
     """Make the current stream wait for every side stream that has gradient work in flight."""
     _JOIN_QUEUED[0] = False
@@ -827,6 +840,77 @@ class _LstmCell(Function):
 
 def lstm_cell(gx, gh, c_prev, h_prev, active):
     return _LstmCell.apply(gx, gh, c_prev, h_prev, active)
+
+
+class _LstmSeq(Function):
+    """One direction of the LSTM recurrence over every video's step sequence as a single autograd node.
+
+    Per time step: one (N, D)×(D, 4D) GEMM + one fused cell kernel forward; one cell kernel + one dgrad GEMM (accumulating onto
+    the pass-through gradient) backward.  The recurrent weight gradient is ONE GEMM over all time steps (K = S·N rows) on a side
+    stream, the input-projection gradient one row gather.  No per-step gathers, adds or fills (reference: nn.LSTM model.py:859-860
+    as used at :1022-1024; time-major state, inactive (padded) steps pass (h, c) through)."""
+
+    @staticmethod
+    def forward(ctx, gx_all, w_hh, rows_t, active_t, pick, wgrad):
+        _need_gpu(gx_all)
+        gx_all, w = _c(gx_all), _c(w_hh)
+        S, N = len(rows_t), rows_t[0].numel()
+        D = w.shape[1]
+        dev = gx_all.device
+        h_all = torch.empty(S + 1, N, D, dtype=torch.float32, device=dev)
+        c_all = torch.empty(S + 1, N, D, dtype=torch.float32, device=dev)
+        h_all[0].zero_(); c_all[0].zero_()
+        gates = torch.empty(S, N, 4 * D, dtype=torch.float32, device=dev)
+        gh = torch.empty(N, 4 * D, dtype=torch.float32, device=dev)
+        for t in range(S):
+            _gemm(h_all[t], D, 1, w, D, 1, gh, N, 4 * D, D)
+            _lib.call("lstm_cell_fwd_idx", _p(gx_all), _p(rows_t[t]), _p(gh), _p(c_all[t]), _p(h_all[t]), _p(active_t[t]),
+                      _p(h_all[t + 1]), _p(c_all[t + 1]), _p(gates[t]), N, D, _stream())
+        out = torch.index_select(h_all[1:].reshape(S * N, D), 0, pick)
+        ctx.save_for_backward(gates, c_all, h_all, w, pick)
+        ctx.lists = (rows_t, active_t)
+        ctx.direct = wgrad
+        ctx.cfg = (S, N, D, gx_all.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        gates, c_all, h_all, w, pick = ctx.saved_tensors
+        rows_t, active_t = ctx.lists
+        S, N, D, T = ctx.cfg
+        dev = dout.device
+        dhs = torch.zeros(S * N, D, dtype=torch.float32, device=dev)
+        dhs.index_copy_(0, pick.long() if pick.dtype != torch.int64 else pick, _c(dout))
+        dhs = dhs.view(S, N, D)
+        dG = torch.empty(S, N, 4 * D, dtype=torch.float32, device=dev)
+        dh = torch.zeros(N, D, dtype=torch.float32, device=dev)
+        dc = torch.zeros(N, D, dtype=torch.float32, device=dev)
+        dh2, dc2 = torch.empty_like(dh), torch.empty_like(dc)
+        for t in range(S - 1, -1, -1):
+            _lib.call("lstm_cell_bwd_seq", _p(dhs[t]), _p(dh), _p(dc), _p(gates[t]), _p(c_all[t]), _p(active_t[t]), _p(dG[t]), _p(dc2),
+                      _p(dh2), N, D, _stream())
+            _gemm(dG[t], 4 * D, 1, w, D, 0, dh2, N, D, 4 * D, accumulate=1)      # dh_{t-1} = pass-through + dgates · W_hh
+            dh, dh2 = dh2, dh
+            dc, dc2 = dc2, dc
+        dG2, hp = dG.view(S * N, 4 * D), h_all[:S].reshape(S * N, D)
+        wgrad = ctx.direct
+        dw = None
+        if wgrad is not None or ctx.needs_input_grad[1]:
+            acc = 1 if wgrad is not None else 0
+            dw = wgrad if wgrad is not None else torch.empty_like(w)
+            with _side_of(wgrad, dG2, hp):
+                _gemm(dG2, 4 * D, 0, hp, D, 0, dw, 4 * D, D, S * N, accumulate=acc)
+            if wgrad is not None:
+                _ready(wgrad, "w")
+                dw = None
+        dgx = torch.index_select(dG2, 0, pick) if ctx.needs_input_grad[0] else None
+        return dgx, dw, None, None, None, None
+
+
+def lstm_sequence(gx_all, w_hh, rows_t, active_t, pick):
+    """gx_all (T, 4D): input projections of every step row; rows_t[t] (N,) the step row each video consumes at time t;
+    active_t[t] (N,) 1/0; pick (T,) position of every step row's output in the time-major (S·N) state → (T, D)."""
+    return _LstmSeq.apply(gx_all, w_hh, rows_t, active_t, pick, _direct(w_hh))
 
 
 class _BceRows(Function):

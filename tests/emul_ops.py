@@ -245,6 +245,22 @@ def lstm_cell(gx, gh, c_prev, h_prev, active):
     return a * h + (1 - a) * h_prev, a * c + (1 - a) * c_prev
 
 
+def lstm_sequence(gx_all, w_hh, rows_t, active_t, pick):
+    """One LSTM direction over every video's step sequence (time-major state, inactive steps pass through)."""
+    N, D = rows_t[0].numel(), w_hh.shape[1]
+    h = gx_all.new_zeros(N, D)
+    c = gx_all.new_zeros(N, D)
+    hs = []
+    for rows, act in zip(rows_t, active_t):
+        h, c = lstm_cell(gx_all[rows.long()], h @ w_hh.t(), c, h, act)
+        hs.append(h)
+    return torch.stack(hs, 0).reshape(-1, D)[pick.long()]
+
+
+def branch_stream(device):
+    return None
+
+
 def bce_rows(p, y, widths):
     """Per-row sum of binary cross-entropy over the first widths[r] columns (nn.BCELoss clamps log at -100)."""
     cols = torch.arange(p.shape[1], device=p.device).unsqueeze(0)

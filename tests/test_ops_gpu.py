@@ -423,3 +423,27 @@ def test_gemm_l32_unsupported_shapes_fall_back(bf16_mode):
     O._gemm(A, 300, 1, B, 300, 1, C, 70, 50, 300)
     ref = A.bfloat16().double() @ B.bfloat16().double().t()
     assert (C.double() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_lstm_sequence_matches_stepwise_statement():
+    """Fused recurrence node (one direction, ragged lengths 3/1/2 of N=3 videos) against the per-step torch statement:
+    outputs, gradient of the input projections and of the recurrent weight."""
+    torch.manual_seed(0)
+    N, D, lens = 3, 32, [3, 1, 2]
+    S, T = max(lens), sum(lens)
+    off = [0, 3, 4]
+    rows_t = [torch.tensor([off[b] + min(t, lens[b] - 1) for b in range(N)], dtype=torch.int32, device=DEV) for t in range(S)]
+    act_t = [torch.tensor([1.0 if t < lens[b] else 0.0 for b in range(N)], device=DEV) for t in range(S)]
+    pick = torch.tensor([s_ * N + b for b in range(N) for s_ in range(lens[b])], dtype=torch.int32, device=DEV)
+    gx = torch.randn(T, 4 * D, device=DEV, requires_grad=True)
+    w = (0.3 * torch.randn(4 * D, D, device=DEV)).requires_grad_(True)
+    wt = torch.randn(T, D, device=DEV)
+    res = []
+    for mod in (O, E):
+        gx.grad = w.grad = None
+        out = mod.lstm_sequence(gx, w, rows_t, act_t, pick)
+        (out * wt).sum().backward()
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), gx.grad.clone(), w.grad.clone()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-5), (a - b).abs().max()
