@@ -284,6 +284,8 @@ class BertDecoderLayerNoMemoryUntied(nn.Module):
         qc = ops.linear(x1, ca_m.query.weight, ca_m.query.bias)
         wkv, bkv, wg, bg, w16 = ca_m.packed("kv")
         kvc = ops.linear(mem, wkv, bkv, wgrad=wg, bgrad=bg, w16=w16)
+        if kvc.dtype != qc.dtype:          # the few memory rows stay fp32 in HBM; the attention core wants one operand type
+            kvc = kvc.to(qc.dtype)
         ca = ops.attention(qc, kvc, (0, 0, D), D, cx.H, seq_cross, key_mask=mem_mask, causal=False, drop=cx.drop(cx.p_a))
         x2 = ops.layernorm(ca, self.norm2.weight, self.norm2.bias, cx.eps, residual=x1)
         o = ops.linear(x2, self.output.dense.weight, self.output.dense.bias)
@@ -300,9 +302,13 @@ class BertDecoderNoMemoryUntied(nn.Module):
         self.layer = nn.ModuleList([BertDecoderLayerNoMemoryUntied(config) for _ in range(config.num_hidden_layers)])
 
     def run(self, x, text_mask, mem, seq_self, seq_cross, mem_mask, cx):
+        # interior-only row counts in bf16 precision: the sentence activations (and their gradients) stream through HBM as bf16
+        stream_bf16 = x.dtype == torch.float32 and ops.bf16_stream_ok(x.shape[0], x.shape[1], self.config.intermediate_size)
+        if stream_bf16:
+            x = x.to(torch.bfloat16)
         for layer in self.layer:
             x = layer.run(x, text_mask, mem, seq_self, seq_cross, mem_mask, cx)
-        return x
+        return x.float() if stream_bf16 else x
 
     def forward(self, dec_hidden_states, dec_mask, enc_outputs, enc_mask, diagonal_mask=True,
                 output_all_encoded_layers=False):
