@@ -30,6 +30,25 @@ struct MAttnArgs {
 
 constexpr int AT_MAX = 128;   // rows per image: 128 (clip encoder) or 32 (22-token decoder, ≤12-step sequences, ≤3-slot memory)
 
+// Dropout multiplier for element index (row_base + key) of the (sequence, head, query, key) probability tensor.  The index
+// arithmetic stays 32-bit whenever the whole tensor has < 2^32 elements (checked once per kernel: `wide`), which is
+// bit-identical to drop_scale(): svpc_hash32 mixes ((uint32)idx ^ key) when the upper index word is 0.
+struct DropCtx {
+    uint32_t key, thr, site; float ik, p; u64 seed; bool wide;
+    __device__ __forceinline__ DropCtx(const u64* seed_ptr, uint32_t site_, float p_, u64 total_elems) {
+        p = p_; site = site_;
+        seed = p_ > 0.f ? seed_ptr[0] : 0ull;
+        ik = p_ > 0.f ? 1.0f / (1.0f - p_) : 1.0f;
+        key = (uint32_t)(seed ^ (seed >> 32)) + (site_ + 1u) * 0x9E3779B9u;
+        thr = (uint32_t)(p_ * 65536.0f);
+        wide = total_elems >= (1ull << 32);
+    }
+    __device__ __forceinline__ float mul(u64 row_base, int k) const {       // row_base = ((s·H + h)·max_q + q)·max_k
+        if (wide) return drop_scale(seed, site, row_base + (u64)k, p, ik);
+        return (svpc_mix32(((uint32_t)row_base + (uint32_t)k) ^ key) >> 16) >= thr ? ik : 0.0f;
+    }
+};
+
 template <int DH> struct AImg { static constexpr int RS = DH * 2 + 16; };
 
 // rows [0, len) of a (·, DH) matrix (fp32 or bf16 in HBM) → bf16 image (zero rows beyond len), optionally scaled.
@@ -171,11 +190,15 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
     if (PERWAVE && sh >= a.n_seq * a.H) return;
     const int s = sh / a.H, h = sh - s * a.H;
     const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
-    stage_pair<DH, T, AT, NT>(tid, Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f,
-                              Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
-    stage_rows<DH, T, AT, NT>(tid, Qs, (const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale);
-    for (int j = tid; j < AT; j += NT)
-        mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
+    {   // all three images in flight at once: one memory round trip for the prologue
+        RowStage<DH, T, AT, NT> sk(tid), sv(tid), sq(tid);
+        sk.load((const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len);
+        sv.load((const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len);
+        sq.load((const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len);
+        for (int j = tid; j < AT; j += NT)
+            mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
+        sk.store(Ks, 1.0f); sv.store(Vs, 1.0f); sq.store(Qs, a.scale);
+    }
     group_sync<PERWAVE>();
     const int q0 = 32 * wave;
     if (q0 >= q_len || wave >= NTL) return;
@@ -196,27 +219,28 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
     const int q = q0 + l31;                 // this lane's query
     float mx = -INFINITY;
 #pragma unroll
-    for (int jt = 0; jt < NTL; ++jt)
+    for (int jt = 0; jt < NTL; ++jt) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int key = 32 * jt + acc_row(e, lane);
             float t = mterm[key];
-            if (a.causal && key > q && key < k_len) t = -10000.0f;
+            if (a.causal) t = (key > q && key < k_len) ? -10000.0f : t;     // uniform branch: no per-element selects otherwise
             const float v = st[jt][e] + t;
             st[jt][e] = v;
             mx = fmaxf(mx, v);
         }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
 #pragma unroll
     for (int jt = 0; jt < NTL; ++jt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { const float p = expf(st[jt][e] - mx); st[jt][e] = p; sum += p; }
+        for (int e = 0; e < 16; ++e) { const float p = __expf(st[jt][e] - mx); st[jt][e] = p; sum += p; }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (lane < 32 && q < q_len && a.LSE) a.LSE[((size_t)s * a.H + h) * a.max_q + q] = mx + logf(sum);
-    const u64 seed = a.p_drop > 0.f ? a.seed[0] : 0ull;
-    const float ik = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    const DropCtx dctx(a.seed, a.site, a.p_drop, (u64)a.n_seq * a.H * a.max_q * a.max_k);
+    const u64 row_base = ((u64)(s * a.H + h) * a.max_q + q) * a.max_k;
     floatx16 acc[DH / 32];
 #pragma unroll
     for (int dt = 0; dt < DH / 32; ++dt)
@@ -227,13 +251,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
         if (jt < nkt) {
             float pv[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float p = st[jt][e] * inv;
-                if (a.p_drop > 0.f) {
-                    const int key = 32 * jt + acc_row(e, lane);
-                    p *= drop_scale(seed, a.site, ((u64)(s * a.H + h) * a.max_q + q) * a.max_k + key, a.p_drop, ik);
-                }
-                pv[e] = p;
+            for (int e = 0; e < 16; ++e) pv[e] = st[jt][e] * inv;
+            if (a.p_drop > 0.f) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) pv[e] *= dctx.mul(row_base, 32 * jt + acc_row(e, lane));
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -265,57 +286,53 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
     if (PERWAVE && sh >= a.n_seq * a.H) return;
     const int s = sh / a.H, h = sh - s * a.H;
     const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
-    stage_pair<DH, T, AT, NT>(tid, Ks, (const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len, 1.0f,
-                              Vs, (const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len, 1.0f);
-    stage_pair<DH, T, AT, NT>(tid, Qs, (const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len, a.scale,
-                              Ds, (const T*)a.dO + (size_t)q_off * a.lddo + h * DH, a.lddo, q_len, 1.0f);
-    for (int j = tid; j < AT; j += NT) {
-        mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
-        lse[j] = j < q_len ? a.LSE[((size_t)s * a.H + h) * a.max_q + j] : 0.f;
-    }
-    if (PERWAVE) {                                // delta = rowsum(dO ⊙ O): lane pair per row (AT = 32), all loads independent
-        const int r = lane >> 1, c0 = (lane & 1) * (DH / 2);
-        float d = 0.f;
+    // Every global load of the prologue (K, V, Q, dO images and the dO/O row segments of delta) is issued before the first
+    // conversion or LDS store: one memory round trip instead of one per image / per delta row.
+    {
+        RowStage<DH, T, AT, NT> sk(tid), sv(tid), sq(tid), sd(tid);
+        sk.load((const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len);
+        sv.load((const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len);
+        sq.load((const T*)a.Q + (size_t)q_off * a.ldq + h * DH, a.ldq, q_len);
+        sd.load((const T*)a.dO + (size_t)q_off * a.lddo + h * DH, a.lddo, q_len);
+        // delta = rowsum(dO ⊙ O): two threads per row (NT = 2·AT), half a head row each
+        const int r = tid >> 1, c0 = (tid & 1) * (DH / 2);
+        constexpr int VW = sizeof(T) == 4 ? 4 : 8, NV = DH / 2 / VW;
+        typedef float dvec __attribute__((ext_vector_type(4)));
+        dvec x[NV], y[NV];
         if (r < q_len) {
             const T* po = (const T*)a.dO + (size_t)(q_off + r) * a.lddo + h * DH + c0;
             const T* oo = (const T*)a.O + (size_t)(q_off + r) * a.ldo + h * DH + c0;
-            if (sizeof(T) == 4) {
-                float4 x[DH / 8], y[DH / 8];
 #pragma unroll
-                for (int c = 0; c < DH / 8; ++c) {
-                    x[c] = reinterpret_cast<const float4*>(po)[c];
-                    y[c] = reinterpret_cast<const float4*>(oo)[c];
+            for (int c = 0; c < NV; ++c) {
+                x[c] = reinterpret_cast<const dvec*>(po)[c];
+                y[c] = reinterpret_cast<const dvec*>(oo)[c];
+            }
+        }
+        for (int j = tid; j < AT; j += NT) {
+            mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
+            lse[j] = j < q_len ? a.LSE[((size_t)s * a.H + h) * a.max_q + j] : 0.f;
+        }
+        sk.store(Ks, 1.0f); sv.store(Vs, 1.0f); sq.store(Qs, a.scale); sd.store(Ds, 1.0f);
+        float d = 0.f;
+        if (r < q_len) {
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                if (sizeof(T) == 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d += x[c][j] * y[c][j];
+                } else {
+                    union { dvec f; bf16x8 h; } ux, uy;
+                    ux.f = x[c]; uy.f = y[c];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d += (float)ux.h[j] * (float)uy.h[j];
                 }
-#pragma unroll
-                for (int c = 0; c < DH / 8; ++c) d += x[c].x * y[c].x + x[c].y * y[c].y + x[c].z * y[c].z + x[c].w * y[c].w;
-            } else {
-                bf16x8 x[DH / 16], y[DH / 16];
-#pragma unroll
-                for (int c = 0; c < DH / 16; ++c) {
-                    x[c] = reinterpret_cast<const bf16x8*>(po)[c];
-                    y[c] = reinterpret_cast<const bf16x8*>(oo)[c];
-                }
-#pragma unroll
-                for (int c = 0; c < DH / 16; ++c)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) d += (float)x[c][j] * (float)y[c][j];
             }
         }
         d += __shfl_xor(d, 1, 64);
-        if ((lane & 1) == 0) delta[r] = d;
-    } else {
-        for (int r = wave; r < AT; r += 4) {
-            float d = 0.f;
-            if (r < q_len && lane < DH)
-                d = (float)((const T*)a.dO)[(size_t)(q_off + r) * a.lddo + h * DH + lane] *
-                    (float)((const T*)a.O)[(size_t)(q_off + r) * a.ldo + h * DH + lane];
-            d = wave_sum(d);
-            if (lane == 0) delta[r] = d;
-        }
+        if ((tid & 1) == 0 && r < AT) delta[r] = d;
     }
     group_sync<PERWAVE>();
-    const u64 seed = a.p_drop > 0.f ? a.seed[0] : 0ull;
-    const float ik = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    const DropCtx dctx(a.seed, a.site, a.p_drop, (u64)a.n_seq * a.H * a.max_q * a.max_k);
     const u64 dbase = (u64)(s * a.H + h) * a.max_q;
     const int nqt = (q_len + 31) >> 5, nkt = (k_len + 31) >> 5;
 
@@ -337,17 +354,29 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
                 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(Qs, 32 * qt, ds, lane), frag_rows<DH>(Ks, k0, ds, lane), sc, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(Ds, 32 * qt, ds, lane), frag_rows<DH>(Vs, k0, ds, lane), dp, 0, 0, 0);
             }
-            float pt[16], dsv[16];
+            // no validity selects: keys ≥ k_len carry t = -inf (p = 0); queries ≥ q_len have zero Q / dO rows and lse = delta = 0,
+            // so whatever finite p they get multiplies zeros in both products
+            float pt[16], dsv[16], dm[16];
+            const int qb = 32 * qt + 4 * (lane >> 5);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int q = 32 * qt + acc_row(e, lane);
+                const int q = qb + (e & 3) + 8 * (e >> 2);
                 float t = mt;
-                if (a.causal && key > q && key < k_len) t = -10000.0f;
-                float p = (q < q_len && key < k_len) ? expf(sc[e] + t - lse[q]) : 0.f;
-                float dm = 1.0f;
-                if (a.p_drop > 0.f) dm = drop_scale(seed, a.site, (dbase + q) * a.max_k + key, a.p_drop, ik);
-                pt[e] = p * dm;
-                dsv[e] = p * (dp[e] * dm - delta[q]);
+                if (a.causal) t = (key > q && key < k_len) ? -10000.0f : t;
+                pt[e] = __expf(sc[e] + t - lse[q]);
+                dm[e] = 1.0f;
+            }
+            if (a.p_drop > 0.f) {
+                const u64 rb = (dbase + qb) * a.max_k;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dm[e] = dctx.mul(rb + (u64)(((e & 3) + 8 * (e >> 2)) * a.max_k), key);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int q = qb + (e & 3) + 8 * (e >> 2);
+                const float p = pt[e];
+                pt[e] = p * dm[e];
+                dsv[e] = p * (dp[e] * dm[e] - delta[q]);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -383,17 +412,23 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
                 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(Ks, 32 * kt, ds, lane), frag_rows<DH>(Qs, q0, ds, lane), sc, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(Vs, 32 * kt, ds, lane), frag_rows<DH>(Ds, q0, ds, lane), dp, 0, 0, 0);
             }
-            float dsv[16];
+            float dsv[16], dm[16];
+            const int kb = 32 * kt + 4 * (lane >> 5);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int key = 32 * kt + acc_row(e, lane);
+                const int key = kb + (e & 3) + 8 * (e >> 2);
                 float t = mterm[key];
-                if (a.causal && key > q && key < k_len) t = -10000.0f;
-                const float p = (q < q_len && key < k_len) ? expf(sc[e] + t - lq) : 0.f;
-                float dm = 1.0f;
-                if (a.p_drop > 0.f) dm = drop_scale(seed, a.site, (dbase + q) * a.max_k + key, a.p_drop, ik);
-                dsv[e] = p * (dp[e] * dm - dq_);
+                if (a.causal) t = (key > q && key < k_len) ? -10000.0f : t;
+                dsv[e] = __expf(sc[e] + t - lq);      // keys ≥ k_len: t = -inf → 0; lanes of queries ≥ q_len are never stored
+                dm[e] = 1.0f;
             }
+            if (a.p_drop > 0.f) {
+                const u64 rb = (dbase + q) * a.max_k;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dm[e] = dctx.mul(rb, kb + (e & 3) + 8 * (e >> 2));
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dsv[e] = dsv[e] * (dp[e] * dm[e] - dq_);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 da = pack8(&dsv[8 * s2]);
