@@ -264,19 +264,6 @@ __global__ __launch_bounds__(128 * NWN) void gemm_bf16_kernel(const TA* __restri
         }
 }
 
-template <typename TC>
-__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ slabs, int splitk, TC* __restrict__ C,
-                                                                 int ldc, int M, int N, Epi epi) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)M * N) return;
-    const int row = (int)(i / N), col = (int)(i - (size_t)row * N);
-    float s = 0.f;
-    for (int k = 0; k < splitk; ++k) s += slabs[(size_t)k * M * N + i];
-    const u64 seed = epi.p_drop > 0.f ? epi.seed[0] : 0ull;
-    const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
-    epilogue_store_t<TC>(s, row, col, C, ldc, epi, seed, inv_keep);
-}
-
 template <int BM, int BN, int NWN, bool AK, bool BKC, bool FULL, typename TA, typename TB, typename TC>
 static void launch_one(dim3 grid, hipStream_t s, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                        Epi epi, int tiles_m, int tiles_n, int splitk, int k_chunk, float* slabs, int a_vec, int b_vec, int remap) {
@@ -368,10 +355,8 @@ int svpc_gemm_mx(const void* A, int a_dt, int lda, int a_kc, const void* B, int 
     int rc = svpc_check_launch("gemm_mx");
     if (rc) return rc;
     if (splitk > 1) {
-        const size_t n = (size_t)M * N;
-        const dim3 g((unsigned)((n + 255) / 256));
-        if (c_dt == 0) hipLaunchKernelGGL(splitk_reduce_bf16_kernel<float>, g, dim3(256), 0, stream, workspace, splitk, (float*)C, ldc, M, N, epi);
-        else hipLaunchKernelGGL(splitk_reduce_bf16_kernel<__bf16>, g, dim3(256), 0, stream, workspace, splitk, (__bf16*)C, ldc, M, N, epi);
+        if (c_dt == 0) launch_splitk_reduce<float>(workspace, splitk, (float*)C, ldc, M, N, epi, stream);
+        else launch_splitk_reduce<__bf16>(workspace, splitk, (__bf16*)C, ldc, M, N, epi, stream);
         rc = svpc_check_launch("gemm_mx splitk reduce");
     }
     return rc;

@@ -40,3 +40,57 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
+
+
+// ---- split-K tail shared by the MFMA GEMM families: C = epi( Σ_k slabs[k] ), slabs summed in k order (deterministic).
+// The vector form handles 4 consecutive columns per thread with 4 slab loads in flight (N % 4 == 0); the sum order per
+// element is the same as in the scalar form, so both give identical bits.
+template <typename TC>
+__global__ __launch_bounds__(256) void splitk_reduce1_kernel(const float* __restrict__ slabs, int splitk, TC* __restrict__ C, int ldc,
+                                                             int M, int N, Epi epi) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    const int row = (int)(i / N), col = (int)(i - (size_t)row * N);
+    float s = 0.f;
+    for (int k = 0; k < splitk; ++k) s += slabs[(size_t)k * M * N + i];
+    const u64 seed = epi.p_drop > 0.f ? epi.seed[0] : 0ull;
+    const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
+    epilogue_store_t<TC>(s, row, col, C, ldc, epi, seed, inv_keep);
+}
+template <typename TC>
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float* __restrict__ slabs, int splitk, TC* __restrict__ C, int ldc,
+                                                             int M, int N, Epi epi) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x, nq = (size_t)M * N / 4;
+    if (q >= nq) return;
+    const size_t i = q * 4;
+    const int row = (int)(i / N), col = (int)(i - (size_t)row * N);
+    const float4* p = reinterpret_cast<const float4*>(slabs) + q;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 4 <= splitk; k += 4) {
+        const float4 a = p[(size_t)k * nq], b = p[(size_t)(k + 1) * nq], c = p[(size_t)(k + 2) * nq], d = p[(size_t)(k + 3) * nq];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+        s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+    }
+    for (; k < splitk; ++k) {
+        const float4 a = p[(size_t)k * nq];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    const u64 seed = epi.p_drop > 0.f ? epi.seed[0] : 0ull;
+    const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
+    epilogue_store_t<TC>(s.x, row, col, C, ldc, epi, seed, inv_keep);
+    epilogue_store_t<TC>(s.y, row, col + 1, C, ldc, epi, seed, inv_keep);
+    epilogue_store_t<TC>(s.z, row, col + 2, C, ldc, epi, seed, inv_keep);
+    epilogue_store_t<TC>(s.w, row, col + 3, C, ldc, epi, seed, inv_keep);
+}
+template <typename TC>
+static inline void launch_splitk_reduce(const float* slabs, int splitk, TC* C, int ldc, int M, int N, const Epi& epi, hipStream_t stream) {
+    const size_t n = (size_t)M * N;
+    if (N % 4 == 0 && ((((uintptr_t)slabs) & 15) == 0))
+        hipLaunchKernelGGL(splitk_reduce4_kernel<TC>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, slabs, splitk, C, ldc, M, N,
+                           epi);
+    else
+        hipLaunchKernelGGL(splitk_reduce1_kernel<TC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, slabs, splitk, C, ldc, M, N, epi);
+}

@@ -157,19 +157,6 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict
         }
 }
 
-template <typename TC>
-__global__ __launch_bounds__(256) void glds_splitk_reduce_kernel(const float* __restrict__ slabs, int splitk, TC* __restrict__ C, int ldc,
-                                                                 int M, int N, Epi epi) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)M * N) return;
-    const int row = (int)(i / N), col = (int)(i - (size_t)row * N);
-    float s = 0.f;
-    for (int k = 0; k < splitk; ++k) s += slabs[(size_t)k * M * N + i];
-    const u64 seed = epi.p_drop > 0.f ? epi.seed[0] : 0ull;
-    const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
-    epilogue_store_t<TC>(s, row, col, C, ldc, epi, seed, inv_keep);
-}
-
 extern "C" {
 
 // 1 if (shape, layout) can run on the direct-to-LDS kernel: bf16 A and B, interior-only, 16-byte aligned rows
@@ -228,10 +215,8 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
     int rc = svpc_check_launch("gemm_glds");
     if (rc) return rc;
     if (splitk > 1) {
-        const size_t n = (size_t)M * N;
-        const dim3 g((unsigned)((n + 255) / 256));
-        if (c_dt == 0) hipLaunchKernelGGL(glds_splitk_reduce_kernel<float>, g, dim3(256), 0, stream, workspace, splitk, (float*)C, ldc, M, N, epi);
-        else hipLaunchKernelGGL(glds_splitk_reduce_kernel<__bf16>, g, dim3(256), 0, stream, workspace, splitk, (__bf16*)C, ldc, M, N, epi);
+        if (c_dt == 0) launch_splitk_reduce<float>(workspace, splitk, (float*)C, ldc, M, N, epi, stream);
+        else launch_splitk_reduce<__bf16>(workspace, splitk, (__bf16*)C, ldc, M, N, epi, stream);
         rc = svpc_check_launch("gemm_glds splitk reduce");
     }
     return rc;

@@ -164,18 +164,6 @@ __global__ __launch_bounds__(256) void gemm_l32_kernel(const float* __restrict__
         }
 }
 
-__global__ __launch_bounds__(256) void l32_splitk_reduce_kernel(const float* __restrict__ slabs, int splitk, float* __restrict__ C, int ldc,
-                                                                int M, int N, Epi epi) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)M * N) return;
-    const int row = (int)(i / N), col = (int)(i - (size_t)row * N);
-    float s = 0.f;
-    for (int k = 0; k < splitk; ++k) s += slabs[(size_t)k * M * N + i];
-    const u64 seed = epi.p_drop > 0.f ? epi.seed[0] : 0ull;
-    const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
-    epilogue_store(s, row, col, C, ldc, epi, seed, inv_keep);
-}
-
 template <int BM, int BN, bool A_KC, bool B_KC, int NS>
 static int l32_launch_one(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
                           int K, Epi epi, int tiles_m, int tiles_n, int splitk, int k_chunk, float* slabs, int remap) {
@@ -269,9 +257,7 @@ int svpc_gemm_l32(const float* A, int lda, int a_kc, const float* B, int ldb, in
     rc = svpc_check_launch("gemm_l32");
     if (rc) return rc;
     if (splitk > 1) {
-        const size_t n = (size_t)M * N;
-        hipLaunchKernelGGL(l32_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, workspace, splitk, C, ldc, M, N,
-                           epi);
+        launch_splitk_reduce<float>(workspace, splitk, C, ldc, M, N, epi, stream);
         rc = svpc_check_launch("gemm_l32 splitk reduce");
     }
     return rc;

@@ -9,6 +9,7 @@
 // Backward recomputes h and x_hat from the saved inputs + (mean, rstd); gamma/beta gradients are accumulated
 // per workgroup in registers → LDS → one partial row per workgroup, reduced by colsum_finalize (deterministic).
 #include "common.h"
+#include <stdlib.h>
 
 template <int W, typename T>
 struct VecIO;
@@ -364,6 +365,14 @@ static int launch_ln_bwd(const LnBwdArgs& a, int G, int x_dt, int y_dt, hipStrea
     const dim3 g(G), b(256);
     const size_t lds = (size_t)2 * a.D * sizeof(float);
     constexpr int RU = (NPL * W <= 16) ? 2 : 1;      // two rows in flight per wave while the registers allow it
+    static int ru_env = -1;
+    if (ru_env < 0) { const char* e = getenv("SVPC_LN_RU"); ru_env = e ? atoi(e) : 0; }
+    if (ru_env == 1) {
+        if (x_dt == 0 && y_dt == 0) hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, float, float, 1>), g, b, lds, s, a);
+        else if (x_dt == 0 && y_dt == 1) hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, float, __bf16, 1>), g, b, lds, s, a);
+        else hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, __bf16, __bf16, 1>), g, b, lds, s, a);
+        return svpc_check_launch("ln_bwd");
+    }
     if (x_dt == 0 && y_dt == 0) hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, float, float, RU>), g, b, lds, s, a);
     else if (x_dt == 0 && y_dt == 1) hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, float, __bf16, RU>), g, b, lds, s, a);
     else hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, __bf16, __bf16, RU>), g, b, lds, s, a);
@@ -408,7 +417,12 @@ int svpc_ln_fwd(const float* x, const int* src_rows, const float* res, const flo
 }
 
 // workspace: at least svpc_ln_bwd_groups(R) * 2 * D floats
-int svpc_ln_bwd_groups(int R) { int g = ceil_div(R, 4); return g < 1 ? 1 : (g > 512 ? 512 : g); }
+int svpc_ln_bwd_groups(int R) {
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("SVPC_LN_GROUPS"); cap = e ? atoi(e) : 512; }
+    int g = ceil_div(R, 4);
+    return g < 1 ? 1 : (g > cap ? cap : g);
+}
 
 // rows part only: dh / dx and the per-workgroup [dgamma ; dbeta] partials (svpc_ln_bwd_groups(R) × 2D floats)
 int svpc_ln_bwd_rows_t(const void* dy, const void* x, int x_dt, int y_dt, const int* src_rows, const void* res, const float* gamma,
