@@ -25,7 +25,7 @@ from svpc_amd import StateAwareRecursiveTransformer, make_batch, make_config  # 
 from svpc_amd import ops, synthetic as syn  # noqa: E402
 from svpc_amd.optim import FusedBertAdam, GradReducer  # noqa: E402
 
-PMC_TRAFFIC_BYTES = 205654105   # (2·FETCH_SIZE + WRITE_SIZE)·1024, means per launch of the dominant symbol: profiles/r01_c_pmc_bench_dominant_gemm.csv
+PMC_TRAFFIC_BYTES = 108541184   # (2·FETCH_SIZE + WRITE_SIZE)·1024, means per launch of the dominant symbol: profiles/r01_d_pmc_bench_dominant_gemm.csv
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense peaks (f32-in MFMA; bf16 MFMA)
 
 
@@ -232,12 +232,12 @@ def main():
     loss = step()
     host_enqueue_ms = 1000.0 * (time.perf_counter() - th)
     torch.cuda.synchronize()
-    # roofline leg: HIP events around the encoder-sized GEMM launches.  Eager mode: inside the timed region.  Graph mode: events
-    # cannot be recorded inside a replay, so the same kernels are bracketed in instrumented eager steps right after it.
-    # Dominant kernel = the forward GEMM of the clip encoder: ONE kernel symbol (gemm_glds_kernel<true,true,__bf16,3>: bf16
-    # activations × bf16 weight shadow → bf16, both operands direct-to-LDS) covering Q/K/V, attention-output, FFN-in/out
-    # projections and the video embedding — every launch of that symbol is bracketed, so the average can be checked against
-    # rocprofv3's per-kernel average.
+    # roofline leg: HIP events around every launch of the dominant kernel symbol.  Eager mode: inside the timed region.  Graph
+    # mode: events cannot be recorded inside a replay, so the same kernels are bracketed in instrumented eager steps right after it.
+    # Dominant kernel = the forward GEMM of the bf16 activation streams: ONE kernel symbol (gemm_glds_kernel<true,true,__bf16,3>:
+    # bf16 activations × bf16 weight shadow → bf16, both operands direct-to-LDS) covering Q/K/V, attention-output, FFN-in/out and
+    # video-embedding projections of the clip encoder (M = 19,200 rows) and the decoder's projections (M = 4,224 rows) — every
+    # launch of that symbol is bracketed, so the average can be checked against rocprofv3's per-kernel average.
     rows_enc = args.batch * args.clips * cfg.max_v_len
     bf16_stream = args.precision == "bf16" and ops.bf16_stream_ok(rows_enc, cfg.hidden_size, cfg.video_feature_size)
     glds = bf16_stream and ops.USE_GLDS      # weights come from the optimizer's bf16 shadow → direct-to-LDS kernel
@@ -245,7 +245,7 @@ def main():
 
     def dom_select(d):
         M_, N_, K_, akc, bkc, adt, bdt, cdt = d
-        return M_ == rows_enc and akc == 1 and bkc == 1 and (adt, bdt, cdt) == want_dt
+        return akc == 1 and bkc == 1 and (adt, bdt, cdt) == want_dt and (glds or M_ == rows_enc)
     if graph is None:
         ops.GEMM_TIMER = ops.KernelTimer(select=dom_select)
     if dist is not None:
@@ -274,13 +274,10 @@ def main():
     if rank == 0:
         ms = 1000.0 * elapsed / args.steps
         achieved = gsum["work"] / (gsum["ms"] * 1e-3) / 1e12 if gsum["ms"] > 0 else 0.0
-        el = 2 if bf16_stream else 4
         D_, F_, L_ = cfg.hidden_size, cfg.video_feature_size, cfg.num_hidden_layers
-        # launches of the symbol per step: per full layer Q/K/V (N=3D), attention-out, FFN-in, FFN-out; last layer K/V only; video embed
-        shapes = [(3 * D_, D_), (D_, D_), (D_, D_), (D_, D_)] * (L_ - 1) + [(2 * D_, D_), (D_, F_)]
-        alg_bytes = sum(rows_enc * (k + n) * el + n * k * (2 if glds else 4) for n, k in shapes) / len(shapes)
-        alg_flop = sum(2.0 * rows_enc * n * k for n, k in shapes) / len(shapes)
-        # mean HBM traffic per launch of this symbol from rocprofv3 PMC passes over this very command (profiles/r01_c_pmc_bench_*.csv):
+        n_l = max(1, gsum["launches"])
+        alg_bytes, alg_flop = gsum["bytes"] / n_l, gsum["work"] / n_l
+        # mean HBM traffic per launch of this symbol from rocprofv3 PMC passes over this very command (profiles/r01_d_pmc_*.csv):
         # FETCH_SIZE × 2 (gfx950 reports half of a 16-B/lane stream) + WRITE_SIZE, in KB.  Only valid for the default workload.
         default_cfg = (args.batch, args.clips, L_, D_, F_, args.model_type) == (16, 12, 6, 768, 3072, "vivt") and bf16_stream
         traffic = PMC_TRAFFIC_BYTES if (default_cfg and glds) else None
@@ -296,15 +293,17 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
                        "host_enqueue_ms_per_step": host_enqueue_ms,
                        "launch": "hipGraph replay" if graph is not None else "eager"},
-            "roofline": {"bound": "mfma", "kernel": "%s — all clip-encoder forward GEMMs (M=%d rows; Q/K/V, attention-out, FFN, "
-                                   "video embedding)" % ("gemm_glds_kernel<true,true,__bf16,3> (bf16·bf16→bf16, direct-to-LDS)" if glds else
-                                                         "gemm_bf16_kernel<128,128,NT,interior,8 waves,%s>" % ("bf16·f32→bf16" if bf16_stream else "f32"),
-                                                         rows_enc),
+            "roofline": {"bound": "mfma", "kernel": "%s — every forward projection of the bf16 activation streams (clip encoder M=%d "
+                                   "rows: Q/K/V, attention-out, FFN, video embedding; decoder M=%d rows)"
+                                   % ("gemm_glds_kernel<true,true,__bf16,3> (bf16·bf16→bf16, direct-to-LDS)" if glds else
+                                      "gemm_bf16_kernel<128,128,NT,interior,8 waves,%s>" % ("bf16·f32→bf16" if bf16_stream else "f32"),
+                                      rows_enc, args.batch * args.clips * cfg.max_t_len),
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS[args.precision],
                          "traffic": traffic, "algorithmic_flop_per_launch": alg_flop, "algorithmic_bytes_per_launch": alg_bytes,
                          "launches": gsum["launches"], "avg_launch_ms": gsum["ms"] / max(1, gsum["launches"]),
-                         "measured": "HIP events on the launch stream, " + ("3 instrumented eager steps after the timed graph replays"
+                         "event_pair_overhead_ms": gsum["event_overhead_ms"],
+                         "measured": "HIP events on the launch stream (net of the calibrated empty event-pair time), " + ("3 instrumented eager steps after the timed graph replays"
                                                                             if graph is not None else "inside the timed region")},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -190,14 +190,25 @@ class KernelTimer:
         if work < self.min_flops or (self.select is not None and not self.select(desc)):
             return None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.records.append((work, e0, e1))
+        self.records.append((work, e0, e1, desc))
         return e0, e1
 
     def summary(self):
         torch.cuda.synchronize()
-        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in self.records)
-        work = sum(w for w, _, _ in self.records)
-        return dict(launches=len(self.records), work=work, ms=ms)
+        ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in self.records)
+        work = sum(w for w, _, _, _ in self.records)
+        # algorithmic HBM bytes: every operand and the result once, in their storage types
+        el = lambda d: 2 if d else 4
+        nbytes = sum(M * K * el(a) + N * K * el(b) + M * N * el(c) for _, _, _, (M, N, K, _, _, a, b, c) in self.records)
+        # an event pair around NOTHING still measures a few µs (record-to-record latency on the stream): calibrate and remove it,
+        # so the per-launch average is comparable with the profiler's kernel durations
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+        for e0, e1 in pairs:
+            e0.record(); e1.record()
+        torch.cuda.synchronize()
+        empty = sorted(e0.elapsed_time(e1) for e0, e1 in pairs)[len(pairs) // 2]
+        net = max(ms - empty * len(self.records), 0.0)
+        return dict(launches=len(self.records), work=work, ms=net, ms_raw=ms, event_overhead_ms=empty, bytes=nbytes)
 
 
 GEMM_TIMER = None   # set by bench.py
