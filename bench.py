@@ -108,7 +108,8 @@ def decode_bench(cfg, model, args, device, world, rank, dist):
             b[k] = [t.to(device) for t in v]
         elif isinstance(v, torch.Tensor):
             b[k] = v.to(device)
-    tr = Translator(type("O", (), {"cuda": True})(), {"model_cfg": cfg, "model": model.state_dict()}, model=model)
+    tr = Translator(type("O", (), {"cuda": True})(), {"model_cfg": cfg, "model": model.state_dict()}, model=model,
+                    incremental=not args.decode_full)
     for _ in range(max(1, args.warmup)):
         tr.translate_batch(syn.translate_inputs(b))
     if dist is not None:
@@ -131,9 +132,11 @@ def decode_bench(cfg, model, args, device, world, rank, dist):
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-                          "config": {"workload": "MODEL_TYPE=%s translate_batch greedy: %d videos/GPU x %d clips, Lt=%d, L=%d; full decoder "
-                                                 "re-run per position (reference semantics), batched over videos, on-device pick"
-                                                 % (args.model_type, n_vid, args.clips, cfg.max_t_len, cfg.num_hidden_layers)}}))
+                          "config": {"workload": "MODEL_TYPE=%s translate_batch greedy: %d videos/GPU x %d clips, Lt=%d, L=%d; %s, batched "
+                                                 "over videos, on-device pick"
+                                                 % (args.model_type, n_vid, args.clips, cfg.max_t_len, cfg.num_hidden_layers,
+                                                    "full decoder re-run per position (reference loop shape)" if args.decode_full
+                                                    else "KV-cached incremental decoder (one new token per sentence and iteration)")}}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -153,6 +156,7 @@ def main():
                     help="arithmetic type of the GEMM operands (accumulation and storage are fp32 either way)")
     ap.add_argument("--decode", action="store_true", help="secondary metric: greedy-decode captions/s (BASELINE config 5: 64 videos)")
     ap.add_argument("--decode-videos", type=int, default=64)
+    ap.add_argument("--decode-full", action="store_true", help="decode with the reference-shaped loop (all Lt positions every iteration)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -293,6 +293,29 @@ class BertDecoderLayerNoMemoryUntied(nn.Module):
                              residual=x2, pre_drop=cx.drop(cx.p_h))
 
 
+    def memory_kv(self, mem):
+        """Cross-attention K|V of the memory rows: constant over the decoding iterations (the reference recomputes it Lt times)."""
+        wkv, bkv, _, _, _ = self.dec_enc_attention.packed("kv")
+        return ops.linear(mem, wkv, bkv)
+
+    def step(self, x, pos, lt, cache, mem_kv, seq_self, seq_cross, cx):
+        """The layer for ONE new token per sentence (position ``pos``): its K|V row is appended to ``cache`` ((T·lt, 2D), sentence-
+        major), the query attends to the pos+1 cached keys (the causal mask of the reference, model.py:630-640, lets position
+        ``pos`` see exactly those), then cross-attention to the precomputed memory K|V and the output block."""
+        T, D = x.shape
+        w, b, _, _, _ = self.self_attention.packed()
+        qkv = ops.linear(x, w, b)
+        cache.view(T, lt, 2 * D)[:, pos].copy_(qkv[:, D:])
+        sa = ops.attention(qkv, cache, (0, 0, D), D, cx.H, seq_self, key_mask=None, causal=False)
+        x1 = ops.layernorm(sa, self.norm1.weight, self.norm1.bias, cx.eps, residual=x)
+        ca_m = self.dec_enc_attention
+        qc = ops.linear(x1, ca_m.query.weight, ca_m.query.bias)
+        ca = ops.attention(qc, mem_kv, (0, 0, D), D, cx.H, seq_cross, key_mask=None, causal=False)
+        x2 = ops.layernorm(ca, self.norm2.weight, self.norm2.bias, cx.eps, residual=x1)
+        o = ops.linear(x2, self.output.dense.weight, self.output.dense.bias)
+        return ops.layernorm(o, self.output.LayerNorm.weight, self.output.LayerNorm.bias, cx.eps, residual=x2)
+
+
 class BertDecoderNoMemoryUntied(nn.Module):
     """reference: model.py:666-694."""
 
@@ -358,6 +381,11 @@ class BertEmbeddingsTextUntied(nn.Module):
         return self.word_fc.run(self.word_embeddings.weight, cx.eps, src_rows=ids_flat, pad_row=PAD_ROW,
                                 drop=cx.drop(cx.p_h), add1=self.position_embeddings_text.pe[:lt].contiguous(),
                                 add1_mod=lt)
+
+    def run_at(self, ids, pos, cx):
+        """One token per sentence, all at sentence position ``pos`` (incremental decoding)."""
+        return self.word_fc.run(self.word_embeddings.weight, cx.eps, src_rows=ids, pad_row=PAD_ROW, drop=cx.drop(cx.p_h),
+                                add1=self.position_embeddings_text.pe[pos:pos + 1].contiguous(), add1_mod=1)
 
     def forward(self, text_input_ids):
         B, Lt = text_input_ids.shape
@@ -572,6 +600,17 @@ class BatchPlan:
             self.lstm_bwd_rows.append(_i32([off[b] + max(step_nums[b] - 1 - t, 0) for b in range(N)], device))
             self.lstm_active.append(torch.tensor(act, dtype=torch.float32, device=device))
         self.sim = (self.step_off, self.step_len, self.ent_off, self.ent_len, self.e_max)
+        self._seq_inc = {}
+
+    def seq_dec_incremental(self, pos, lt, device):
+        """Segmentation of incremental decoding at position ``pos``: one query row per sentence, keys = the pos+1 cached rows of
+        that sentence in a (T·lt)-row sentence-major cache."""
+        key = (pos, lt)
+        sq = self._seq_inc.get(key)
+        if sq is None:
+            T = self.T
+            sq = self._seq_inc[key] = ops.SeqInfo(list(range(T)), [1] * T, [s * lt for s in range(T)], [pos + 1] * T, device)
+        return sq
 
 
 class StateAwareRecursiveTransformer(nn.Module):
@@ -703,7 +742,7 @@ class StateAwareRecursiveTransformer(nn.Module):
             return self.encoder.run(h, seq, key_mask_v, cx, last_rows=cls_only[0], last_seq=cls_only[1])
         return self.encoder.run(h, seq, key_mask_v, cx)
 
-    def _lm_probs(self, dec, bank, plan_like, cx, labels=None):
+    def _lm_probs(self, dec, bank, plan_like, cx, labels=None, proj=None):
         """Head + pointer-generator (+ caption loss rows).  plan_like carries step_ne, row_vid, csr, row_c, c_max."""
         cfg = self.config
         lt = plan_like["lt"]
@@ -716,12 +755,18 @@ class StateAwareRecursiveTransformer(nn.Module):
                                     plan_like["csr_off"], plan_like["csr_ent"], plan_like["csr_id"], plan_like["csr_w"],
                                     plan_like["c_max"], self.label_smoothing)
         T, e_max, D = bank.shape
-        proj = ops.linear(bank.reshape(T * e_max, D), self.Wing.weight, self.Wing.bias).view(T, e_max, D)
+        if proj is None:
+            proj = self.bank_projection(bank)
         pi, att = ops.ptr_attn(dec, proj, bank, plan_like["step_ne"], lt)
         g = ops.linear(torch.cat([dec, att], 1), self.pgen_linear[0].weight, self.pgen_linear[0].bias, act=ACT_SIGMOID)
         return ops.ptr_mix_loss(logits, g, pi, labels, plan_like["row_c"], plan_like["row_vid"], plan_like["csr_off"],
                                 plan_like["csr_ent"], plan_like["csr_id"], plan_like["csr_w"], plan_like["c_max"],
                                 self.label_smoothing)
+
+    def bank_projection(self, bank):
+        """Wing(E) for the pointer scores (model.py:899) — constant over decoding iterations."""
+        T, e_max, D = bank.shape
+        return ops.linear(bank.reshape(T * e_max, D), self.Wing.weight, self.Wing.bias).view(T, e_max, D)
 
     def _ptr_plan(self, ingr_dicts, c_list, lt, step_ne, row_vid):
         """CSR of (ingredient → word ids, weight 1/len) per video + per-row class counts; cached by content."""

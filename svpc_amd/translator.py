@@ -4,8 +4,13 @@ Same constructor and ``translate_batch`` contract (12-element ``model_inputs`` l
 out, one ``(S_b, Lt)`` int64 id matrix per video, extended ids ≥ V kept for copied OOV words).  Restructured for the GPU:
 all videos of the batch are decoded together — clip encoder, step-wise encoder and visual simulator run once over every
 clip of the batch, then the ``max_t_len`` decoding iterations advance all T = Σ_b S_b sentences at once with arg-max, UNK
-suppression and OOV→UNK remapping done by a kernel (no host synchronisation inside the loop).  Each iteration re-runs the
-decoder over all Lt positions exactly like the reference (translator.py:88-100), so ids are bit-identical in fp32.
+suppression and OOV→UNK remapping done by a kernel (no host synchronisation inside the loop).
+
+Decoding is **incremental** by default: iteration i embeds only the token chosen at i-1, appends its self-attention K|V row to a
+per-layer cache and attends to the i+1 cached keys; cross-attention K|V of the memory slots and the pointer's bank projection
+are computed once.  Under the reference's causal∧pad mask (translator.py:88-100 re-runs all Lt positions every iteration) position
+i's output depends on exactly those keys, so the ids are the same — ``incremental=False`` keeps the re-run-everything form, and
+the parity tests check both against the reference's ids.
 """
 from __future__ import annotations
 
@@ -18,8 +23,9 @@ from .synthetic import BOS, PAD, UNK
 
 
 class Translator(object):
-    def __init__(self, opt, checkpoint, model=None):
+    def __init__(self, opt, checkpoint, model=None, incremental=True):
         self.opt = opt
+        self.incremental = incremental
         self.device = torch.device("cuda" if getattr(opt, "cuda", True) else "cpu")
         self.model_config = checkpoint["model_cfg"]
         self.max_t_len = self.model_config.max_t_len
@@ -98,20 +104,42 @@ class Translator(object):
         row_x = Idx([n_oov[b] for b in plan.row_vid.host])
         text = torch.full((T, Lt), PAD, dtype=torch.int32, device=dev)
         ext = torch.full((T, Lt), PAD, dtype=torch.int32, device=dev)
-        tmask = torch.zeros(T, Lt, dtype=torch.float32, device=dev)
         nxt = torch.full((T,), BOS, dtype=torch.int32, device=dev)
         nxt_ext = nxt.clone()
-        for i in range(Lt):
-            text[:, i] = nxt
-            ext[:, i] = nxt_ext
-            tmask[:, i] = 1.0
-            xt = model.text_embeddings.run(text.reshape(-1), Lt, cx)
-            dec = model.decoder.run(xt, tmask.reshape(-1), mem, plan.seq_dec_self, plan.seq_dec_cross, None, cx)
-            if mode == "video":
-                scores = model.decoder_classifier.run(dec, cx.eps)          # raw logits (translator.py:159)
-            else:
-                scores, _ = model._lm_probs(dec, bank, pl, cx)
-            nxt_ext, nxt = ops.greedy_pick(scores, pl["row_c"], row_x, Lt, i, UNK)
+        if self.incremental:
+            n_mem = mem.shape[0] // T
+            layers = model.decoder.layer
+            caches = [torch.zeros(T * Lt, 2 * D, dtype=torch.float32, device=dev) for _ in layers]
+            mem_kv = [layer.memory_kv(mem) for layer in layers]
+            proj = model.bank_projection(bank) if bank is not None else None
+            seq_cross = ops.SeqInfo(list(range(T)), [1] * T, [s_ * n_mem for s_ in range(T)], [n_mem] * T, dev)
+            pl1 = model._ptr_plan(ingr_id_dict if mode != "video" else [{}] * N, c_list, 1, plan.step_ne, plan.step_vid)
+            row_x1 = Idx([n_oov[b] for b in plan.step_vid.host])
+            for i in range(Lt):
+                text[:, i] = nxt
+                ext[:, i] = nxt_ext
+                seq_self = plan.seq_dec_incremental(i, Lt, dev)
+                x = model.text_embeddings.run_at(nxt, i, cx)
+                for layer, cache, kv in zip(layers, caches, mem_kv):
+                    x = layer.step(x, i, Lt, cache, kv, seq_self, seq_cross, cx)
+                if mode == "video":
+                    scores = model.decoder_classifier.run(x, cx.eps)          # raw logits (translator.py:159)
+                else:
+                    scores, _ = model._lm_probs(x, bank, pl1, cx, proj=proj)
+                nxt_ext, nxt = ops.greedy_pick(scores, pl1["row_c"], row_x1, 1, 0, UNK)
+        else:
+            tmask = torch.zeros(T, Lt, dtype=torch.float32, device=dev)
+            for i in range(Lt):
+                text[:, i] = nxt
+                ext[:, i] = nxt_ext
+                tmask[:, i] = 1.0
+                xt = model.text_embeddings.run(text.reshape(-1), Lt, cx)
+                dec = model.decoder.run(xt, tmask.reshape(-1), mem, plan.seq_dec_self, plan.seq_dec_cross, None, cx)
+                if mode == "video":
+                    scores = model.decoder_classifier.run(dec, cx.eps)          # raw logits (translator.py:159)
+                else:
+                    scores, _ = model._lm_probs(dec, bank, pl, cx)
+                nxt_ext, nxt = ops.greedy_pick(scores, pl["row_c"], row_x, Lt, i, UNK)
         out = text if mode == "video" else ext
         res = []
         for b in range(N):

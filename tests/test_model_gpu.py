@@ -96,12 +96,14 @@ def test_matches_oracle_on_fresh_seeded_inputs(golden_dir):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=3e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("incremental", [True, False])
 @pytest.mark.parametrize("case,mt", [("tiny", "v"), ("tiny", "vi"), ("tiny", "viv"), ("tiny", "vivt"), ("c1", "v"), ("c1", "vivt")])
-def test_greedy_decode_ids_bit_exact_vs_reference(golden_dir, case, mt):
-    """translate_batch on the MI355X reproduces the reference Translator's token-id matrices exactly."""
+def test_greedy_decode_ids_bit_exact_vs_reference(golden_dir, case, mt, incremental):
+    """translate_batch on the MI355X reproduces the reference Translator's token-id matrices exactly — with the KV-cached
+    incremental loop (default) and with the reference-shaped loop that re-runs all Lt positions every iteration."""
     from svpc_amd.translator import Translator
     z, cfg, batch, model = build_model(case, mt, golden_dir, DEV)
-    tr = Translator(type("O", (), {"cuda": True})(), {"model_cfg": cfg, "model": model.state_dict()}, model=model)
+    tr = Translator(type("O", (), {"cuda": True})(), {"model_cfg": cfg, "model": model.state_dict()}, model=model, incremental=incremental)
     dec, _ = tr.translate_batch(syn.translate_inputs(batch))
     for b, d in enumerate(dec):
         np.testing.assert_array_equal(d.cpu().numpy(), z["decode/%d" % b])

@@ -118,15 +118,18 @@ def test_reference_shaped_submodules(golden_dir, mt):
         np.testing.assert_allclose(lg.numpy(), orc.lm_head(P, torch.ones(2, 3, cfg.hidden_size), cfg).numpy(), rtol=1e-4, atol=2e-6)
 
 
+@pytest.mark.parametrize("incremental", [True, False])
 @pytest.mark.parametrize("mt", ["v", "vi", "viv", "vivt"])
-def test_translator_greedy_ids_bit_exact_vs_reference(golden_dir, mt):
-    """Batched on-device greedy decoding reproduces the reference Translator's id matrices (tests/golden decode/*)."""
+def test_translator_greedy_ids_bit_exact_vs_reference(golden_dir, mt, incremental):
+    """Batched greedy decoding (host logic over the emulated ops) reproduces the reference Translator's id matrices
+    (tests/golden decode/*), KV-cached and re-run-everything forms alike."""
     from svpc_amd import translator as TR
     z, cfg, batch, model = build("tiny", mt, golden_dir)
     import svpc_amd.translator as trmod
     trmod.ops = emul_ops
     try:
-        tr = TR.Translator(type("O", (), {"cuda": False})(), {"model_cfg": cfg, "model": model.state_dict()}, model=model)
+        tr = TR.Translator(type("O", (), {"cuda": False})(), {"model_cfg": cfg, "model": model.state_dict()}, model=model,
+                           incremental=incremental)
         dec, oov = tr.translate_batch(syn.translate_inputs(batch))
     finally:
         from svpc_amd import ops as real_ops
