@@ -179,6 +179,12 @@ int svpc_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, co
                        float* c, float* gates_act, int N, int D, svpc_stream_t stream);
 int svpc_lstm_cell_bwd(const float* dh, const float* dc, const float* gates_act, const float* c_prev, const float* active,
                        float* dgates, float* dc_prev, float* dh_prev, int N, int D, svpc_stream_t stream);
+/* input staging: gather the frame windows of a batch out of an HBM-resident feature bank (idx < 0 → zero row) —
+ * recursive_caption_dataset.py:187-189 (resnet‖bn concat), :389-416 (window / down-sample / [CLS]…[SEP] layout), train.py:91 (H2D);
+ * and the video half of input_ids / input_mask built on the device from the valid-frame counts (:409-415) */
+int svpc_gather_rows_f32(const float* src, const int* idx, float* dst, int rows, int width, svpc_stream_t stream);
+int svpc_video_tokens(const int* n_valid, long long* ids, float* mask, int clips, int Lv, int L, int cls_id, int vid_id, int sep_id,
+                      int pad_id, svpc_stream_t stream);
 /* sequence forms for the fused recurrence (nn.LSTM model.py:859-860, used at :1022-1024): gx rows gathered in place; the
  * backward adds the gradient from the layer above (dh_out) to the recurrent one (dh_rec) */
 int svpc_lstm_cell_fwd_idx(const float* gx_all, const int* rows, const float* gh, const float* c_prev, const float* h_prev,

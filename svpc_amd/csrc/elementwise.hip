@@ -281,6 +281,39 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
     dh_prev[i] = (1.f - a) * dh[i];
 }
 
+// ---- input staging (reference: recursive_caption_dataset.py:389-416 feature windowing, :536-575 collate, train.py:91 H2D) ------------
+// dst[r][:] = idx[r] >= 0 ? src[idx[r]][:] : 0  — the per-clip frame windows of a batch gathered out of an HBM-resident feature
+// bank straight into the (S, N, Lv+Lt, F) layout the model consumes; HBM-bound (one read + one write of the gathered rows).
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx,
+                                                          float* __restrict__ dst, int rows, int width4) {
+    const int r = blockIdx.x;
+    const int s = idx[r];
+    float4* o = reinterpret_cast<float4*>(dst) + (size_t)r * width4;
+    if (s < 0) {
+        for (int c = threadIdx.x; c < width4; c += 256) o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        const float4* in = reinterpret_cast<const float4*>(src) + (size_t)s * width4;
+        for (int c = threadIdx.x; c < width4; c += 256) o[c] = in[c];
+    }
+}
+// video half of input_ids / input_mask for every clip: [CLS] [VID]×n [SEP] [PAD]…  (n = valid frames; n < 0 marks a padded step:
+// all PAD, mask 0).  ids / mask are (clips, L) with the text half [Lv, L) left untouched.
+__global__ __launch_bounds__(256) void video_tokens_kernel(const int* __restrict__ n_valid, long long* __restrict__ ids,
+                                                           float* __restrict__ mask, int clips, int Lv, int L, int cls_id, int vid_id,
+                                                           int sep_id, int pad_id) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= clips * Lv) return;
+    const int c = i / Lv, p = i - c * Lv, n = n_valid[c];
+    int tok = pad_id; float m = 0.f;
+    if (n >= 0) {
+        if (p == 0) { tok = cls_id; m = 1.f; }
+        else if (p <= n) { tok = vid_id; m = 1.f; }
+        else if (p == n + 1) { tok = sep_id; m = 1.f; }
+    }
+    ids[(size_t)c * L + p] = tok;
+    mask[(size_t)c * L + p] = m;
+}
+
 // Sequence forms used by the fused BiLSTM recurrence: the step's input-projection rows are gathered in place
 // (gx_all[rows[n]]), and the backward adds the gradient arriving from the layer above (dh_out) to the recurrent one.
 __global__ __launch_bounds__(256) void lstm_cell_fwd_idx_kernel(const float* __restrict__ gx_all, const int* __restrict__ rows,
@@ -477,6 +510,19 @@ int svpc_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, co
     hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ceil_div(N * D, 256)), dim3(256), 0, s, gx, gh, c_prev, h_prev, active, h, c,
                        gates_act, N, D);
     return svpc_check_launch("lstm_cell_fwd");
+}
+int svpc_gather_rows_f32(const float* src, const int* idx, float* dst, int rows, int width, hipStream_t s) {
+    if (rows == 0) return 0;
+    SVPC_REQUIRE(width % 4 == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "gather_rows: rows must be 16-byte aligned float4 multiples");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, s, src, idx, dst, rows, width / 4);
+    return svpc_check_launch("gather_rows");
+}
+int svpc_video_tokens(const int* n_valid, long long* ids, float* mask, int clips, int Lv, int L, int cls_id, int vid_id, int sep_id,
+                      int pad_id, hipStream_t s) {
+    if (clips == 0) return 0;
+    hipLaunchKernelGGL(video_tokens_kernel, dim3(ceil_div(clips * Lv, 256)), dim3(256), 0, s, n_valid, ids, mask, clips, Lv, L, cls_id,
+                       vid_id, sep_id, pad_id);
+    return svpc_check_launch("video_tokens");
 }
 int svpc_lstm_cell_fwd_idx(const float* gx_all, const int* rows, const float* gh, const float* c_prev, const float* h_prev,
                            const float* active, float* h, float* c, float* gates_act, int N, int D, hipStream_t s) {
