@@ -179,6 +179,12 @@ int svpc_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, co
                        float* c, float* gates_act, int N, int D, svpc_stream_t stream);
 int svpc_lstm_cell_bwd(const float* dh, const float* dc, const float* gates_act, const float* c_prev, const float* active,
                        float* dgates, float* dc_prev, float* dh_prev, int N, int D, svpc_stream_t stream);
+/* on-device logging counters (doubles in HBM; one read-back per logging interval instead of ≈10 .item() syncs per step):
+ * src/train.py:32-38 cal_performance → counters[0] += #labelled rows, counters[1] += #rows whose first-index arg-max == label;
+ * src/train.py:40-49 calculate_f1   → counters[0] += Σ gold[prob>0.5], [1] += Σ gold, [2] += #(prob>0.5) */
+int svpc_metric_argmax(const float* scores, int ld, int R, int C, const long long* labels, int ignore, double* counters,
+                       svpc_stream_t stream);
+int svpc_metric_f1(const float* prob, const float* gold, size_t n, double* counters, svpc_stream_t stream);
 /* input staging: gather the frame windows of a batch out of an HBM-resident feature bank (idx < 0 → zero row) —
  * recursive_caption_dataset.py:187-189 (resnet‖bn concat), :389-416 (window / down-sample / [CLS]…[SEP] layout), train.py:91 (H2D);
  * and the video half of input_ids / input_mask built on the device from the valid-frame counts (:409-415) */

@@ -38,6 +38,8 @@ def parse_header(path=HEADER_PATH):
                     types.append(ctypes.c_size_t)
                 elif a.startswith("float"):
                     types.append(ctypes.c_float)
+                elif a.startswith("double"):
+                    types.append(ctypes.c_double)
                 elif a.startswith("unsigned"):
                     types.append(ctypes.c_uint)
                 elif a.startswith("long long"):

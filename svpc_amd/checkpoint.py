@@ -1,0 +1,53 @@
+"""Checkpoint files interchangeable with the reference's ``.chkpt``.
+
+reference: src/train.py:401-405 writes ``{"model": state_dict, "model_cfg": EasyDict, "opt": EasyDict, "epoch": int}`` with
+``torch.save``; src/translator.py:33-38 / src/translate.py read ``checkpoint["model_cfg"]`` and ``checkpoint["model"]``.
+
+``save_checkpoint`` writes the same four keys (configs as plain dicts with attribute access, so the file needs no third-party
+class to load).  ``load_checkpoint`` also opens files written by the reference: their ``model_cfg`` / ``opt`` are pickled
+``easydict.EasyDict`` objects — a package this image does not have — so that one class name is mapped onto ``ModelConfig``
+while unpickling; nothing else is remapped.
+"""
+from __future__ import annotations
+
+import pickle
+import types
+
+import torch
+
+from .synthetic import ModelConfig
+
+
+class _Unpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module == "easydict" and name == "EasyDict":
+            return ModelConfig
+        return super().find_class(module, name)
+
+
+_pickle_module = types.ModuleType("svpc_amd._checkpoint_pickle")
+_pickle_module.Unpickler = _Unpickler
+_pickle_module.load = lambda f, **kw: _Unpickler(f, **kw).load()
+_pickle_module.__name__ = "pickle"
+
+
+def save_checkpoint(path, model, opt=None, epoch=0, state_dict=None):
+    """``state_dict`` overrides ``model.state_dict()`` (e.g. the EMA weights, as train.py:401 saves them)."""
+    sd = state_dict if state_dict is not None else model.state_dict()
+    sd = {k: v.detach().cpu().clone() for k, v in sd.items()}
+    ckpt = {"model": sd, "model_cfg": ModelConfig(dict(model.config)), "opt": ModelConfig(dict(opt)) if opt is not None else None,
+            "epoch": int(epoch)}
+    torch.save(ckpt, path)
+    return ckpt
+
+
+def load_checkpoint(path, model=None, map_location="cpu", strict=True):
+    """→ the checkpoint dict; with ``model`` given its weights are loaded (same key set and shapes as the reference's
+    ``state_dict`` — svpc_amd/model_shapes.py)."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=False, pickle_module=_pickle_module)
+    for k in ("model_cfg", "opt"):
+        if isinstance(ckpt.get(k), dict) and not isinstance(ckpt[k], ModelConfig):
+            ckpt[k] = ModelConfig(ckpt[k])
+    if model is not None:
+        model.load_state_dict(ckpt["model"], strict=strict)
+    return ckpt

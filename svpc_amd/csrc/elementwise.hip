@@ -314,6 +314,49 @@ __global__ __launch_bounds__(256) void video_tokens_kernel(const int* __restrict
     mask[(size_t)c * L + p] = m;
 }
 
+// ---- on-device training metrics (reference: src/train.py:32-49) — counters live in HBM, read back once per logging interval -------
+// counters[0] += #rows with label != ignore ; counters[1] += #rows whose first-index arg-max equals the label  (cal_performance)
+__global__ __launch_bounds__(256) void metric_argmax_kernel(const float* __restrict__ scores, int ld, int C,
+                                                            const long long* __restrict__ labels, int ignore, double* __restrict__ counters) {
+    __shared__ float sval[4];
+    __shared__ int sidx[4];
+    const int r = blockIdx.x;
+    const long long lab = labels[r];
+    if (lab == ignore) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int v = threadIdx.x; v < C; v += 256) {
+        const float sc = scores[(size_t)r * ld + v];
+        if (sc > best) { best = sc; bi = v; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { sval[wave] = best; sidx[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sval[w] > best || (sval[w] == best && sidx[w] < bi)) { best = sval[w]; bi = sidx[w]; }
+        atomicAdd(&counters[0], 1.0);
+        if ((long long)bi == lab) atomicAdd(&counters[1], 1.0);
+    }
+}
+// counters[0] += Σ gold[prob > 0.5] ; counters[1] += Σ gold ; counters[2] += #(prob > 0.5)   (calculate_f1)
+__global__ __launch_bounds__(256) void metric_f1_kernel(const float* __restrict__ prob, const float* __restrict__ gold, size_t n,
+                                                        double* __restrict__ counters) {
+    __shared__ float red[4];
+    float c = 0.f, g = 0.f, p = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const bool on = prob[i] > 0.5f;
+        const float gv = gold[i];
+        c += on ? gv : 0.f; g += gv; p += on ? 1.f : 0.f;
+    }
+    c = block_sum_256(c, red); g = block_sum_256(g, red); p = block_sum_256(p, red);
+    if (threadIdx.x == 0) { atomicAdd(&counters[0], (double)c); atomicAdd(&counters[1], (double)g); atomicAdd(&counters[2], (double)p); }
+}
+
 // Sequence forms used by the fused BiLSTM recurrence: the step's input-projection rows are gathered in place
 // (gx_all[rows[n]]), and the backward adds the gradient arriving from the layer above (dh_out) to the recurrent one.
 __global__ __launch_bounds__(256) void lstm_cell_fwd_idx_kernel(const float* __restrict__ gx_all, const int* __restrict__ rows,
@@ -510,6 +553,17 @@ int svpc_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, co
     hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ceil_div(N * D, 256)), dim3(256), 0, s, gx, gh, c_prev, h_prev, active, h, c,
                        gates_act, N, D);
     return svpc_check_launch("lstm_cell_fwd");
+}
+int svpc_metric_argmax(const float* scores, int ld, int R, int C, const long long* labels, int ignore, double* counters, hipStream_t s) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(metric_argmax_kernel, dim3(R), dim3(256), 0, s, scores, ld, C, labels, ignore, counters);
+    return svpc_check_launch("metric_argmax");
+}
+int svpc_metric_f1(const float* prob, const float* gold, size_t n, double* counters, hipStream_t s) {
+    if (n == 0) return 0;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256);
+    hipLaunchKernelGGL(metric_f1_kernel, dim3(blocks), dim3(256), 0, s, prob, gold, n, counters);
+    return svpc_check_launch("metric_f1");
 }
 int svpc_gather_rows_f32(const float* src, const int* idx, float* dst, int rows, int width, hipStream_t s) {
     if (rows == 0) return 0;
