@@ -202,7 +202,8 @@ def main():
         arena = opt.ensure_built()
         if world > 1:
             if reducer is None:
-                reducer = GradReducer(arena, overlap=True)
+                # graph mode: the exchange runs between two captured graphs (no hooks); eager mode: overlapped with backward
+                reducer = GradReducer(arena, overlap=args.no_graph)
                 reducer.reset()
                 for bi in range(len(reducer.buckets)):   # first step: hooks were not installed during this backward
                     reducer.launched[bi] = False
@@ -214,14 +215,15 @@ def main():
         loss = step()
     torch.cuda.synchronize()
 
-    # ---- capture the whole step (zero_grad → forward → backward → clip+BertAdam) in one hipGraph: ≈2,000 launches per step
-    # would otherwise make the step host-bound.  Single-GPU only (the RCCL exchange stays eager); falls back to eager on failure.
+    # ---- capture the step in hipGraphs: ≈1,100 launches per step would otherwise make it host-bound.  One GPU: one graph
+    # (zero_grad → forward → backward → clip+BertAdam).  N GPUs: {zero_grad, forward, backward} and {clip+BertAdam} with the
+    # bucketed RCCL all-reduce issued eagerly in between.  Falls back to eager (overlapped exchange) on failure.
     graph = None
-    if not args.no_graph and world == 1:
+    if not args.no_graph:
         try:
             from svpc_amd.graph import GraphedTrainStep
             loss = None          # drop the last eager autograd graph before capture
-            graph = GraphedTrainStep(model, opt, fargs, warmup=2)
+            graph = GraphedTrainStep(model, opt, fargs, warmup=2, exchange=(reducer.finish if world > 1 else None))
             eager_step = step
             step = graph
             for _ in range(2):
@@ -296,7 +298,8 @@ def main():
                                       cfg.hidden_size, cfg.num_attention_heads, cfg.num_hidden_layers, cfg.vocab_size, cfg.action_vocab_size),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
                        "host_enqueue_ms_per_step": host_enqueue_ms,
-                       "launch": "hipGraph replay" if graph is not None else "eager"},
+                       "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (fwd+bwd | eager bucketed all-reduce | optimizer)")
+                                 if graph is not None else "eager"},
             "roofline": {"bound": "mfma", "kernel": "%s — every forward projection of the bf16 activation streams (clip encoder M=%d "
                                    "rows: Q/K/V, attention-out, FFN, video embedding; decoder M=%d rows)"
                                    % ("gemm_glds_kernel<true,true,__bf16,3> (bf16·bf16→bf16, direct-to-LDS)" if glds else

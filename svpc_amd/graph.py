@@ -6,6 +6,11 @@ synchronises inside the C-ABI, index maps are cached in HBM by ``BatchPlan``, dr
 by a kernel, and the optimizer's hyper-parameters are read from a device buffer refreshed before each replay.
 Inputs are static: refill the tensors handed to the constructor in place (``tensor.copy_``) to train on a new batch of the
 same shape (step counts / ingredient counts / copy tables are part of the captured plan).
+
+Data parallel (``exchange=`` given): the step is captured as TWO graphs — {zero_grad, forward, backward} and {clip + BertAdam} —
+with the gradient all-reduce (RCCL, a handful of 64 MB buckets) issued eagerly between the two replays.  The exchange is then not
+overlapped with backward, but an eager step is host-bound (≈25 ms of Python/launch work for ≈19 ms of kernels), which costs more
+than the ≈2–3 ms the exposed exchange of 369 MB takes over xGMI.
 """
 from __future__ import annotations
 
@@ -15,8 +20,9 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, forward_args, warmup=2):
+    def __init__(self, model, optimizer, forward_args, warmup=2, exchange=None):
         self.model, self.opt, self.args = model, optimizer, forward_args
+        self.exchange = exchange
         assert optimizer.arena is not None, "run at least one eager step first (the gradient arena is built lazily)"
         gc.collect()     # stale autograd graphs keep AccumulateGrad nodes bound to the default stream
         side = torch.cuda.Stream()
@@ -28,17 +34,32 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         gc.collect()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            optimizer.zero_grad()
-            self.loss = model(*forward_args)[0]
-            self.loss.backward()
-            optimizer.launch()
+        self.graph_opt = None
+        if exchange is None:
+            with torch.cuda.graph(self.graph):
+                optimizer.zero_grad()
+                self.loss = model(*forward_args)[0]
+                self.loss.backward()
+                optimizer.launch()
+        else:
+            from . import ops
+            # other threads (the collective library's watchdog) keep making driver calls: only this thread's are policed
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                optimizer.zero_grad()
+                self.loss = model(*forward_args)[0]
+                self.loss.backward()
+                ops.join_side()
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                optimizer.launch()
         self._versions = optimizer.weights.versions()
 
     def _eager(self):
         self.opt.zero_grad()
         loss = self.model(*self.args)[0]
         loss.backward()
+        if self.exchange is not None:
+            self.exchange()
         self.opt.step()
         return loss
 
@@ -49,5 +70,8 @@ class GraphedTrainStep:
             self._versions = self.opt.weights.versions()
         self.opt.set_hyper()
         self.graph.replay()
+        if self.graph_opt is not None:
+            self.exchange()
+            self.graph_opt.replay()
         self.opt.step_count += 1
         return self.loss
