@@ -20,7 +20,7 @@ struct SimArgs {
     float* dq; float* dc; float* dw4f; float* dE0;
 };
 
-__global__ __launch_bounds__(256) void sim_recur_fwd_kernel(SimArgs a) {
+__global__ __launch_bounds__(1024) void sim_recur_fwd_kernel(SimArgs a) {
     extern __shared__ float smem[];
     const int b = blockIdx.x, D = a.D, em = a.e_max;
     const int s0 = a.step_off[b], S = a.step_len[b], e0 = a.ent_off[b], E = a.ent_len[b];
@@ -28,14 +28,14 @@ __global__ __launch_bounds__(256) void sim_recur_fwd_kernel(SimArgs a) {
     float* ev = Es + (size_t)em * D;  // 32
     float* prev = ev + SIM_EMAX;      // 32
     float* al = prev + SIM_EMAX;      // 32
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < E * D; i += 256) Es[i] = a.E0[(size_t)e0 * D + i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NT = blockDim.x, NW = blockDim.x >> 6;
+    for (int i = threadIdx.x; i < E * D; i += NT) Es[i] = a.E0[(size_t)e0 * D + i];
     if (threadIdx.x < SIM_EMAX) prev[threadIdx.x] = 0.f;
     __syncthreads();
     for (int t = 0; t < S; ++t) {
         const int j = s0 + t;
         const float* qj = a.q + (size_t)j * D;
-        for (int e = wave; e < E; e += 4) {
+        for (int e = wave; e < E; e += NW) {
             float dot = 0.f;
             for (int d = lane; d < D; d += 64) dot += Es[(size_t)e * D + d] * qj[d];
             dot = wave_sum(dot);
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void sim_recur_fwd_kernel(SimArgs a) {
         for (int e = 0; e < E; ++e) Z += al[e];
         const float invZ = 1.0f / Z;
         const float w = a.w4f[j];
-        for (int d = threadIdx.x; d < D; d += 256) {
+        for (int d = threadIdx.x; d < D; d += NT) {
             float eb = 0.f;
             for (int e = 0; e < E; ++e) eb += al[e] * Es[(size_t)e * D + d];
             eb *= invZ;
@@ -74,41 +74,86 @@ __global__ __launch_bounds__(256) void sim_recur_fwd_kernel(SimArgs a) {
     }
 }
 
-// CPT = columns per thread (D <= 256*CPT)
-template <int CPT>
-__global__ __launch_bounds__(256) void sim_recur_bwd_kernel(SimArgs a) {
-    extern __shared__ float smem[];
+// NT threads, CPT = columns per thread (D <= NT*CPT).  The recurrence is a chain of S_b dependent steps per video and only
+// n_videos workgroups exist, so the step latency is what counts: a wide workgroup (one column per thread at D = 768) keeps the
+// per-thread serial work and the number of outstanding loads per thread small.
+// The state before step t (saved by the forward) and the upstream gradient of the state after step t are E_b·D contiguous floats
+// each.  DMA = true (D % 256 == 0): both are brought into LDS by global_load_lds, double-buffered — the copy for step t-1 is issued
+// at the top of step t and lands under its arithmetic, so no global load sits inside the per-entity loops (conditional loads
+// there serialise into one memory round trip per entity).  DMA = false: the same images are staged synchronously.
+typedef const void __attribute__((address_space(1))) * sim_gptr;
+typedef void __attribute__((address_space(3))) * sim_lptr;
+
+template <int NT>
+__device__ __forceinline__ void sim_dma(const float* __restrict__ src, float* __restrict__ dst, int n_floats, int wave, int lane) {
+    const int pieces = n_floats >> 8;                 // 1 KiB = 256 floats per wave-instruction
+    for (int i = wave; i < pieces; i += NT / 64)
+        __builtin_amdgcn_global_load_lds((sim_gptr)(src + (size_t)i * 256 + lane * 4), (sim_lptr)(dst + (size_t)i * 256), 16, 0, 0);
+}
+
+// MODE 2: DMA double-buffered (4 images in LDS) · MODE 1: both images staged synchronously (2 images) · MODE 0: only the state is
+// staged, the upstream gradient is read from HBM inside the loops (1 image: up to 32 entities × 768)
+// EM = compile-time bound on the entities per video (16 or 32): the per-entity scalars and gradient columns are register arrays
+// unrolled to EM, so the smaller bound halves the register pressure and the predicated code when the batch allows it.
+template <int CPT, int NT, int MODE, int EM>
+__global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
+    constexpr int NW = NT / 64;
+    constexpr bool DMA = MODE == 2;
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
     const int b = blockIdx.x, D = a.D, em = a.e_max;
     const int s0 = a.step_off[b], S = a.step_len[b], e0 = a.ent_off[b], E = a.ent_len[b];
-    float* Es = smem;                              // em × D : state BEFORE step t
-    float* red = Es + (size_t)em * D;              // (2*32+1) × 4 wave partials
-    float* sc = red + (2 * SIM_EMAX + 1) * 4;      // scalars: ds[32]
-    float* dprev = sc + SIM_EMAX;                  // 32: gradient flowing into e_{t-1} through "prev"
+    const int img = ((em * D + 255) / 256) * 256;  // floats per image, 1-KiB aligned
+    float* Ebuf = smem;                            // DMA: [2][img] state BEFORE step t;  else [img]
+    float* Ubuf = Ebuf + (DMA ? 2 : 1) * img;      // same shape: upstream gradient of the state AFTER step t (zeros if absent)
+    float* red = Ubuf + (MODE == 0 ? 0 : (DMA ? 2 : 1)) * img;       // (2*32+1) × NW wave partials
+    float* sc = red + (2 * EM + 1) * NW;     // scalars: ds[32]
+    float* dprev = sc + EM;                  // 32: gradient flowing into e_{t-1} through "prev"
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    float dE[SIM_EMAX][CPT];
+    float dE[EM][CPT];
 #pragma unroll
-    for (int e = 0; e < SIM_EMAX; ++e)
+    for (int e = 0; e < EM; ++e)
 #pragma unroll
         for (int u = 0; u < CPT; ++u) dE[e][u] = 0.f;
-    if (threadIdx.x < SIM_EMAX) dprev[threadIdx.x] = 0.f;
+    if (threadIdx.x < EM) dprev[threadIdx.x] = 0.f;
+    if (MODE != 0 && !a.deall)
+        for (int i = threadIdx.x; i < (DMA ? 2 : 1) * img; i += NT) Ubuf[i] = 0.f;
+
+    auto state_before = [&](int t) -> const float* {
+        return t == 0 ? a.E0 + (size_t)e0 * D : a.eall + (size_t)(s0 + t - 1) * em * D;
+    };
+    if (DMA && S > 0) {
+        sim_dma<NT>(state_before(S - 1), Ebuf, E * D, wave, lane);
+        if (a.deall) sim_dma<NT>(a.deall + (size_t)(s0 + S - 1) * em * D, Ubuf, E * D, wave, lane);
+    }
 
     for (int t = S - 1; t >= 0; --t) {
         const int j = s0 + t;
-        __syncthreads();
-        // state before step t
-        const float* Eprev = t == 0 ? a.E0 + (size_t)e0 * D : nullptr;
-        for (int i = threadIdx.x; i < E * D; i += 256) {
-            const int e = i / D, d = i - e * D;
-            Es[i] = t == 0 ? Eprev[i] : a.eall[((size_t)(j - 1) * em + e) * D + d];
+        const int cur = DMA ? ((S - 1 - t) & 1) : 0;
+        float* Es = Ebuf + cur * img;
+        const float* Us = Ubuf + cur * img;
+        if (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of step t have landed
+            __syncthreads();                                       // everyone's have; everyone is done with the other buffers
+            if (t > 0) {
+                sim_dma<NT>(state_before(t - 1), Ebuf + (cur ^ 1) * img, E * D, wave, lane);
+                if (a.deall) sim_dma<NT>(a.deall + (size_t)(j - 1) * em * D, Ubuf + (cur ^ 1) * img, E * D, wave, lane);
+            }
+        } else {
+            __syncthreads();
+            const float* sb = state_before(t);
+            for (int i = threadIdx.x; i < E * D; i += NT) {
+                Es[i] = sb[i];
+                if (MODE != 0 && a.deall) Ubuf[i] = a.deall[(size_t)j * em * D + i];
+            }
+            __syncthreads();
         }
-        __syncthreads();
         const float c0 = a.c[(size_t)j * 3], c1 = a.c[(size_t)j * 3 + 1];
         const float w = a.w4f[j];
-        float al[SIM_EMAX], evv[SIM_EMAX], pv[SIM_EMAX];
+        float al[EM], evv[EM], pv[EM];
         float Z = 0.f;
 #pragma unroll
-        for (int e = 0; e < SIM_EMAX; ++e) {
+        for (int e = 0; e < EM; ++e) {
             evv[e] = e < E ? a.e_out[(size_t)j * em + e] : 0.f;
             pv[e] = (e < E && t > 0) ? a.e_out[(size_t)(j - 1) * em + e] : 0.f;
             al[e] = e < E ? c0 * evv[e] + c1 * pv[e] : 0.f;
@@ -116,23 +161,23 @@ __global__ __launch_bounds__(256) void sim_recur_bwd_kernel(SimArgs a) {
         }
         const float invZ = 1.0f / Z;
         // per-thread partials of A1[e], dab[e], dw
-        float pA[SIM_EMAX], pB[SIM_EMAX];
+        float pA[EM], pB[EM];
         float pw = 0.f;
 #pragma unroll
-        for (int e = 0; e < SIM_EMAX; ++e) { pA[e] = 0.f; pB[e] = 0.f; }
+        for (int e = 0; e < EM; ++e) { pA[e] = 0.f; pB[e] = 0.f; }
         float debar_l[CPT], kq[CPT];
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
-            const int d = threadIdx.x + 256 * u;
+            const int d = threadIdx.x + NT * u;
             debar_l[u] = 0.f; kq[u] = 0.f;
             if (d < D) {
                 const float eb = a.ebar[(size_t)j * D + d];
                 const float k = fmaxf(w * eb, 0.f);
                 float dk = 0.f;
 #pragma unroll
-                for (int e = 0; e < SIM_EMAX; ++e) {
+                for (int e = 0; e < EM; ++e) {
                     if (e < E) {
-                        const float up = a.deall ? a.deall[((size_t)j * em + e) * D + d] : 0.f;
+                        const float up = MODE != 0 ? Us[(size_t)e * D + d] : (a.deall ? a.deall[((size_t)j * em + e) * D + d] : 0.f);
                         const float g = dE[e][u] + up;
                         const float Ev = Es[(size_t)e * D + d];
                         pA[e] += g * (k - Ev);
@@ -145,7 +190,7 @@ __global__ __launch_bounds__(256) void sim_recur_bwd_kernel(SimArgs a) {
                 const float deb = dpre * w + (a.debar ? a.debar[(size_t)j * D + d] : 0.f);
                 debar_l[u] = deb;
 #pragma unroll
-                for (int e = 0; e < SIM_EMAX; ++e) {
+                for (int e = 0; e < EM; ++e) {
                     if (e < E) {
                         pB[e] += deb * Es[(size_t)e * D + d];
                         dE[e][u] += al[e] * invZ * deb;
@@ -156,35 +201,40 @@ __global__ __launch_bounds__(256) void sim_recur_bwd_kernel(SimArgs a) {
         }
         // block reduction of 2E+1 scalars
 #pragma unroll
-        for (int e = 0; e < SIM_EMAX; ++e) {
+        for (int e = 0; e < EM; ++e) {
             if (e < E) {
                 const float ra = wave_sum(pA[e]), rb = wave_sum(pB[e]);
-                if (lane == 0) { red[e * 4 + wave] = ra; red[(SIM_EMAX + e) * 4 + wave] = rb; }
+                if (lane == 0) { red[e * NW + wave] = ra; red[(EM + e) * NW + wave] = rb; }
             }
         }
         pw = wave_sum(pw);
-        if (lane == 0) red[(2 * SIM_EMAX) * 4 + wave] = pw;
+        if (lane == 0) red[(2 * EM) * NW + wave] = pw;
         __syncthreads();
         // every thread finishes the scalar algebra redundantly (E <= 32)
-        float dab[SIM_EMAX], dal[SIM_EMAX];
+        float dab[EM], dal[EM];
         float mix = 0.f;
 #pragma unroll
-        for (int e = 0; e < SIM_EMAX; ++e) {
+        for (int e = 0; e < EM; ++e) {
             dab[e] = 0.f; dal[e] = 0.f;
             if (e < E) {
-                const float* rb = red + (SIM_EMAX + e) * 4;
-                dab[e] = rb[0] + rb[1] + rb[2] + rb[3];
+                const float* rb = red + (EM + e) * NW;
+                float t_ = rb[0];
+#pragma unroll
+                for (int w_ = 1; w_ < NW; ++w_) t_ += rb[w_];
+                dab[e] = t_;
                 mix += dab[e] * al[e] * invZ;
             }
         }
         float dc0 = 0.f, dc1 = 0.f;
-        float dsv[SIM_EMAX];
+        float dsv[EM];
 #pragma unroll
-        for (int e = 0; e < SIM_EMAX; ++e) {
+        for (int e = 0; e < EM; ++e) {
             dsv[e] = 0.f;
             if (e < E) {
-                const float* ra = red + e * 4;
-                const float A1 = ra[0] + ra[1] + ra[2] + ra[3];
+                const float* ra = red + e * NW;
+                float A1 = ra[0];
+#pragma unroll
+                for (int w_ = 1; w_ < NW; ++w_) A1 += ra[w_];
                 dal[e] = A1 + (dab[e] - mix) * invZ;
                 dc0 += dal[e] * evv[e];
                 dc1 += dal[e] * pv[e];
@@ -192,10 +242,12 @@ __global__ __launch_bounds__(256) void sim_recur_bwd_kernel(SimArgs a) {
                 dsv[e] = de_tot * evv[e] * (1.f - evv[e]);
             }
         }
-        const float* rw = red + (2 * SIM_EMAX) * 4;
-        const float dw = rw[0] + rw[1] + rw[2] + rw[3];
+        const float* rw = red + (2 * EM) * NW;
+        float dw = rw[0];
+#pragma unroll
+        for (int w_ = 1; w_ < NW; ++w_) dw += rw[w_];
         __syncthreads();   // all threads have read dprev / red before they are overwritten
-        if (threadIdx.x < SIM_EMAX) dprev[threadIdx.x] = threadIdx.x < E ? c1 * dal[threadIdx.x] : 0.f;
+        if (threadIdx.x < EM) dprev[threadIdx.x] = threadIdx.x < E ? c1 * dal[threadIdx.x] : 0.f;
         if (threadIdx.x == 0) {
             a.dc[(size_t)j * 3] = dc0; a.dc[(size_t)j * 3 + 1] = dc1; a.dc[(size_t)j * 3 + 2] = 0.f;
             a.dw4f[j] = dw;
@@ -203,11 +255,11 @@ __global__ __launch_bounds__(256) void sim_recur_bwd_kernel(SimArgs a) {
         // dq and the last piece of dE
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
-            const int d = threadIdx.x + 256 * u;
+            const int d = threadIdx.x + NT * u;
             if (d < D) {
                 float dqv = 0.f;
 #pragma unroll
-                for (int e = 0; e < SIM_EMAX; ++e) {
+                for (int e = 0; e < EM; ++e) {
                     if (e < E) {
                         dqv += dsv[e] * Es[(size_t)e * D + d];
                         dE[e][u] += dsv[e] * kq[u];
@@ -219,10 +271,10 @@ __global__ __launch_bounds__(256) void sim_recur_bwd_kernel(SimArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
-        const int d = threadIdx.x + 256 * u;
+        const int d = threadIdx.x + NT * u;
         if (d < D) {
 #pragma unroll
-            for (int e = 0; e < SIM_EMAX; ++e)
+            for (int e = 0; e < EM; ++e)
                 if (e < E) a.dE0[((size_t)e0 + e) * D + d] = dE[e][u];
         }
     }
@@ -230,9 +282,9 @@ __global__ __launch_bounds__(256) void sim_recur_bwd_kernel(SimArgs a) {
 
 static int sim_set_lds(const void* fn, size_t bytes) {
     // raised once per kernel to the device maximum (never inside a stream capture after the first call)
-    static const void* done[16]; static int n_done = 0;
+    static const void* done[64]; static int n_done = 0;
     for (int i = 0; i < n_done; ++i) if (done[i] == fn) return 0;
-    if (n_done < 16) done[n_done++] = fn;
+    if (n_done < 64) done[n_done++] = fn;
     bytes = 160 * 1024;
     if (bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -255,7 +307,8 @@ int svpc_sim_recur_fwd(const float* q, const float* c, const float* w4f, const f
     a.ent_len = ent_len; a.e_out = e_out; a.ebar = ebar; a.eall = eall; a.e_max = e_max; a.D = D;
     int rc = sim_set_lds((const void*)sim_recur_fwd_kernel, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(sim_recur_fwd_kernel, dim3(n_videos), dim3(256), lds, stream, a);
+    const int nt_f = D > 512 ? 768 : (D > 256 ? 512 : 256);
+    hipLaunchKernelGGL(sim_recur_fwd_kernel, dim3(n_videos), dim3(nt_f), lds, stream, a);
     return svpc_check_launch("sim_recur_fwd");
 }
 
@@ -266,27 +319,37 @@ int svpc_sim_recur_bwd(const float* q, const float* c, const float* w4f, const f
     if (n_videos == 0) return 0;
     SVPC_REQUIRE(e_max >= 1 && e_max <= SIM_EMAX, "sim_recur: at most 32 entities per video");
     SVPC_REQUIRE(D <= 1024, "sim_recur: hidden size must be <= 1024");
-    const size_t lds = ((size_t)e_max * D + (2 * SIM_EMAX + 1) * 4 + 2 * SIM_EMAX) * sizeof(float);
-    SVPC_REQUIRE(lds <= 150 * 1024, "sim_recur: entity state does not fit LDS");
+    const int nt = D > 768 ? 1024 : (D > 512 ? 768 : (D > 256 ? 512 : 256));      // one column per thread up to D = 1024
+    const size_t img = (((size_t)e_max * D + 255) / 256) * 256;
+    const int EMv = e_max <= 16 ? 16 : 32;
+    const size_t tail = ((2 * EMv + 1) * (nt / 64) + 2 * EMv) * sizeof(float);
+    const size_t budget = 150 * 1024;
+    const bool aligned = ((((uintptr_t)E0) | ((uintptr_t)eall) | ((uintptr_t)deall)) & 15) == 0;
+    int mode = 0;
+    if (D % 256 == 0 && aligned && 4 * img * sizeof(float) + tail <= budget) mode = 2;
+    else if (2 * img * sizeof(float) + tail <= budget) mode = 1;
+    const size_t lds = (mode == 2 ? 4 : (mode == 1 ? 2 : 1)) * img * sizeof(float) + tail;
+    SVPC_REQUIRE(lds <= budget, "sim_recur: entity state does not fit LDS");
     SimArgs a{};
     a.q = q; a.c = c; a.w4f = w4f; a.E0 = E0; a.step_off = step_off; a.step_len = step_len; a.ent_off = ent_off;
     a.ent_len = ent_len; a.e_out = const_cast<float*>(e_out); a.ebar = const_cast<float*>(ebar);
     a.eall = const_cast<float*>(eall); a.e_max = e_max; a.D = D; a.de = de; a.debar = debar; a.deall = deall;
     a.dq = dq; a.dc = dc; a.dw4f = dw4f; a.dE0 = dE0;
     int rc;
-    if (D <= 256) {
-        rc = sim_set_lds((const void*)sim_recur_bwd_kernel<1>, lds); if (rc) return rc;
-        hipLaunchKernelGGL(sim_recur_bwd_kernel<1>, dim3(n_videos), dim3(256), lds, stream, a);
-    } else if (D <= 512) {
-        rc = sim_set_lds((const void*)sim_recur_bwd_kernel<2>, lds); if (rc) return rc;
-        hipLaunchKernelGGL(sim_recur_bwd_kernel<2>, dim3(n_videos), dim3(256), lds, stream, a);
-    } else if (D <= 768) {
-        rc = sim_set_lds((const void*)sim_recur_bwd_kernel<3>, lds); if (rc) return rc;
-        hipLaunchKernelGGL(sim_recur_bwd_kernel<3>, dim3(n_videos), dim3(256), lds, stream, a);
-    } else {
-        rc = sim_set_lds((const void*)sim_recur_bwd_kernel<4>, lds); if (rc) return rc;
-        hipLaunchKernelGGL(sim_recur_bwd_kernel<4>, dim3(n_videos), dim3(256), lds, stream, a);
-    }
+#define SIM_BWD_GO2(NTV, MV, EMV)                                                                                  \
+    do {                                                                                                           \
+        rc = sim_set_lds((const void*)sim_recur_bwd_kernel<1, NTV, MV, EMV>, lds); if (rc) return rc;               \
+        hipLaunchKernelGGL((sim_recur_bwd_kernel<1, NTV, MV, EMV>), dim3(n_videos), dim3(NTV), lds, stream, a);     \
+    } while (0)
+#define SIM_BWD_GO(NTV, MV) do { if (EMv == 16) SIM_BWD_GO2(NTV, MV, 16); else SIM_BWD_GO2(NTV, MV, 32); } while (0)
+#define SIM_BWD_NT(NTV) do { if (mode == 2) SIM_BWD_GO(NTV, 2); else if (mode == 1) SIM_BWD_GO(NTV, 1); else SIM_BWD_GO(NTV, 0); } while (0)
+    if (nt == 256) SIM_BWD_NT(256);
+    else if (nt == 512) SIM_BWD_NT(512);
+    else if (nt == 768) SIM_BWD_NT(768);
+    else SIM_BWD_NT(1024);
+#undef SIM_BWD_NT
+#undef SIM_BWD_GO
+#undef SIM_BWD_GO2
     return svpc_check_launch("sim_recur_bwd");
 }
 

@@ -215,11 +215,13 @@ def test_lstm_cell():
 
 
 # ------------------------------------------------------------------------------------------------ simulator / pointer / gumbel
-@pytest.mark.parametrize("D", [32, 768])
-def test_sim_recur(D):
-    step_len, ent_len = [3, 1, 12], [3, 31, 10]
-    step_off, ent_off = [0, 3, 4], [0, 3, 34]
-    T, NE, em = 16, 44, 31
+@pytest.mark.parametrize("D,ent_len", [(32, [3, 31, 10]), (768, [3, 31, 10]), (768, [3, 10, 7]), (256, [12, 1, 5]), (512, [3, 24, 2])])
+def test_sim_recur(D, ent_len):
+    """entity-state recurrence fwd/bwd; the cases cover the three backward staging modes (state + upstream gradient by
+    double-buffered LDS-DMA / both staged synchronously / state only) and 256…768-thread workgroups"""
+    step_len = [3, 1, 12]
+    step_off, ent_off = [0, 3, 4], [0, ent_len[0], ent_len[0] + ent_len[1]]
+    T, NE, em = 16, sum(ent_len), max(ent_len)
     q = rnd(T, D, seed=1, scale=1 / math.sqrt(D))
     c = torch.softmax(rnd(T, 3, seed=2), -1).detach().requires_grad_(True)
     w4f = rnd(T, seed=3)
