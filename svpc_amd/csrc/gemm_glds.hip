@@ -2,7 +2,10 @@
 // no staging registers, no conversion, no ds_write — the loads of three k-tiles stay in flight behind a counted vmcnt while the
 // matrix cores work on the current one (4-deep LDS ring, one raw s_barrier per k-tile).
 //
-//   C[M,N] = epi( sum_k A(m,k) · B(n,k) ),  A: a_kc ? [M][lda] : [K][lda],  B: b_kc ? [N][ldb] : [K][ldb]   (bf16, interior shapes)
+//   C[M,N] = epi( sum_k A(m,k) · B(n,k) ),  A: a_kc ? [M][lda] : [K][lda],  B: b_kc ? [N][ldb] : [K][ldb]   (bf16)
+// Any M, N: rows past the edge are clamped to the last valid row / 16-byte chunk (their products are never stored).  K: whole
+// 32-deep tiles for a k-contiguous operand (K is a feature width there); for a k-strided operand (wgrad: K = the row count of the
+// activation stream, arbitrary) the k-rows past K are fetched from a block of zeros instead.
 //
 // Tile 128×128×32, 512 threads = 8 waves (2×4), each wave 64×32 as two 32×32 v_mfma_f32_32x32x16_bf16 tiles.
 // One k-tile of one operand is 8 KiB = 8 wave-instructions of 1 KiB (64 lanes × 16 B, LDS destination = wave-uniform base
@@ -24,18 +27,24 @@ constexpr int GL_STAGE = 2 * GL_OP;
 typedef const void __attribute__((address_space(1))) * gl_gptr;
 typedef void __attribute__((address_space(3))) * gl_lptr;
 
+__device__ __attribute__((aligned(16))) const float glds_zeros[4] = {0.f, 0.f, 0.f, 0.f};     // source of k-rows past K
+
+// per-lane source of this wave's 1-KiB piece of an operand tile; `krow` = the lane's k-row inside the tile (k-strided operands)
 template <bool KC>
-__device__ __forceinline__ const __bf16* glds_src(const __bf16* P, int ld, int m0, int k0, int wave, int lane, size_t& step) {
+__device__ __forceinline__ const __bf16* glds_src(const __bf16* P, int ld, int m0, int rows, int k0, int wave, int lane, size_t& step,
+                                                  int& krow) {
     if (KC) {
         const int row = 16 * wave + (lane >> 2), pos = lane & 3;
         const int c = pos ^ ((row >> 2) & 3);
         step = GL_BK;
-        return P + (size_t)(m0 + row) * ld + k0 + 8 * c;
+        krow = 0;
+        return P + (size_t)min(m0 + row, rows - 1) * ld + k0 + 8 * c;
     } else {
-        const int krow = 4 * wave + (lane >> 4), pos = lane & 15;
+        krow = 4 * wave + (lane >> 4);
+        const int pos = lane & 15;
         const int c = pos ^ ((krow & 3) << 2);
         step = (size_t)GL_BK * ld;
-        return P + (size_t)(k0 + krow) * ld + m0 + 8 * c;
+        return P + (size_t)(k0 + krow) * ld + min(m0 + 8 * c, rows - 8);      // rows % 8 == 0 (host check)
     }
 }
 
@@ -73,14 +82,17 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict
     const int m0 = tm * GL_BM, n0 = tn * GL_BN;
     const int k_begin = ks_id * k_chunk;
     const int k_end = min(K, k_begin + k_chunk);
-    const int nk = (k_end - k_begin) / GL_BK;
+    const int nk = (k_end - k_begin + GL_BK - 1) / GL_BK;     // a partial last tile exists only with k-strided operands
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 2, wc = wave & 3;
 
     size_t stepA, stepB;
-    const __bf16* ga = glds_src<A_KC>(A, lda, m0, k_begin, wave, lane, stepA);
-    const __bf16* gb = glds_src<B_KC>(B, ldb, n0, k_begin, wave, lane, stepB);
+    int kra, krb;
+    const __bf16* ga = glds_src<A_KC>(A, lda, m0, M, k_begin, wave, lane, stepA, kra);
+    const __bf16* gb = glds_src<B_KC>(B, ldb, n0, N, k_begin, wave, lane, stepB, krb);
+    const __bf16* const zsrc = reinterpret_cast<const __bf16*>(glds_zeros);
+    kra += k_begin; krb += k_begin;                           // absolute k-row of this lane in tile 0
     char* const my = smem + wave * 1024;        // this wave's 1-KiB slice inside an operand tile
 
     floatx16 acc[2];
@@ -92,8 +104,10 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict
 #define GL_ISSUE(t)                                                                                                       \
     do {                                                                                                                  \
         char* st = my + ((t) % NS) * GL_STAGE;                                                                            \
-        __builtin_amdgcn_global_load_lds((gl_gptr)ga, (gl_lptr)st, 16, 0, 0);                                             \
-        __builtin_amdgcn_global_load_lds((gl_gptr)gb, (gl_lptr)(st + GL_OP), 16, 0, 0);                                   \
+        const __bf16* pa_ = (!A_KC && kra + (t) * GL_BK >= k_end) ? zsrc : ga;                                           \
+        const __bf16* pb_ = (!B_KC && krb + (t) * GL_BK >= k_end) ? zsrc : gb;                                           \
+        __builtin_amdgcn_global_load_lds((gl_gptr)pa_, (gl_lptr)st, 16, 0, 0);                                            \
+        __builtin_amdgcn_global_load_lds((gl_gptr)pb_, (gl_lptr)(st + GL_OP), 16, 0, 0);                                  \
         ga += stepA; gb += stepB;                                                                                         \
     } while (0)
 
@@ -126,7 +140,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict
     const int col = n0 + wc * 32 + l31;
     if (sizeof(TC) == 2 && splitk == 1 && epi.p_drop <= 0.f && !epi.accumulate) {
         const bool odd = lane & 1;
-        const float bias = epi.bias ? epi.bias[col] : 0.f;
+        const float bias = (epi.bias && col < N) ? epi.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -139,6 +153,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict
                 const size_t o = (size_t)row * ldc + (col & ~1);
                 union { __bf16 h[2]; uint32_t u; } pk;
                 pk.h[0] = (__bf16)(odd ? py : y0); pk.h[1] = (__bf16)(odd ? y1 : py);
+                if (row >= M || col >= N) continue;              // N is even: a column pair is valid or invalid as a whole
                 *reinterpret_cast<uint32_t*>(reinterpret_cast<__bf16*>(C) + o) = pk.u;
                 if (epi.Z) {
                     pk.h[0] = (__bf16)(odd ? pz : z0); pk.h[1] = (__bf16)(odd ? z1 : pz);
@@ -152,6 +167,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+            if (row >= M || col >= N) continue;
             if (splitk == 1) epilogue_store_t<TC>(acc[i][e], row, col, C, ldc, epi, seed, inv_keep);
             else slabs[((size_t)ks_id * M + row) * N + col] = acc[i][e];
         }
@@ -159,9 +175,15 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict
 
 extern "C" {
 
-// 1 if (shape, layout) can run on the direct-to-LDS kernel: bf16 A and B, interior-only, 16-byte aligned rows
+// 1 if (shape, layout) can run on the direct-to-LDS kernel: bf16 A and B with 16-byte aligned rows; any M and N (even N) for
+// k-contiguous operands, multiples of 8 for k-strided ones (their 16-byte chunks run along the rows); K a multiple of 32 unless
+// BOTH operands are k-strided (wgrad), where any K works (k-rows past K come from a block of zeros).
 int svpc_gemm_glds_supported(int a_kc, int b_kc, int lda, int ldb, int M, int N, int K) {
-    return (M % GL_BM == 0 && N % GL_BN == 0 && K % GL_BK == 0 && M > 0 && N > 0 && K > 0 && lda % 8 == 0 && ldb % 8 == 0) ? 1 : 0;
+    if (M <= 0 || N <= 0 || K <= 0 || lda % 8 != 0 || ldb % 8 != 0 || N % 2 != 0) return 0;
+    if (!a_kc && M % 8 != 0) return 0;
+    if (!b_kc && N % 8 != 0) return 0;
+    if ((a_kc || b_kc) && K % GL_BK != 0) return 0;
+    return 1;
 }
 
 // A, B bf16; C bf16 (c_dt = 1) or fp32 (c_dt = 0); Z (optional pre-activation copy) has C's type.
@@ -170,10 +192,10 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
                    size_t workspace_bytes, hipStream_t stream) {
     if (M == 0 || N == 0) return 0;
     SVPC_REQUIRE(svpc_gemm_glds_supported(a_kc, b_kc, lda, ldb, M, N, K) && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0,
-                 "gemm_glds: needs interior-only shapes (128 × 128 × 32) and 16-byte aligned bf16 rows");
+                 "gemm_glds: unsupported shape (see svpc_gemm_glds_supported) or operands not 16-byte aligned");
     SVPC_REQUIRE(p_drop <= 0.f || seed != nullptr, "gemm: dropout needs a seed pointer");
     Epi epi{bias, act, p_drop, site, seed, accumulate, (float*)Z};
-    const int tiles_m = M / GL_BM, tiles_n = N / GL_BN, tiles = tiles_m * tiles_n;
+    const int tiles_m = ceil_div(M, GL_BM), tiles_n = ceil_div(N, GL_BN), tiles = tiles_m * tiles_n;
     int splitk = 1;
     if (K >= 512 && tiles < 256) {
         splitk = ceil_div(512, tiles);
@@ -184,7 +206,6 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
         if (splitk < 1) splitk = 1;
     }
     int k_chunk = ceil_div(ceil_div(K, splitk), GL_BK) * GL_BK;
-    while (splitk > 1 && K % k_chunk != 0) { --splitk; k_chunk = ceil_div(ceil_div(K, splitk), GL_BK) * GL_BK; }
     splitk = ceil_div(K, k_chunk);
     static int remap = -1;
     if (remap < 0) { const char* e = getenv("SVPC_GEMM_REMAP"); remap = e ? atoi(e) : 1; }

@@ -228,9 +228,10 @@ def get_precision():
     return _PRECISION
 
 
-# bf16 activation stream: in "bf16" precision the clip encoder may keep its activations (and their gradients) in HBM as
-# bf16 — half the bytes for every LayerNorm / attention / GEMM operand; statistics, softmax, accumulation and all parameter
-# gradients stay fp32.  Only interior-only shapes qualify (rows % 128 == 0, feature dims % 128 == 0).
+# bf16 activation stream: in "bf16" precision the clip encoder and the decoder keep their activations (and their gradients) in
+# HBM as bf16 — half the bytes for every LayerNorm / attention / GEMM operand; statistics, softmax, accumulation and all parameter
+# gradients stay fp32.  Any row count qualifies (the direct-to-LDS GEMM clamps its M/N edges and zero-fills the K tail of the
+# wgrad); feature dims must be multiples of 32.  Without the direct-to-LDS kernel only interior-only shapes do (multiples of 128).
 BF16_STREAM = True
 USE_GLDS = True        # direct-to-LDS GEMM for bf16 × bf16 interior shapes
 USE_L32 = True         # direct-to-LDS GEMM for fp32 × fp32 operands (latency-bound text / step-level side)
@@ -241,7 +242,11 @@ def _dt(t):
 
 
 def bf16_stream_ok(rows, *dims):
-    return (_PRECISION == "bf16" and BF16_STREAM and rows % 128 == 0 and rows > 0 and all(d % 128 == 0 for d in dims))
+    if not (_PRECISION == "bf16" and BF16_STREAM and rows > 0):
+        return False
+    if USE_GLDS:
+        return all(d % 32 == 0 for d in dims)
+    return rows % 128 == 0 and all(d % 128 == 0 for d in dims)
 
 
 def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NONE, p=0.0, site=0, seed=None, accumulate=0):
@@ -380,6 +385,8 @@ def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgr
     if x.dtype == torch.bfloat16 and USE_GLDS:
         if w16 is None:
             w16 = _shadow(w)
+        if w16 is None:            # no weight store yet (first step, inference without one): a transient bf16 copy
+            w16 = w.detach().to(torch.bfloat16)
     else:
         w16 = None
     return _Linear.apply(x, w, b, act, trans_w, drop, wgrad, bgrad, w16)

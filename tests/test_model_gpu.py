@@ -300,8 +300,10 @@ def test_weight_store_and_bf16_shadow():
         assert torch.equal(st.flat, opt.ema) and torch.equal(st.shadow, opt.ema.bfloat16())
         opt.ema_resume()
         assert torch.equal(st.flat, before) and torch.equal(st.shadow, before.bfloat16())
+    # with the direct-to-LDS kernels the bf16 streams engage at any row count (here also the 24-row decoder), without them only
+    # at interior-only shapes: the two runs differ by the bf16 rounding of those activations — the stream tolerance applies
     for a, b in zip(losses[True], losses[False]):
-        assert abs(a - b) <= 2e-4 * abs(b), (losses)
+        assert abs(a - b) <= 1e-2 * abs(b), (losses)
 
 
 def test_bf16_decoder_stream_close_to_fp32():

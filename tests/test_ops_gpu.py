@@ -365,10 +365,15 @@ def test_gemm_mx_bf16_storage(bf16_mode, M, N, K, a_kc, b_kc, dts):
 
 @pytest.mark.parametrize("M,N,K,a_kc,b_kc,c_bf16", [
     (128, 128, 32, 1, 1, False), (256, 768, 768, 1, 1, True), (19200, 768, 768, 1, 1, True), (256, 2304, 768, 1, 0, True),
-    (768, 2304, 19200, 0, 0, False), (128, 256, 4096, 0, 0, False), (256, 128, 1024, 0, 1, False), (384, 3072, 768, 1, 1, False)])
+    (768, 2304, 19200, 0, 0, False), (128, 256, 4096, 0, 0, False), (256, 128, 1024, 0, 1, False), (384, 3072, 768, 1, 1, False),
+    # ragged shapes: clamped M / N edges, K tail of the wgrad layout served from zeros
+    (200, 96, 64, 1, 1, True), (19210, 768, 768, 1, 1, True), (100, 768, 2304, 1, 0, True), (1, 128, 32, 1, 1, True),
+    (768, 256, 1000, 0, 0, False), (136, 72, 50, 0, 0, False), (768, 768, 4230, 0, 0, False), (8, 8, 7, 0, 0, False),
+    (250, 130, 96, 1, 1, False), (72, 200, 160, 0, 1, False)])
 def test_gemm_glds_direct_to_lds(bf16_mode, M, N, K, a_kc, b_kc, c_bf16):
     """Direct-to-LDS bf16×bf16 GEMM (global_load_lds ring, source-side chunk swizzle, row and transposed fragments):
-    exact up to accumulation order for fp32 output, bf16 rounding for bf16 output; all four layouts, split-K."""
+    exact up to accumulation order for fp32 output, bf16 rounding for bf16 output; all four layouts, split-K, ragged edges."""
+    assert O._lib.load().svpc_gemm_glds_supported(a_kc, b_kc, K if a_kc else M, K if b_kc else N, M, N, K) == 1
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
     A = torch.randn(M, K, generator=g).bfloat16().to(DEV)
     B = torch.randn(N, K, generator=g).bfloat16().to(DEV)
