@@ -21,8 +21,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short short4v __attribute__((ext_vector_type(4)));
 
 constexpr int GL_BM = 128, GL_BN = 128, GL_BK = 32;
-constexpr int GL_OP = 8192;                 // bytes of one operand tile
-constexpr int GL_STAGE = 2 * GL_OP;
+constexpr int GL_OP = 8192;                 // bytes of one 128-row operand tile
 
 typedef const void __attribute__((address_space(1))) * gl_gptr;
 typedef void __attribute__((address_space(3))) * gl_lptr;
@@ -30,9 +29,12 @@ typedef void __attribute__((address_space(3))) * gl_lptr;
 __device__ __attribute__((aligned(16))) const float glds_zeros[4] = {0.f, 0.f, 0.f, 0.f};     // source of k-rows past K
 
 // per-lane source of this wave's 1-KiB piece of an operand tile; `krow` = the lane's k-row inside the tile (k-strided operands)
+// (k-contiguous: piece `wave` = tile rows 16·wave…; a 256-row tile is two 128-row halves, `half` selects one.  k-strided: piece
+//  `wave` = k-rows 4·wave…, 256 B = 128 columns per k-row; `half` selects columns 128·half…)
 template <bool KC>
 __device__ __forceinline__ const __bf16* glds_src(const __bf16* P, int ld, int m0, int rows, int k0, int wave, int lane, size_t& step,
-                                                  int& krow) {
+                                                  int& krow, int half = 0) {
+    m0 += 128 * half;
     if (KC) {
         const int row = 16 * wave + (lane >> 2), pos = lane & 3;
         const int c = pos ^ ((row >> 2) & 3);
@@ -70,66 +72,88 @@ __device__ __forceinline__ bf16x8 glds_fragment(const char* __restrict__ img, in
     }
 }
 
-template <bool A_KC, bool B_KC, typename TC, int NS>
+// BM = 128: waves 2 (m) × 4 (n), wave tile 64×32.  BM = 256: the A tile is two 128-row images, waves 4 (m) × 2 (n), wave tile
+// 64×64 — 4 MFMAs per 4 fragment reads instead of 2 per 3, and half as many workgroups, which matters when 128-row tiles would
+// leave a mostly empty second round of workgroups (900 tiles on 768 resident slots → 450 on 512).
+template <bool A_KC, bool B_KC, typename TC, int NS, int BM>
 __global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B, int ldb,
                                                         TC* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_m,
                                                         int tiles_n, int splitk, int k_chunk, float* __restrict__ slabs, int remap) {
-    __shared__ __attribute__((aligned(1024))) char smem[NS * GL_STAGE];
+    constexpr int AH = BM / 128;                         // 128-row halves of the A tile
+    constexpr int STAGE = (AH + 1) * GL_OP;
+    constexpr int TNF = BM == 256 ? 2 : 1;               // B fragments (32 columns each) per wave
+    constexpr int P = AH + 1;                            // LDS-DMA pieces per wave and k-tile
+    __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
     const int wg = remap ? xcd_remap(blockIdx.x, tiles_m * tiles_n * splitk) : (int)blockIdx.x;
     const int ks_id = wg / (tiles_m * tiles_n);
     const int tile = wg - ks_id * (tiles_m * tiles_n);
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * GL_BM, n0 = tn * GL_BN;
+    const int m0 = tm * BM, n0 = tn * GL_BN;
     const int k_begin = ks_id * k_chunk;
     const int k_end = min(K, k_begin + k_chunk);
     const int nk = (k_end - k_begin + GL_BK - 1) / GL_BK;     // a partial last tile exists only with k-strided operands
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = BM == 256 ? wave >> 1 : wave >> 2, wc = BM == 256 ? wave & 1 : wave & 3;
 
     size_t stepA, stepB;
     int kra, krb;
-    const __bf16* ga = glds_src<A_KC>(A, lda, m0, M, k_begin, wave, lane, stepA, kra);
+    const __bf16* ga[AH];
+#pragma unroll
+    for (int h = 0; h < AH; ++h) ga[h] = glds_src<A_KC>(A, lda, m0, M, k_begin, wave, lane, stepA, kra, h);
     const __bf16* gb = glds_src<B_KC>(B, ldb, n0, N, k_begin, wave, lane, stepB, krb);
     const __bf16* const zsrc = reinterpret_cast<const __bf16*>(glds_zeros);
     kra += k_begin; krb += k_begin;                           // absolute k-row of this lane in tile 0
-    char* const my = smem + wave * 1024;        // this wave's 1-KiB slice inside an operand tile
+    char* const my = smem + wave * 1024;        // this wave's 1-KiB slice inside an operand image
 
-    floatx16 acc[2];
+    floatx16 acc[2][TNF];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int j = 0; j < TNF; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
 #define GL_ISSUE(t)                                                                                                       \
     do {                                                                                                                  \
-        char* st = my + ((t) % NS) * GL_STAGE;                                                                            \
-        const __bf16* pa_ = (!A_KC && kra + (t) * GL_BK >= k_end) ? zsrc : ga;                                           \
+        char* st = my + ((t) % NS) * STAGE;                                                                               \
+        const bool za_ = !A_KC && kra + (t) * GL_BK >= k_end;                                                             \
+        _Pragma("unroll") for (int h = 0; h < AH; ++h) {                                                                  \
+            __builtin_amdgcn_global_load_lds((gl_gptr)(za_ ? zsrc : ga[h]), (gl_lptr)(st + h * GL_OP), 16, 0, 0);        \
+            ga[h] += stepA;                                                                                               \
+        }                                                                                                                 \
         const __bf16* pb_ = (!B_KC && krb + (t) * GL_BK >= k_end) ? zsrc : gb;                                           \
-        __builtin_amdgcn_global_load_lds((gl_gptr)pa_, (gl_lptr)st, 16, 0, 0);                                            \
-        __builtin_amdgcn_global_load_lds((gl_gptr)pb_, (gl_lptr)(st + GL_OP), 16, 0, 0);                                  \
-        ga += stepA; gb += stepB;                                                                                         \
+        __builtin_amdgcn_global_load_lds((gl_gptr)pb_, (gl_lptr)(st + AH * GL_OP), 16, 0, 0);                             \
+        gb += stepB;                                                                                                      \
     } while (0)
 
     for (int t = 0; t < NS - 1 && t < nk; ++t) GL_ISSUE(t);
 
     for (int t = 0; t < nk; ++t) {
-        // this wave's two loads of tile t have landed once at most 2·(tiles issued after t) remain outstanding
+        // this wave's P loads of tile t have landed once at most P·(tiles issued after t) remain outstanding
         const int rem = nk - 1 - t;
-        if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+        else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();               // every wave's slice of tile t is in LDS; every wave is done with tile t-1
         __builtin_amdgcn_sched_barrier(0);
         if (t + NS - 1 < nk) GL_ISSUE(t + NS - 1);  // refills the stage tile t-1 used
-        const char* sa = smem + (t % NS) * GL_STAGE;
-        const char* sb = sa + GL_OP;
+        const char* sa = smem + (t % NS) * STAGE;
+        const char* sb = sa + AH * GL_OP;
+        // this wave's 64 A rows: BM = 128 → rows 64·wr of the single image; BM = 256 → image wr>>1, rows 64·(wr&1)
+        const char* sa_w = BM == 256 ? sa + (wr >> 1) * GL_OP : sa;
+        const int arow = BM == 256 ? (wr & 1) * 64 : wr * 64;
 #pragma unroll
         for (int ks = 0; ks < GL_BK / 16; ++ks) {
-            const bf16x8 b = glds_fragment<B_KC>(sb, wc * 32, ks, lane);
+            bf16x8 bfr[TNF];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(glds_fragment<A_KC>(sa, wr * 64 + i * 32, ks, lane), b, acc[i], 0, 0, 0);
+            for (int j = 0; j < TNF; ++j) bfr[j] = glds_fragment<B_KC>(sb, wc * 32 * TNF + j * 32, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8 af = glds_fragment<A_KC>(sa_w, arow + i * 32, ks, lane);
+#pragma unroll
+                for (int j = 0; j < TNF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
+            }
         }
     }
 #undef GL_ISSUE
@@ -137,40 +161,43 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict
     const u64 seed = (epi.p_drop > 0.f && splitk == 1) ? epi.seed[0] : 0ull;
     const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int col = n0 + wc * 32 + l31;
-    if (sizeof(TC) == 2 && splitk == 1 && epi.p_drop <= 0.f && !epi.accumulate) {
-        const bool odd = lane & 1;
-        const float bias = (epi.bias && col < N) ? epi.bias[col] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TNF; ++j) {
+        const int col = n0 + wc * 32 * TNF + j * 32 + l31;
+        if (sizeof(TC) == 2 && splitk == 1 && epi.p_drop <= 0.f && !epi.accumulate) {
+            const bool odd = lane & 1;
+            const float bias = (epi.bias && col < N) ? epi.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const float z0 = acc[i][j][e] + bias, z1 = acc[i][j][e + 1] + bias;
+                    const float y0 = apply_act(z0, epi.act), y1 = apply_act(z1, epi.act);
+                    const float py = __shfl_xor(odd ? y0 : y1, 1, 64);
+                    const float pz = __shfl_xor(odd ? z0 : z1, 1, 64);
+                    const int row = m0 + wr * 64 + i * 32 + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2) + 4 * lhi;
+                    const size_t o = (size_t)row * ldc + (col & ~1);
+                    union { __bf16 h[2]; uint32_t u; } pk;
+                    pk.h[0] = (__bf16)(odd ? py : y0); pk.h[1] = (__bf16)(odd ? y1 : py);
+                    if (row >= M || col >= N) continue;              // N is even: a column pair is valid or invalid as a whole
+                    *reinterpret_cast<uint32_t*>(reinterpret_cast<__bf16*>(C) + o) = pk.u;
+                    if (epi.Z) {
+                        pk.h[0] = (__bf16)(odd ? pz : z0); pk.h[1] = (__bf16)(odd ? z1 : pz);
+                        *reinterpret_cast<uint32_t*>(reinterpret_cast<__bf16*>(epi.Z) + o) = pk.u;
+                    }
+                }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                const float z0 = acc[i][e] + bias, z1 = acc[i][e + 1] + bias;
-                const float y0 = apply_act(z0, epi.act), y1 = apply_act(z1, epi.act);
-                const float py = __shfl_xor(odd ? y0 : y1, 1, 64);
-                const float pz = __shfl_xor(odd ? z0 : z1, 1, 64);
-                const int row = m0 + wr * 64 + i * 32 + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2) + 4 * lhi;
-                const size_t o = (size_t)row * ldc + (col & ~1);
-                union { __bf16 h[2]; uint32_t u; } pk;
-                pk.h[0] = (__bf16)(odd ? py : y0); pk.h[1] = (__bf16)(odd ? y1 : py);
-                if (row >= M || col >= N) continue;              // N is even: a column pair is valid or invalid as a whole
-                *reinterpret_cast<uint32_t*>(reinterpret_cast<__bf16*>(C) + o) = pk.u;
-                if (epi.Z) {
-                    pk.h[0] = (__bf16)(odd ? pz : z0); pk.h[1] = (__bf16)(odd ? z1 : pz);
-                    *reinterpret_cast<uint32_t*>(reinterpret_cast<__bf16*>(epi.Z) + o) = pk.u;
-                }
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                if (row >= M || col >= N) continue;
+                if (splitk == 1) epilogue_store_t<TC>(acc[i][j][e], row, col, C, ldc, epi, seed, inv_keep);
+                else slabs[((size_t)ks_id * M + row) * N + col] = acc[i][j][e];
             }
-        return;
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-            if (row >= M || col >= N) continue;
-            if (splitk == 1) epilogue_store_t<TC>(acc[i][e], row, col, C, ldc, epi, seed, inv_keep);
-            else slabs[((size_t)ks_id * M + row) * N + col] = acc[i][e];
-        }
 }
 
 extern "C" {
@@ -195,7 +222,17 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
                  "gemm_glds: unsupported shape (see svpc_gemm_glds_supported) or operands not 16-byte aligned");
     SVPC_REQUIRE(p_drop <= 0.f || seed != nullptr, "gemm: dropout needs a seed pointer");
     Epi epi{bias, act, p_drop, site, seed, accumulate, (float*)Z};
-    const int tiles_m = ceil_div(M, GL_BM), tiles_n = ceil_div(N, GL_BN), tiles = tiles_m * tiles_n;
+    // 256-row tiles when 128-row tiles would need more than one round of resident workgroups and the taller tile fills its rounds
+    // better (3 × 48 KiB workgroups per CU vs 2 × 72 KiB)
+    static int bm_env = -1;
+    if (bm_env < 0) { const char* e = getenv("SVPC_GLDS_BM"); bm_env = e ? atoi(e) : 0; }
+    const int t128 = ceil_div(M, 128) * ceil_div(N, GL_BN), t256 = ceil_div(M, 256) * ceil_div(N, GL_BN);
+    const int slots128 = 256 * 3, slots256 = 256 * 2;
+    const double eff128 = (double)t128 / ((double)ceil_div(t128, slots128) * slots128);
+    const double eff256 = (double)t256 / ((double)ceil_div(t256, slots256) * slots256);
+    int BMv = (t128 > slots128 && eff256 >= eff128) ? 256 : 128;
+    if (bm_env == 128 || bm_env == 256) BMv = bm_env;
+    const int tiles_m = ceil_div(M, BMv), tiles_n = ceil_div(N, GL_BN), tiles = tiles_m * tiles_n;
     int splitk = 1;
     if (K >= 512 && tiles < 256) {
         splitk = ceil_div(512, tiles);
@@ -212,14 +249,14 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
     dim3 grid(tiles * splitk), block(512);
     static int ns = -1;
     if (ns < 0) { const char* e = getenv("SVPC_GLDS_NS"); ns = e ? atoi(e) : 3; }   // 3 stages = 48 KiB → 3 workgroups per CU (measured best)
+#define GL_LAUNCH1(AK, BKC, TC, NSV, BMV)                                                                                            \
+    hipLaunchKernelGGL((gemm_glds_kernel<AK, BKC, TC, NSV, BMV>), grid, block, 0, stream, (const __bf16*)A, lda, (const __bf16*)B, ldb,   \
+                       (TC*)C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, workspace, remap)
 #define GL_LAUNCH(AK, BKC, TC)                                                                                                       \
     do {                                                                                                                             \
-        if (ns == 3)                                                                                                                 \
-            hipLaunchKernelGGL((gemm_glds_kernel<AK, BKC, TC, 3>), grid, block, 0, stream, (const __bf16*)A, lda, (const __bf16*)B, ldb, \
-                               (TC*)C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, workspace, remap);                      \
-        else                                                                                                                         \
-            hipLaunchKernelGGL((gemm_glds_kernel<AK, BKC, TC, 4>), grid, block, 0, stream, (const __bf16*)A, lda, (const __bf16*)B, ldb, \
-                               (TC*)C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, workspace, remap);                      \
+        if (BMv == 256) GL_LAUNCH1(AK, BKC, TC, 3, 256);                                                                             \
+        else if (ns == 3) GL_LAUNCH1(AK, BKC, TC, 3, 128);                                                                           \
+        else GL_LAUNCH1(AK, BKC, TC, 4, 128);                                                                                        \
     } while (0)
     if (c_dt == 1) {
         if (a_kc && b_kc) GL_LAUNCH(true, true, __bf16);
@@ -233,6 +270,7 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
         else GL_LAUNCH(false, false, float);
     }
 #undef GL_LAUNCH
+#undef GL_LAUNCH1
     int rc = svpc_check_launch("gemm_glds");
     if (rc) return rc;
     if (splitk > 1) {
