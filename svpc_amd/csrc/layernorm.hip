@@ -289,40 +289,49 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     for (int c = threadIdx.x; c < 2 * D; c += 256) out[c] = smem[c];
 }
 
-// out[c] (+)= sum_g partial[g][c] : 32 columns × 8 row-groups per workgroup, LDS tree for the 8 partial sums
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int G, int ncols,
-                                                              float* __restrict__ out, int accumulate) {
-    __shared__ float red[8][33];
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+// Column sums of the per-workgroup partials: 32 columns × 32 row-groups per workgroup (1,024 threads), every thread's loads
+// issued four at a time, then a fixed-order LDS tree over the 32 row-groups — deterministic.  These launches are pure latency
+// (≤3 MB read), so memory-level parallelism is what matters.
+__device__ __forceinline__ float finalize_column(const float* __restrict__ partial, int G, int ncols, int c, int rg, float (*red)[33]) {
+    const int cl = threadIdx.x & 31;
     float s = 0.f;
-    if (c < ncols)
-        for (int g = rg; g < G; g += 8) s += partial[(size_t)g * ncols + c];
+    if (c < ncols) {
+        int g = rg;
+        for (; g + 96 < G; g += 128) {
+            const float a0 = partial[(size_t)g * ncols + c], a1 = partial[(size_t)(g + 32) * ncols + c];
+            const float a2 = partial[(size_t)(g + 64) * ncols + c], a3 = partial[(size_t)(g + 96) * ncols + c];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; g < G; g += 32) s += partial[(size_t)g * ncols + c];
+    }
     red[rg][cl] = s;
     __syncthreads();
-    if (rg == 0 && c < ncols) {
-        float t = red[0][cl];
+    float t = 0.f;
+    if (rg == 0) {
+        t = red[0][cl];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) t += red[k][cl];
-        out[c] = accumulate ? out[c] + t : t;
+        for (int k = 1; k < 32; ++k) t += red[k][cl];
     }
+    return t;
+}
+// out[c] (+)= sum_g partial[g][c]
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ partial, int G, int ncols,
+                                                               float* __restrict__ out, int accumulate) {
+    __shared__ float red[32][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const float t = finalize_column(partial, G, ncols, c, rg, red);
+    if (rg == 0 && c < ncols) out[c] = accumulate ? out[c] + t : t;
 }
 
 // LayerNorm backward tail: [dgamma ; dbeta] = sum_g partial[g][0:2D], one launch for both vectors
-__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ partial, int G, int D, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, int accumulate) {
-    __shared__ float red[8][33];
+__global__ __launch_bounds__(1024) void ln_finalize_kernel(const float* __restrict__ partial, int G, int D, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int accumulate) {
+    __shared__ float red[32][33];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl, ncols = 2 * D;
-    float s = 0.f;
-    if (c < ncols)
-        for (int g = rg; g < G; g += 8) s += partial[(size_t)g * ncols + c];
-    red[rg][cl] = s;
-    __syncthreads();
+    const float t = finalize_column(partial, G, ncols, c, rg, red);
     if (rg == 0 && c < ncols) {
-        float t = red[0][cl];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) t += red[k][cl];
         float* out = c < D ? dgamma + c : dbeta + (c - D);
         *out = accumulate ? *out + t : t;
     }
@@ -451,7 +460,7 @@ int svpc_ln_bwd_rows_t(const void* dy, const void* x, int x_dt, int y_dt, const 
 // parameter-gradient part: dgamma / dbeta (+)= column sums of the partials (may run on another stream than the rows part)
 int svpc_ln_param_grads(const float* partial, int R, int D, float* dgamma, float* dbeta, int accumulate, hipStream_t stream) {
     if (R == 0) return 0;
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3(ceil_div(2 * D, 32)), dim3(256), 0, stream, partial, svpc_ln_bwd_groups(R), D, dgamma, dbeta,
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(ceil_div(2 * D, 32)), dim3(1024), 0, stream, partial, svpc_ln_bwd_groups(R), D, dgamma, dbeta,
                        accumulate);
     return svpc_check_launch("ln_param_grads");
 }
@@ -496,7 +505,7 @@ int svpc_bucket_colsum_t(const void* xv, int x_dt, int ldx, const int* idx, int 
     }
     int rc = svpc_check_launch("bucket_colsum");
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(K * C, 32)), dim3(256), 0, stream, workspace, chunks, K * C,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(K * C, 32)), dim3(1024), 0, stream, workspace, chunks, K * C,
                        out, accumulate);
     return svpc_check_launch("bucket_colsum finalize");
 }
