@@ -361,6 +361,53 @@ __global__ __launch_bounds__(256) void bucket_colsum_kernel(const T* __restrict_
     }
 }
 
+// Plain column sum (K = 1, no bucket index), vector form: a thread owns 16 bytes of a row (4 fp32 / 8 bf16 columns); the 256
+// threads are 64 column groups × 4 row lanes, each row lane keeps four rows in flight.  partial[chunk][c] as above.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x, int ldx, int R, int C, int rows_per_chunk,
+                                                         float* __restrict__ partial) {
+    constexpr int V = 16 / sizeof(T);
+    typedef float vec16 __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+    __shared__ float red[4][64 * V];
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + cg) * V;
+    const int chunk = blockIdx.y;
+    const int r0 = chunk * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    auto add = [&](const vec16& raw) {
+        if (sizeof(T) == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += raw[j];
+        } else {
+            union { vec16 f; bf16x8v h; } u;
+            u.f = raw;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j % V] += (float)u.h[j];
+        }
+    };
+    if (c0 < C) {
+        int r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {
+            const vec16 a0 = *reinterpret_cast<const vec16*>(x + (size_t)r * ldx + c0);
+            const vec16 a1 = *reinterpret_cast<const vec16*>(x + (size_t)(r + 4) * ldx + c0);
+            const vec16 a2 = *reinterpret_cast<const vec16*>(x + (size_t)(r + 8) * ldx + c0);
+            const vec16 a3 = *reinterpret_cast<const vec16*>(x + (size_t)(r + 12) * ldx + c0);
+            add(a0); add(a1); add(a2); add(a3);
+        }
+        for (; r < r1; r += 4) add(*reinterpret_cast<const vec16*>(x + (size_t)r * ldx + c0));
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) red[rl][cg * V + j] = acc[j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * V; i += 256) {
+        const int c = blockIdx.x * 64 * V + i;
+        if (c < C) partial[(size_t)chunk * C + c] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    }
+}
+
 template <int NPL, int W>
 static int launch_ln_fwd(const LnArgs& a, int x_dt, int y_dt, hipStream_t s) {
     const dim3 g(ceil_div(a.R, 4)), b(256);
@@ -492,7 +539,12 @@ int svpc_bucket_colsum_t(const void* xv, int x_dt, int ldx, const int* idx, int 
     const int chunks = svpc_colsum_chunks(R);
     const int rpc = ceil_div(R, chunks);
     dim3 grid(ceil_div(C, 256), chunks);
-    if (x_dt == 0) {
+    const int V = x_dt ? 8 : 4;
+    if (K == 1 && idx == nullptr && C % V == 0 && ldx % V == 0 && ((((uintptr_t)xv)) & 15) == 0) {
+        const dim3 vg(ceil_div(C, 64 * V), chunks);
+        if (x_dt == 0) hipLaunchKernelGGL(colsum_vec_kernel<float>, vg, dim3(256), 0, stream, (const float*)xv, ldx, R, C, rpc, workspace);
+        else hipLaunchKernelGGL(colsum_vec_kernel<__bf16>, vg, dim3(256), 0, stream, (const __bf16*)xv, ldx, R, C, rpc, workspace);
+    } else if (x_dt == 0) {
         const float* x = (const float*)xv;
         if (K == 1) hipLaunchKernelGGL((bucket_colsum_kernel<1, float>), grid, dim3(256), 0, stream, x, ldx, idx, R, C, K, rpc, workspace);
         else if (K <= 4) hipLaunchKernelGGL((bucket_colsum_kernel<4, float>), grid, dim3(256), 0, stream, x, ldx, idx, R, C, K, rpc, workspace);
