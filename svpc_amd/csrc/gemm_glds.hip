@@ -234,7 +234,9 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
     if (bm_env == 128 || bm_env == 256) BMv = bm_env;
     const int tiles_m = ceil_div(M, BMv), tiles_n = ceil_div(N, GL_BN), tiles = tiles_m * tiles_n;
     int splitk = 1;
-    if (K >= 512 && tiles < 256) {
+    static int split_below = -1;
+    if (split_below < 0) { const char* e = getenv("SVPC_GLDS_SPLIT_BELOW"); split_below = e ? atoi(e) : 150; }   // ≥150 tiles already fill most CUs: a split would only add the reduce launch (measured)
+    if (K >= 512 && tiles < split_below) {
         splitk = ceil_div(512, tiles);
         const int max_by_k = K / 256;
         if (splitk > max_by_k) splitk = max_by_k;
