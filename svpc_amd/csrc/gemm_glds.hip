@@ -236,8 +236,10 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
     int splitk = 1;
     static int split_below = -1;
     if (split_below < 0) { const char* e = getenv("SVPC_GLDS_SPLIT_BELOW"); split_below = e ? atoi(e) : 150; }   // ≥150 tiles already fill most CUs: a split would only add the reduce launch (measured)
+    static int split_target = -1;
+    if (split_target < 0) { const char* e = getenv("SVPC_GLDS_SPLIT_TARGET"); split_target = e ? atoi(e) : 256; }   // ≈one workgroup per CU: fewer slabs to reduce (measured best of 128…1024)
     if (K >= 512 && tiles < split_below) {
-        splitk = ceil_div(512, tiles);
+        splitk = ceil_div(split_target, tiles);
         const int max_by_k = K / 256;
         if (splitk > max_by_k) splitk = max_by_k;
         if (splitk > 64) splitk = 64;

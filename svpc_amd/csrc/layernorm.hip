@@ -289,6 +289,70 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     for (int c = threadIdx.x; c < 2 * D; c += 256) out[c] = smem[c];
 }
 
+// LayerNorm backward when NO input gradient is wanted (the first LayerNorm over the frame features: model.py:548, the features
+// are data): only dgamma = Σ_r dy·x̂ and dbeta = Σ_r dy remain — a two-output column sum.  A thread owns 4 columns, the 256
+// threads are 64 column groups × 4 row lanes with two rows in flight each; partial[group][0:2D] as ln_bwd_kernel writes it.
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(LnBwdArgs a, int rows_per_group) {
+    __shared__ float red[4][2][256];
+    const TY* __restrict__ dyp = reinterpret_cast<const TY*>(a.dy);
+    const TX* __restrict__ xp = reinterpret_cast<const TX*>(a.x);
+    const TY* __restrict__ rp = reinterpret_cast<const TY*>(a.res);
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6, D = a.D;
+    const int c0 = (blockIdx.x * 64 + cg) * 4;
+    const int group = blockIdx.y;
+    const int r0 = group * rows_per_group, r1 = min(a.R, r0 + rows_per_group);
+    const bool any_drop = (a.p_pre > 0.f) || (a.p_post > 0.f);
+    const u64 seed = any_drop ? a.seed[0] : 0ull;
+    const float ik_pre = a.p_pre > 0.f ? 1.0f / (1.0f - a.p_pre) : 1.0f;
+    const float ik_post = a.p_post > 0.f ? 1.0f / (1.0f - a.p_post) : 1.0f;
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    auto one = [&](int r, const float* h, const float* d, const float* t, float mean, float rstd) {
+        const size_t orow = (size_t)r * D;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float hv = h[j];
+            if (a.p_pre > 0.f) hv *= drop_scale(seed, a.site_pre, orow + c0 + j, a.p_pre, ik_pre);
+            if (a.res) hv += t[j];
+            float dy0 = d[j];
+            if (a.p_post > 0.f) dy0 *= drop_scale(seed, a.site_post, orow + c0 + j, a.p_post, ik_post);
+            ag[j] += dy0 * (hv - mean) * rstd;
+            ab[j] += dy0;
+        }
+    };
+    if (c0 < D) {
+        int r = r0 + rl;
+        for (; r + 4 < r1; r += 8) {
+            const int ra = r, rb = r + 4;
+            float ha[4], hb[4], da[4], db[4], ta[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f};
+            VecIO<4, TX>::load(xp + (size_t)(a.src_rows ? a.src_rows[ra] : ra) * D + c0, ha);
+            VecIO<4, TX>::load(xp + (size_t)(a.src_rows ? a.src_rows[rb] : rb) * D + c0, hb);
+            VecIO<4, TY>::load(dyp + (size_t)ra * D + c0, da);
+            VecIO<4, TY>::load(dyp + (size_t)rb * D + c0, db);
+            if (a.res) { VecIO<4, TY>::load(rp + (size_t)ra * D + c0, ta); VecIO<4, TY>::load(rp + (size_t)rb * D + c0, tb); }
+            const float ma = a.mean[ra], sa = a.rstd[ra], mb = a.mean[rb], sb = a.rstd[rb];
+            one(ra, ha, da, ta, ma, sa);
+            one(rb, hb, db, tb, mb, sb);
+        }
+        for (; r < r1; r += 4) {
+            float h[4], d[4], t[4] = {0.f, 0.f, 0.f, 0.f};
+            VecIO<4, TX>::load(xp + (size_t)(a.src_rows ? a.src_rows[r] : r) * D + c0, h);
+            VecIO<4, TY>::load(dyp + (size_t)r * D + c0, d);
+            if (a.res) VecIO<4, TY>::load(rp + (size_t)r * D + c0, t);
+            one(r, h, d, t, a.mean[r], a.rstd[r]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[rl][0][cg * 4 + j] = ag[j]; red[rl][1][cg * 4 + j] = ab[j]; }
+    __syncthreads();
+    float* out = a.partial + (size_t)group * 2 * D;
+    const int i = threadIdx.x, c = blockIdx.x * 256 + i;
+    if (c < D) {
+        out[c] = (red[0][0][i] + red[1][0][i]) + (red[2][0][i] + red[3][0][i]);
+        out[D + c] = (red[0][1][i] + red[1][1][i]) + (red[2][1][i] + red[3][1][i]);
+    }
+}
+
 // Column sums of the per-workgroup partials: 32 columns × 32 row-groups per workgroup (1,024 threads), every thread's loads
 // issued four at a time, then a fixed-order LDS tree over the 32 row-groups — deterministic.  These launches are pure latency
 // (≤3 MB read), so memory-level parallelism is what matters.
@@ -491,6 +555,14 @@ int svpc_ln_bwd_rows_t(const void* dy, const void* x, int x_dt, int y_dt, const 
     const bool vec = (D % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(gamma) && (!res || aligned16(res)) &&
                      (!dh || aligned16(dh)) && (!dx || aligned16(dx));
     int rc = -1;
+    if (vec && !dh && !dx) {       // parameter gradients only: streaming two-output column sum
+        const dim3 grid(ceil_div(D, 256), G);
+        const int rpg = ceil_div(R, G);
+        if (x_dt == 0 && y_dt == 0) hipLaunchKernelGGL((ln_param_grad_kernel<float, float>), grid, dim3(256), 0, stream, a, rpg);
+        else if (x_dt == 0 && y_dt == 1) hipLaunchKernelGGL((ln_param_grad_kernel<float, __bf16>), grid, dim3(256), 0, stream, a, rpg);
+        else hipLaunchKernelGGL((ln_param_grad_kernel<__bf16, __bf16>), grid, dim3(256), 0, stream, a, rpg);
+        return svpc_check_launch("ln_param_grad");
+    }
     if (vec) {
         if (D <= 256) rc = launch_ln_bwd<1, 4>(a, G, x_dt, y_dt, stream);
         else if (D <= 1024) rc = launch_ln_bwd<4, 4>(a, G, x_dt, y_dt, stream);

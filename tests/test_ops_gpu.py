@@ -124,6 +124,21 @@ def test_layernorm_fused_everything():
     compare(hip, ref, [table, res, g, b, tt], name="ln fused")
 
 
+@pytest.mark.parametrize("R,D,with_res", [(300, 3072, False), (77, 128, True), (4100, 768, False)])
+def test_layernorm_parameter_gradients_only(R, D, with_res):
+    """No input needs a gradient (the frame-feature LayerNorm): the backward is the streaming two-output column-sum kernel;
+    gathered rows, post-LayerNorm dropout and an (ungraded) residual are honoured."""
+    rng = O.make_rng(DEV, seed=5)
+    table = rnd(R + 9, D, seed=1, grad=False)
+    src = torch.randint(0, R + 9, (R,), generator=torch.Generator().manual_seed(3)).to(torch.int32).to(DEV)
+    res = rnd(R, D, seed=2, grad=False) if with_res else None
+    g, b = rnd(D, seed=3), rnd(D, seed=4)
+    post = (0.2, rng, 2)
+    compare(lambda g, b: O.layernorm(table, g, b, 1e-12, residual=res, src_rows=src, pad_row=-1, post_drop=post),
+            lambda g, b: E.layernorm(table, g, b, 1e-12, residual=res, src_rows=src, pad_row=-1, post_drop=post),
+            [g, b], name="ln param grads")
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def _attn_case(seq, D, H, causal, with_mask, drop, packed=True, cross=False, seed=0):
     Rq, Rk = seq.n_q_rows, seq.n_k_rows
