@@ -25,7 +25,7 @@ from svpc_amd import StateAwareRecursiveTransformer, make_batch, make_config  # 
 from svpc_amd import ops, synthetic as syn  # noqa: E402
 from svpc_amd.optim import FusedBertAdam, GradReducer  # noqa: E402
 
-PMC_TRAFFIC_BYTES = 108541184   # (2·FETCH_SIZE + WRITE_SIZE)·1024, means per launch of the dominant symbol: profiles/r01_d_pmc_bench_dominant_gemm.csv
+PMC_TRAFFIC_BYTES = 94625150   # (2·FETCH_SIZE + WRITE_SIZE)·1024, means per launch of the dominant kernel: profiles/r01_e_pmc_bench_dominant_gemm.csv
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense peaks (f32-in MFMA; bf16 MFMA)
 
 
@@ -240,7 +240,7 @@ def main():
     torch.cuda.synchronize()
     # roofline leg: HIP events around every launch of the dominant kernel symbol.  Eager mode: inside the timed region.  Graph
     # mode: events cannot be recorded inside a replay, so the same kernels are bracketed in instrumented eager steps right after it.
-    # Dominant kernel = the forward GEMM of the bf16 activation streams: ONE kernel symbol (gemm_glds_kernel<true,true,__bf16,3>:
+    # Dominant kernel = the forward GEMM of the bf16 activation streams: ONE kernel template (gemm_glds_kernel<true,true,__bf16,3,BM>, two tile heights:
     # bf16 activations × bf16 weight shadow → bf16, both operands direct-to-LDS) covering Q/K/V, attention-output, FFN-in/out and
     # video-embedding projections of the clip encoder (M = 19,200 rows) and the decoder's projections (M = 4,224 rows) — every
     # launch of that symbol is bracketed, so the average can be checked against rocprofv3's per-kernel average.
@@ -283,7 +283,7 @@ def main():
         D_, F_, L_ = cfg.hidden_size, cfg.video_feature_size, cfg.num_hidden_layers
         n_l = max(1, gsum["launches"])
         alg_bytes, alg_flop = gsum["bytes"] / n_l, gsum["work"] / n_l
-        # mean HBM traffic per launch of this symbol from rocprofv3 PMC passes over this very command (profiles/r01_d_pmc_*.csv):
+        # mean HBM traffic per launch of this symbol from rocprofv3 PMC passes over this very command (profiles/r01_e_pmc_*.csv):
         # FETCH_SIZE × 2 (gfx950 reports half of a 16-B/lane stream) + WRITE_SIZE, in KB.  Only valid for the default workload.
         default_cfg = (args.batch, args.clips, L_, D_, F_, args.model_type) == (16, 12, 6, 768, 3072, "vivt") and bf16_stream
         traffic = PMC_TRAFFIC_BYTES if (default_cfg and glds) else None
@@ -302,7 +302,7 @@ def main():
                                  if graph is not None else "eager"},
             "roofline": {"bound": "mfma", "kernel": "%s — every forward projection of the bf16 activation streams (clip encoder M=%d "
                                    "rows: Q/K/V, attention-out, FFN, video embedding; decoder M=%d rows)"
-                                   % ("gemm_glds_kernel<true,true,__bf16,3> (bf16·bf16→bf16, direct-to-LDS)" if glds else
+                                   % ("gemm_glds_kernel<true,true,__bf16,3,BM> (bf16·bf16→bf16, direct-to-LDS; BM = 256-row tiles at M=19,200, 128-row at M=4,224)" if glds else
                                       "gemm_bf16_kernel<128,128,NT,interior,8 waves,%s>" % ("bf16·f32→bf16" if bf16_stream else "f32"),
                                       rows_enc, args.batch * args.clips * cfg.max_t_len),
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
