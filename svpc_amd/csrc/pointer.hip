@@ -14,22 +14,56 @@
 constexpr int PTR_EMAX = 32;
 
 // ------------------------------------------------------------------------------------------------ ptr_attn
-// grid: T steps. LDS: lt*32 floats (scores/pi).
+// grid: T steps, 256 threads.  The Lt×D decoder rows (resp. their attended-vector gradients) and the entity rows, 16 at a time,
+// are staged in LDS with all of a thread's loads in flight, so the Lt·E dot products read LDS (≈100-cycle latency) instead of
+// paying one memory round trip each; the column-wise products (att, ddec, dproj, dbank) read every global row once, with the E
+// (or Lt) values of a column held in registers.  No atomics: every reduction is local to the step.
+constexpr int PTR_EC = 16;      // entity rows staged per pass
+constexpr int PTR_LTMAX = 32;   // sentence length bound of the register-resident columns
+
+__device__ __forceinline__ void ptr_stage(float* __restrict__ dst, const float* __restrict__ src, int n_floats) {
+    // n_floats % 4 == 0, both 16-byte aligned; four float4 per thread in flight
+    const int n4 = n_floats >> 2;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    int i = threadIdx.x;
+    for (; i + 768 < n4; i += 1024) {
+        const float4 a = s4[i], b = s4[i + 256], c = s4[i + 512], d = s4[i + 768];
+        d4[i] = a; d4[i + 256] = b; d4[i + 512] = c; d4[i + 768] = d;
+    }
+    for (; i < n4; i += 256) d4[i] = s4[i];
+}
+// sc[t*32 + e0+e] = <rows_t[t], ent[e]> for t < lt, e < ec, both operands in LDS (one wave per dot, lanes over D)
+__device__ __forceinline__ void ptr_dots(const float* __restrict__ rows_t, const float* __restrict__ ent, float* __restrict__ sc, int lt,
+                                         int ec, int e0, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int pe = wave; pe < lt * ec; pe += 4) {
+        const int t = pe / ec, e = pe - t * ec;
+        float dot = 0.f;
+        for (int d = lane; d < D; d += 64) dot += rows_t[(size_t)t * D + d] * ent[(size_t)e * D + d];
+        dot = wave_sum(dot);
+        if (lane == 0) sc[t * PTR_EMAX + e0 + e] = dot;
+    }
+}
+
+// LDS: lt·D (decoder rows) + PTR_EC·D (entity chunk) + lt·32 (scores/pi) floats
 __global__ __launch_bounds__(256) void ptr_attn_fwd_kernel(const float* __restrict__ dec, const float* __restrict__ proj,
                                                            const float* __restrict__ bank, const int* __restrict__ step_ne,
                                                            float* __restrict__ pi, float* __restrict__ att, int lt, int em, int D) {
-    extern __shared__ float sc[];   // lt × PTR_EMAX
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    float* rows = psm;                         // lt × D
+    float* ent = rows + (size_t)lt * D;        // PTR_EC × D
+    float* sc = ent + (size_t)PTR_EC * D;      // lt × PTR_EMAX
     const int j = blockIdx.x, E = step_ne[j];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* pj = proj + (size_t)j * em * D;
     const float* bj = bank + (size_t)j * em * D;
-    const float* dj = dec + (size_t)j * lt * D;
-    for (int pe = wave; pe < lt * E; pe += 4) {
-        const int t = pe / E, e = pe - t * E;
-        float dot = 0.f;
-        for (int d = lane; d < D; d += 64) dot += pj[(size_t)e * D + d] * dj[(size_t)t * D + d];
-        dot = wave_sum(dot);
-        if (lane == 0) sc[t * PTR_EMAX + e] = dot;
+    ptr_stage(rows, dec + (size_t)j * lt * D, lt * D);
+    for (int e0 = 0; e0 < E; e0 += PTR_EC) {
+        const int ec = min(PTR_EC, E - e0);
+        __syncthreads();
+        ptr_stage(ent, pj + (size_t)e0 * D, ec * D);
+        __syncthreads();
+        ptr_dots(rows, ent, sc, lt, ec, e0, D);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < lt; t += 256) {
@@ -45,39 +79,51 @@ __global__ __launch_bounds__(256) void ptr_attn_fwd_kernel(const float* __restri
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < lt * D; i += 256) {
-        const int t = i / D, d = i - t * D;
-        float acc = 0.f;
-        for (int e = 0; e < E; ++e) acc += sc[t * PTR_EMAX + e] * bj[(size_t)e * D + d];
-        att[((size_t)j * lt + t) * D + d] = acc;
+    // att[t][d] = Σ_e pi[t][e]·bank[e][d]: a thread owns column d, the E bank values of the column sit in registers
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float bv[PTR_EMAX];
+#pragma unroll
+        for (int e = 0; e < PTR_EMAX; ++e) bv[e] = e < E ? bj[(size_t)e * D + d] : 0.f;
+        for (int t = 0; t < lt; ++t) {
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < PTR_EMAX; ++e)
+                if (e < E) acc += sc[t * PTR_EMAX + e] * bv[e];
+            att[((size_t)j * lt + t) * D + d] = acc;
+        }
     }
 }
 
 // dproj/dbank are (T, em, D) and fully written (zeros for e ≥ E); ddec (T*lt, D) fully written.
+// LDS: lt·D (datt rows) + PTR_EC·D (entity chunk) + 2·lt·32 floats
 __global__ __launch_bounds__(256) void ptr_attn_bwd_kernel(const float* __restrict__ dec, const float* __restrict__ proj,
                                                            const float* __restrict__ bank, const int* __restrict__ step_ne,
                                                            const float* __restrict__ pi, const float* __restrict__ dpi,
                                                            const float* __restrict__ datt, float* __restrict__ ddec,
                                                            float* __restrict__ dproj, float* __restrict__ dbank, int lt, int em, int D) {
-    extern __shared__ float sm[];   // dsc: lt × 32, pis: lt × 32
-    float* dsc = sm;
-    float* pis = sm + lt * PTR_EMAX;
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    float* rows = psm;                         // lt × D : datt rows of this step
+    float* ent = rows + (size_t)lt * D;        // PTR_EC × D
+    float* dsc = ent + (size_t)PTR_EC * D;     // lt × PTR_EMAX
+    float* pis = dsc + lt * PTR_EMAX;          // lt × PTR_EMAX
     const int j = blockIdx.x, E = step_ne[j];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* pj = proj + (size_t)j * em * D;
     const float* bj = bank + (size_t)j * em * D;
     const float* dj = dec + (size_t)j * lt * D;
-    const float* daj = datt + (size_t)j * lt * D;
-    for (int pe = wave; pe < lt * E; pe += 4) {
-        const int t = pe / E, e = pe - t * E;
-        float dot = 0.f;
-        for (int d = lane; d < D; d += 64) dot += daj[(size_t)t * D + d] * bj[(size_t)e * D + d];
-        dot = wave_sum(dot);
-        if (lane == 0) {
-            const size_t o = ((size_t)j * lt + t) * em + e;
-            dsc[t * PTR_EMAX + e] = dot + (dpi ? dpi[o] : 0.f);
-            pis[t * PTR_EMAX + e] = pi[o];
-        }
+    ptr_stage(rows, datt + (size_t)j * lt * D, lt * D);
+    for (int e0 = 0; e0 < E; e0 += PTR_EC) {
+        const int ec = min(PTR_EC, E - e0);
+        __syncthreads();
+        ptr_stage(ent, bj + (size_t)e0 * D, ec * D);
+        __syncthreads();
+        ptr_dots(rows, ent, dsc, lt, ec, e0, D);      // datt[t]·bank[e]
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < lt * E; i += 256) {
+        const int t = i / E, e = i - t * E;
+        const size_t o = ((size_t)j * lt + t) * em + e;
+        dsc[t * PTR_EMAX + e] += dpi ? dpi[o] : 0.f;
+        pis[t * PTR_EMAX + e] = pi[o];
     }
     __syncthreads();
     for (int t = threadIdx.x; t < lt; t += 256) {
@@ -86,23 +132,35 @@ __global__ __launch_bounds__(256) void ptr_attn_bwd_kernel(const float* __restri
         for (int e = 0; e < E; ++e) dsc[t * PTR_EMAX + e] = pis[t * PTR_EMAX + e] * (dsc[t * PTR_EMAX + e] - mix);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < lt * D; i += 256) {
-        const int t = i / D, d = i - t * D;
-        float acc = 0.f;
-        for (int e = 0; e < E; ++e) acc += dsc[t * PTR_EMAX + e] * pj[(size_t)e * D + d];
-        ddec[((size_t)j * lt + t) * D + d] = acc;
-    }
-    for (int i = threadIdx.x; i < em * D; i += 256) {
-        const int e = i / D, d = i - e * D;
-        float ap = 0.f, ab = 0.f;
-        if (e < E) {
-            for (int t = 0; t < lt; ++t) {
-                ap += dsc[t * PTR_EMAX + e] * dj[(size_t)t * D + d];
-                ab += pis[t * PTR_EMAX + e] * daj[(size_t)t * D + d];
-            }
+    for (int d = threadIdx.x; d < D; d += 256) {
+        // ddec[t][d] = Σ_e dsc[t][e]·proj[e][d]
+        float pv[PTR_EMAX];
+#pragma unroll
+        for (int e = 0; e < PTR_EMAX; ++e) pv[e] = e < E ? pj[(size_t)e * D + d] : 0.f;
+        // dproj[e][d] = Σ_t dsc[t][e]·dec[t][d],  dbank[e][d] = Σ_t pi[t][e]·datt[t][d]: the Lt values of the column in registers
+        float dv[PTR_LTMAX], av[PTR_LTMAX];
+#pragma unroll
+        for (int t = 0; t < PTR_LTMAX; ++t) {
+            dv[t] = t < lt ? dj[(size_t)t * D + d] : 0.f;
+            av[t] = t < lt ? rows[(size_t)t * D + d] : 0.f;
         }
-        dproj[(size_t)j * em * D + i] = ap;
-        dbank[(size_t)j * em * D + i] = ab;
+        for (int t = 0; t < lt; ++t) {
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < PTR_EMAX; ++e)
+                if (e < E) acc += dsc[t * PTR_EMAX + e] * pv[e];
+            ddec[((size_t)j * lt + t) * D + d] = acc;
+        }
+        for (int e = 0; e < em; ++e) {
+            float ap = 0.f, ab = 0.f;
+            if (e < E) {
+#pragma unroll
+                for (int t = 0; t < PTR_LTMAX; ++t)
+                    if (t < lt) { ap += dsc[t * PTR_EMAX + e] * dv[t]; ab += pis[t * PTR_EMAX + e] * av[t]; }
+            }
+            dproj[((size_t)j * em + e) * D + d] = ap;
+            dbank[((size_t)j * em + e) * D + d] = ab;
+        }
     }
 }
 
@@ -275,22 +333,42 @@ __global__ __launch_bounds__(256) void gumbel_emb_grad_kernel(const float* __res
     for (int c = threadIdx.x; c < W; c += 256) atomicAdd(&demb[(size_t)t * W + c], coef * dbow[(size_t)r * W + c]);
 }
 
+static int ptr_set_lds(const void* fn) {
+    // raised once per kernel to the device maximum (never inside a stream capture after the first call)
+    static const void* done[8]; static int n_done = 0;
+    for (int i = 0; i < n_done; ++i) if (done[i] == fn) return 0;
+    if (n_done < 8) done[n_done++] = fn;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { svpc_set_error("ptr_attn: cannot raise dynamic LDS limit"); return (int)e; }
+    return 0;
+}
+
 extern "C" {
 
 int svpc_ptr_attn_fwd(const float* dec, const float* proj, const float* bank, const int* step_ne, float* pi, float* att, int T,
                       int lt, int e_max, int D, hipStream_t s) {
     if (T == 0) return 0;
     SVPC_REQUIRE(e_max <= PTR_EMAX, "ptr_attn: at most 32 entities");
-    hipLaunchKernelGGL(ptr_attn_fwd_kernel, dim3(T), dim3(256), (size_t)lt * PTR_EMAX * sizeof(float), s, dec, proj, bank, step_ne, pi,
-                       att, lt, e_max, D);
+    SVPC_REQUIRE(D % 4 == 0 && ((((uintptr_t)dec) | ((uintptr_t)proj) | ((uintptr_t)bank)) & 15) == 0, "ptr_attn: rows must be 16-byte aligned");
+    const size_t lds = ((size_t)(lt + PTR_EC) * D + (size_t)lt * PTR_EMAX) * sizeof(float);
+    SVPC_REQUIRE(lds <= 150 * 1024, "ptr_attn: sentence rows do not fit LDS");
+    int rc = ptr_set_lds((const void*)ptr_attn_fwd_kernel);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ptr_attn_fwd_kernel, dim3(T), dim3(256), lds, s, dec, proj, bank, step_ne, pi, att, lt, e_max, D);
     return svpc_check_launch("ptr_attn_fwd");
 }
 int svpc_ptr_attn_bwd(const float* dec, const float* proj, const float* bank, const int* step_ne, const float* pi, const float* dpi,
                       const float* datt, float* ddec, float* dproj, float* dbank, int T, int lt, int e_max, int D, hipStream_t s) {
     if (T == 0) return 0;
     SVPC_REQUIRE(e_max <= PTR_EMAX, "ptr_attn: at most 32 entities");
-    hipLaunchKernelGGL(ptr_attn_bwd_kernel, dim3(T), dim3(256), (size_t)2 * lt * PTR_EMAX * sizeof(float), s, dec, proj, bank, step_ne,
-                       pi, dpi, datt, ddec, dproj, dbank, lt, e_max, D);
+    SVPC_REQUIRE(lt <= PTR_LTMAX, "ptr_attn: at most 32 tokens per sentence");
+    SVPC_REQUIRE(D % 4 == 0 && ((((uintptr_t)datt) | ((uintptr_t)proj) | ((uintptr_t)bank)) & 15) == 0, "ptr_attn: rows must be 16-byte aligned");
+    const size_t lds = ((size_t)(lt + PTR_EC) * D + (size_t)2 * lt * PTR_EMAX) * sizeof(float);
+    SVPC_REQUIRE(lds <= 150 * 1024, "ptr_attn: sentence rows do not fit LDS");
+    int rc = ptr_set_lds((const void*)ptr_attn_bwd_kernel);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ptr_attn_bwd_kernel, dim3(T), dim3(256), lds, s, dec, proj, bank, step_ne, pi, dpi, datt, ddec, dproj, dbank, lt,
+                       e_max, D);
     return svpc_check_launch("ptr_attn_bwd");
 }
 int svpc_ptr_mix_loss_fwd(const float* logits, const float* g, const float* pi, const int* labels, const int* row_c,

@@ -246,6 +246,16 @@ def test_sim_recur(D, ent_len):
             [q, c, w4f, E0], rtol=5e-4, grad_rtol=2e-3, grad_atol=2e-4, name="sim_recur")
 
 
+def test_ptr_attn_entity_chunks_and_full_width():
+    """pointer attention at the production row width with more entities than one staged chunk (16) holds, and lt = 1
+    (incremental decoding)"""
+    for T, lt, em, D, ne in ((3, 22, 20, 768, [20, 17, 3]), (4, 1, 5, 128, [5, 1, 4, 2])):
+        step_ne = Idx(ne)
+        dec, proj, bank = rnd(T * lt, D, seed=1, scale=0.2), rnd(T, em, D, seed=2, scale=0.2), rnd(T, em, D, seed=3)
+        compare(lambda d, p, b: O.ptr_attn(d, p, b, step_ne, lt), lambda d, p, b: E.ptr_attn(d, p, b, step_ne, lt), [dec, proj, bank],
+                name="ptr_attn wide")
+
+
 def test_ptr_attn_and_mix_loss_and_gumbel():
     T, lt, em, D, V = 5, 6, 4, 64, 50
     step_ne = Idx([3, 3, 4, 2, 2])
