@@ -164,7 +164,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict
 #pragma unroll
     for (int j = 0; j < TNF; ++j) {
         const int col = n0 + wc * 32 * TNF + j * 32 + l31;
-        if (sizeof(TC) == 2 && splitk == 1 && epi.p_drop <= 0.f && !epi.accumulate) {
+        if (sizeof(TC) == 2 && splitk == 1 && epi.p_drop <= 0.f && !(epi.accumulate && epi.Z)) {
             const bool odd = lane & 1;
             const float bias = (epi.bias && col < N) ? epi.bias[col] : 0.f;
 #pragma unroll
@@ -178,8 +178,13 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict
                     const int row = m0 + wr * 64 + i * 32 + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2) + 4 * lhi;
                     const size_t o = (size_t)row * ldc + (col & ~1);
                     union { __bf16 h[2]; uint32_t u; } pk;
-                    pk.h[0] = (__bf16)(odd ? py : y0); pk.h[1] = (__bf16)(odd ? y1 : py);
+                    float lo = odd ? py : y0, hi = odd ? y1 : py;
                     if (row >= M || col >= N) continue;              // N is even: a column pair is valid or invalid as a whole
+                    if (epi.accumulate) {                            // C += …: the residual-gradient sink of a dgrad
+                        pk.u = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const __bf16*>(C) + o);
+                        lo += (float)pk.h[0]; hi += (float)pk.h[1];
+                    }
+                    pk.h[0] = (__bf16)lo; pk.h[1] = (__bf16)hi;
                     *reinterpret_cast<uint32_t*>(reinterpret_cast<__bf16*>(C) + o) = pk.u;
                     if (epi.Z) {
                         pk.h[0] = (__bf16)(odd ? pz : z0); pk.h[1] = (__bf16)(odd ? z1 : pz);
