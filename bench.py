@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 from svpc_amd import StateAwareRecursiveTransformer, make_batch, make_config  # noqa: E402
 from svpc_amd import ops, synthetic as syn  # noqa: E402
+from svpc_amd.graph import backward_all
 from svpc_amd.optim import FusedBertAdam, GradReducer  # noqa: E402
 
 PMC_TRAFFIC_BYTES = 94625150   # (2·FETCH_SIZE + WRITE_SIZE)·1024, means per launch of the dominant kernel: profiles/r01_e_pmc_bench_dominant_gemm.csv
@@ -198,7 +199,7 @@ def main():
         nonlocal reducer
         opt.zero_grad()
         loss = model(*fargs)[0]
-        loss.backward()
+        backward_all(model, loss)
         arena = opt.ensure_built()
         if world > 1:
             if reducer is None:
@@ -223,7 +224,7 @@ def main():
         try:
             from svpc_amd.graph import GraphedTrainStep
             loss = None          # drop the last eager autograd graph before capture
-            graph = GraphedTrainStep(model, opt, fargs, warmup=2, exchange=(reducer.finish if world > 1 else None))
+            graph = GraphedTrainStep(model, opt, fargs, warmup=2, exchange=(reducer if world > 1 else None))
             eager_step = step
             step = graph
             for _ in range(2):
@@ -298,7 +299,7 @@ def main():
                                       cfg.hidden_size, cfg.num_attention_heads, cfg.num_hidden_layers, cfg.vocab_size, cfg.action_vocab_size),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
                        "host_enqueue_ms_per_step": host_enqueue_ms,
-                       "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (fwd+bwd | eager bucketed all-reduce | optimizer)")
+                       "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (fwd + text-side bwd | clip-encoder bwd beside the text-side all-reduce | remaining all-reduce | optimizer)")
                                  if graph is not None else "eager"},
             "roofline": {"bound": "mfma", "kernel": "%s — every forward projection of the bf16 activation streams (clip encoder M=%d "
                                    "rows: Q/K/V, attention-out, FFN, video embedding; decoder M=%d rows)"

@@ -7,16 +7,29 @@ by a kernel, and the optimizer's hyper-parameters are read from a device buffer 
 Inputs are static: refill the tensors handed to the constructor in place (``tensor.copy_``) to train on a new batch of the
 same shape (step counts / ingredient counts / copy tables are part of the captured plan).
 
-Data parallel (``exchange=`` given): the step is captured as TWO graphs — {zero_grad, forward, backward} and {clip + BertAdam} —
-with the gradient all-reduce (RCCL, a handful of 64 MB buckets) issued eagerly between the two replays.  The exchange is then not
-overlapped with backward, but an eager step is host-bound (≈25 ms of Python/launch work for ≈19 ms of kernels), which costs more
-than the ≈2–3 ms the exposed exchange of 369 MB takes over xGMI.
+Data parallel (``exchange=`` a GradReducer): an eager step is host-bound (≈25 ms of Python/launch work for ≈17 ms of kernels), so
+the step is captured as THREE graphs with the RCCL exchange issued eagerly between their replays:
+  G1 {zero_grad, forward, backward of everything downstream of the [CLS] rows}   → start all-reduce of the text-side buckets (≈74 %
+  of the gradient bytes: decoder, step encoder, simulators, LSTM, head, embeddings) asynchronously,
+  G2 {backward of the clip encoder}, which runs while those buckets travel over xGMI           → all-reduce of the remaining buckets,
+  G3 {clip + BertAdam (+EMA)} after every bucket has arrived.
+The cut uses ``model.split_backward`` (svpc_amd/model.py): the [CLS] rows are the only path from the loss into the clip encoder.
 """
 from __future__ import annotations
 
 import gc
 
 import torch
+
+
+def backward_all(model, loss):
+    """``loss.backward()`` plus, when the model cut its autograd graph at the [CLS] rows (``model.split_backward``), the second
+    phase through the clip encoder."""
+    loss.backward()
+    cut = getattr(model, "split_boundary", None)
+    if cut is not None:
+        cut[0].backward(cut[1].grad)
+        model.split_boundary = None
 
 
 class GraphedTrainStep:
@@ -43,11 +56,17 @@ class GraphedTrainStep:
                 optimizer.launch()
         else:
             from . import ops
+            model.split_backward = True
             # other threads (the collective library's watchdog) keep making driver calls: only this thread's are policed
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 optimizer.zero_grad()
                 self.loss = model(*forward_args)[0]
                 self.loss.backward()
+                ops.join_side()
+            self.graph_clip = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_clip, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                out, cut = model.split_boundary
+                out.backward(cut.grad)
                 ops.join_side()
             self.graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), capture_error_mode="thread_local"):
@@ -57,9 +76,9 @@ class GraphedTrainStep:
     def _eager(self):
         self.opt.zero_grad()
         loss = self.model(*self.args)[0]
-        loss.backward()
+        backward_all(self.model, loss)
         if self.exchange is not None:
-            self.exchange()
+            self.exchange.finish()
         self.opt.step()
         return loss
 
@@ -71,7 +90,9 @@ class GraphedTrainStep:
         self.opt.set_hyper()
         self.graph.replay()
         if self.graph_opt is not None:
-            self.exchange()
+            self.exchange.start_early()          # text-side buckets travel while the clip encoder's backward runs
+            self.graph_clip.replay()
+            self.exchange.finish()
             self.graph_opt.replay()
         self.opt.step_count += 1
         return self.loss

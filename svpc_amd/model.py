@@ -828,6 +828,14 @@ class StateAwareRecursiveTransformer(nn.Module):
         cls = self._encode_clips(feats, plan.video_rows, ops.take_rows(ids_all, plan.video_rows),
                                  ops.take_rows(masks_all, plan.video_rows), plan.seq_enc, cx,
                                  cls_only=(plan.cls_rows_dev, plan.seq_enc_cls))                  # (T, D): [CLS] rows only
+        # Optional two-phase backward for data parallelism (svpc_amd/graph.py): the [CLS] rows are the ONLY tensor through which
+        # the loss reaches the clip encoder, so cutting the autograd graph here lets the caller run the text-side backward,
+        # start exchanging those gradients (74 % of the bytes), then run ``split_boundary[0].backward(split_boundary[1].grad)``.
+        self.split_boundary = None
+        if getattr(self, "split_backward", False) and torch.is_grad_enabled() and cls.requires_grad:
+            cut = cls.detach().requires_grad_(True)
+            self.split_boundary = (cls, cut)
+            cls = cut
 
         # (3) [CLS] rows + step PE → step-wise encoder over ragged per-video step sequences (:1062-1065)
         x = ops.span_mean(cls, plan.arange_T, plan.ones_T, add=self.step_positional_encoding.pe, add_idx=plan.step_idx)

@@ -385,6 +385,19 @@ class GradReducer:
                 self._launch(bi)
         return hook
 
+    CLIP_SIDE = ("video_embeddings.", "encoder.", "token_type_embeddings.")
+
+    def start_early(self):
+        """Two-phase backward (svpc_amd/graph.py): launch, without waiting, every bucket none of whose members belongs to the clip
+        encoder — their gradients are final once the text-side backward has been enqueued."""
+        if self.world <= 1:
+            return
+        for bi, (_, _, members) in enumerate(self.buckets):
+            if self.launched[bi]:
+                continue
+            if not any(self.arena.names[i].startswith(self.CLIP_SIDE) for i in members):
+                self._launch(bi)
+
     def finish(self):
         """Launch whatever has not been launched (tensors without a gradient this step never fire a hook) and wait."""
         if self.world > 1:

@@ -49,7 +49,25 @@ def _worker(rank, world, port, golden_dir, overlap, out_q):
         shard[k] = batch[k][rank:rank + 1]
     model.gumbel_noise = [model.gumbel_noise[rank]]
     named = [(n, p) for n, p in model.named_parameters() if "memory_intermediate" not in n]
-    if overlap:
+    if overlap == "split":
+        # two-phase backward (svpc_amd/graph.py): cut at the [CLS] rows, exchange the text-side buckets before the clip encoder's
+        # backward has run, the rest afterwards
+        from svpc_amd.graph import backward_all
+        for _, p in named:
+            p.grad = torch.zeros_like(p)
+        arena = GradArena(named)
+        red = GradReducer(arena, bucket_bytes=16 << 10, overlap=False)
+        model.split_backward = True
+        loss = model(*syn.forward_args(shard))[0]
+        loss.backward()
+        out, cut = model.split_boundary
+        assert all(p.grad.abs().max() == 0 for n, p in named if n.startswith(GradReducer.CLIP_SIDE))      # phase 1 left them untouched
+        red.start_early()
+        n_early = sum(red.launched)
+        assert 0 < n_early < len(red.buckets)
+        out.backward(cut.grad)
+        red.finish()
+    elif overlap:
         for _, p in named:
             p.grad = torch.zeros_like(p)
         arena = GradArena(named)
@@ -76,7 +94,7 @@ def arena_named(arena):
     return list(zip(arena.names, arena.params))
 
 
-@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("overlap", [False, True, "split"])
 def test_two_rank_sum_allreduce_equals_full_batch_gradient(golden_dir, overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

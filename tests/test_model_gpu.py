@@ -340,3 +340,23 @@ def test_bf16_decoder_stream_close_to_fp32():
     assert abs(loss - ref_loss) <= 1e-2 * abs(ref_loss), (loss, ref_loss)
     for n in names:
         assert (gr[n] - ref_g[n]).norm().item() <= 0.08 * ref_g[n].norm().item() + 1e-4, n
+
+
+def test_split_backward_equals_single_backward(golden_dir):
+    """Cutting the autograd graph at the [CLS] rows and running the backward in two phases (what the data-parallel graphs do to
+    overlap the gradient exchange) yields the same gradients as one backward pass."""
+    from svpc_amd.graph import backward_all
+    z, cfg, batch, model = build_model("tiny", "vivt", golden_dir, DEV)
+    loss = model(*syn.forward_args(batch))[0]
+    loss.backward()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad()
+    model.split_backward = True
+    loss2 = model(*syn.forward_args(batch))[0]
+    assert model.split_boundary is not None
+    backward_all(model, loss2)
+    assert model.split_boundary is None and abs(loss2.item() - loss.item()) <= 1e-6 * abs(loss.item())
+    got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(ref)
+    for n in ref:
+        assert torch.allclose(got[n], ref[n], rtol=1e-5, atol=1e-7), n
