@@ -110,7 +110,7 @@ def decode_bench(cfg, model, args, device, world, rank, dist):
         elif isinstance(v, torch.Tensor):
             b[k] = v.to(device)
     tr = Translator(type("O", (), {"cuda": True})(), {"model_cfg": cfg, "model": model.state_dict()}, model=model,
-                    incremental=not args.decode_full)
+                    incremental=not args.decode_full, graph=not args.decode_eager)
     for _ in range(max(1, args.warmup)):
         tr.translate_batch(syn.translate_inputs(b))
     if dist is not None:
@@ -137,7 +137,8 @@ def decode_bench(cfg, model, args, device, world, rank, dist):
                                                  "over videos, on-device pick"
                                                  % (args.model_type, n_vid, args.clips, cfg.max_t_len, cfg.num_hidden_layers,
                                                     "full decoder re-run per position (reference loop shape)" if args.decode_full
-                                                    else "KV-cached incremental decoder (one new token per sentence and iteration)")}}))
+                                                    else "KV-cached incremental decoder (one new token per sentence and iteration)"),
+                                     "launch": "eager" if args.decode_eager else "hipGraph replay per batch structure (inputs copied into the captured buffers)"}}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -158,6 +159,7 @@ def main():
     ap.add_argument("--decode", action="store_true", help="secondary metric: greedy-decode captions/s (BASELINE config 5: 64 videos)")
     ap.add_argument("--decode-videos", type=int, default=64)
     ap.add_argument("--decode-full", action="store_true", help="decode with the reference-shaped loop (all Lt positions every iteration)")
+    ap.add_argument("--decode-eager", action="store_true", help="launch the decode kernels eagerly instead of replaying the batch structure's hipGraph")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -23,9 +23,11 @@ from .synthetic import BOS, PAD, UNK
 
 
 class Translator(object):
-    def __init__(self, opt, checkpoint, model=None, incremental=True):
+    def __init__(self, opt, checkpoint, model=None, incremental=True, graph=False):
         self.opt = opt
         self.incremental = incremental
+        self.graph = graph          # replay the decode of a recurring batch structure as one hipGraph (see _decode_graphed)
+        self._preps = {}
         self.device = torch.device("cuda" if getattr(opt, "cuda", True) else "cpu")
         self.model_config = checkpoint["model_cfg"]
         self.max_t_len = self.model_config.max_t_len
@@ -56,29 +58,42 @@ class Translator(object):
                                            ingr_input_ids, ingr_masks, ingr_sep_masks, ingr_id_dict, oov_word_dict,
                                            alignments, actions, batch_step_num, self.model)
 
-    @torch.no_grad()
-    def translate_batch_greedy(self, input_ids_list, video_features_list, input_masks_list, token_type_ids_list,
-                               ingr_input_ids, ingr_masks, ingr_sep_masks, ingr_id_dict, oov_word_dict, alignments, actions,
-                               batch_step_num, rt_model):
-        model = rt_model
+    # ------------------------------------------------------------------ host part: everything that depends on the batch STRUCTURE only
+    def _prepare(self, model, batch_step_num, ingr_sep_masks, ingr_id_dict, oov_word_dict, S_pad, N, L, dev):
         cfg = model.config
         mode = cfg.model_mode
-        input_ids_list, input_masks_list = self.prepare_video_only_inputs(input_ids_list, input_masks_list, token_type_ids_list)
-        dev = video_features_list[0].device
-        N, L, F = video_features_list[0].shape
-        S_pad = len(input_ids_list)
-        Lv, Lt, D, V = cfg.max_v_len, cfg.max_t_len, cfg.hidden_size, cfg.vocab_size
-        cx = _Ctx(cfg, False, model.rng(dev))
-        ingr_ids_t = torch.as_tensor(ingr_input_ids).to(dev)
-        sep_t = torch.as_tensor(ingr_sep_masks)
-        spans = model.ingredient_embeddings.spans(sep_t.cpu())   # one host read per batch
+        Lt, V = cfg.max_t_len, cfg.vocab_size
+        sep_t = torch.as_tensor(ingr_sep_masks).cpu()
+        dicts = ingr_id_dict if mode != "video" else [{}] * N
+        n_oov = [len(d) if mode != "video" else 0 for d in oov_word_dict]
+        key = (tuple(int(v) for v in batch_step_num), sep_t.numpy().tobytes(), tuple(n_oov), S_pad, N, L, str(dev), self.incremental,
+               tuple(tuple((int(e), tuple(int(i) for i in lst)) for e, lst in d.items()) for d in dicts))
+        prep = self._preps.get(key)
+        if prep is not None:
+            return prep
+        spans = model.ingredient_embeddings.spans(sep_t)   # one host read per batch structure
         plan = model.plan_for(batch_step_num, spans[3], S_pad, N, L, dev)
         T = plan.T
+        c_list = [V + x_ for x_ in n_oov]
+        prep = dict(key=key, spans=spans, plan=plan, c_list=c_list, T=T,
+                    pl=model._ptr_plan(dicts, c_list, Lt, plan.step_ne, plan.row_vid),
+                    row_x=Idx([n_oov[b] for b in plan.row_vid.host]),
+                    pl1=model._ptr_plan(dicts, c_list, 1, plan.step_ne, plan.step_vid),
+                    row_x1=Idx([n_oov[b] for b in plan.step_vid.host]), seq_cross={}, graph=None)
+        if len(self._preps) > 32:
+            self._preps.clear()
+        self._preps[key] = prep
+        return prep
 
-        feats = model._stacked(video_features_list).reshape(S_pad * N * L, F)
-        ids_all = torch.stack(input_ids_list).reshape(-1).to(torch.int32)
-        masks_all = torch.stack(input_masks_list).reshape(-1).float()
-        ents = model.ingredient_embeddings.run(ingr_ids_t.reshape(-1).to(torch.int32), spans, cx)
+    # ------------------------------------------------------------------ device part: encoder side once, then the decoding iterations
+    def _decode_core(self, model, prep, feats, ids_all, masks_all, ingr_ids_flat):
+        cfg = model.config
+        mode = cfg.model_mode
+        plan, T = prep["plan"], prep["T"]
+        dev = feats.device
+        Lt, D = cfg.max_t_len, cfg.hidden_size
+        cx = _Ctx(cfg, False, model.rng(dev))
+        ents = model.ingredient_embeddings.run(ingr_ids_flat, prep["spans"], cx)
         cls = model._encode_clips(feats, plan.video_rows, ops.take_rows(ids_all, plan.video_rows),
                                   ops.take_rows(masks_all, plan.video_rows), plan.seq_enc, cx,
                                   cls_only=(plan.cls_rows_dev, plan.seq_enc_cls))
@@ -98,10 +113,6 @@ class Translator(object):
             mem = g
             bank = None
 
-        n_oov = [len(d) if mode != "video" else 0 for d in oov_word_dict]
-        c_list = [V + x_ for x_ in n_oov]
-        pl = model._ptr_plan(ingr_id_dict if mode != "video" else [{}] * N, c_list, Lt, plan.step_ne, plan.row_vid)
-        row_x = Idx([n_oov[b] for b in plan.row_vid.host])
         text = torch.full((T, Lt), PAD, dtype=torch.int32, device=dev)
         ext = torch.full((T, Lt), PAD, dtype=torch.int32, device=dev)
         nxt = torch.full((T,), BOS, dtype=torch.int32, device=dev)
@@ -112,9 +123,11 @@ class Translator(object):
             caches = [torch.zeros(T * Lt, 2 * D, dtype=torch.float32, device=dev) for _ in layers]
             mem_kv = [layer.memory_kv(mem) for layer in layers]
             proj = model.bank_projection(bank) if bank is not None else None
-            seq_cross = ops.SeqInfo(list(range(T)), [1] * T, [s_ * n_mem for s_ in range(T)], [n_mem] * T, dev)
-            pl1 = model._ptr_plan(ingr_id_dict if mode != "video" else [{}] * N, c_list, 1, plan.step_ne, plan.step_vid)
-            row_x1 = Idx([n_oov[b] for b in plan.step_vid.host])
+            seq_cross = prep["seq_cross"].get(n_mem)
+            if seq_cross is None:
+                seq_cross = prep["seq_cross"][n_mem] = ops.SeqInfo(list(range(T)), [1] * T, [s_ * n_mem for s_ in range(T)],
+                                                                   [n_mem] * T, dev)
+            pl1, row_x1 = prep["pl1"], prep["row_x1"]
             for i in range(Lt):
                 text[:, i] = nxt
                 ext[:, i] = nxt_ext
@@ -128,6 +141,7 @@ class Translator(object):
                     scores, _ = model._lm_probs(x, bank, pl1, cx, proj=proj)
                 nxt_ext, nxt = ops.greedy_pick(scores, pl1["row_c"], row_x1, 1, 0, UNK)
         else:
+            pl, row_x = prep["pl"], prep["row_x"]
             tmask = torch.zeros(T, Lt, dtype=torch.float32, device=dev)
             for i in range(Lt):
                 text[:, i] = nxt
@@ -140,9 +154,54 @@ class Translator(object):
                 else:
                     scores, _ = model._lm_probs(dec, bank, pl, cx)
                 nxt_ext, nxt = ops.greedy_pick(scores, pl["row_c"], row_x, Lt, i, UNK)
-        out = text if mode == "video" else ext
+        return text if mode == "video" else ext
+
+    @torch.no_grad()
+    def translate_batch_greedy(self, input_ids_list, video_features_list, input_masks_list, token_type_ids_list,
+                               ingr_input_ids, ingr_masks, ingr_sep_masks, ingr_id_dict, oov_word_dict, alignments, actions,
+                               batch_step_num, rt_model):
+        model = rt_model
+        input_ids_list, input_masks_list = self.prepare_video_only_inputs(input_ids_list, input_masks_list, token_type_ids_list)
+        dev = video_features_list[0].device
+        N, L, F = video_features_list[0].shape
+        S_pad = len(input_ids_list)
+        prep = self._prepare(model, batch_step_num, ingr_sep_masks, ingr_id_dict, oov_word_dict, S_pad, N, L, dev)
+        plan = prep["plan"]
+        feats = model._stacked(video_features_list).reshape(S_pad * N * L, F)
+        ids_all = torch.stack(input_ids_list).reshape(-1).to(torch.int32)
+        masks_all = torch.stack(input_masks_list).reshape(-1).float()
+        ingr_flat = torch.as_tensor(ingr_input_ids).to(dev).reshape(-1).to(torch.int32)
+        if not self.graph or dev.type != "cuda":
+            out = self._decode_core(model, prep, feats, ids_all, masks_all, ingr_flat)
+        else:
+            out = self._decode_graphed(model, prep, feats, ids_all, masks_all, ingr_flat)
         res = []
         for b in range(N):
             o, n = plan.h_step_off[b], plan.h_step_len[b]
             res.append(out[o:o + n].to(torch.int64))
         return res, oov_word_dict
+
+    def _decode_graphed(self, model, prep, feats, ids_all, masks_all, ingr_flat):
+        """The ≈2,000 launches of a batch's decode (encoder side + Lt iterations × 6 layers) replayed as ONE hipGraph.  The graph
+        is tied to the batch structure (step / ingredient / OOV counts: ``_prepare``'s key): the first batch of a structure runs
+        eagerly twice (warm-up: index tables reach the device, kernels set their attributes) and is then captured; later batches of
+        the same structure copy their tensors into the captured inputs and replay."""
+        g = prep["graph"]
+        if g is None:
+            self._decode_core(model, prep, feats, ids_all, masks_all, ingr_flat)
+            static = [feats.clone(), ids_all.clone(), masks_all.clone(), ingr_flat.clone()]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._decode_core(model, prep, *static)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._decode_core(model, prep, *static)
+            g = prep["graph"] = (graph, static, out)
+        graph, static, out = g
+        for dst, src in zip(static, (feats, ids_all, masks_all, ingr_flat)):
+            dst.copy_(src)
+        graph.replay()
+        return out.clone()
