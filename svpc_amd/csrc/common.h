@@ -28,15 +28,36 @@ static inline int svpc_check_launch(const char* what) {
     } while (0)
 
 // ---- wave / block reductions -------------------------------------------------------------------
+// Sum over the 64 lanes, result in every lane.  Four DPP steps inside each row of 16 lanes (quad swaps, half-mirror, mirror — VALU
+// cross-lane moves, no LDS) and three scalar adds of the four row sums (v_readlane): ≈10× shorter dependency chain than six
+// __shfl_xor (= ds_bpermute through the LDS crossbar).  All 64 lanes must be active (every caller is in wave-uniform control flow).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_(float v) {
+    const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+    return v + __int_as_float(r);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = dpp_add_<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add_<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add_<0x141>(v);     // row_half_mirror
+    v = dpp_add_<0x140>(v);     // row_mirror: every lane now holds the sum of its 16-lane row
+    const int iv = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48)));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_max_(float v) {
+    const int r = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false);
+    return fmaxf(v, __int_as_float(r));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = dpp_max_<0xB1>(v);
+    v = dpp_max_<0x4E>(v);
+    v = dpp_max_<0x141>(v);
+    v = dpp_max_<0x140>(v);
+    const int iv = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 0)), __int_as_float(__builtin_amdgcn_readlane(iv, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48))));
 }
 // block-wide sum for blockDim.x == 256 (4 waves); `red` is 4 floats of LDS. Result valid in all threads.
 __device__ __forceinline__ float block_sum_256(float v, float* red) {

@@ -491,7 +491,13 @@ class _Attention(Function):
         qp, kp, vp = qt.data_ptr() + cols[0] * es, kvt_c.data_ptr() + cols[1] * es, kvt_c.data_ptr() + cols[2] * es
         mfma = (_PRECISION == "bf16" and ((qp | kp | vp) & (4 * es - 1)) == 0 and
                 _lib.load().svpc_attn_mfma_supported(dh, seq.max_q, seq.max_k, qt.stride(0), kvt_c.stride(0), kvt_c.stride(0)) == 1)
-        if mfma:
+        if (not torch.is_grad_enabled() and seq.max_q == 1 and p <= 0.0 and not causal and qt.dtype == torch.float32 and dh <= 64
+                and not (qt.requires_grad or kvt_c.requires_grad)):
+            # incremental decoding: one query per sequence — a wave per (sequence, head), no tiles, no LDS
+            _lib.call("attn_q1_fwd", qp, qt.stride(0), kp, kvt_c.stride(0), vp, kvt_c.stride(0), _p(out), D, _p(lse), _p(tbl), seq.n, H,
+                      dh, _p(key_mask), 1.0 / math.sqrt(dh), _stream())
+            mfma = False
+        elif mfma:
             _lib.call("attn_mfma_fwd_t", qp, qt.stride(0), kp, kvt_c.stride(0), vp, kvt_c.stride(0), _p(out), D, _dt(qt), _p(lse),
                       _p(tbl), seq.n, H, dh, seq.max_q, seq.max_k, _p(key_mask), 1 if causal else 0, 1.0 / math.sqrt(dh), p, site,
                       _p(seed), _stream())

@@ -479,3 +479,22 @@ def test_lstm_sequence_matches_stepwise_statement():
         res.append((out.detach().clone(), gx.grad.clone(), w.grad.clone()))
     for a, b in zip(res[0], res[1]):
         assert torch.allclose(a, b, rtol=2e-4, atol=2e-5), (a - b).abs().max()
+
+
+@pytest.mark.parametrize("H,dh,k_lens", [(12, 64, [1, 22, 7, 3]), (4, 32, [100, 33, 64, 1]), (2, 16, [5, 5])])
+def test_single_query_attention_for_decoding(H, dh, k_lens):
+    """q_len == 1 per sequence under no_grad takes the wave-per-(sequence, head) kernel; against the torch statement, with a key mask"""
+    D = H * dh
+    n = len(k_lens)
+    k_off = [sum(k_lens[:i]) for i in range(n)]
+    seq = SeqInfo(list(range(n)), [1] * n, k_off, k_lens, DEV)
+    Rk = sum(k_lens)
+    q, kv = rnd(n, D, seed=1, grad=False), rnd(Rk, 2 * D, seed=2, grad=False)
+    km = (torch.rand(Rk, generator=torch.Generator().manual_seed(3)) > 0.3).float().to(DEV)
+    for o in k_off:
+        km[o] = 1.0
+    for mask in (None, km):
+        with torch.no_grad():
+            got = O.attention(q, kv, (0, 0, D), D, H, seq, key_mask=mask, causal=False)
+            ref = E.attention(q, kv, (0, 0, D), D, H, seq, key_mask=mask, causal=False)
+        assert torch.allclose(got, ref, rtol=2e-5, atol=2e-6), (got - ref).abs().max()
