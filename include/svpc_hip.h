@@ -104,7 +104,7 @@ int svpc_attn_fwd(const float* Q, int ldq, const float* K, int ldk, const float*
 /* single-query form for incremental greedy decoding (src/translator.py:88-100: position i attends to positions ≤ i): every sequence
  * has exactly one query row; fp32, forward only */
 int svpc_attn_q1_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, float* LSE,
-                     const int* seq, int n_seq, int H, int dh, const float* key_mask, float scale, svpc_stream_t stream);
+                     const int* seq, int n_seq, int H, int dh, int max_k, const float* key_mask, float scale, svpc_stream_t stream);
 int svpc_attn_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                   const float* LSE, const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
                   float* delta, const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,

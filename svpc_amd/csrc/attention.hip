@@ -246,6 +246,7 @@ static int set_lds(const void* fn, size_t bytes) {
 // ---- single-query attention (incremental decoding: one new token per sentence attends to its cached keys; translator.py:88-100
 // under the causal mask).  One wave per (sequence, head), lane = head dimension; the keys/values of up to 32 positions are
 // fetched together (all loads in flight), scores by wave reductions, softmax in registers.  fp32 throughout, forward only.
+template <int CH>
 __global__ __launch_bounds__(256) void attn_q1_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63;
     const int sh = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -255,18 +256,18 @@ __global__ __launch_bounds__(256) void attn_q1_kernel(AttnArgs a) {
     const bool on = lane < dh;
     const float q = on ? a.Q[(size_t)q_off * a.ldq + h * dh + lane] * a.scale : 0.f;
     float m = -INFINITY, l = 0.f, acc = 0.f;
-    for (int j0 = 0; j0 < k_len; j0 += 32) {
-        float kr[32], vr[32];
+    for (int j0 = 0; j0 < k_len; j0 += CH) {
+        float kr[CH], vr[CH];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
+        for (int j = 0; j < CH; ++j) {
             const bool ok = on && (j0 + j < k_len);
             kr[j] = ok ? a.K[(size_t)(k_off + j0 + j) * a.ldk + h * dh + lane] : 0.f;
             vr[j] = ok ? a.V[(size_t)(k_off + j0 + j) * a.ldv + h * dh + lane] : 0.f;
         }
-        float sc[32];
+        float sc[CH];
         float mx = m;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
+        for (int j = 0; j < CH; ++j) {
             float d = wave_sum(q * kr[j]);
             if (j0 + j < k_len) {
                 if (a.key_mask) d += (1.0f - a.key_mask[k_off + j0 + j]) * -10000.0f;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void attn_q1_kernel(AttnArgs a) {
         const float corr = expf(m - mx);            // 0 on the first chunk (m = -inf)
         l *= corr; acc *= corr;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
+        for (int j = 0; j < CH; ++j) {
             const float p = expf(sc[j] - mx);       // 0 for padded positions
             l += p;
             acc += p * vr[j];
@@ -292,13 +293,15 @@ extern "C" {
 
 // one query row per sequence (q_len == 1 for every sequence), no dropout, not causal-masked beyond k_len: forward only
 int svpc_attn_q1_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, float* LSE,
-                     const int* seq, int n_seq, int H, int dh, const float* key_mask, float scale, hipStream_t stream) {
+                     const int* seq, int n_seq, int H, int dh, int max_k, const float* key_mask, float scale, hipStream_t stream) {
     if (n_seq == 0) return 0;
     SVPC_REQUIRE(dh <= 64, "attention: head dim must be <= 64");
     AttnArgs a{};
     a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.LSE = LSE; a.seq = seq;
     a.n_seq = n_seq; a.H = H; a.dh = dh; a.max_q = 1; a.key_mask = key_mask; a.scale = scale;
-    hipLaunchKernelGGL(attn_q1_kernel, dim3(ceil_div(n_seq * H, 4)), dim3(256), 0, stream, a);
+    // chunk of keys fetched and reduced together: 8 for the 1–3 memory slots of the cross-attention, 32 otherwise
+    if (max_k <= 8) hipLaunchKernelGGL(attn_q1_kernel<8>, dim3(ceil_div(n_seq * H, 4)), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_q1_kernel<32>, dim3(ceil_div(n_seq * H, 4)), dim3(256), 0, stream, a);
     return svpc_check_launch("attn_q1_fwd");
 }
 

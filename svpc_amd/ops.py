@@ -495,7 +495,7 @@ class _Attention(Function):
                 and not (qt.requires_grad or kvt_c.requires_grad)):
             # incremental decoding: one query per sequence — a wave per (sequence, head), no tiles, no LDS
             _lib.call("attn_q1_fwd", qp, qt.stride(0), kp, kvt_c.stride(0), vp, kvt_c.stride(0), _p(out), D, _p(lse), _p(tbl), seq.n, H,
-                      dh, _p(key_mask), 1.0 / math.sqrt(dh), _stream())
+                      dh, seq.max_k, _p(key_mask), 1.0 / math.sqrt(dh), _stream())
             mfma = False
         elif mfma:
             _lib.call("attn_mfma_fwd_t", qp, qt.stride(0), kp, kvt_c.stride(0), vp, kvt_c.stride(0), _p(out), D, _dt(qt), _p(lse),
