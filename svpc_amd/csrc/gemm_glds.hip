@@ -236,6 +236,9 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
     const double eff128 = (double)t128 / ((double)ceil_div(t128, slots128) * slots128);
     const double eff256 = (double)t256 / ((double)ceil_div(t256, slots256) * slots256);
     int BMv = (t128 > slots128 && eff256 >= eff128) ? 256 : 128;
+    static int wgrad_bm = -1;
+    if (wgrad_bm < 0) { const char* e = getenv("SVPC_GLDS_WGRAD_BM"); wgrad_bm = e ? atoi(e) : 128; }
+    if (!a_kc && !b_kc && M >= 256 && wgrad_bm == 256) BMv = 256;      // wgrad: split-K supplies the parallelism
     if (bm_env == 128 || bm_env == 256) BMv = bm_env;
     const int tiles_m = ceil_div(M, BMv), tiles_n = ceil_div(N, GL_BN), tiles = tiles_m * tiles_n;
     int splitk = 1;

@@ -383,3 +383,65 @@ def test_graphed_decode_equals_eager_decode(golden_dir, case, mt):
             for b, d in enumerate(got):
                 np.testing.assert_array_equal(d.cpu().numpy(), z["decode/%d" % b])
     assert len(tr_g._preps) == 1 and next(iter(tr_g._preps.values()))["graph"] is not None
+
+
+@pytest.mark.parametrize("mt,steps,n_ingr,n_oov", [
+    ("vivt", [1], [1], [0]),                       # one video, one step, one ingredient
+    ("vivt", [1, 5], [31, 1], [3, 0]),             # the reference data's maximum of 31 ingredients next to a single one; OOV copies
+    ("viv", [2, 3], [4, 17], [0, 2]),              # > 16 entities: two staged chunks in the pointer attention
+    ("vi", [3, 1, 2], [2, 9, 1], [1, 0, 0]),
+    ("v", [2, 1], [3, 3], [0, 0]),
+])
+def test_edge_shapes_forward_backward_match_oracle(mt, steps, n_ingr, n_oov):
+    """Shapes the golden fixtures do not reach (single step / single ingredient / 31 ingredients / > 16 entities, every mode):
+    loss, probabilities and ALL parameter gradients of the HIP path against the pinned CPU oracle's autograd on the same weights."""
+    from oracle.cases import CASES
+    from svpc_amd.model import StateAwareRecursiveTransformer
+    cfg_kw, _ = CASES["tiny"]
+    cfg_kw = dict(cfg_kw, max_i_len=100, max_position_embeddings=40)
+    cfg = syn.make_config(model_type=mt, **cfg_kw)
+    N = len(steps)
+    batch_cpu = syn.make_batch(cfg, n_videos=N, max_steps=max(steps), step_nums=steps, n_ingr=n_ingr, n_oov=n_oov, seed=11, full_clips=False)
+    torch.manual_seed(1)
+    model = StateAwareRecursiveTransformer(cfg)
+    g = torch.Generator().manual_seed(2)
+    V, W, A = cfg.vocab_size, cfg.word_vec_size, cfg.action_vocab_size
+    for m in (model.ingredient_embeddings, model.text_embeddings):
+        m.set_pretrained_embedding(0.4 * torch.randn(V, W, generator=g), freeze=False)
+    if mt in ("viv", "vivt"):
+        model.reasoner.set_pretrained_embedding(0.4 * torch.randn(A, W, generator=g), freeze=False)
+    if mt == "vivt":
+        model.recipe_reasoner.set_pretrained_embedding(0.4 * torch.randn(A, W, generator=g), freeze=False)
+    drawn = syn.draw_parameters(list(model.named_parameters()), seed=5)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(drawn[n])
+    model.eval()
+    P = {k: v.detach().clone().requires_grad_(v.is_floating_point() and k in dict(model.named_parameters()))
+         for k, v in model.state_dict().items()}
+    noise = None
+    if mt == "vivt":
+        noise = [-torch.empty(s, cfg.max_t_len, V + x).exponential_(generator=g).log() for s, x in zip(steps, n_oov)]
+    tot_ref, probs_ref, _, _ = orc.forward(P, cfg, *syn.forward_args(batch_cpu), gumbel_noise=noise)
+    tot_ref.backward()
+    model.to(DEV)
+    model.gumbel_noise = [n.to(DEV) for n in noise] if noise is not None else None
+    batch = {k: ([t.to(DEV) if isinstance(t, torch.Tensor) else t for t in v] if isinstance(v, list) else
+                 (v.to(DEV) if isinstance(v, torch.Tensor) else v)) for k, v in batch_cpu.items()}
+    tot, probs, _, _ = model(*syn.forward_args(batch))
+    tot.backward()
+    assert abs(tot.item() - tot_ref.item()) <= 1e-4 * abs(tot_ref.item())
+    for a, b in zip(probs, probs_ref):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=3e-4, atol=1e-6)
+    checked = 0
+    gmax = max(v.grad.abs().max().item() for v in P.values() if v.grad is not None)
+    floor = 2e-6 * gmax        # analytically-zero gradients (key biases under softmax) are rounding noise on both sides
+    for n, p in model.named_parameters():
+        rg = P[n].grad
+        if rg is None or rg.abs().max() == 0:
+            assert p.grad is None or p.grad.abs().max().item() <= floor, n
+            continue
+        scale = rg.abs().max().item()
+        assert (p.grad.cpu() - rg).abs().max().item() <= 3e-3 * scale + floor, n
+        checked += 1
+    assert checked > 20
