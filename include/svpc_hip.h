@@ -89,6 +89,15 @@ int svpc_gemm_l32_preferred(int a_kc, int b_kc, int lda, int ldb, int M, int N, 
 int svpc_gemm_l32(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, int M, int N, int K,
                   const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed, int accumulate, float* workspace,
                   size_t workspace_bytes, svpc_stream_t stream);
+/* grouped weight (+ bias) gradients of up to svpc_gemm_group_wgrad_max() independent linears in one launch:
+ *   dw[n_out, n_in] += dzᵀ · x,   db[n_out] += Σ_rows dz   (db may be NULL)       — the wgrad half of every nn.Linear backward
+ * `problems` is a HOST array of svpc_wgrad_problem; rows % 32 == 0, n_out % 4 == 0, n_in % 4 == 0, 16-byte aligned operands */
+typedef struct svpc_wgrad_problem {
+    const float* dz; const float* x; float* dw; float* db;
+    int n_out, n_in, rows, ld_dz, ld_x, ld_dw;
+} svpc_wgrad_problem;
+int svpc_gemm_group_wgrad_max(void);
+int svpc_gemm_group_wgrad(const svpc_wgrad_problem* problems, int n, svpc_stream_t stream);
 /* dz = dy · act'(aux) · dropout  (aux = pre-activation for GELU, activated output for ReLU / sigmoid) */
 int svpc_act_bwd(const float* dy, const float* aux, float* dz, size_t n, int act, float p, unsigned site, const svpc_u64* seed,
                  svpc_stream_t stream);

@@ -164,6 +164,165 @@ __global__ __launch_bounds__(256) void gemm_l32_kernel(const float* __restrict__
         }
 }
 
+// ---- wave-split-K form for grids of a few dozen tiles: ONE 64×64 tile per workgroup, but each of the 4 waves owns every 4th
+// k-tile of it — its own 2-stage LDS ring (32 KiB), its own loads, no workgroup barrier inside the k-loop — and computes the whole
+// 64×64 tile (2×2 MFMA tiles) over its k-tiles; the four partial tiles are summed through LDS in wave order (deterministic) by all
+// 256 threads, which then run the epilogue with coalesced rows.  A 24-deep k-loop becomes 6 steps per wave with four times the
+// bytes in flight per CU — these launches are bound by the memory round trip per k-tile, nothing else.
+// `asum` (optional): += Σ_k A(m, k) for the tile's 64 rows m — the bias gradient of a wgrad (A = dz, k-strided) — taken from the
+// fp32 LDS image (not the bf16-rounded fragments) by the workgroups of the first tile column.
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void l32w_tile(char* l32_smem, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                          float* __restrict__ C, int ldc, int M, int N, int K, const Epi& epi, int tm, int tn,
+                                          float* __restrict__ asum) {
+    constexpr int T = 64, OP = T * L32_BK * 4, STAGE = 2 * OP, NS = 2, PIECES = OP / 1024;      // 8 pieces of 1 KiB per operand tile
+    const int m0 = tm * T, n0 = tn * T;
+    const bool want_asum = !A_KC && asum != nullptr && tn == 0;
+    float bsum = 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nk_all = K / L32_BK;
+    const int nk = (nk_all - wave + 3) / 4;                 // k-tiles wave, wave+4, wave+8, …
+    char* const ring = l32_smem + wave * (NS * STAGE);
+
+    const float* ga[PIECES];
+    const float* gb[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        ga[i] = l32_src<T, A_KC>(A, lda, m0, M, wave * L32_BK, i, lane);
+        gb[i] = l32_src<T, B_KC>(B, ldb, n0, N, wave * L32_BK, i, lane);
+    }
+    const size_t stepA = 4 * (A_KC ? (size_t)L32_BK : (size_t)L32_BK * lda);      // elements: this wave's next k-tile is 4 tiles on
+    const size_t stepB = 4 * (B_KC ? (size_t)L32_BK : (size_t)L32_BK * ldb);
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#define L32W_ISSUE(t)                                                                                                       \
+    do {                                                                                                                    \
+        char* st = ring + ((t) & 1) * STAGE;                                                                                \
+        _Pragma("unroll") for (int i = 0; i < PIECES; ++i) {                                                                \
+            __builtin_amdgcn_global_load_lds((l32_gptr)ga[i], (l32_lptr)(st + i * 1024), 16, 0, 0);                         \
+            __builtin_amdgcn_global_load_lds((l32_gptr)gb[i], (l32_lptr)(st + OP + i * 1024), 16, 0, 0);                    \
+            ga[i] += stepA; gb[i] += stepB;                                                                                 \
+        }                                                                                                                   \
+    } while (0)
+
+    if (nk > 0) L32W_ISSUE(0);
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) {
+            L32W_ISSUE(t + 1);
+            l32_wait_vmcnt<2 * PIECES>();          // tile t landed; tile t+1 (16 pieces) may still be in flight
+        } else {
+            l32_wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_wave_barrier();
+        const char* sa = ring + (t & 1) * STAGE;
+        const char* sb = sa + OP;
+        if (want_asum) {                                    // k-strided image: [32 k-rows][64 columns] fp32, lane = column
+            const float* img = reinterpret_cast<const float*>(sa);
+#pragma unroll
+            for (int q = 0; q < L32_BK; ++q) bsum += img[q * T + lane];
+        }
+#pragma unroll
+        for (int ks = 0; ks < L32_BK / 16; ++ks) {
+            bf16x8 bf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = l32_fragment<T, B_KC>(sb, j * 32, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8 af = l32_fragment<T, A_KC>(sa, i * 32, ks, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        // the stage just read is refilled two iterations later by THIS wave (after its own fragment reads): no hazard
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef L32W_ISSUE
+
+    // partial tiles → LDS ([wave][64][64] fp32, reusing the rings), summed in wave order
+    __syncthreads();
+    float* part = reinterpret_cast<float*>(l32_smem) + wave * (T * T);
+    float* bpart = reinterpret_cast<float*>(l32_smem) + 4 * T * T;       // [wave][64] row sums of A
+    if (want_asum) bpart[wave * T + lane] = bsum;
+    const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                part[r * T + j * 32 + l31] = acc[i][j][e];
+            }
+    __syncthreads();
+    const float* p0 = reinterpret_cast<const float*>(l32_smem);
+    const u64 seed = epi.p_drop > 0.f ? epi.seed[0] : 0ull;
+    const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
+#pragma unroll
+    for (int u = 0; u < T * T / 256; ++u) {
+        const int idx = threadIdx.x + 256 * u;
+        const int r = idx >> 6, c = idx & 63;
+        const float v = ((p0[idx] + p0[T * T + idx]) + p0[2 * T * T + idx]) + p0[3 * T * T + idx];
+        const int row = m0 + r, col = n0 + c;
+        if (row < M && col < N) epilogue_store(v, row, col, C, ldc, epi, seed, inv_keep);
+    }
+    if (want_asum && threadIdx.x < T && m0 + (int)threadIdx.x < M) {
+        const int i = threadIdx.x;
+        asum[m0 + i] += ((bpart[i] + bpart[T + i]) + bpart[2 * T + i]) + bpart[3 * T + i];
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_l32w_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                        float* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_m,
+                                                        int tiles_n) {
+    extern __shared__ __attribute__((aligned(1024))) char l32_smem[];
+    const int tile = blockIdx.x;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    l32w_tile<A_KC, B_KC>(l32_smem, A, lda, B, ldb, C, ldc, M, N, K, epi, tm, tn, nullptr);
+}
+
+// ---- grouped weight gradients: up to 48 independent problems  dW_p[n_out, n_in] += dz_pᵀ · x_p  (+ db_p[n_out] += Σ_rows dz_p) in ONE
+// launch.  The text-side and step-level linears each have a handful of 64² tiles; launched one by one they cost ≈12 µs apiece
+// (plus two more launches for the bias gradient) for a few µs of work.  The problem table travels by value in the kernel arguments.
+struct GProb { const float* dz; const float* x; float* dw; float* db; int n_out, n_in, rows, ld_dz, ld_x, ld_dw, tile0, tiles_n; };
+constexpr int GROUP_MAX = 48;
+struct GArgs { int n; GProb p[GROUP_MAX]; };
+
+__global__ __launch_bounds__(256) void gemm_group_wgrad_kernel(GArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) char l32_smem[];
+    int pi = 0;
+    while (pi + 1 < g.n && (int)blockIdx.x >= g.p[pi + 1].tile0) ++pi;
+    const GProb& q = g.p[pi];
+    const int tile = blockIdx.x - q.tile0;
+    const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
+    Epi epi{nullptr, ACT_NONE, 0.f, 0u, nullptr, 1, nullptr};
+    l32w_tile<false, false>(l32_smem, q.dz, q.ld_dz, q.x, q.ld_x, q.dw, q.ld_dw, q.n_out, q.n_in, q.rows, epi, tm, tn, q.db);
+}
+
+
+template <bool A_KC, bool B_KC>
+static int l32w_launch_one(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
+                           int K, Epi epi, int tiles_m, int tiles_n) {
+    constexpr int LDS = 4 * 2 * 2 * 64 * L32_BK * 4;      // 4 waves × 2 stages × (A + B) = 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_l32w_kernel<A_KC, B_KC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { svpc_set_error("gemm_l32w: cannot raise the dynamic LDS limit"); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_l32w_kernel<A_KC, B_KC>), grid, dim3(256), LDS, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tiles_m,
+                       tiles_n);
+    return 0;
+}
+
 template <int BM, int BN, bool A_KC, bool B_KC, int NS>
 static int l32_launch_one(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
                           int K, Epi epi, int tiles_m, int tiles_n, int splitk, int k_chunk, float* slabs, int remap) {
@@ -206,8 +365,45 @@ int svpc_gemm_l32_supported(int a_kc, int b_kc, int lda, int ldb, int M, int N, 
 // long k-loops on few tiles want split-K slabs, which that kernel already does.
 int svpc_gemm_l32_preferred(int a_kc, int b_kc, int lda, int ldb, int M, int N, int K) {
     if (!svpc_gemm_l32_supported(a_kc, b_kc, lda, ldb, M, N, K)) return 0;
-    const int t128 = ceil_div(M, 128) * ceil_div(N, 128);
+    const int t128 = ceil_div(M, 128) * ceil_div(N, 128), t64 = ceil_div(M, 64) * ceil_div(N, 64);
+    static int env_w = -1;
+    if (env_w < 0) { const char* e = getenv("SVPC_L32_WAVESPLIT"); env_w = e ? atoi(e) : 1; }
+    if (env_w && t64 <= 256 && K >= 4 * L32_BK && t64 * 4 >= 32) return 1;      // wave-split-K form, any K
     return (t128 <= 300 && K < 2048) ? 1 : 0;
+}
+
+// dz/x/dw/db layout as in include/svpc_hip.h (svpc_wgrad_problem); every problem must satisfy svpc_gemm_l32_supported(0, 0, …)
+struct HostWgradProblem { const float* dz; const float* x; float* dw; float* db; int n_out, n_in, rows, ld_dz, ld_x, ld_dw; };
+
+int svpc_gemm_group_wgrad_max(void) { return GROUP_MAX; }
+
+int svpc_gemm_group_wgrad(const void* problems, int n, hipStream_t stream) {
+    if (n == 0) return 0;
+    SVPC_REQUIRE(n > 0 && n <= GROUP_MAX, "gemm_group_wgrad: 1..48 problems per launch");
+    const HostWgradProblem* hp = reinterpret_cast<const HostWgradProblem*>(problems);
+    GArgs g{};
+    g.n = n;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const HostWgradProblem& h = hp[i];
+        SVPC_REQUIRE(svpc_gemm_l32_supported(0, 0, h.ld_dz, h.ld_x, h.n_out, h.n_in, h.rows) && h.rows >= L32_BK &&
+                         ((((uintptr_t)h.dz) | ((uintptr_t)h.x)) & 15) == 0,
+                     "gemm_group_wgrad: rows % 32, n_out % 4, n_in % 4 and 16-byte alignment required");
+        GProb& q = g.p[i];
+        q.dz = h.dz; q.x = h.x; q.dw = h.dw; q.db = h.db; q.n_out = h.n_out; q.n_in = h.n_in; q.rows = h.rows; q.ld_dz = h.ld_dz;
+        q.ld_x = h.ld_x; q.ld_dw = h.ld_dw; q.tile0 = tiles; q.tiles_n = ceil_div(h.n_in, 64);
+        tiles += ceil_div(h.n_out, 64) * q.tiles_n;
+    }
+    constexpr int LDS = 4 * 2 * 2 * 64 * L32_BK * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_group_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           LDS);
+        if (e != hipSuccess) { svpc_set_error("gemm_group_wgrad: cannot raise the dynamic LDS limit"); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_group_wgrad_kernel, dim3(tiles), dim3(256), LDS, stream, g);
+    return svpc_check_launch("gemm_group_wgrad");
 }
 
 // Same contract as svpc_gemm_mx with fp32 A, B, C (reference: every nn.Linear / matmul of model.py that is not on the
@@ -228,8 +424,22 @@ int svpc_gemm_l32(const float* A, int lda, int a_kc, const float* B, int ldb, in
     // 64² tiles with a 4-stage ring (two workgroups per CU) were the fastest form for every small grid in the sweep; 128² tiles
     // (one workgroup per CU) and the 8-stage ring stay selectable through SVPC_L32_TILE for experiments
     int mode = (M >= 96 && N >= 96 && t128 > 300) ? 128 : 65;
-    (void)t64;
-    if (env_tile == 128 || env_tile == 64 || env_tile == 65) mode = env_tile;
+    // ≤ 256 tiles of 64² (one per CU at most) with at least 4 k-tiles: the wave-split-K form (no slabs, no reduce launch)
+    static int env_w = -1;
+    if (env_w < 0) { const char* e = getenv("SVPC_L32_WAVESPLIT"); env_w = e ? atoi(e) : 1; }
+    if (env_w && t64 <= 256 && K >= 4 * L32_BK) mode = 66;
+    if (env_tile == 128 || env_tile == 64 || env_tile == 65 || env_tile == 66) mode = env_tile;
+    if (mode == 66) {
+        const int tm_ = ceil_div(M, 64), tn_ = ceil_div(N, 64);
+        dim3 gridw(tm_ * tn_);
+        int rcw;
+        if (a_kc && b_kc) rcw = l32w_launch_one<true, true>(gridw, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tm_, tn_);
+        else if (a_kc) rcw = l32w_launch_one<true, false>(gridw, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tm_, tn_);
+        else if (b_kc) rcw = l32w_launch_one<false, true>(gridw, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tm_, tn_);
+        else rcw = l32w_launch_one<false, false>(gridw, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tm_, tn_);
+        if (rcw) return rcw;
+        return svpc_check_launch("gemm_l32w");
+    }
     const int BMN = mode == 128 ? 128 : 64;
     const int tiles_m = ceil_div(M, BMN), tiles_n = ceil_div(N, BMN), tiles = tiles_m * tiles_n;
     // split K only when the grid would leave most CUs idle AND every slice still has a long k-loop (a short loop is already

@@ -7,7 +7,9 @@ GPU tests compare against.
 """
 from __future__ import annotations
 
+import ctypes
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -62,8 +64,83 @@ def branch_stream(device):
     return st
 
 
+# Grouped weight gradients: the wgrad (+ bias gradient) of an fp32-storage linear whose gradients go straight to the arena is not
+# launched in its backward but queued; the queue is flushed as ONE grouped launch (svpc_gemm_group_wgrad) on a side stream when it
+# is full, when a queued target would be written twice, and at every join point (end of backward, before a gradient bucket is
+# all-reduced, before the optimizer).  ≈50 text-side / step-level linears per step × 3 launches (wgrad, column sum, finalize) of
+# ≈5–15 µs each become 2–3 launches.
+USE_GROUPED_WGRAD = os.environ.get("SVPC_NO_GROUPED_WGRAD", "") == ""
+_WQ = []            # (dz, x, wgrad, bgrad)
+
+
+class _WgradProblem(ctypes.Structure):
+    _fields_ = [("dz", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("db", ctypes.c_void_p),
+                ("n_out", ctypes.c_int), ("n_in", ctypes.c_int), ("rows", ctypes.c_int), ("ld_dz", ctypes.c_int),
+                ("ld_x", ctypes.c_int), ("ld_dw", ctypes.c_int)]
+
+
+def _queue_end_of_backward_join():
+    if not _JOIN_QUEUED[0]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(join_side)
+            _JOIN_QUEUED[0] = True
+        except RuntimeError:      # not inside a backward pass: the caller joins (optimizer / reducer do)
+            pass
+
+
+def defer_wgrad(dz, x, wgrad, bgrad):
+    """Queue dW += dzᵀ·x (and db += Σ dz) for the grouped launch; False if this problem must be launched on its own."""
+    if not (USE_GROUPED_WGRAD and _PRECISION == "bf16" and wgrad is not None and dz.dtype == torch.float32 and x.dtype == torch.float32):
+        return False
+    rows, n_out = dz.shape
+    n_in = x.shape[1]
+    if rows % 32 or rows < 32 or n_out % 4 or n_in % 4 or dz.stride(0) % 4 or x.stride(0) % 4 or wgrad.stride(0) % 4:
+        return False
+    if (dz.data_ptr() | x.data_ptr()) % 16 or dz.stride(1) != 1 or x.stride(1) != 1 or not wgrad.is_contiguous():
+        return False
+    tiles = -(-n_out // 64) * -(-n_in // 64)
+    if tiles > 256:               # a grid of its own fills the chip: nothing to gain from grouping
+        return False
+    wp = wgrad.data_ptr()
+    if any(q[2].data_ptr() == wp for q in _WQ):
+        flush_wgrads()            # two accumulations into one gradient stay ordered
+    _WQ.append((dz, x, wgrad, bgrad))
+    if len(_WQ) >= _lib.load().svpc_gemm_group_wgrad_max():
+        flush_wgrads()
+    _queue_end_of_backward_join()
+    return True
+
+
+def flush_wgrads():
+    if not _WQ:
+        return
+    dev = _WQ[0][0].device
+    pool = _SIDE.get(dev)
+    if pool is None:
+        pool = _SIDE[dev] = [torch.cuda.Stream(device=dev) for _ in range(_N_SIDE)]
+    side = pool[0] if SIDE_WGRAD else torch.cuda.current_stream()
+    probs = (_WgradProblem * len(_WQ))()
+    for i, (dz, x, wg, bg) in enumerate(_WQ):
+        probs[i] = _WgradProblem(dz.data_ptr(), x.data_ptr(), wg.data_ptr(), bg.data_ptr() if bg is not None else None,
+                                 dz.shape[1], x.shape[1], dz.shape[0], dz.stride(0), x.stride(0), wg.stride(0))
+    if SIDE_WGRAD:
+        side.wait_stream(torch.cuda.current_stream())
+        for dz, x, _, _ in _WQ:
+            dz.record_stream(side); x.record_stream(side)
+        if side not in _SIDE_DIRTY:
+            _SIDE_DIRTY.append(side)
+    _lib.call("gemm_group_wgrad", ctypes.addressof(probs), len(_WQ), side.cuda_stream)
+    done = list(_WQ)
+    del _WQ[:]
+    for _, _, wg, bg in done:
+        _ready(wg, "w")
+        if bg is not None:
+            _ready(bg, "b")
+
+
 def join_side():
     """Make the current stream wait for every side stream that has gradient work in flight."""
+    flush_wgrads()
     _JOIN_QUEUED[0] = False
     if _SIDE_DIRTY:
         cur = torch.cuda.current_stream()
@@ -352,6 +429,8 @@ class _Linear(Function):
             dx = torch.empty(M, K, dtype=x.dtype, device=dy.device)
             _gemm(dz, N, 1, w, w.stride(0), 1 if trans_w else 0, dx, M, K, N)
         wgrad, bgrad = ctx.direct
+        if wgrad is not None and not trans_w and (not has_b or bgrad is not None) and defer_wgrad(dz, x, wgrad, bgrad if has_b else None):
+            return dx, None, None, None, None, None, None, None, None
         if wgrad is not None or ctx.needs_input_grad[1]:
             acc = 1 if wgrad is not None else 0
             dw = wgrad if wgrad is not None else torch.empty_like(w)

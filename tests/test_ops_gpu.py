@@ -415,7 +415,10 @@ def test_gemm_glds_direct_to_lds(bf16_mode, M, N, K, a_kc, b_kc, c_bf16):
     (192, 768, 768, 1, 1, 0, True), (200, 951, 768, 1, 1, 0, True), (4224, 768, 768, 1, 0, 0, False), (768, 768, 192, 0, 0, 1, False),
     (16, 3072, 768, 1, 1, 0, True), (3072, 768, 32, 0, 0, 1, False), (100, 60, 64, 1, 1, 0, False), (64, 64, 4224, 0, 0, 0, False),
     (768, 768, 4224, 0, 0, 1, False), (4224, 2304, 768, 1, 1, 0, True), (12, 20, 96, 0, 1, 0, False), (36, 8, 160, 1, 0, 0, False),
-    (2304, 768, 4224, 0, 0, 0, False), (132, 136, 2048, 0, 0, 0, False)])
+    (2304, 768, 4224, 0, 0, 0, False), (132, 136, 2048, 0, 0, 0, False),
+    # wave-split-K form (≤ 256 tiles of 64², ≥ 4 k-tiles): uneven k-tile counts per wave, edges, every layout, long K
+    (192, 768, 160, 1, 1, 0, True), (16, 768, 3072, 1, 0, 0, False), (576, 1536, 768, 1, 1, 0, True), (700, 60, 224, 0, 1, 1, False),
+    (64, 64, 128, 0, 0, 0, False), (192, 2304, 768, 1, 1, 1, True)])
 def test_gemm_l32_fp32_direct_to_lds(bf16_mode, M, N, K, a_kc, b_kc, acc, bias_act):
     """fp32-operand direct-to-LDS GEMM (deep ring, bf16 rounding at fragment build): all four layouts, clamped M/N edges,
     128² / 64² tiles, split-K, accumulate and bias+activation epilogues — against fp64 on the bf16-rounded operands."""
@@ -498,3 +501,31 @@ def test_single_query_attention_for_decoding(H, dh, k_lens):
             got = O.attention(q, kv, (0, 0, D), D, H, seq, key_mask=mask, causal=False)
             ref = E.attention(q, kv, (0, 0, D), D, H, seq, key_mask=mask, causal=False)
         assert torch.allclose(got, ref, rtol=2e-5, atol=2e-6), (got - ref).abs().max()
+
+
+def test_grouped_weight_gradients(bf16_mode):
+    """svpc_gemm_group_wgrad: several independent dW += dzᵀ·x (+ db += Σ dz) problems of different shapes in one launch, against
+    fp64 on the bf16-rounded operands (weights) and an fp32 column sum (bias); accumulation into non-zero targets."""
+    import ctypes
+    shapes = [(192, 768, 768, True), (576, 1536, 768, True), (192, 64, 300, False), (4224, 768, 768, True), (32, 8, 4, True),
+              (192, 3072, 768, True), (96, 100, 60, False)]
+    g = torch.Generator().manual_seed(5)
+    keep, probs = [], (O._WgradProblem * len(shapes))()
+    for i, (rows, n_out, n_in, with_b) in enumerate(shapes):
+        dz = torch.randn(rows, n_out, generator=g).to(DEV)
+        x = torch.randn(rows, n_in, generator=g).to(DEV)
+        dw0 = torch.randn(n_out, n_in, generator=g).to(DEV)
+        db0 = torch.randn(n_out, generator=g).to(DEV) if with_b else None
+        dw, db = dw0.clone(), (db0.clone() if with_b else None)
+        keep.append((dz, x, dw0, db0, dw, db))
+        probs[i] = O._WgradProblem(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if with_b else None, n_out, n_in, rows,
+                                   dz.stride(0), x.stride(0), dw.stride(0))
+    O._lib.call("gemm_group_wgrad", ctypes.addressof(probs), len(shapes), O._stream())
+    torch.cuda.synchronize()
+    for (rows, n_out, n_in, with_b), (dz, x, dw0, db0, dw, db) in zip(shapes, keep):
+        ref = dw0.double() + dz.bfloat16().double().t() @ x.bfloat16().double()
+        tol = 2e-6 * math.sqrt(rows) * max(1.0, ref.abs().max().item())
+        assert (dw.double() - ref).abs().max().item() <= tol, (rows, n_out, n_in)
+        if with_b:
+            rb = db0.double() + dz.double().sum(0)
+            assert (db.double() - rb).abs().max().item() <= 1e-5 * max(1.0, rb.abs().max().item()), (rows, n_out)
