@@ -70,6 +70,7 @@ def branch_stream(device):
 # all-reduced, before the optimizer).  ≈50 text-side / step-level linears per step × 3 launches (wgrad, column sum, finalize) of
 # ≈5–15 µs each become 2–3 launches.
 USE_GROUPED_WGRAD = os.environ.get("SVPC_NO_GROUPED_WGRAD", "") == ""
+GROUP_FLUSH_AT = int(os.environ.get("SVPC_GROUP_FLUSH_AT", "8"))
 _WQ = []            # (dz, x, wgrad, bgrad)
 
 
@@ -105,8 +106,8 @@ def defer_wgrad(dz, x, wgrad, bgrad):
     if any(q[2].data_ptr() == wp for q in _WQ):
         flush_wgrads()            # two accumulations into one gradient stay ordered
     _WQ.append((dz, x, wgrad, bgrad))
-    if len(_WQ) >= _lib.load().svpc_gemm_group_wgrad_max():
-        flush_wgrads()
+    if len(_WQ) >= min(GROUP_FLUSH_AT, _lib.load().svpc_gemm_group_wgrad_max()):
+        flush_wgrads()            # early enough that the launch still runs beside the rest of the backward
     _queue_end_of_backward_join()
     return True
 
