@@ -39,24 +39,28 @@ def _ws(device):
     return w
 
 
-# Side streams for parameter gradients: a weight / bias gradient written straight into the optimizer's arena has no consumer
-# until the optimizer (or the gradient all-reduce) runs, so its kernels are forked onto a side stream and run beside the
-# dgrad chain — the text-side and step-level launches occupy a fraction of the 256 CUs each.  A gradient always uses the same
+# Side streams for parameter gradients (OFF by default, SVPC_SIDE=1 / SVPC_BRANCH=1 enable them): a weight / bias gradient written
+# straight into the optimizer's arena has no consumer until the optimizer (or the gradient all-reduce) runs, so its kernels can be
+# forked onto a side stream and run beside the dgrad chain.  Measured: this won 6 % while the side kernels were slow and numerous;
+# since the finalizers / column sums were rewritten and the weight gradients grouped, the captured graph replays 3 % FASTER as one
+# linear chain — the graph executor spreads a forked graph over four hardware queues and a main-chain kernel then waits behind
+# unrelated side work that happens to share its queue (gaps of 20–80 µs in the kernel trace).  A gradient always uses the same
 # side stream (accumulating launches stay ordered); the streams are joined at the end of backward (autograd callback), before a
 # gradient bucket is all-reduced, and before the optimizer kernels.  Inside a hipGraph capture the forks/joins become edges.
-SIDE_WGRAD = True
-_N_SIDE = 2
+SIDE_WGRAD = os.environ.get("SVPC_SIDE", "") != ""
+_N_SIDE = int(os.environ.get("SVPC_N_SIDE", "2"))
 _SIDE = {}
 _SIDE_DIRTY = []
 _JOIN_QUEUED = [False]
 
 
 _BRANCH = {}
+BRANCH_STREAMS = os.environ.get("SVPC_BRANCH", "") != ""
 
 
 def branch_stream(device):
     """Stream for an independent forward branch (its autograd nodes run their backward there too); None when disabled."""
-    if not SIDE_WGRAD:
+    if not BRANCH_STREAMS:
         return None
     st = _BRANCH.get(device)
     if st is None:
@@ -70,7 +74,7 @@ def branch_stream(device):
 # all-reduced, before the optimizer).  ≈50 text-side / step-level linears per step × 3 launches (wgrad, column sum, finalize) of
 # ≈5–15 µs each become 2–3 launches.
 USE_GROUPED_WGRAD = os.environ.get("SVPC_NO_GROUPED_WGRAD", "") == ""
-GROUP_FLUSH_AT = int(os.environ.get("SVPC_GROUP_FLUSH_AT", "8"))
+GROUP_FLUSH_AT = int(os.environ.get("SVPC_GROUP_FLUSH_AT", "16"))
 _WQ = []            # (dz, x, wgrad, bgrad)
 
 
