@@ -50,6 +50,13 @@ int svpc_ln_bwd_rows_t(const void* dy, const void* x, int x_dt, int y_dt, const 
 int svpc_ln_param_grads(const float* partial, int R, int D, float* dgamma, float* dbeta, int accumulate, svpc_stream_t stream);
 int svpc_bucket_colsum_t(const void* x, int x_dt, int ldx, const int* idx, int R, int C, int K, float* out, int accumulate,
                          float* workspace, svpc_stream_t stream);
+/* deferred reduction tails: the first stage of a plain column sum into a caller-owned partial buffer, and ONE launch that adds the
+ * column sums of up to svpc_multi_finalize_max() partial buffers (bias gradients; LayerNorm [dgamma ; dbeta] with split = D) into
+ * their arena targets: out(c) += Σ_g partial[g][c], c < split → out0[c], else out1[c - split].  `entries` is a HOST array. */
+typedef struct svpc_finalize_entry { const float* partial; float* out0; float* out1; int groups, ncols, split; } svpc_finalize_entry;
+int svpc_colsum_partial_t(const void* x, int x_dt, int ldx, int R, int C, float* partial, svpc_stream_t stream);
+int svpc_multi_finalize_max(void);
+int svpc_multi_finalize(const svpc_finalize_entry* entries, int n, svpc_stream_t stream);
 int svpc_ln_bwd_groups(int R); /* workspace floats needed by svpc_ln_bwd = (groups + 1) * 2 * D */
 int svpc_ln_bwd(const float* dy, const float* x, const int* src_rows, const float* res, const float* gamma,
                 const float* mean, const float* rstd, float* dh, float* dx, float* dgamma, float* dbeta, int accumulate,

@@ -401,6 +401,27 @@ __global__ __launch_bounds__(1024) void ln_finalize_kernel(const float* __restri
     }
 }
 
+// Table-driven form: up to 64 pending finalizes (bias gradients, LayerNorm gain/shift gradients) in ONE launch at the end of the
+// backward pass.  Every entry adds the column sums of its partial buffer into its arena target(s); columns < split go to out0,
+// the rest to out1 (LayerNorm: [dgamma ; dbeta]).  The table travels by value in the kernel arguments.
+struct FEntry { const float* partial; float* out0; float* out1; int groups, ncols, split, block0; };
+constexpr int FIN_MAX = 64;
+struct FArgs { int n; FEntry e[FIN_MAX]; };
+
+__global__ __launch_bounds__(1024) void multi_finalize_kernel(FArgs a) {
+    __shared__ float red[32][33];
+    int ei = 0;
+    while (ei + 1 < a.n && (int)blockIdx.x >= a.e[ei + 1].block0) ++ei;
+    const FEntry& en = a.e[ei];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = ((int)blockIdx.x - en.block0) * 32 + cl;
+    const float t = finalize_column(en.partial, en.groups, en.ncols, c, rg, red);
+    if (rg == 0 && c < en.ncols) {
+        float* out = c < en.split ? en.out0 + c : en.out1 + (c - en.split);
+        *out += t;
+    }
+}
+
 // partial[chunk][k][c] = sum over rows r of the chunk with idx[r]==k (idx null → k = 0) of x[r][c]
 template <int KMAX, typename T>
 __global__ __launch_bounds__(256) void bucket_colsum_kernel(const T* __restrict__ x, int ldx, const int* __restrict__ idx,
@@ -603,6 +624,37 @@ int svpc_ln_bwd(const float* dy, const float* x, const int* src_rows, const floa
 // out[k][c] (+)= sum_{r : idx[r]==k} x[r][c]   (idx null → plain column sum, K must be 1).  K <= 8.
 // workspace: svpc_colsum_chunks(R) * K * C floats
 int svpc_colsum_chunks(int R) { int g = ceil_div(R, 32); return g < 1 ? 1 : (g > 600 ? 600 : g); }
+
+// first stage only of a plain column sum: partial = svpc_colsum_chunks(R) × C floats (to be finalized later, see svpc_multi_finalize)
+int svpc_colsum_partial_t(const void* xv, int x_dt, int ldx, int R, int C, float* partial, hipStream_t stream) {
+    if (R == 0 || C == 0) return 0;
+    const int V = x_dt ? 8 : 4;
+    SVPC_REQUIRE(C % V == 0 && ldx % V == 0 && ((((uintptr_t)xv)) & 15) == 0, "colsum_partial: 16-byte aligned rows required");
+    const int chunks = svpc_colsum_chunks(R);
+    const int rpc = ceil_div(R, chunks);
+    const dim3 vg(ceil_div(C, 64 * V), chunks);
+    if (x_dt == 0) hipLaunchKernelGGL(colsum_vec_kernel<float>, vg, dim3(256), 0, stream, (const float*)xv, ldx, R, C, rpc, partial);
+    else hipLaunchKernelGGL(colsum_vec_kernel<__bf16>, vg, dim3(256), 0, stream, (const __bf16*)xv, ldx, R, C, rpc, partial);
+    return svpc_check_launch("colsum_partial");
+}
+
+struct HostFinalizeEntry { const float* partial; float* out0; float* out1; int groups, ncols, split; };
+int svpc_multi_finalize_max(void) { return FIN_MAX; }
+int svpc_multi_finalize(const void* entries, int n, hipStream_t stream) {
+    if (n == 0) return 0;
+    SVPC_REQUIRE(n > 0 && n <= FIN_MAX, "multi_finalize: 1..64 entries per launch");
+    const HostFinalizeEntry* he = reinterpret_cast<const HostFinalizeEntry*>(entries);
+    FArgs a{};
+    a.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        a.e[i].partial = he[i].partial; a.e[i].out0 = he[i].out0; a.e[i].out1 = he[i].out1; a.e[i].groups = he[i].groups;
+        a.e[i].ncols = he[i].ncols; a.e[i].split = he[i].split; a.e[i].block0 = blocks;
+        blocks += ceil_div(he[i].ncols, 32);
+    }
+    hipLaunchKernelGGL(multi_finalize_kernel, dim3(blocks), dim3(1024), 0, stream, a);
+    return svpc_check_launch("multi_finalize");
+}
 
 int svpc_bucket_colsum_t(const void* xv, int x_dt, int ldx, const int* idx, int R, int C, int K, float* out, int accumulate,
                          float* workspace, hipStream_t stream) {

@@ -143,9 +143,47 @@ def flush_wgrads():
             _ready(bg, "b")
 
 
+# Deferred reduction tails: the second stage of every bias-gradient column sum and of every LayerNorm gain/shift gradient (≈90 per
+# step, 5–6 µs each, a few KB of work) is queued and run as ONE table-driven launch (svpc_multi_finalize) at the join points.
+USE_MULTI_FINALIZE = os.environ.get("SVPC_NO_MULTI_FINALIZE", "") == ""
+_FQ = []            # (partial, out0, out1, groups, ncols, split)
+
+
+class _FinalizeEntry(ctypes.Structure):
+    _fields_ = [("partial", ctypes.c_void_p), ("out0", ctypes.c_void_p), ("out1", ctypes.c_void_p), ("groups", ctypes.c_int),
+                ("ncols", ctypes.c_int), ("split", ctypes.c_int)]
+
+
+def defer_finalize(partial, groups, ncols, out0, out1=None, split=None):
+    """out0/out1 (+)= column sums of ``partial`` (groups × ncols), later, together with every other pending tail"""
+    tgt = (out0.data_ptr(), out1.data_ptr() if out1 is not None else 0)
+    if any(q[1].data_ptr() in tgt or (q[2] is not None and q[2].data_ptr() in tgt) for q in _FQ):
+        flush_finalizes()
+    _FQ.append((partial, out0, out1, int(groups), int(ncols), int(ncols if split is None else split)))
+    if len(_FQ) >= _lib.load().svpc_multi_finalize_max():
+        flush_finalizes()
+    _queue_end_of_backward_join()
+
+
+def flush_finalizes():
+    if not _FQ:
+        return
+    ents = (_FinalizeEntry * len(_FQ))()
+    for i, (partial, o0, o1, g, nc, sp) in enumerate(_FQ):
+        ents[i] = _FinalizeEntry(partial.data_ptr(), o0.data_ptr(), (o1 if o1 is not None else o0).data_ptr(), g, nc, sp)
+    _lib.call("multi_finalize", ctypes.addressof(ents), len(_FQ), _stream())
+    done = list(_FQ)
+    del _FQ[:]
+    for _, o0, o1, _, _, _ in done:
+        _ready(o0, "b" if o1 is None else None)
+        if o1 is not None:
+            _ready(o1)
+
+
 def join_side():
     """Make the current stream wait for every side stream that has gradient work in flight."""
     flush_wgrads()
+    flush_finalizes()
     _JOIN_QUEUED[0] = False
     if _SIDE_DIRTY:
         cur = torch.cuda.current_stream()
@@ -449,9 +487,16 @@ class _Linear(Function):
                 dw = None
         if has_b and (bgrad is not None or ctx.needs_input_grad[2]):
             if bgrad is not None:
-                with _side_of(bgrad, dz):
-                    _colsum(dz, out=bgrad.view(1, -1), accumulate=1)
-                _ready(bgrad, "b")
+                V = 8 if dz.dtype == torch.bfloat16 else 4
+                if (USE_MULTI_FINALIZE and not SIDE_WGRAD and N % V == 0 and dz.stride(0) % V == 0 and dz.data_ptr() % 16 == 0 and M > 0):
+                    chunks = _lib.load().svpc_colsum_chunks(M)
+                    partial = torch.empty(chunks * N, dtype=torch.float32, device=dz.device)
+                    _lib.call("colsum_partial_t", _p(dz), _dt(dz), dz.stride(0), M, N, _p(partial), _stream())
+                    defer_finalize(partial, chunks, N, bgrad)
+                else:
+                    with _side_of(bgrad, dz):
+                        _colsum(dz, out=bgrad.view(1, -1), accumulate=1)
+                    _ready(bgrad, "b")
             else:
                 db = _colsum(dz).view(-1)
         return dx, dw, db, None, None, None, None, None, None
@@ -525,11 +570,15 @@ class _LayerNorm(Function):
         partial = torch.empty(_lib.load().svpc_ln_bwd_groups(R) * 2 * D, dtype=torch.float32, device=dev)
         _lib.call("ln_bwd_rows_t", _p(dy), _p(x), _dt(x), _dt(dy), _p(src_rows), _p(residual), _p(gamma), _p(mean), _p(rstd), _p(dh),
                   _p(dx_rows), _p(partial), R, D, p_pre, s_pre, p_post, s_post, _p(seed), _stream())
-        with _side_of(g_dir if direct_gb else None, partial):
-            _lib.call("ln_param_grads", _p(partial), R, D, _p(dgamma), _p(dbeta), 1 if direct_gb else 0, _stream())
-        if direct_gb:
-            _ready(dgamma); _ready(dbeta)
+        if direct_gb and USE_MULTI_FINALIZE and not SIDE_WGRAD:
+            defer_finalize(partial, _lib.load().svpc_ln_bwd_groups(R), 2 * D, dgamma, dbeta, D)
             dgamma = dbeta = None
+        else:
+            with _side_of(g_dir if direct_gb else None, partial):
+                _lib.call("ln_param_grads", _p(partial), R, D, _p(dgamma), _p(dbeta), 1 if direct_gb else 0, _stream())
+            if direct_gb:
+                _ready(dgamma); _ready(dbeta)
+                dgamma = dbeta = None
         dx = None
         if need_x:
             if src_rows is not None:
