@@ -1043,10 +1043,11 @@ class _LstmSeq(Function):
         dh = torch.zeros(N, D, dtype=torch.float32, device=dev)
         dc = torch.zeros(N, D, dtype=torch.float32, device=dev)
         dh2, dc2 = torch.empty_like(dh), torch.empty_like(dc)
+        wt = w.t().contiguous()         # (D, 4D): the S dgrad GEMMs then read both operands k-contiguously (12 tiles × K = 4D)
         for t in range(S - 1, -1, -1):
             _lib.call("lstm_cell_bwd_seq", _p(dhs[t]), _p(dh), _p(dc), _p(gates[t]), _p(c_all[t]), _p(active_t[t]), _p(dG[t]), _p(dc2),
                       _p(dh2), N, D, _stream())
-            _gemm(dG[t], 4 * D, 1, w, D, 0, dh2, N, D, 4 * D, accumulate=1)      # dh_{t-1} = pass-through + dgates · W_hh
+            _gemm(dG[t], 4 * D, 1, wt, 4 * D, 1, dh2, N, D, 4 * D, accumulate=1)      # dh_{t-1} = pass-through + dgates · W_hh
             dh, dh2 = dh2, dh
             dc, dc2 = dc2, dc
         dG2, hp = dG.view(S * N, 4 * D), h_all[:S].reshape(S * N, D)
