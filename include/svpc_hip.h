@@ -99,6 +99,10 @@ int svpc_gemm_l32(const float* A, int lda, int a_kc, const float* B, int ldb, in
 /* grouped weight (+ bias) gradients of up to svpc_gemm_group_wgrad_max() independent linears in one launch:
  *   dw[n_out, n_in] += dzᵀ · x,   db[n_out] += Σ_rows dz   (db may be NULL)       — the wgrad half of every nn.Linear backward
  * `problems` is a HOST array of svpc_wgrad_problem; rows % 32 == 0, n_out % 4 == 0, n_in % 4 == 0, 16-byte aligned operands */
+/* grouped small GEMMs of one layout in one launch (fp32 operands, bf16 MFMA): C_p = (accumulate ? C_p : 0) + Σ_k A_p(m,k)·B_p(n,k);
+ * `problems` is a HOST array, at most 32 entries, K % 32 == 0 — e.g. the recurrent projections of both LSTM directions at one step */
+typedef struct svpc_gemm_problem { const float* A; const float* B; float* C; int M, N, K, lda, ldb, ldc; } svpc_gemm_problem;
+int svpc_gemm_group(const svpc_gemm_problem* problems, int n, int a_kc, int b_kc, int accumulate, svpc_stream_t stream);
 typedef struct svpc_wgrad_problem {
     const float* dz; const float* x; float* dw; float* db;
     int n_out, n_in, rows, ld_dz, ld_x, ld_dw;
@@ -217,6 +221,14 @@ int svpc_lstm_cell_fwd_idx(const float* gx_all, const int* rows, const float* gh
                            const float* active, float* h, float* c, float* gates_act, int N, int D, svpc_stream_t stream);
 int svpc_lstm_cell_bwd_seq(const float* dh_out, const float* dh_rec, const float* dc, const float* gates_act, const float* c_prev,
                            const float* active, float* dgates, float* dc_prev, float* dh_prev, int N, int D, svpc_stream_t stream);
+/* both directions of the BiLSTM at one time step in one launch: every argument is a HOST array of 2 device pointers
+ * (direction 0 = forward in time, 1 = reverse); `active` is shared */
+int svpc_lstm_pair_fwd(const float* const* gx, const int* const* rows, const float* const* gh, const float* const* c_prev,
+                       const float* const* h_prev, const float* active, float* const* h, float* const* c, float* const* gates, int N, int D,
+                       svpc_stream_t stream);
+int svpc_lstm_pair_bwd(const float* const* dh_out, const float* const* dh_rec, const float* const* dc, const float* const* gates,
+                       const float* const* c_prev, const float* active, float* const* dgates, float* const* dc_prev,
+                       float* const* dh_prev, int N, int D, svpc_stream_t stream);
 /* greedy decoding step: argmax with the UNK column suppressed + OOV→UNK remap, src/translator.py:104-112 */
 int svpc_greedy_pick(const float* scores, int ld, const int* row_c, const int* row_x, int n_sent, int lt, int pos, int unk,
                      int* next_ext, int* next_model, svpc_stream_t stream);

@@ -404,6 +404,56 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_seq_kernel(const float* __r
     dh_prev[i] = (1.f - a) * dht;
 }
 
+// Both directions of the BiLSTM at one time step in one launch: blockIdx.y = direction, per-direction pointers in the struct.
+struct LstmPair {
+    const float* gx[2]; const int* rows[2]; const float* gh[2]; const float* c_prev[2]; const float* h_prev[2]; const float* active;
+    float* h[2]; float* c[2]; float* gates[2];
+    // backward
+    const float* dh_out[2]; const float* dh_rec[2]; const float* dc[2]; float* dgates[2]; float* dc_prev[2]; float* dh_prev[2];
+};
+__global__ __launch_bounds__(256) void lstm_pair_fwd_kernel(LstmPair a, int N, int D) {
+    const int i = blockIdx.x * 256 + threadIdx.x, z = blockIdx.y;
+    if (i >= N * D) return;
+    const int n = i / D, d = i - n * D;
+    const size_t g0 = (size_t)n * 4 * D + d;
+    const float* gx = a.gx[z] + (size_t)a.rows[z][n] * 4 * D + d;
+    const float* gh = a.gh[z];
+    const float gi = sigmoidf_(gx[0] + gh[g0]);
+    const float gf = sigmoidf_(gx[D] + gh[g0 + D]);
+    const float gg = tanhf(gx[2 * D] + gh[g0 + 2 * D]);
+    const float go = sigmoidf_(gx[3 * D] + gh[g0 + 3 * D]);
+    float* ga = a.gates[z];
+    ga[g0] = gi; ga[g0 + D] = gf; ga[g0 + 2 * D] = gg; ga[g0 + 3 * D] = go;
+    const float cp = a.c_prev[z][i];
+    const float cn = gf * cp + gi * gg;
+    const float hn = go * tanhf(cn);
+    const float act = a.active[n];
+    a.c[z][i] = act * cn + (1.f - act) * cp;
+    a.h[z][i] = act * hn + (1.f - act) * a.h_prev[z][i];
+}
+__global__ __launch_bounds__(256) void lstm_pair_bwd_kernel(LstmPair a, int N, int D) {
+    const int i = blockIdx.x * 256 + threadIdx.x, z = blockIdx.y;
+    if (i >= N * D) return;
+    const int n = i / D, d = i - n * D;
+    const size_t g0 = (size_t)n * 4 * D + d;
+    const float* ga = a.gates[z];
+    const float gi = ga[g0], gf = ga[g0 + D], gg = ga[g0 + 2 * D], go = ga[g0 + 3 * D];
+    const float act = a.active[n];
+    const float dht = a.dh_out[z][i] + a.dh_rec[z][i];
+    const float dci = a.dc[z][i], cp = a.c_prev[z][i];
+    const float dhn = act * dht, dcn_in = act * dci;
+    const float cn = gf * cp + gi * gg;
+    const float tc = tanhf(cn);
+    const float dcn = dcn_in + dhn * go * (1.f - tc * tc);
+    float* dg = a.dgates[z];
+    dg[g0] = dcn * gg * gi * (1.f - gi);
+    dg[g0 + D] = dcn * cp * gf * (1.f - gf);
+    dg[g0 + 2 * D] = dcn * gi * (1.f - gg * gg);
+    dg[g0 + 3 * D] = dhn * tc * go * (1.f - go);
+    a.dc_prev[z][i] = dcn * gf + (1.f - act) * dci;
+    a.dh_prev[z][i] = (1.f - act) * dht;
+}
+
 // ---- greedy pick (src/translator.py:104-112): per sentence j take row j*lt+pos of the score matrix, suppress the UNK
 // column (-1e10), first-index argmax over the row's C_j classes; the emitted stream keeps the extended id, the model
 // side sees UNK for copied out-of-vocabulary words (id >= C_j - X_j).
@@ -591,6 +641,33 @@ int svpc_lstm_cell_bwd_seq(const float* dh_out, const float* dh_rec, const float
     hipLaunchKernelGGL(lstm_cell_bwd_seq_kernel, dim3(ceil_div(N * D, 256)), dim3(256), 0, s, dh_out, dh_rec, dc, gates_act, c_prev, active,
                        dgates, dc_prev, dh_prev, N, D);
     return svpc_check_launch("lstm_cell_bwd_seq");
+}
+// pair forms: arrays of 2 pointers (direction 0 = forward in time, 1 = reverse); `active` is shared (the same videos are alive)
+int svpc_lstm_pair_fwd(const float* const* gx, const int* const* rows, const float* const* gh, const float* const* c_prev,
+                       const float* const* h_prev, const float* active, float* const* h, float* const* c, float* const* gates, int N, int D,
+                       hipStream_t s) {
+    if (N == 0) return 0;
+    LstmPair a{};
+    for (int z = 0; z < 2; ++z) {
+        a.gx[z] = gx[z]; a.rows[z] = rows[z]; a.gh[z] = gh[z]; a.c_prev[z] = c_prev[z]; a.h_prev[z] = h_prev[z]; a.h[z] = h[z];
+        a.c[z] = c[z]; a.gates[z] = gates[z];
+    }
+    a.active = active;
+    hipLaunchKernelGGL(lstm_pair_fwd_kernel, dim3(ceil_div(N * D, 256), 2), dim3(256), 0, s, a, N, D);
+    return svpc_check_launch("lstm_pair_fwd");
+}
+int svpc_lstm_pair_bwd(const float* const* dh_out, const float* const* dh_rec, const float* const* dc, const float* const* gates,
+                       const float* const* c_prev, const float* active, float* const* dgates, float* const* dc_prev,
+                       float* const* dh_prev, int N, int D, hipStream_t s) {
+    if (N == 0) return 0;
+    LstmPair a{};
+    for (int z = 0; z < 2; ++z) {
+        a.dh_out[z] = dh_out[z]; a.dh_rec[z] = dh_rec[z]; a.dc[z] = dc[z]; a.gates[z] = const_cast<float*>(gates[z]);
+        a.c_prev[z] = c_prev[z]; a.dgates[z] = dgates[z]; a.dc_prev[z] = dc_prev[z]; a.dh_prev[z] = dh_prev[z];
+    }
+    a.active = active;
+    hipLaunchKernelGGL(lstm_pair_bwd_kernel, dim3(ceil_div(N * D, 256), 2), dim3(256), 0, s, a, N, D);
+    return svpc_check_launch("lstm_pair_bwd");
 }
 int svpc_lstm_cell_bwd(const float* dh, const float* dc, const float* gates_act, const float* c_prev, const float* active,
                        float* dgates, float* dc_prev, float* dh_prev, int N, int D, hipStream_t s) {

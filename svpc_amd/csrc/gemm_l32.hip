@@ -349,6 +349,39 @@ static int l32_launch(int a_kc, int b_kc, dim3 grid, hipStream_t stream, const f
 #undef L32_ARGS
 }
 
+// ---- grouped small GEMMs of one layout (e.g. the two directions of the BiLSTM at one time step): C_p = (acc ? C_p : 0) + A_p·B_pᵀ
+struct GemmProb { const float* A; const float* B; float* C; int M, N, K, lda, ldb, ldc, tile0, tiles_n; };
+constexpr int GEMM_GROUP_MAX = 32;
+struct GemmGroupArgs { int n; int accumulate; GemmProb p[GEMM_GROUP_MAX]; };
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroupArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) char l32_smem[];
+    int pi = 0;
+    while (pi + 1 < g.n && (int)blockIdx.x >= g.p[pi + 1].tile0) ++pi;
+    const GemmProb& q = g.p[pi];
+    const int tile = blockIdx.x - q.tile0;
+    const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
+    Epi epi{nullptr, ACT_NONE, 0.f, 0u, nullptr, g.accumulate, nullptr};
+    l32w_tile<A_KC, B_KC>(l32_smem, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, epi, tm, tn, nullptr);
+}
+
+struct HostGemmProblem { const float* A; const float* B; float* C; int M, N, K, lda, ldb, ldc; };
+
+template <bool A_KC, bool B_KC>
+static int gemm_group_go(const GemmGroupArgs& g, int tiles, hipStream_t stream) {
+    constexpr int LDS = 4 * 2 * 2 * 64 * L32_BK * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_group_kernel<A_KC, B_KC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { svpc_set_error("gemm_group: cannot raise the dynamic LDS limit"); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_group_kernel<A_KC, B_KC>), dim3(tiles), dim3(256), LDS, stream, g);
+    return svpc_check_launch("gemm_group");
+}
+
 extern "C" {
 
 // 1 if the fp32 direct-to-LDS kernel can run this (shape, layout): whole k-tiles, 16-byte aligned chunks, and for a k-strided
@@ -376,6 +409,29 @@ int svpc_gemm_l32_preferred(int a_kc, int b_kc, int lda, int ldb, int M, int N, 
 struct HostWgradProblem { const float* dz; const float* x; float* dw; float* db; int n_out, n_in, rows, ld_dz, ld_x, ld_dw; };
 
 int svpc_gemm_group_wgrad_max(void) { return GROUP_MAX; }
+
+// fp32 operands, same layout flags for every problem (a_kc / b_kc as in svpc_gemm_l32), K % 32 == 0, ≤ 32 problems
+int svpc_gemm_group(const void* problems, int n, int a_kc, int b_kc, int accumulate, hipStream_t stream) {
+    if (n == 0) return 0;
+    SVPC_REQUIRE(n > 0 && n <= GEMM_GROUP_MAX, "gemm_group: 1..32 problems per launch");
+    const HostGemmProblem* hp = reinterpret_cast<const HostGemmProblem*>(problems);
+    GemmGroupArgs g{};
+    g.n = n; g.accumulate = accumulate;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const HostGemmProblem& h = hp[i];
+        SVPC_REQUIRE(svpc_gemm_l32_supported(a_kc, b_kc, h.lda, h.ldb, h.M, h.N, h.K) && ((((uintptr_t)h.A) | ((uintptr_t)h.B)) & 15) == 0,
+                     "gemm_group: needs K % 32 == 0 and 16-byte aligned fp32 rows");
+        GemmProb& q = g.p[i];
+        q.A = h.A; q.B = h.B; q.C = h.C; q.M = h.M; q.N = h.N; q.K = h.K; q.lda = h.lda; q.ldb = h.ldb; q.ldc = h.ldc;
+        q.tile0 = tiles; q.tiles_n = ceil_div(h.N, 64);
+        tiles += ceil_div(h.M, 64) * q.tiles_n;
+    }
+    if (a_kc && b_kc) return gemm_group_go<true, true>(g, tiles, stream);
+    if (a_kc) return gemm_group_go<true, false>(g, tiles, stream);
+    if (b_kc) return gemm_group_go<false, true>(g, tiles, stream);
+    return gemm_group_go<false, false>(g, tiles, stream);
+}
 
 int svpc_gemm_group_wgrad(const void* problems, int n, hipStream_t stream) {
     if (n == 0) return 0;

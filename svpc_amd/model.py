@@ -942,29 +942,18 @@ class StateAwareRecursiveTransformer(nn.Module):
 
     def _bilstm(self, x, plan):
         """Bidirectional LSTM over each video's step sequence, directions summed (model.py:1022-1024).
-        Input projections for all steps are one GEMM per direction; each direction's recurrence is one fused autograd node
-        (ops.lstm_sequence) that advances all videos together.  The two directions are independent chains of small launches,
-        so the reverse one runs on a side stream beside the forward one (its backward follows it there)."""
+        Input projections for all steps are one GEMM per direction; the two recurrences advance in lockstep inside one fused
+        autograd node (ops.bilstm_sequences: one grouped GEMM + one cell launch per time step for both directions)."""
         rnn = self.recipe_encoder
-        outs = []
-        main = torch.cuda.current_stream() if x.is_cuda else None
-        for sfx, rows_t in (("", plan.lstm_fwd_rows), ("_reverse", plan.lstm_bwd_rows)):
+        gx, whh = [], []
+        for sfx in ("", "_reverse"):
             w_ih, w_hh = getattr(rnn, "weight_ih_l0" + sfx), getattr(rnn, "weight_hh_l0" + sfx)
             bias = getattr(rnn, "bias_ih_l0" + sfx) + getattr(rnn, "bias_hh_l0" + sfx)
-            side = ops.branch_stream(x.device) if (sfx and main is not None) else None
-            if side is None:
-                gx_all = ops.linear(x, w_ih, bias)                                           # (T, 4D)
-                outs.append(ops.lstm_sequence(gx_all, w_hh, rows_t, plan.lstm_active, plan.lstm_pick[sfx]))
-            else:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    gx_all = ops.linear(x, w_ih, bias)
-                    d = ops.lstm_sequence(gx_all, w_hh, rows_t, plan.lstm_active, plan.lstm_pick[sfx])
-                x.record_stream(side)
-                d.record_stream(main)
-                main.wait_stream(side)
-                outs.append(d)
-        return ops.add(outs[0], outs[1])
+            gx.append(ops.linear(x, w_ih, bias))                                             # (T, 4D)
+            whh.append(w_hh)
+        out_f, out_b = ops.bilstm_sequences(gx[0], gx[1], whh[0], whh[1], plan.lstm_fwd_rows, plan.lstm_bwd_rows, plan.lstm_active,
+                                            plan.lstm_pick[""], plan.lstm_pick["_reverse"])
+        return ops.add(out_f, out_b)
 
     def reconstruct(self, prediction_scores, text_mask, ga_ingr_vectors):
         """reference-shaped wrapper (model.py:1017-1025) for one video."""

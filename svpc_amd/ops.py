@@ -1065,6 +1065,112 @@ class _LstmSeq(Function):
         return dgx, dw, None, None, None, None
 
 
+class _GemmProblem(ctypes.Structure):
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("M", ctypes.c_int), ("N", ctypes.c_int),
+                ("K", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int), ("ldc", ctypes.c_int)]
+
+
+def _gemm_pair(As, Bs, Cs, M, N, K, accumulate=0):
+    """C_z (+)= A_z · B_zᵀ for z = 0, 1 (all k-contiguous fp32) in one grouped launch"""
+    probs = (_GemmProblem * 2)()
+    for z in range(2):
+        probs[z] = _GemmProblem(As[z].data_ptr(), Bs[z].data_ptr(), Cs[z].data_ptr(), M, N, K, As[z].stride(0), Bs[z].stride(0),
+                                Cs[z].stride(0))
+    _lib.call("gemm_group", ctypes.addressof(probs), 2, 1, 1, accumulate, _stream())
+
+
+def _ptr2(a, b):
+    arr = (ctypes.c_void_p * 2)(a.data_ptr(), b.data_ptr())
+    return ctypes.addressof(arr), arr          # keep `arr` alive until the call returns
+
+
+class _BiLstmSeq(Function):
+    """Both directions of the BiLSTM recurrence as ONE autograd node advancing in lockstep: per time step one grouped GEMM (the two
+    recurrent projections) and one cell launch (both directions) forward, one cell launch and one grouped dgrad GEMM backward —
+    half the launches of two independent direction nodes (see _LstmSeq for the per-direction scheme).  bf16-MFMA precision only."""
+
+    @staticmethod
+    def forward(ctx, gx_f, gx_b, w_f, w_b, rows_f, rows_b, active_t, pick_f, pick_b, wgrad_f, wgrad_b):
+        _need_gpu(gx_f)
+        gx = [_c(gx_f), _c(gx_b)]
+        w = [_c(w_f), _c(w_b)]
+        rows = [rows_f, rows_b]
+        S, N = len(rows_f), rows_f[0].numel()
+        D = w[0].shape[1]
+        dev = gx_f.device
+        mk = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        h_all, c_all = [mk(S + 1, N, D) for _ in range(2)], [mk(S + 1, N, D) for _ in range(2)]
+        for z in range(2):
+            h_all[z][0].zero_(); c_all[z][0].zero_()
+        gates = [mk(S, N, 4 * D) for _ in range(2)]
+        gh = [mk(N, 4 * D) for _ in range(2)]
+        st = _stream()
+        for t in range(S):
+            _gemm_pair([h_all[0][t], h_all[1][t]], w, gh, N, 4 * D, D)
+            args = [_ptr2(gx[0], gx[1]), _ptr2(rows[0][t], rows[1][t]), _ptr2(gh[0], gh[1]), _ptr2(c_all[0][t], c_all[1][t]),
+                    _ptr2(h_all[0][t], h_all[1][t]), None, _ptr2(h_all[0][t + 1], h_all[1][t + 1]),
+                    _ptr2(c_all[0][t + 1], c_all[1][t + 1]), _ptr2(gates[0][t], gates[1][t])]
+            _lib.call("lstm_pair_fwd", args[0][0], args[1][0], args[2][0], args[3][0], args[4][0], _p(active_t[t]), args[6][0],
+                      args[7][0], args[8][0], N, D, st)
+        outs = [torch.index_select(h_all[z][1:].reshape(S * N, D), 0, pk) for z, pk in enumerate((pick_f, pick_b))]
+        ctx.save_for_backward(gates[0], gates[1], c_all[0], c_all[1], h_all[0], h_all[1], w[0], w[1], pick_f, pick_b)
+        ctx.lists = active_t
+        ctx.direct = (wgrad_f, wgrad_b)
+        ctx.cfg = (S, N, D)
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, dout_f, dout_b):
+        g0, g1, c0, c1, h0, h1, w0, w1, pick_f, pick_b = ctx.saved_tensors
+        gates, c_all, h_all, w, picks = [g0, g1], [c0, c1], [h0, h1], [w0, w1], [pick_f, pick_b]
+        active_t = ctx.lists
+        S, N, D = ctx.cfg
+        dev = g0.device
+        mk = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        dhs = []
+        for z, d in enumerate((dout_f, dout_b)):
+            t_ = torch.zeros(S * N, D, dtype=torch.float32, device=dev)
+            if d is not None:
+                t_.index_copy_(0, picks[z].long(), _c(d))
+            dhs.append(t_.view(S, N, D))
+        dG = [mk(S, N, 4 * D) for _ in range(2)]
+        dh = [torch.zeros(N, D, dtype=torch.float32, device=dev) for _ in range(2)]
+        dc = [torch.zeros(N, D, dtype=torch.float32, device=dev) for _ in range(2)]
+        dh2, dc2 = [mk(N, D) for _ in range(2)], [mk(N, D) for _ in range(2)]
+        wt = [w[z].t().contiguous() for z in range(2)]        # (D, 4D): k-contiguous operand of the per-step dgrad
+        st = _stream()
+        for t in range(S - 1, -1, -1):
+            a = [_ptr2(dhs[0][t], dhs[1][t]), _ptr2(dh[0], dh[1]), _ptr2(dc[0], dc[1]), _ptr2(gates[0][t], gates[1][t]),
+                 _ptr2(c_all[0][t], c_all[1][t]), None, _ptr2(dG[0][t], dG[1][t]), _ptr2(dc2[0], dc2[1]), _ptr2(dh2[0], dh2[1])]
+            _lib.call("lstm_pair_bwd", a[0][0], a[1][0], a[2][0], a[3][0], a[4][0], _p(active_t[t]), a[6][0], a[7][0], a[8][0], N, D, st)
+            _gemm_pair([dG[0][t], dG[1][t]], wt, dh2, N, D, 4 * D, accumulate=1)      # dh_{t-1} = pass-through + dgates · W_hh
+            dh, dh2 = dh2, dh
+            dc, dc2 = dc2, dc
+        dws, dgx = [None, None], [None, None]
+        for z in range(2):
+            dG2, hp = dG[z].view(S * N, 4 * D), h_all[z][:S].reshape(S * N, D)
+            wgrad = ctx.direct[z]
+            if wgrad is not None or ctx.needs_input_grad[2 + z]:
+                if not (wgrad is not None and defer_wgrad(dG2, hp, wgrad, None)):
+                    acc = 1 if wgrad is not None else 0
+                    dw = wgrad if wgrad is not None else torch.empty_like(w[z])
+                    _gemm(dG2, 4 * D, 0, hp, D, 0, dw, 4 * D, D, S * N, accumulate=acc)
+                    if wgrad is not None:
+                        _ready(wgrad, "w")
+                    else:
+                        dws[z] = dw
+            if ctx.needs_input_grad[z]:
+                dgx[z] = torch.index_select(dG2, 0, picks[z])
+        return dgx[0], dgx[1], dws[0], dws[1], None, None, None, None, None, None, None
+
+
+def bilstm_sequences(gx_f, gx_b, w_f, w_b, rows_f, rows_b, active_t, pick_f, pick_b):
+    """Both LSTM directions (see lstm_sequence for the arguments) → (out_f, out_b), each (T, D)."""
+    if _PRECISION == "bf16" and gx_f.is_cuda:
+        return _BiLstmSeq.apply(gx_f, gx_b, w_f, w_b, rows_f, rows_b, active_t, pick_f, pick_b, _direct(w_f), _direct(w_b))
+    return lstm_sequence(gx_f, w_f, rows_f, active_t, pick_f), lstm_sequence(gx_b, w_b, rows_b, active_t, pick_b)
+
+
 def lstm_sequence(gx_all, w_hh, rows_t, active_t, pick):
     """gx_all (T, 4D): input projections of every step row; rows_t[t] (N,) the step row each video consumes at time t;
     active_t[t] (N,) 1/0; pick (T,) position of every step row's output in the time-major (S·N) state → (T, D)."""

@@ -529,3 +529,31 @@ def test_grouped_weight_gradients(bf16_mode):
         if with_b:
             rb = db0.double() + dz.double().sum(0)
             assert (db.double() - rb).abs().max().item() <= 1e-5 * max(1.0, rb.abs().max().item()), (rows, n_out)
+
+
+def test_bilstm_lockstep_matches_two_direction_nodes(bf16_mode):
+    """Fused two-direction recurrence (grouped GEMM + pair cell kernels) against the per-direction torch statement: outputs and
+    gradients of both input projections and both recurrent weights (bf16 MFMA operands → 2e-2 tolerance), ragged lengths."""
+    torch.manual_seed(0)
+    N, D, lens = 3, 32, [3, 1, 2]
+    S, T = max(lens), sum(lens)
+    off = [0, 3, 4]
+    mk = lambda f: [torch.tensor([f(b, t) for b in range(N)], dtype=torch.int32, device=DEV) for t in range(S)]
+    rows_f = mk(lambda b, t: off[b] + min(t, lens[b] - 1))
+    rows_b = mk(lambda b, t: off[b] + max(lens[b] - 1 - t, 0))
+    act_t = [torch.tensor([1.0 if t < lens[b] else 0.0 for b in range(N)], device=DEV) for t in range(S)]
+    pick_f = torch.tensor([s_ * N + b for b in range(N) for s_ in range(lens[b])], dtype=torch.int32, device=DEV)
+    pick_b = torch.tensor([(lens[b] - 1 - s_) * N + b for b in range(N) for s_ in range(lens[b])], dtype=torch.int32, device=DEV)
+    leaves = [torch.randn(T, 4 * D, device=DEV, requires_grad=True), torch.randn(T, 4 * D, device=DEV, requires_grad=True),
+              (0.3 * torch.randn(4 * D, D, device=DEV)).requires_grad_(True), (0.3 * torch.randn(4 * D, D, device=DEV)).requires_grad_(True)]
+    wt_f, wt_b = torch.randn(T, D, device=DEV), torch.randn(T, D, device=DEV)
+    res = []
+    for mod in (O, E):
+        for l in leaves:
+            l.grad = None
+        of, ob = mod.bilstm_sequences(leaves[0], leaves[1], leaves[2], leaves[3], rows_f, rows_b, act_t, pick_f, pick_b)
+        ((of * wt_f).sum() + (ob * wt_b).sum()).backward()
+        torch.cuda.synchronize()
+        res.append([of.detach().clone(), ob.detach().clone()] + [l.grad.clone() for l in leaves])
+    for a, b in zip(res[0], res[1]):
+        assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item()), (a - b).abs().max()
