@@ -245,7 +245,7 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
     static int split_below = -1;
     if (split_below < 0) { const char* e = getenv("SVPC_GLDS_SPLIT_BELOW"); split_below = e ? atoi(e) : 150; }   // ≥150 tiles already fill most CUs: a split would only add the reduce launch (measured)
     static int split_target = -1;
-    if (split_target < 0) { const char* e = getenv("SVPC_GLDS_SPLIT_TARGET"); split_target = e ? atoi(e) : 256; }   // ≈one workgroup per CU: fewer slabs to reduce (measured best of 128…1024)
+    if (split_target < 0) { const char* e = getenv("SVPC_GLDS_SPLIT_TARGET"); split_target = e ? atoi(e) : 512; }   // two workgroups per CU (measured best of 128…1024 when the step replays as one linear chain)
     if (K >= 512 && tiles < split_below) {
         splitk = ceil_div(split_target, tiles);
         const int max_by_k = K / 256;
