@@ -108,6 +108,9 @@ typedef struct svpc_wgrad_problem {
     int n_out, n_in, rows, ld_dz, ld_x, ld_dw;
 } svpc_wgrad_problem;
 int svpc_gemm_group_wgrad_max(void);
+/* the same for the bf16 activation streams (dz, x bf16; dw fp32; db must be NULL; n_out % 8 == 0, n_in % 8 == 0, any row count):
+ * every 128² tile runs its whole k-loop — no split-K slabs, no reduce launches */
+int svpc_gemm_group_wgrad_bf16(const svpc_wgrad_problem* problems, int n, svpc_stream_t stream);
 int svpc_gemm_group_wgrad(const svpc_wgrad_problem* problems, int n, svpc_stream_t stream);
 /* dz = dy · act'(aux) · dropout  (aux = pre-activation for GELU, activated output for ReLU / sigmoid) */
 int svpc_act_bwd(const float* dy, const float* aux, float* dz, size_t n, int act, float p, unsigned site, const svpc_u64* seed,

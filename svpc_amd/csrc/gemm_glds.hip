@@ -75,19 +75,15 @@ __device__ __forceinline__ bf16x8 glds_fragment(const char* __restrict__ img, in
 // BM = 128: waves 2 (m) × 4 (n), wave tile 64×32.  BM = 256: the A tile is two 128-row images, waves 4 (m) × 2 (n), wave tile
 // 64×64 — 4 MFMAs per 4 fragment reads instead of 2 per 3, and half as many workgroups, which matters when 128-row tiles would
 // leave a mostly empty second round of workgroups (900 tiles on 768 resident slots → 450 on 512).
+// one (tile, k-slice) of one problem; `smem` = NS·(BM/128 + 1)·8 KiB of LDS
 template <bool A_KC, bool B_KC, typename TC, int NS, int BM>
-__global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B, int ldb,
-                                                        TC* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_m,
-                                                        int tiles_n, int splitk, int k_chunk, float* __restrict__ slabs, int remap) {
+__device__ __forceinline__ void glds_tile(char* __restrict__ smem, const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B, int ldb,
+                                          TC* __restrict__ C, int ldc, int M, int N, int K, const Epi& epi, int tm, int tn, int ks_id,
+                                          int splitk, int k_chunk, float* __restrict__ slabs) {
     constexpr int AH = BM / 128;                         // 128-row halves of the A tile
     constexpr int STAGE = (AH + 1) * GL_OP;
     constexpr int TNF = BM == 256 ? 2 : 1;               // B fragments (32 columns each) per wave
     constexpr int P = AH + 1;                            // LDS-DMA pieces per wave and k-tile
-    __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
-    const int wg = remap ? xcd_remap(blockIdx.x, tiles_m * tiles_n * splitk) : (int)blockIdx.x;
-    const int ks_id = wg / (tiles_m * tiles_n);
-    const int tile = wg - ks_id * (tiles_m * tiles_n);
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * GL_BN;
     const int k_begin = ks_id * k_chunk;
     const int k_end = min(K, k_begin + k_chunk);
@@ -205,6 +201,39 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict
     }
 }
 
+template <bool A_KC, bool B_KC, typename TC, int NS, int BM>
+__global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B, int ldb,
+                                                        TC* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_m,
+                                                        int tiles_n, int splitk, int k_chunk, float* __restrict__ slabs, int remap) {
+    constexpr int STAGE = (BM / 128 + 1) * GL_OP;
+    __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
+    const int wg = remap ? xcd_remap(blockIdx.x, tiles_m * tiles_n * splitk) : (int)blockIdx.x;
+    const int ks_id = wg / (tiles_m * tiles_n);
+    const int tile = wg - ks_id * (tiles_m * tiles_n);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    glds_tile<A_KC, B_KC, TC, NS, BM>(smem, A, lda, B, ldb, C, ldc, M, N, K, epi, tm, tn, ks_id, splitk, k_chunk, slabs);
+}
+
+// ---- grouped weight gradients of the bf16 activation streams: up to 48 problems dW_p[n_out, n_in] += dz_pᵀ·x_p (bf16 operands,
+// k-strided, any row count) in ONE launch, every 128² tile running its WHOLE k-loop (no split-K slabs, no reduce launches):
+// the ≈40 wgrads of a step (22 × K = 19,200 rows, 18 × K = 4,224) are ≈2,300 tiles — enough to fill the chip several times over.
+struct G16Prob { const __bf16* dz; const __bf16* x; float* dw; int n_out, n_in, rows, ld_dz, ld_x, ld_dw, tile0, tiles_n; };
+constexpr int G16_MAX = 48;
+struct G16Args { int n; int total; G16Prob p[G16_MAX]; };
+
+__global__ __launch_bounds__(512) void gemm_group_wgrad16_kernel(G16Args g) {
+    __shared__ __attribute__((aligned(1024))) char smem[3 * 2 * GL_OP];
+    const int wg = xcd_remap(blockIdx.x, g.total);
+    int pi = 0;
+    while (pi + 1 < g.n && wg >= g.p[pi + 1].tile0) ++pi;
+    const G16Prob& q = g.p[pi];
+    const int tile = wg - q.tile0;
+    const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
+    Epi epi{nullptr, ACT_NONE, 0.f, 0u, nullptr, 1, nullptr};
+    glds_tile<false, false, float, 3, 128>(smem, q.dz, q.ld_dz, q.x, q.ld_x, q.dw, q.ld_dw, q.n_out, q.n_in, q.rows, epi, tm, tn, 0, 1,
+                                           ((q.rows + GL_BK - 1) / GL_BK) * GL_BK, nullptr);
+}
+
 extern "C" {
 
 // 1 if (shape, layout) can run on the direct-to-LDS kernel: bf16 A and B with 16-byte aligned rows; any M and N (even N) for
@@ -216,6 +245,30 @@ int svpc_gemm_glds_supported(int a_kc, int b_kc, int lda, int ldb, int M, int N,
     if (!b_kc && N % 8 != 0) return 0;
     if ((a_kc || b_kc) && K % GL_BK != 0) return 0;
     return 1;
+}
+
+struct HostWgrad16Problem { const void* dz; const void* x; float* dw; float* db; int n_out, n_in, rows, ld_dz, ld_x, ld_dw; };
+
+int svpc_gemm_group_wgrad_bf16(const void* problems, int n, hipStream_t stream) {
+    if (n == 0) return 0;
+    SVPC_REQUIRE(n > 0 && n <= G16_MAX, "gemm_group_wgrad_bf16: 1..48 problems per launch");
+    const HostWgrad16Problem* hp = reinterpret_cast<const HostWgrad16Problem*>(problems);
+    G16Args g{};
+    g.n = n;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const HostWgrad16Problem& h = hp[i];
+        SVPC_REQUIRE(svpc_gemm_glds_supported(0, 0, h.ld_dz, h.ld_x, h.n_out, h.n_in, h.rows) &&
+                         ((((uintptr_t)h.dz) | ((uintptr_t)h.x)) & 15) == 0 && h.db == nullptr,
+                     "gemm_group_wgrad_bf16: n_out % 8, n_in % 8, 16-byte aligned bf16 rows; no bias output");
+        G16Prob& q = g.p[i];
+        q.dz = (const __bf16*)h.dz; q.x = (const __bf16*)h.x; q.dw = h.dw; q.n_out = h.n_out; q.n_in = h.n_in; q.rows = h.rows;
+        q.ld_dz = h.ld_dz; q.ld_x = h.ld_x; q.ld_dw = h.ld_dw; q.tile0 = tiles; q.tiles_n = ceil_div(h.n_in, GL_BN);
+        tiles += ceil_div(h.n_out, 128) * q.tiles_n;
+    }
+    g.total = tiles;
+    hipLaunchKernelGGL(gemm_group_wgrad16_kernel, dim3(tiles), dim3(512), 0, stream, g);
+    return svpc_check_launch("gemm_group_wgrad_bf16");
 }
 
 // A, B bf16; C bf16 (c_dt = 1) or fp32 (c_dt = 0); Z (optional pre-activation copy) has C's type.

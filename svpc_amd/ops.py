@@ -74,6 +74,7 @@ def branch_stream(device):
 # all-reduced, before the optimizer).  ≈50 text-side / step-level linears per step × 3 launches (wgrad, column sum, finalize) of
 # ≈5–15 µs each become 2–3 launches.
 USE_GROUPED_WGRAD = os.environ.get("SVPC_NO_GROUPED_WGRAD", "") == ""
+GROUP_BF16 = os.environ.get("SVPC_NO_GROUP_BF16", "") == ""      # also the bf16-stream wgrads (one launch, no split-K)
 GROUP_FLUSH_AT = int(os.environ.get("SVPC_GROUP_FLUSH_AT", "16"))
 _WQ = []            # (dz, x, wgrad, bgrad)
 
@@ -93,8 +94,29 @@ def _queue_end_of_backward_join():
             pass
 
 
+_WQ16 = []          # bf16-stream problems (dz, x, wgrad, None): one launch at the join points, whole k-loop per tile
+
+
+def _defer_wgrad16(dz, x, wgrad):
+    rows, n_out = dz.shape
+    n_in = x.shape[1]
+    if n_out % 8 or n_in % 8 or dz.stride(0) % 8 or x.stride(0) % 8 or wgrad.stride(0) % 4 or rows < 1:
+        return False
+    if (dz.data_ptr() | x.data_ptr()) % 16 or dz.stride(1) != 1 or x.stride(1) != 1 or not wgrad.is_contiguous():
+        return False
+    wp = wgrad.data_ptr()
+    if any(q[2].data_ptr() == wp for q in _WQ16) or len(_WQ16) >= _lib.load().svpc_gemm_group_wgrad_max():
+        flush_wgrads()
+    _WQ16.append((dz, x, wgrad, None))
+    _queue_end_of_backward_join()
+    return True
+
+
 def defer_wgrad(dz, x, wgrad, bgrad):
     """Queue dW += dzᵀ·x (and db += Σ dz) for the grouped launch; False if this problem must be launched on its own."""
+    if USE_GROUPED_WGRAD and GROUP_BF16 and _PRECISION == "bf16" and wgrad is not None and bgrad is None and not SIDE_WGRAD and \
+            dz.dtype == torch.bfloat16 and x.dtype == torch.bfloat16:
+        return _defer_wgrad16(dz, x, wgrad)
     if not (USE_GROUPED_WGRAD and _PRECISION == "bf16" and wgrad is not None and dz.dtype == torch.float32 and x.dtype == torch.float32):
         return False
     rows, n_out = dz.shape
@@ -117,6 +139,16 @@ def defer_wgrad(dz, x, wgrad, bgrad):
 
 
 def flush_wgrads():
+    if _WQ16:
+        probs = (_WgradProblem * len(_WQ16))()
+        for i, (dz, x, wg, _) in enumerate(_WQ16):
+            probs[i] = _WgradProblem(dz.data_ptr(), x.data_ptr(), wg.data_ptr(), None, dz.shape[1], x.shape[1], dz.shape[0],
+                                     dz.stride(0), x.stride(0), wg.stride(0))
+        _lib.call("gemm_group_wgrad_bf16", ctypes.addressof(probs), len(_WQ16), _stream())
+        done = list(_WQ16)
+        del _WQ16[:]
+        for _, _, wg, _ in done:
+            _ready(wg, "w")
     if not _WQ:
         return
     dev = _WQ[0][0].device
@@ -472,9 +504,14 @@ class _Linear(Function):
             dx = torch.empty(M, K, dtype=x.dtype, device=dy.device)
             _gemm(dz, N, 1, w, w.stride(0), 1 if trans_w else 0, dx, M, K, N)
         wgrad, bgrad = ctx.direct
-        if wgrad is not None and not trans_w and (not has_b or bgrad is not None) and defer_wgrad(dz, x, wgrad, bgrad if has_b else None):
-            return dx, None, None, None, None, None, None, None, None
-        if wgrad is not None or ctx.needs_input_grad[1]:
+        w_done = False
+        if wgrad is not None and not trans_w and (not has_b or bgrad is not None):
+            if dz.dtype == torch.bfloat16:
+                if defer_wgrad(dz, x, wgrad, None):           # bf16 stream: grouped wgrad; the bias gradient goes its usual way below
+                    w_done = True
+            elif defer_wgrad(dz, x, wgrad, bgrad if has_b else None):
+                return dx, None, None, None, None, None, None, None, None
+        if not w_done and (wgrad is not None or ctx.needs_input_grad[1]):
             acc = 1 if wgrad is not None else 0
             dw = wgrad if wgrad is not None else torch.empty_like(w)
             with _side_of(wgrad, dz, x):

@@ -557,3 +557,25 @@ def test_bilstm_lockstep_matches_two_direction_nodes(bf16_mode):
         res.append([of.detach().clone(), ob.detach().clone()] + [l.grad.clone() for l in leaves])
     for a, b in zip(res[0], res[1]):
         assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item()), (a - b).abs().max()
+
+
+def test_grouped_weight_gradients_bf16(bf16_mode):
+    """svpc_gemm_group_wgrad_bf16: bf16-stream problems (ragged row counts, both tile edges) in one launch, whole k-loop per tile,
+    accumulating into non-zero fp32 targets — against fp64."""
+    import ctypes
+    shapes = [(19200, 768, 768), (4224, 2304, 768), (1000, 768, 3072), (100, 136, 72), (4230, 768, 768), (7, 8, 8)]
+    g = torch.Generator().manual_seed(9)
+    keep, probs = [], (O._WgradProblem * len(shapes))()
+    for i, (rows, n_out, n_in) in enumerate(shapes):
+        dz = torch.randn(rows, n_out, generator=g).bfloat16().to(DEV)
+        x = torch.randn(rows, n_in, generator=g).bfloat16().to(DEV)
+        dw0 = torch.randn(n_out, n_in, generator=g).to(DEV)
+        dw = dw0.clone()
+        keep.append((dz, x, dw0, dw))
+        probs[i] = O._WgradProblem(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), None, n_out, n_in, rows, dz.stride(0), x.stride(0), dw.stride(0))
+    O._lib.call("gemm_group_wgrad_bf16", ctypes.addressof(probs), len(shapes), O._stream())
+    torch.cuda.synchronize()
+    for (rows, n_out, n_in), (dz, x, dw0, dw) in zip(shapes, keep):
+        ref = dw0.double() + dz.double().t() @ x.double()
+        tol = 2e-6 * math.sqrt(rows) * max(1.0, ref.abs().max().item())
+        assert (dw.double() - ref).abs().max().item() <= tol, (rows, n_out, n_in)
