@@ -221,8 +221,9 @@ struct G16Prob { const __bf16* dz; const __bf16* x; float* dw; int n_out, n_in, 
 constexpr int G16_MAX = 48;
 struct G16Args { int n; int total; G16Prob p[G16_MAX]; };
 
+template <int BM>
 __global__ __launch_bounds__(512) void gemm_group_wgrad16_kernel(G16Args g) {
-    __shared__ __attribute__((aligned(1024))) char smem[3 * 2 * GL_OP];
+    __shared__ __attribute__((aligned(1024))) char smem[3 * (BM / 128 + 1) * GL_OP];
     const int wg = xcd_remap(blockIdx.x, g.total);
     int pi = 0;
     while (pi + 1 < g.n && wg >= g.p[pi + 1].tile0) ++pi;
@@ -230,8 +231,8 @@ __global__ __launch_bounds__(512) void gemm_group_wgrad16_kernel(G16Args g) {
     const int tile = wg - q.tile0;
     const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
     Epi epi{nullptr, ACT_NONE, 0.f, 0u, nullptr, 1, nullptr};
-    glds_tile<false, false, float, 3, 128>(smem, q.dz, q.ld_dz, q.x, q.ld_x, q.dw, q.ld_dw, q.n_out, q.n_in, q.rows, epi, tm, tn, 0, 1,
-                                           ((q.rows + GL_BK - 1) / GL_BK) * GL_BK, nullptr);
+    glds_tile<false, false, float, 3, BM>(smem, q.dz, q.ld_dz, q.x, q.ld_x, q.dw, q.ld_dw, q.n_out, q.n_in, q.rows, epi, tm, tn, 0, 1,
+                                          ((q.rows + GL_BK - 1) / GL_BK) * GL_BK, nullptr);
 }
 
 extern "C" {
@@ -256,6 +257,10 @@ int svpc_gemm_group_wgrad_bf16(const void* problems, int n, hipStream_t stream) 
     G16Args g{};
     g.n = n;
     int tiles = 0;
+    static int bm_env = -1;
+    if (bm_env < 0) { const char* e = getenv("SVPC_GROUP16_BM"); bm_env = e ? atoi(e) : 256; }
+    int BMv = bm_env == 128 ? 128 : 256;          // 256-row tiles (wave tile 64×64) unless a problem is narrower than that
+    for (int i = 0; i < n; ++i) if (hp[i].n_out < 256) BMv = 128;
     for (int i = 0; i < n; ++i) {
         const HostWgrad16Problem& h = hp[i];
         SVPC_REQUIRE(svpc_gemm_glds_supported(0, 0, h.ld_dz, h.ld_x, h.n_out, h.n_in, h.rows) &&
@@ -264,10 +269,11 @@ int svpc_gemm_group_wgrad_bf16(const void* problems, int n, hipStream_t stream) 
         G16Prob& q = g.p[i];
         q.dz = (const __bf16*)h.dz; q.x = (const __bf16*)h.x; q.dw = h.dw; q.n_out = h.n_out; q.n_in = h.n_in; q.rows = h.rows;
         q.ld_dz = h.ld_dz; q.ld_x = h.ld_x; q.ld_dw = h.ld_dw; q.tile0 = tiles; q.tiles_n = ceil_div(h.n_in, GL_BN);
-        tiles += ceil_div(h.n_out, 128) * q.tiles_n;
+        tiles += ceil_div(h.n_out, BMv) * q.tiles_n;
     }
     g.total = tiles;
-    hipLaunchKernelGGL(gemm_group_wgrad16_kernel, dim3(tiles), dim3(512), 0, stream, g);
+    if (BMv == 256) hipLaunchKernelGGL(gemm_group_wgrad16_kernel<256>, dim3(tiles), dim3(512), 0, stream, g);
+    else hipLaunchKernelGGL(gemm_group_wgrad16_kernel<128>, dim3(tiles), dim3(512), 0, stream, g);
     return svpc_check_launch("gemm_group_wgrad_bf16");
 }
 

@@ -130,16 +130,16 @@ def defer_wgrad(dz, x, wgrad, bgrad):
         return False
     wp = wgrad.data_ptr()
     if any(q[2].data_ptr() == wp for q in _WQ):
-        flush_wgrads()            # two accumulations into one gradient stay ordered
+        flush_wgrads(bf16=False)  # two accumulations into one gradient stay ordered
     _WQ.append((dz, x, wgrad, bgrad))
     if len(_WQ) >= min(GROUP_FLUSH_AT, _lib.load().svpc_gemm_group_wgrad_max()):
-        flush_wgrads()            # early enough that the launch still runs beside the rest of the backward
+        flush_wgrads(bf16=False)
     _queue_end_of_backward_join()
     return True
 
 
-def flush_wgrads():
-    if _WQ16:
+def flush_wgrads(bf16=True):
+    if _WQ16 and bf16:
         probs = (_WgradProblem * len(_WQ16))()
         for i, (dz, x, wg, _) in enumerate(_WQ16):
             probs[i] = _WgradProblem(dz.data_ptr(), x.data_ptr(), wg.data_ptr(), None, dz.shape[1], x.shape[1], dz.shape[0],
