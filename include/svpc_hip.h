@@ -55,6 +55,9 @@ int svpc_bucket_colsum_t(const void* x, int x_dt, int ldx, const int* idx, int R
  * their arena targets: out(c) += Σ_g partial[g][c], c < split → out0[c], else out1[c - split].  `entries` is a HOST array. */
 typedef struct svpc_finalize_entry { const float* partial; float* out0; float* out1; int groups, ncols, split; } svpc_finalize_entry;
 int svpc_colsum_partial_t(const void* x, int x_dt, int ldx, int R, int C, float* partial, svpc_stream_t stream);
+/* first stages of up to 48 plain column sums (dt: 0 = fp32, 1 = bf16 input) in one launch; partial_i = svpc_colsum_chunks(R_i) × C_i */
+typedef struct svpc_colsum_entry { const void* x; float* partial; int dt, ldx, R, C; } svpc_colsum_entry;
+int svpc_multi_colsum(const svpc_colsum_entry* entries, int n, svpc_stream_t stream);
 int svpc_multi_finalize_max(void);
 int svpc_multi_finalize(const svpc_finalize_entry* entries, int n, svpc_stream_t stream);
 int svpc_ln_bwd_groups(int R); /* workspace floats needed by svpc_ln_bwd = (groups + 1) * 2 * D */

@@ -449,15 +449,13 @@ __global__ __launch_bounds__(256) void bucket_colsum_kernel(const T* __restrict_
 // Plain column sum (K = 1, no bucket index), vector form: a thread owns 16 bytes of a row (4 fp32 / 8 bf16 columns); the 256
 // threads are 64 column groups × 4 row lanes, each row lane keeps four rows in flight.  partial[chunk][c] as above.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x, int ldx, int R, int C, int rows_per_chunk,
-                                                         float* __restrict__ partial) {
+__device__ __forceinline__ void colsum_vec_block(float (*red)[512], const T* __restrict__ x, int ldx, int R, int C, int rows_per_chunk,
+                                                 float* __restrict__ partial, int colblock, int chunk) {
     constexpr int V = 16 / sizeof(T);
     typedef float vec16 __attribute__((ext_vector_type(4)));
     typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
-    __shared__ float red[4][64 * V];
     const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c0 = (blockIdx.x * 64 + cg) * V;
-    const int chunk = blockIdx.y;
+    const int c0 = (colblock * 64 + cg) * V;
     const int r0 = chunk * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
     float acc[V];
 #pragma unroll
@@ -488,9 +486,31 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x
     for (int j = 0; j < V; ++j) red[rl][cg * V + j] = acc[j];
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * V; i += 256) {
-        const int c = blockIdx.x * 64 * V + i;
+        const int c = colblock * 64 * V + i;
         if (c < C) partial[(size_t)chunk * C + c] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x, int ldx, int R, int C, int rows_per_chunk,
+                                                         float* __restrict__ partial) {
+    __shared__ float red[4][512];
+    colsum_vec_block<T>(red, x, ldx, R, C, rows_per_chunk, partial, blockIdx.x, blockIdx.y);
+}
+
+// Table-driven form: the first stage of up to 48 pending bias-gradient column sums (fp32 or bf16 inputs) in one launch.
+struct CEntry { const void* x; float* partial; int dt, ldx, R, C, rpc, colblocks, block0; };
+constexpr int CSUM_MAX = 48;
+struct CArgs { int n; CEntry e[CSUM_MAX]; };
+__global__ __launch_bounds__(256) void multi_colsum_kernel(CArgs a) {
+    __shared__ float red[4][512];
+    int ei = 0;
+    while (ei + 1 < a.n && (int)blockIdx.x >= a.e[ei + 1].block0) ++ei;
+    const CEntry& en = a.e[ei];
+    const int local = blockIdx.x - en.block0;
+    const int colblock = local % en.colblocks, chunk = local / en.colblocks;
+    if (en.dt == 0) colsum_vec_block<float>(red, (const float*)en.x, en.ldx, en.R, en.C, en.rpc, en.partial, colblock, chunk);
+    else colsum_vec_block<__bf16>(red, (const __bf16*)en.x, en.ldx, en.R, en.C, en.rpc, en.partial, colblock, chunk);
 }
 
 template <int NPL, int W>
@@ -636,6 +656,28 @@ int svpc_colsum_partial_t(const void* xv, int x_dt, int ldx, int R, int C, float
     if (x_dt == 0) hipLaunchKernelGGL(colsum_vec_kernel<float>, vg, dim3(256), 0, stream, (const float*)xv, ldx, R, C, rpc, partial);
     else hipLaunchKernelGGL(colsum_vec_kernel<__bf16>, vg, dim3(256), 0, stream, (const __bf16*)xv, ldx, R, C, rpc, partial);
     return svpc_check_launch("colsum_partial");
+}
+
+struct HostColsumEntry { const void* x; float* partial; int dt, ldx, R, C; };
+int svpc_multi_colsum(const void* entries, int n, hipStream_t stream) {
+    if (n == 0) return 0;
+    SVPC_REQUIRE(n > 0 && n <= CSUM_MAX, "multi_colsum: 1..48 entries per launch");
+    const HostColsumEntry* he = reinterpret_cast<const HostColsumEntry*>(entries);
+    CArgs a{};
+    a.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const int V = he[i].dt ? 8 : 4;
+        SVPC_REQUIRE(he[i].R > 0 && he[i].C % V == 0 && he[i].ldx % V == 0 && ((((uintptr_t)he[i].x)) & 15) == 0,
+                     "multi_colsum: 16-byte aligned rows required");
+        const int chunks = svpc_colsum_chunks(he[i].R);
+        a.e[i].x = he[i].x; a.e[i].partial = he[i].partial; a.e[i].dt = he[i].dt; a.e[i].ldx = he[i].ldx; a.e[i].R = he[i].R;
+        a.e[i].C = he[i].C; a.e[i].rpc = ceil_div(he[i].R, chunks); a.e[i].colblocks = ceil_div(he[i].C, 64 * V);
+        a.e[i].block0 = blocks;
+        blocks += a.e[i].colblocks * chunks;
+    }
+    hipLaunchKernelGGL(multi_colsum_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    return svpc_check_launch("multi_colsum");
 }
 
 struct HostFinalizeEntry { const float* partial; float* out0; float* out1; int groups, ncols, split; };

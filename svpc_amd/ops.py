@@ -178,6 +178,7 @@ def flush_wgrads(bf16=True):
 # Deferred reduction tails: the second stage of every bias-gradient column sum and of every LayerNorm gain/shift gradient (≈90 per
 # step, 5–6 µs each, a few KB of work) is queued and run as ONE table-driven launch (svpc_multi_finalize) at the join points.
 USE_MULTI_FINALIZE = os.environ.get("SVPC_NO_MULTI_FINALIZE", "") == ""
+GROUP_COLSUM = os.environ.get("SVPC_NO_GROUP_COLSUM", "") == ""
 _FQ = []            # (partial, out0, out1, groups, ncols, split)
 
 
@@ -197,7 +198,36 @@ def defer_finalize(partial, groups, ncols, out0, out1=None, split=None):
     _queue_end_of_backward_join()
 
 
+_CQ = []            # pending first stages of bias-gradient column sums: (x, partial)
+
+
+class _ColsumEntry(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("partial", ctypes.c_void_p), ("dt", ctypes.c_int), ("ldx", ctypes.c_int), ("R", ctypes.c_int),
+                ("C", ctypes.c_int)]
+
+
+def defer_colsum(x, out):
+    """out += Σ_rows x, both stages deferred: the column sums of all pending tensors run as one launch, then the finalizes"""
+    R, C = x.shape
+    partial = torch.empty(_lib.load().svpc_colsum_chunks(R) * C, dtype=torch.float32, device=x.device)
+    if len(_CQ) >= 48:
+        flush_finalizes()
+    _CQ.append((x, partial))
+    defer_finalize(partial, _lib.load().svpc_colsum_chunks(R), C, out)
+
+
+def _flush_colsums():
+    if not _CQ:
+        return
+    ents = (_ColsumEntry * len(_CQ))()
+    for i, (x, partial) in enumerate(_CQ):
+        ents[i] = _ColsumEntry(x.data_ptr(), partial.data_ptr(), _dt(x), x.stride(0), x.shape[0], x.shape[1])
+    _lib.call("multi_colsum", ctypes.addressof(ents), len(_CQ), _stream())
+    del _CQ[:]
+
+
 def flush_finalizes():
+    _flush_colsums()
     if not _FQ:
         return
     ents = (_FinalizeEntry * len(_FQ))()
@@ -526,10 +556,13 @@ class _Linear(Function):
             if bgrad is not None:
                 V = 8 if dz.dtype == torch.bfloat16 else 4
                 if (USE_MULTI_FINALIZE and not SIDE_WGRAD and N % V == 0 and dz.stride(0) % V == 0 and dz.data_ptr() % 16 == 0 and M > 0):
-                    chunks = _lib.load().svpc_colsum_chunks(M)
-                    partial = torch.empty(chunks * N, dtype=torch.float32, device=dz.device)
-                    _lib.call("colsum_partial_t", _p(dz), _dt(dz), dz.stride(0), M, N, _p(partial), _stream())
-                    defer_finalize(partial, chunks, N, bgrad)
+                    if GROUP_COLSUM:
+                        defer_colsum(dz, bgrad)
+                    else:
+                        chunks = _lib.load().svpc_colsum_chunks(M)
+                        partial = torch.empty(chunks * N, dtype=torch.float32, device=dz.device)
+                        _lib.call("colsum_partial_t", _p(dz), _dt(dz), dz.stride(0), M, N, _p(partial), _stream())
+                        defer_finalize(partial, chunks, N, bgrad)
                 else:
                     with _side_of(bgrad, dz):
                         _colsum(dz, out=bgrad.view(1, -1), accumulate=1)
