@@ -72,39 +72,143 @@ __device__ __forceinline__ bf16x8 glds_fragment(const char* __restrict__ img, in
     }
 }
 
+// ---- bf16 epilogue with an output ROW on a lane.  With the operands swapped (mfma(Bfrag, Afrag)) a 32×32 accumulator block holds
+// row `lane & 31` on the lane and columns (e&3) + 8·(e>>2) + 4·(lane>>5) in its 16 registers: four runs of 4 consecutive
+// columns.  Two v_permlane32_swap per pair of runs give every lane 8 consecutive columns → ONE 16-byte store per lane and pair
+// (2 store instructions per block instead of 8 dword stores through LDS-crossbar shuffles), the activation is a template constant.
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    union { __bf16 h[2]; uint32_t u; } pk;
+    pk.h[0] = (__bf16)lo; pk.h[1] = (__bf16)hi;
+    return pk.u;
+}
+template <int TMF, int TNF, int ACT>
+__device__ __forceinline__ void glds_store_rows(const floatx16 (&acc)[TMF][TNF], __bf16* __restrict__ C, int ldc, __bf16* __restrict__ Z,
+                                                const float* __restrict__ bias, int row0, int col0, int M, int N, int lane) {
+    const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TNF; ++j) {
+        const int cb = col0 + j * 32;
+        float bb[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int c = cb + 8 * g + 4 * lhi;
+            if (bias && c + 4 <= N) t = *reinterpret_cast<const float4*>(bias + c);
+            bb[4 * g] = t.x; bb[4 * g + 1] = t.y; bb[4 * g + 2] = t.z; bb[4 * g + 3] = t.w;
+        }
+#pragma unroll
+        for (int i = 0; i < TMF; ++i) {
+            const int row = row0 + i * 32 + l31;
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {            // runs k and k+1 → 8-column chunks k (lanes 0-31) and k+1 (lanes 32-63)
+                uint32_t y[4], z[4];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int e = 4 * (k + g);
+                    const float z0 = acc[i][j][e] + bb[e], z1 = acc[i][j][e + 1] + bb[e + 1];
+                    const float z2 = acc[i][j][e + 2] + bb[e + 2], z3 = acc[i][j][e + 3] + bb[e + 3];
+                    y[2 * g] = pack_bf16x2(apply_act(z0, ACT), apply_act(z1, ACT));
+                    y[2 * g + 1] = pack_bf16x2(apply_act(z2, ACT), apply_act(z3, ACT));
+                    if (Z) { z[2 * g] = pack_bf16x2(z0, z1); z[2 * g + 1] = pack_bf16x2(z2, z3); }
+                }
+                auto r0 = __builtin_amdgcn_permlane32_swap(y[0], y[2], false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(y[1], y[3], false, false);
+                const int cc = cb + 8 * (k + lhi);
+                const bool ok = row < M && cc + 8 <= N;
+                const size_t o = (size_t)row * ldc + cc;
+                if (ok) *reinterpret_cast<uint4*>(C + o) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                if (Z) {
+                    auto q0 = __builtin_amdgcn_permlane32_swap(z[0], z[2], false, false);
+                    auto q1 = __builtin_amdgcn_permlane32_swap(z[1], z[3], false, false);
+                    if (ok) *reinterpret_cast<uint4*>(Z + o) = make_uint4(q0[0], q1[0], q0[1], q1[1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one chunk at a time: keeps the register footprint of the tail small
+            }
+        }
+    }
+}
+// generic element-wise form of the same orientation (dropout, accumulate, split-K slabs, unaligned or ragged-by-less-than-8 outputs)
+template <int TMF, int TNF, typename TC>
+__device__ __forceinline__ void glds_store_rows_generic(const floatx16 (&acc)[TMF][TNF], TC* __restrict__ C, int ldc, const Epi& epi,
+                                                        int row0, int col0, int M, int N, int lane, int splitk, int ks_id,
+                                                        float* __restrict__ slabs) {
+    const u64 seed = (epi.p_drop > 0.f && splitk == 1) ? epi.seed[0] : 0ull;
+    const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
+    const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TNF; ++j)
+#pragma unroll
+        for (int i = 0; i < TMF; ++i) {
+            const int row = row0 + i * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int col = col0 + j * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                if (row >= M || col >= N) continue;
+                if (splitk == 1) epilogue_store_t<TC>(acc[i][j][e], row, col, C, ldc, epi, seed, inv_keep);
+                else slabs[((size_t)ks_id * M + row) * N + col] = acc[i][j][e];
+            }
+        }
+}
+template <int TMF, int TNF, typename TC>
+__device__ __forceinline__ void glds_store_tr(const floatx16 (&acc)[TMF][TNF], TC* __restrict__ C, int ldc, const Epi& epi, int row0,
+                                              int col0, int M, int N, int lane, int splitk, int ks_id, float* __restrict__ slabs) {
+    const bool fast = splitk == 1 && epi.p_drop <= 0.f && !epi.accumulate && (N & 7) == 0 && (ldc & 7) == 0 &&
+                      ((((uintptr_t)C) | ((uintptr_t)epi.Z) | ((uintptr_t)epi.bias)) & 15) == 0;
+    if (!fast) {
+        glds_store_rows_generic<TMF, TNF, TC>(acc, C, ldc, epi, row0, col0, M, N, lane, splitk, ks_id, slabs);
+        return;
+    }
+    __bf16* Cb = reinterpret_cast<__bf16*>(C);
+    __bf16* Zb = reinterpret_cast<__bf16*>(epi.Z);
+    switch (epi.act) {
+        case ACT_RELU: glds_store_rows<TMF, TNF, ACT_RELU>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane); break;
+        case ACT_GELU: glds_store_rows<TMF, TNF, ACT_GELU>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane); break;
+        case ACT_SIGMOID: glds_store_rows<TMF, TNF, ACT_SIGMOID>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane); break;
+        default: glds_store_rows<TMF, TNF, ACT_NONE>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane); break;
+    }
+}
+
+
 // BM = 128: waves 2 (m) × 4 (n), wave tile 64×32.  BM = 256: the A tile is two 128-row images, waves 4 (m) × 2 (n), wave tile
 // 64×64 — 4 MFMAs per 4 fragment reads instead of 2 per 3, and half as many workgroups, which matters when 128-row tiles would
 // leave a mostly empty second round of workgroups (900 tiles on 768 resident slots → 450 on 512).
 // one (tile, k-slice) of one problem; `smem` = NS·(BM/128 + 1)·8 KiB of LDS
-template <bool A_KC, bool B_KC, typename TC, int NS, int BM>
+template <bool A_KC, bool B_KC, typename TC, int NS, int BM, int BN = 128>
 __device__ __forceinline__ void glds_tile(char* __restrict__ smem, const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B, int ldb,
                                           TC* __restrict__ C, int ldc, int M, int N, int K, const Epi& epi, int tm, int tn, int ks_id,
                                           int splitk, int k_chunk, float* __restrict__ slabs) {
     constexpr int AH = BM / 128;                         // 128-row halves of the A tile
-    constexpr int STAGE = (AH + 1) * GL_OP;
+    constexpr int BH = BN / 128;                         // 128-column halves of the B tile
+    constexpr int STAGE = (AH + BH) * GL_OP;
+    constexpr bool BIG = BM == 256 && BN == 256;         // waves 2 (m) × 4 (n), wave tile 128×64
+    constexpr int TMF = BIG ? 4 : 2;                     // A fragments (32 rows each) per wave
     constexpr int TNF = BM == 256 ? 2 : 1;               // B fragments (32 columns each) per wave
-    constexpr int P = AH + 1;                            // LDS-DMA pieces per wave and k-tile
-    const int m0 = tm * BM, n0 = tn * GL_BN;
+    constexpr int P = AH + BH;                           // LDS-DMA pieces per wave and k-tile
+    constexpr bool TR = sizeof(TC) == 2;                 // bf16 outputs are accumulated transposed (operands swapped)
+    constexpr int WROWS = 32 * TMF;                      // rows of a wave tile
+    const int m0 = tm * BM, n0 = tn * BN;
     const int k_begin = ks_id * k_chunk;
     const int k_end = min(K, k_begin + k_chunk);
     const int nk = (k_end - k_begin + GL_BK - 1) / GL_BK;     // a partial last tile exists only with k-strided operands
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = BM == 256 ? wave >> 1 : wave >> 2, wc = BM == 256 ? wave & 1 : wave & 3;
+    const int wr = (BM == 256 && !BIG) ? wave >> 1 : wave >> 2, wc = (BM == 256 && !BIG) ? wave & 1 : wave & 3;
 
     size_t stepA, stepB;
     int kra, krb;
     const __bf16* ga[AH];
 #pragma unroll
     for (int h = 0; h < AH; ++h) ga[h] = glds_src<A_KC>(A, lda, m0, M, k_begin, wave, lane, stepA, kra, h);
-    const __bf16* gb = glds_src<B_KC>(B, ldb, n0, N, k_begin, wave, lane, stepB, krb);
+    const __bf16* gb[BH];
+#pragma unroll
+    for (int h = 0; h < BH; ++h) gb[h] = glds_src<B_KC>(B, ldb, n0, N, k_begin, wave, lane, stepB, krb, h);
     const __bf16* const zsrc = reinterpret_cast<const __bf16*>(glds_zeros);
     kra += k_begin; krb += k_begin;                           // absolute k-row of this lane in tile 0
     char* const my = smem + wave * 1024;        // this wave's 1-KiB slice inside an operand image
 
-    floatx16 acc[2][TNF];
+    floatx16 acc[TMF][TNF];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TMF; ++i)
 #pragma unroll
         for (int j = 0; j < TNF; ++j)
 #pragma unroll
@@ -118,9 +222,11 @@ __device__ __forceinline__ void glds_tile(char* __restrict__ smem, const __bf16*
             __builtin_amdgcn_global_load_lds((gl_gptr)(za_ ? zsrc : ga[h]), (gl_lptr)(st + h * GL_OP), 16, 0, 0);        \
             ga[h] += stepA;                                                                                               \
         }                                                                                                                 \
-        const __bf16* pb_ = (!B_KC && krb + (t) * GL_BK >= k_end) ? zsrc : gb;                                           \
-        __builtin_amdgcn_global_load_lds((gl_gptr)pb_, (gl_lptr)(st + AH * GL_OP), 16, 0, 0);                             \
-        gb += stepB;                                                                                                      \
+        const bool zb_ = !B_KC && krb + (t) * GL_BK >= k_end;                                                             \
+        _Pragma("unroll") for (int h = 0; h < BH; ++h) {                                                                  \
+            __builtin_amdgcn_global_load_lds((gl_gptr)(zb_ ? zsrc : gb[h]), (gl_lptr)(st + (AH + h) * GL_OP), 16, 0, 0); \
+            gb[h] += stepB;                                                                                               \
+        }                                                                                                                 \
     } while (0)
 
     for (int t = 0; t < NS - 1 && t < nk; ++t) GL_ISSUE(t);
@@ -137,22 +243,32 @@ __device__ __forceinline__ void glds_tile(char* __restrict__ smem, const __bf16*
         const char* sa = smem + (t % NS) * STAGE;
         const char* sb = sa + AH * GL_OP;
         // this wave's 64 A rows: BM = 128 → rows 64·wr of the single image; BM = 256 → image wr>>1, rows 64·(wr&1)
-        const char* sa_w = BM == 256 ? sa + (wr >> 1) * GL_OP : sa;
-        const int arow = BM == 256 ? (wr & 1) * 64 : wr * 64;
+        // (256×256: the wave's 128 A rows are image wr, its 64 B columns are columns 64·(wc&1) of image wc>>1)
+        const char* sa_w = BIG ? sa + wr * GL_OP : BM == 256 ? sa + (wr >> 1) * GL_OP : sa;
+        const int arow = BIG ? 0 : BM == 256 ? (wr & 1) * 64 : wr * 64;
+        const char* sb_w = BIG ? sb + (wc >> 1) * GL_OP : sb;
+        const int bcol = BIG ? (wc & 1) * 64 : wc * 32 * TNF;
 #pragma unroll
         for (int ks = 0; ks < GL_BK / 16; ++ks) {
             bf16x8 bfr[TNF];
 #pragma unroll
-            for (int j = 0; j < TNF; ++j) bfr[j] = glds_fragment<B_KC>(sb, wc * 32 * TNF + j * 32, ks, lane);
+            for (int j = 0; j < TNF; ++j) bfr[j] = glds_fragment<B_KC>(sb_w, bcol + j * 32, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TMF; ++i) {
                 const bf16x8 af = glds_fragment<A_KC>(sa_w, arow + i * 32, ks, lane);
 #pragma unroll
-                for (int j = 0; j < TNF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TNF; ++j)
+                    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af, acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
             }
         }
     }
 #undef GL_ISSUE
+
+    if (TR) {      // bf16 output: a row on a lane (see glds_store_rows)
+        glds_store_tr<TMF, TNF, TC>(acc, C, ldc, epi, m0 + wr * 32 * TMF, n0 + wc * 32 * TNF, M, N, lane, splitk, ks_id, slabs);
+        return;
+    }
 
     const u64 seed = (epi.p_drop > 0.f && splitk == 1) ? epi.seed[0] : 0ull;
     const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
@@ -160,40 +276,11 @@ __device__ __forceinline__ void glds_tile(char* __restrict__ smem, const __bf16*
 #pragma unroll
     for (int j = 0; j < TNF; ++j) {
         const int col = n0 + wc * 32 * TNF + j * 32 + l31;
-        if (sizeof(TC) == 2 && splitk == 1 && epi.p_drop <= 0.f && !(epi.accumulate && epi.Z)) {
-            const bool odd = lane & 1;
-            const float bias = (epi.bias && col < N) ? epi.bias[col] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const float z0 = acc[i][j][e] + bias, z1 = acc[i][j][e + 1] + bias;
-                    const float y0 = apply_act(z0, epi.act), y1 = apply_act(z1, epi.act);
-                    const float py = __shfl_xor(odd ? y0 : y1, 1, 64);
-                    const float pz = __shfl_xor(odd ? z0 : z1, 1, 64);
-                    const int row = m0 + wr * 64 + i * 32 + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2) + 4 * lhi;
-                    const size_t o = (size_t)row * ldc + (col & ~1);
-                    union { __bf16 h[2]; uint32_t u; } pk;
-                    float lo = odd ? py : y0, hi = odd ? y1 : py;
-                    if (row >= M || col >= N) continue;              // N is even: a column pair is valid or invalid as a whole
-                    if (epi.accumulate) {                            // C += …: the residual-gradient sink of a dgrad
-                        pk.u = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const __bf16*>(C) + o);
-                        lo += (float)pk.h[0]; hi += (float)pk.h[1];
-                    }
-                    pk.h[0] = (__bf16)lo; pk.h[1] = (__bf16)hi;
-                    *reinterpret_cast<uint32_t*>(reinterpret_cast<__bf16*>(C) + o) = pk.u;
-                    if (epi.Z) {
-                        pk.h[0] = (__bf16)(odd ? pz : z0); pk.h[1] = (__bf16)(odd ? z1 : pz);
-                        *reinterpret_cast<uint32_t*>(reinterpret_cast<__bf16*>(epi.Z) + o) = pk.u;
-                    }
-                }
-            continue;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TMF; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                const int row = m0 + wr * WROWS + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
                 if (row >= M || col >= N) continue;
                 if (splitk == 1) epilogue_store_t<TC>(acc[i][j][e], row, col, C, ldc, epi, seed, inv_keep);
                 else slabs[((size_t)ks_id * M + row) * N + col] = acc[i][j][e];
@@ -201,17 +288,175 @@ __device__ __forceinline__ void glds_tile(char* __restrict__ smem, const __bf16*
     }
 }
 
-template <bool A_KC, bool B_KC, typename TC, int NS, int BM>
-__global__ __launch_bounds__(512) void gemm_glds_kernel(const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B, int ldb,
+// ---- 256×256 tile, two wave groups in ping-pong ("pp").  Waves 0-3 and 4-7 (one of each per SIMD) own the upper / lower 128 rows;
+// a wave tile is 128×64 = 4×2 MFMA tiles.  Time is cut into barrier intervals; in every interval ONE group runs the 16 MFMAs of a
+// 32-deep k-tile (512 matrix-pipe cycles) while the OTHER reads its next 12 fragments from LDS and issues its share of the LDS-DMA
+// prefetch — the matrix pipe of a SIMD always has exactly one wave feeding it and the LDS reads hide behind the partner's MFMAs.
+//   group 0: reads k-tile t in interval 2t, multiplies it in interval 2t+1;  group 1: one interval later
+//   stage ring of 4 × 32 KiB (A0 A1 B0 B1 images of one 32-deep k-tile); tile t+3 is issued from the read phase of tile t
+//   (its stage held tile t-1, whose last read retired — lgkmcnt(0) before the barrier — in interval 2t-1);
+//   tile t+1 is waited for (counted vmcnt, never 0 in steady state) by every wave at the END of interval 2t+1, one barrier before
+//   its first read in interval 2t+2.
+template <bool A_KC, bool B_KC, typename TC>
+__device__ __forceinline__ void glds_tile_pp(char* __restrict__ smem, const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B,
+                                             int ldb, TC* __restrict__ C, int ldc, int M, int N, int K, const Epi& epi, int tm, int tn, int dbg = 0) {
+    constexpr int NS = 4, STAGE = 4 * GL_OP;
+    constexpr bool TR = sizeof(TC) == 2;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int nk = (K + GL_BK - 1) / GL_BK;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;             // wr = the wave's group
+
+    size_t stepA, stepB;
+    int kra, krb;
+    const __bf16* ga[2];
+    const __bf16* gb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) ga[h] = glds_src<A_KC>(A, lda, m0, M, 0, wave, lane, stepA, kra, h);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) gb[h] = glds_src<B_KC>(B, ldb, n0, N, 0, wave, lane, stepB, krb, h);
+    const __bf16* const zsrc = reinterpret_cast<const __bf16*>(glds_zeros);
+    char* const my = smem + wave * 1024;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // the two A pieces (which = 0) or the two B pieces (which = 1) of k-tile t
+#define PP_ISSUE(t, which)                                                                                                \
+    do {                                                                                                                  \
+        char* st = my + ((t) % NS) * STAGE;                                                                               \
+        if ((which) == 0) {                                                                                               \
+            const bool z_ = !A_KC && kra + (t) * GL_BK >= K;                                                              \
+            _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                               \
+                __builtin_amdgcn_global_load_lds((gl_gptr)(z_ ? zsrc : ga[h]), (gl_lptr)(st + h * GL_OP), 16, 0, 0);    \
+                ga[h] += stepA;                                                                                           \
+            }                                                                                                             \
+        } else {                                                                                                          \
+            const bool z_ = !B_KC && krb + (t) * GL_BK >= K;                                                              \
+            _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                               \
+                __builtin_amdgcn_global_load_lds((gl_gptr)(z_ ? zsrc : gb[h]), (gl_lptr)(st + (2 + h) * GL_OP), 16, 0, 0); \
+                gb[h] += stepB;                                                                                           \
+            }                                                                                                             \
+        }                                                                                                                 \
+    } while (0)
+    // every load of k-tile `t` issued by this wave has landed (tiles t+1 … t+2 may stay in flight)
+#define PP_WAIT(t)                                                                                                        \
+    do {                                                                                                                  \
+        const int rem_ = nk - 1 - (t);                                                                                    \
+        if (rem_ >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                   \
+        else if (rem_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                              \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                             \
+    } while (0)
+
+    for (int t = 0; t < NS - 1 && t < nk; ++t) { PP_ISSUE(t, 0); PP_ISSUE(t, 1); }
+    PP_WAIT(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) {                                       // group 1 runs one interval behind
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    for (int t = 0; t < nk; ++t) {
+        const char* sa_w = smem + (t % NS) * STAGE + wr * GL_OP;
+        const char* sb_w = smem + (t % NS) * STAGE + (2 + (wc >> 1)) * GL_OP;
+        const int bcol = (wc & 1) * 64;
+        // ---- read interval: the 12 fragments of k-tile t, then this wave's 4 pieces of k-tile t+3
+        bf16x8 bfr[2][2], afr[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[ks][j] = glds_fragment<B_KC>(sb_w, bcol + j * 32, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) afr[ks][i] = glds_fragment<A_KC>(sa_w, i * 32, ks, lane);
+        }
+        const bool more = t + NS - 1 < nk && !(dbg & 1);
+        if (more) PP_ISSUE(t + NS - 1, 0);                // A pieces here, B pieces between the MFMAs below
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (wr == 1 && t + 1 < nk) {                      // group 1 has issued only the A half of tile t+3 so far
+            if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA interval
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (!(dbg & 2))
+                    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], afr[ks][i], acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+            if (ks == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) PP_ISSUE(t + NS - 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (wr == 0 && t + 1 < nk) PP_WAIT(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();           // both groups pass the same number of barriers
+#undef PP_ISSUE
+#undef PP_WAIT
+
+    if (dbg & 4) return;
+    if (TR) {
+        glds_store_tr<4, 2, TC>(acc, C, ldc, epi, m0 + wr * 128, n0 + wc * 64, M, N, lane, 1, 0, nullptr);
+        return;
+    }
+    const u64 seed = epi.p_drop > 0.f ? epi.seed[0] : 0ull;
+    const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
+    const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wc * 64 + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                if (row >= M || col >= N) continue;
+                epilogue_store_t<TC>(acc[i][j][e], row, col, C, ldc, epi, seed, inv_keep);
+            }
+    }
+}
+
+template <bool A_KC, bool B_KC, typename TC>
+__global__ __launch_bounds__(512) void gemm_glds_pp_kernel(const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B, int ldb,
+                                                           TC* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_m,
+                                                           int tiles_n, int remap) {
+    __shared__ __attribute__((aligned(1024))) char smem[4 * 4 * GL_OP];
+    const int wg = remap ? xcd_remap(blockIdx.x, tiles_m * tiles_n) : (int)blockIdx.x;
+    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    glds_tile_pp<A_KC, B_KC, TC>(smem, A, lda, B, ldb, C, ldc, M, N, K, epi, tm, tn, remap >> 1);
+}
+
+// (second launch bound = waves per SIMD the register budget must allow: 3 / 2 / 1 workgroups of 8 waves per CU)
+template <bool A_KC, bool B_KC, typename TC, int NS, int BM, int BN = 128>
+__global__ __launch_bounds__(512, (BM == 256 && BN == 256) ? 2 : BM == 256 ? 4 : NS == 3 ? 6 : 4) void gemm_glds_kernel(const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B, int ldb,
                                                         TC* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_m,
                                                         int tiles_n, int splitk, int k_chunk, float* __restrict__ slabs, int remap) {
-    constexpr int STAGE = (BM / 128 + 1) * GL_OP;
+    constexpr int STAGE = (BM / 128 + BN / 128) * GL_OP;
     __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
     const int wg = remap ? xcd_remap(blockIdx.x, tiles_m * tiles_n * splitk) : (int)blockIdx.x;
     const int ks_id = wg / (tiles_m * tiles_n);
     const int tile = wg - ks_id * (tiles_m * tiles_n);
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    glds_tile<A_KC, B_KC, TC, NS, BM>(smem, A, lda, B, ldb, C, ldc, M, N, K, epi, tm, tn, ks_id, splitk, k_chunk, slabs);
+    glds_tile<A_KC, B_KC, TC, NS, BM, BN>(smem, A, lda, B, ldb, C, ldc, M, N, K, epi, tm, tn, ks_id, splitk, k_chunk, slabs);
 }
 
 // ---- grouped weight gradients of the bf16 activation streams: up to 48 problems dW_p[n_out, n_in] += dz_pᵀ·x_p (bf16 operands,
@@ -299,7 +544,15 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
     if (wgrad_bm < 0) { const char* e = getenv("SVPC_GLDS_WGRAD_BM"); wgrad_bm = e ? atoi(e) : 128; }
     if (!a_kc && !b_kc && M >= 256 && wgrad_bm == 256) BMv = 256;      // wgrad: split-K supplies the parallelism
     if (bm_env == 128 || bm_env == 256) BMv = bm_env;
-    const int tiles_m = ceil_div(M, BMv), tiles_n = ceil_div(N, GL_BN), tiles = tiles_m * tiles_n;
+    // 256×256 tiles (wave tile 128×64, 4-stage ring of 32 KiB stages = 128 KiB, one workgroup per CU): half the LDS reads and
+    // half the L2→LDS bytes per MFMA of the 256×128 tile; taken when such tiles alone fill most of the chip
+    static int big_env = -1;
+    if (big_env < 0) { const char* e = getenv("SVPC_GLDS_BIG"); big_env = e ? atoi(e) : 1; }
+    const int t_big = ceil_div(M, 256) * ceil_div(N, 256);
+    const bool big = big_env && (a_kc || b_kc) && t_big >= 200;
+    const int BNv = big ? 256 : GL_BN;
+    if (big) BMv = 256;
+    const int tiles_m = ceil_div(M, BMv), tiles_n = ceil_div(N, BNv), tiles = tiles_m * tiles_n;
     int splitk = 1;
     static int split_below = -1;
     if (split_below < 0) { const char* e = getenv("SVPC_GLDS_SPLIT_BELOW"); split_below = e ? atoi(e) : 150; }   // ≥150 tiles already fill most CUs: a split would only add the reduce launch (measured)
@@ -317,6 +570,8 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
     splitk = ceil_div(K, k_chunk);
     static int remap = -1;
     if (remap < 0) { const char* e = getenv("SVPC_GEMM_REMAP"); remap = e ? atoi(e) : 1; }
+    static int ppdbg = -1;
+    if (ppdbg < 0) { const char* e = getenv("SVPC_PP_DBG"); ppdbg = e ? atoi(e) : 0; }
     dim3 grid(tiles * splitk), block(512);
     static int ns = -1;
     if (ns < 0) { const char* e = getenv("SVPC_GLDS_NS"); ns = e ? atoi(e) : 3; }   // 3 stages = 48 KiB → 3 workgroups per CU (measured best)
@@ -325,7 +580,13 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
                        (TC*)C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, workspace, remap)
 #define GL_LAUNCH(AK, BKC, TC)                                                                                                       \
     do {                                                                                                                             \
-        if (BMv == 256) GL_LAUNCH1(AK, BKC, TC, 3, 256);                                                                             \
+        if (big && big_env == 2)                                                                                                     \
+            hipLaunchKernelGGL((gemm_glds_kernel<AK, BKC, TC, 4, 256, 256>), grid, block, 0, stream, (const __bf16*)A, lda,          \
+                               (const __bf16*)B, ldb, (TC*)C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, workspace, remap); \
+        else if (big)                                                                                                                \
+            hipLaunchKernelGGL((gemm_glds_pp_kernel<AK, BKC, TC>), grid, block, 0, stream, (const __bf16*)A, lda, (const __bf16*)B,  \
+                               ldb, (TC*)C, ldc, M, N, K, epi, tiles_m, tiles_n, remap | (ppdbg << 1));                              \
+        else if (BMv == 256) GL_LAUNCH1(AK, BKC, TC, 3, 256);                                                                          \
         else if (ns == 3) GL_LAUNCH1(AK, BKC, TC, 3, 128);                                                                           \
         else GL_LAUNCH1(AK, BKC, TC, 4, 128);                                                                                        \
     } while (0)
