@@ -297,9 +297,10 @@ __device__ __forceinline__ void glds_tile(char* __restrict__ smem, const __bf16*
 //   (its stage held tile t-1, whose last read retired — lgkmcnt(0) before the barrier — in interval 2t-1);
 //   tile t+1 is waited for (counted vmcnt, never 0 in steady state) by every wave at the END of interval 2t+1, one barrier before
 //   its first read in interval 2t+2.
-template <bool A_KC, bool B_KC, typename TC>
+template <bool A_KC, bool B_KC, typename TC, bool STAMP = false>
 __device__ __forceinline__ void glds_tile_pp(char* __restrict__ smem, const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B,
-                                             int ldb, TC* __restrict__ C, int ldc, int M, int N, int K, const Epi& epi, int tm, int tn, int dbg = 0) {
+                                             int ldb, TC* __restrict__ C, int ldc, int M, int N, int K, const Epi& epi, int tm, int tn,
+                                             unsigned long long* __restrict__ stamps = nullptr) {
     constexpr int NS = 4, STAGE = 4 * GL_OP;
     constexpr bool TR = sizeof(TC) == 2;
     const int m0 = tm * 256, n0 = tn * 256;
@@ -353,6 +354,14 @@ __device__ __forceinline__ void glds_tile_pp(char* __restrict__ smem, const __bf
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                             \
     } while (0)
 
+    // development aid: s_memtime stamps of workgroup 0, waves 0 and 4, five per k-tile, kept in the LDS tail and copied out at the end
+    unsigned long long* const slog = reinterpret_cast<unsigned long long*>(smem + NS * STAGE) + (wr * 6 * 64);
+    const bool stamping = STAMP && blockIdx.x == 0 && (wave & 3) == 0;
+#define PP_STAMP(t, i)                                                                                                    \
+    do {                                                                                                                  \
+        if (STAMP && stamping && (t) < 64) slog[(i) * 64 + (t)] = __builtin_amdgcn_s_memtime();                           \
+    } while (0)
+
     for (int t = 0; t < NS - 1 && t < nk; ++t) { PP_ISSUE(t, 0); PP_ISSUE(t, 1); }
     PP_WAIT(0);
     __builtin_amdgcn_s_barrier();
@@ -367,6 +376,7 @@ __device__ __forceinline__ void glds_tile_pp(char* __restrict__ smem, const __bf
         const char* sb_w = smem + (t % NS) * STAGE + (2 + (wc >> 1)) * GL_OP;
         const int bcol = (wc & 1) * 64;
         // ---- read interval: the 12 fragments of k-tile t, then this wave's 4 pieces of k-tile t+3
+        PP_STAMP(t, 0);
         bf16x8 bfr[2][2], afr[2][4];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -375,18 +385,16 @@ __device__ __forceinline__ void glds_tile_pp(char* __restrict__ smem, const __bf
 #pragma unroll
             for (int i = 0; i < 4; ++i) afr[ks][i] = glds_fragment<A_KC>(sa_w, i * 32, ks, lane);
         }
-        const bool more = t + NS - 1 < nk && !(dbg & 1);
-        if (more) PP_ISSUE(t + NS - 1, 0);                // A pieces here, B pieces between the MFMAs below
+        const bool more = t + NS - 1 < nk;
+        if (more) { PP_ISSUE(t + NS - 1, 0); PP_ISSUE(t + NS - 1, 1); }   // (issued between the MFMAs instead they cost more: measured)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (wr == 1 && t + 1 < nk) {                      // group 1 has issued only the A half of tile t+3 so far
-            if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        PP_STAMP(t, 1);
+        if (wr == 1 && t + 1 < nk) PP_WAIT(t + 1);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- MFMA interval
+        PP_STAMP(t, 2);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -394,26 +402,27 @@ __device__ __forceinline__ void glds_tile_pp(char* __restrict__ smem, const __bf
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    if (!(dbg & 2))
                     acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], afr[ks][i], acc[i][j], 0, 0, 0)
                                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
-            if (ks == 0) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) PP_ISSUE(t + NS - 1, 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
         __builtin_amdgcn_s_setprio(0);
+        PP_STAMP(t, 3);
         if (wr == 0 && t + 1 < nk) PP_WAIT(t + 1);
+        PP_STAMP(t, 4);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(t, 5);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();           // both groups pass the same number of barriers
 #undef PP_ISSUE
 #undef PP_WAIT
+#undef PP_STAMP
+    if (STAMP && stamping && stamps) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = lane; i < 6 * 64; i += 64) stamps[wr * 6 * 64 + i] = slog[i];
+    }
 
-    if (dbg & 4) return;
     if (TR) {
         glds_store_tr<4, 2, TC>(acc, C, ldc, epi, m0 + wr * 128, n0 + wc * 64, M, N, lane, 1, 0, nullptr);
         return;
@@ -435,14 +444,14 @@ __device__ __forceinline__ void glds_tile_pp(char* __restrict__ smem, const __bf
     }
 }
 
-template <bool A_KC, bool B_KC, typename TC>
+template <bool A_KC, bool B_KC, typename TC, bool STAMP = false>
 __global__ __launch_bounds__(512) void gemm_glds_pp_kernel(const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B, int ldb,
                                                            TC* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_m,
-                                                           int tiles_n, int remap) {
-    __shared__ __attribute__((aligned(1024))) char smem[4 * 4 * GL_OP];
+                                                           int tiles_n, int remap, unsigned long long* __restrict__ stamps = nullptr) {
+    __shared__ __attribute__((aligned(1024))) char smem[4 * 4 * GL_OP + (STAMP ? 2 * 6 * 64 * 8 : 0)];
     const int wg = remap ? xcd_remap(blockIdx.x, tiles_m * tiles_n) : (int)blockIdx.x;
     const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
-    glds_tile_pp<A_KC, B_KC, TC>(smem, A, lda, B, ldb, C, ldc, M, N, K, epi, tm, tn, remap >> 1);
+    glds_tile_pp<A_KC, B_KC, TC, STAMP>(smem, A, lda, B, ldb, C, ldc, M, N, K, epi, tm, tn, stamps);
 }
 
 // (second launch bound = waves per SIMD the register budget must allow: 3 / 2 / 1 workgroups of 8 waves per CU)
@@ -480,6 +489,19 @@ __global__ __launch_bounds__(512) void gemm_group_wgrad16_kernel(G16Args g) {
                                           ((q.rows + GL_BK - 1) / GL_BK) * GL_BK, nullptr);
 }
 
+// the same table on 256×256 ping-pong tiles (problems at least 256 wide both ways); deep problems are dealt first
+__global__ __launch_bounds__(512) void gemm_group_wgrad16_pp_kernel(G16Args g) {
+    __shared__ __attribute__((aligned(1024))) char smem[4 * 4 * GL_OP];
+    const int wg = blockIdx.x;
+    int pi = 0;
+    while (pi + 1 < g.n && wg >= g.p[pi + 1].tile0) ++pi;
+    const G16Prob& q = g.p[pi];
+    const int tile = wg - q.tile0;
+    const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
+    Epi epi{nullptr, ACT_NONE, 0.f, 0u, nullptr, 1, nullptr};
+    glds_tile_pp<false, false, float>(smem, q.dz, q.ld_dz, q.x, q.ld_x, q.dw, q.ld_dw, q.n_out, q.n_in, q.rows, epi, tm, tn);
+}
+
 extern "C" {
 
 // 1 if (shape, layout) can run on the direct-to-LDS kernel: bf16 A and B with 16-byte aligned rows; any M and N (even N) for
@@ -505,19 +527,36 @@ int svpc_gemm_group_wgrad_bf16(const void* problems, int n, hipStream_t stream) 
     static int bm_env = -1;
     if (bm_env < 0) { const char* e = getenv("SVPC_GROUP16_BM"); bm_env = e ? atoi(e) : 256; }
     int BMv = bm_env == 128 ? 128 : 256;          // 256-row tiles (wave tile 64×64) unless a problem is narrower than that
-    for (int i = 0; i < n; ++i) if (hp[i].n_out < 256) BMv = 128;
+    static int pp_env = -1;
+    if (pp_env < 0) { const char* e = getenv("SVPC_GROUP16_PP"); pp_env = e ? atoi(e) : 1; }
+    bool pp = pp_env != 0;                        // 256×256 ping-pong tiles when every problem is at least that wide
     for (int i = 0; i < n; ++i) {
-        const HostWgrad16Problem& h = hp[i];
+        if (hp[i].n_out < 256) BMv = 128;
+        if (hp[i].n_out < 256 || hp[i].n_in < 256) pp = false;
+    }
+    int order[G16_MAX];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    if (pp)                                       // deepest reductions first: the short ones fill the tail of the launch
+        for (int i = 1; i < n; ++i) {
+            const int v = order[i];
+            int j = i - 1;
+            while (j >= 0 && hp[order[j]].rows < hp[v].rows) { order[j + 1] = order[j]; --j; }
+            order[j + 1] = v;
+        }
+    for (int ii = 0; ii < n; ++ii) {
+        const int i = ii;
+        const HostWgrad16Problem& h = hp[order[ii]];
         SVPC_REQUIRE(svpc_gemm_glds_supported(0, 0, h.ld_dz, h.ld_x, h.n_out, h.n_in, h.rows) &&
                          ((((uintptr_t)h.dz) | ((uintptr_t)h.x)) & 15) == 0 && h.db == nullptr,
                      "gemm_group_wgrad_bf16: n_out % 8, n_in % 8, 16-byte aligned bf16 rows; no bias output");
         G16Prob& q = g.p[i];
         q.dz = (const __bf16*)h.dz; q.x = (const __bf16*)h.x; q.dw = h.dw; q.n_out = h.n_out; q.n_in = h.n_in; q.rows = h.rows;
-        q.ld_dz = h.ld_dz; q.ld_x = h.ld_x; q.ld_dw = h.ld_dw; q.tile0 = tiles; q.tiles_n = ceil_div(h.n_in, GL_BN);
+        q.ld_dz = h.ld_dz; q.ld_x = h.ld_x; q.ld_dw = h.ld_dw; q.tile0 = tiles; q.tiles_n = ceil_div(h.n_in, pp ? 256 : GL_BN);
         tiles += ceil_div(h.n_out, BMv) * q.tiles_n;
     }
     g.total = tiles;
-    if (BMv == 256) hipLaunchKernelGGL(gemm_group_wgrad16_kernel<256>, dim3(tiles), dim3(512), 0, stream, g);
+    if (pp) hipLaunchKernelGGL(gemm_group_wgrad16_pp_kernel, dim3(tiles), dim3(512), 0, stream, g);
+    else if (BMv == 256) hipLaunchKernelGGL(gemm_group_wgrad16_kernel<256>, dim3(tiles), dim3(512), 0, stream, g);
     else hipLaunchKernelGGL(gemm_group_wgrad16_kernel<128>, dim3(tiles), dim3(512), 0, stream, g);
     return svpc_check_launch("gemm_group_wgrad_bf16");
 }
@@ -585,11 +624,16 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
                                (const __bf16*)B, ldb, (TC*)C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, workspace, remap); \
         else if (big)                                                                                                                \
             hipLaunchKernelGGL((gemm_glds_pp_kernel<AK, BKC, TC>), grid, block, 0, stream, (const __bf16*)A, lda, (const __bf16*)B,  \
-                               ldb, (TC*)C, ldc, M, N, K, epi, tiles_m, tiles_n, remap | (ppdbg << 1));                              \
+                               ldb, (TC*)C, ldc, M, N, K, epi, tiles_m, tiles_n, remap, nullptr);                                    \
         else if (BMv == 256) GL_LAUNCH1(AK, BKC, TC, 3, 256);                                                                          \
         else if (ns == 3) GL_LAUNCH1(AK, BKC, TC, 3, 128);                                                                           \
         else GL_LAUNCH1(AK, BKC, TC, 4, 128);                                                                                        \
     } while (0)
+    if (big && (ppdbg & 8) && c_dt == 1 && a_kc && b_kc && workspace) {      // development aid: stamped instance, stamps → workspace
+        hipLaunchKernelGGL((gemm_glds_pp_kernel<true, true, __bf16, true>), grid, block, 0, stream, (const __bf16*)A, lda, (const __bf16*)B,
+                           ldb, (__bf16*)C, ldc, M, N, K, epi, tiles_m, tiles_n, remap, (unsigned long long*)workspace);
+        return svpc_check_launch("gemm_glds pp stamped");
+    }
     if (c_dt == 1) {
         if (a_kc && b_kc) GL_LAUNCH(true, true, __bf16);
         else if (a_kc && !b_kc) GL_LAUNCH(true, false, __bf16);

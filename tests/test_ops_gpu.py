@@ -503,6 +503,34 @@ def test_single_query_attention_for_decoding(H, dh, k_lens):
         assert torch.allclose(got, ref, rtol=2e-5, atol=2e-6), (got - ref).abs().max()
 
 
+@pytest.mark.parametrize("M,N,K,a_kc,b_kc", [(19200, 768, 768, 1, 1), (19200, 768, 2304, 1, 0), (18000, 760, 768, 1, 1), (15608, 1000, 96, 1, 0),
+                                              (13000, 1024, 64, 1, 1)])
+def test_glds_pingpong_tiles(bf16_mode, M, N, K, a_kc, b_kc):
+    """stream-sized bf16 GEMMs take the 256×256 ping-pong kernel (≥200 such tiles): forward (NT) and dgrad (NN) layouts, ragged M and N
+    edges, K shallower than the prefetch ring; plain, bias + GELU + pre-activation copy (16-byte row stores), and the element-wise
+    epilogue (accumulate) — against fp64 of the same bf16 operands"""
+    g = torch.Generator().manual_seed(M + N + K)
+    bf = torch.bfloat16
+    A = torch.randn((M, K) if a_kc else (K, M), generator=g).to(bf).to(DEV)
+    B = (0.05 * torch.randn((N, K) if b_kc else (K, N), generator=g)).to(bf).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    ref = (A.double() if a_kc else A.double().t()) @ (B.double().t() if b_kc else B.double())
+    scale = max(1.0, ref.abs().max().item())
+    C = torch.empty(M, N, device=DEV, dtype=bf)
+    O._gemm(A, A.stride(0), a_kc, B, B.stride(0), b_kc, C, M, N, K)
+    assert (C.double() - ref).abs().max().item() <= 6e-3 * scale
+    Z = torch.empty(M, N, device=DEV, dtype=bf)
+    O._gemm(A, A.stride(0), a_kc, B, B.stride(0), b_kc, C, M, N, K, bias=bias, act=O.ACT_GELU, Z=Z)
+    zr = ref + bias.double()
+    zscale = max(scale, zr.abs().max().item())                     # bf16 storage: half an ulp of the largest stored value
+    assert (Z.double() - zr).abs().max().item() <= 6e-3 * zscale
+    assert (C.double() - torch.nn.functional.gelu(zr)).abs().max().item() <= 6e-3 * zscale
+    C0 = torch.randn(M, N, generator=g).to(bf).to(DEV)
+    C = C0.clone()
+    O._gemm(A, A.stride(0), a_kc, B, B.stride(0), b_kc, C, M, N, K, accumulate=True)
+    assert (C.double() - (C0.double() + ref)).abs().max().item() <= 1.2e-2 * max(scale, C0.abs().max().item())
+
+
 def test_grouped_weight_gradients(bf16_mode):
     """svpc_gemm_group_wgrad: several independent dW += dzᵀ·x (+ db += Σ dz) problems of different shapes in one launch, against
     fp64 on the bf16-rounded operands (weights) and an fp32 column sum (bias); accumulation into non-zero targets."""
@@ -563,7 +591,17 @@ def test_grouped_weight_gradients_bf16(bf16_mode):
     """svpc_gemm_group_wgrad_bf16: bf16-stream problems (ragged row counts, both tile edges) in one launch, whole k-loop per tile,
     accumulating into non-zero fp32 targets — against fp64."""
     import ctypes
-    shapes = [(19200, 768, 768), (4224, 2304, 768), (1000, 768, 3072), (100, 136, 72), (4230, 768, 768), (7, 8, 8)]
+    _grouped_wgrad_bf16_case([(19200, 768, 768), (4224, 2304, 768), (1000, 768, 3072), (100, 136, 72), (4230, 768, 768), (7, 8, 8)])
+
+
+def test_grouped_weight_gradients_bf16_pingpong_tiles(bf16_mode):
+    """every problem at least 256 wide both ways → the 256×256 ping-pong tiles (deepest problems dealt first); ragged row counts
+    (zero-sourced k tail), widths that are not multiples of 256, one problem shallower than the 3-tile prefetch"""
+    _grouped_wgrad_bf16_case([(4230, 768, 768), (19200, 768, 768), (1000, 264, 776), (4224, 2304, 768), (40, 256, 256), (1537, 768, 3072)])
+
+
+def _grouped_wgrad_bf16_case(shapes):
+    import ctypes
     g = torch.Generator().manual_seed(9)
     keep, probs = [], (O._WgradProblem * len(shapes))()
     for i, (rows, n_out, n_in) in enumerate(shapes):
