@@ -26,7 +26,7 @@ from svpc_amd import ops, synthetic as syn  # noqa: E402
 from svpc_amd.graph import backward_all
 from svpc_amd.optim import FusedBertAdam, GradReducer  # noqa: E402
 
-PMC_TRAFFIC_BYTES = 94625150   # (2·FETCH_SIZE + WRITE_SIZE)·1024, means per launch of the dominant kernel: profiles/r01_e_pmc_bench_dominant_gemm.csv
+PMC_TRAFFIC_BYTES = 119381333   # (2·FETCH_SIZE + WRITE_SIZE)·1024, means per launch of the dominant kernel: profiles/r01_i_pmc_bench_dominant_gemm.csv
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense peaks (f32-in MFMA; bf16 MFMA)
 
 
@@ -243,10 +243,10 @@ def main():
     torch.cuda.synchronize()
     # roofline leg: HIP events around every launch of the dominant kernel symbol.  Eager mode: inside the timed region.  Graph
     # mode: events cannot be recorded inside a replay, so the same kernels are bracketed in instrumented eager steps right after it.
-    # Dominant kernel = the forward GEMM of the bf16 activation streams: ONE kernel template (gemm_glds_kernel<true,true,__bf16,3,BM>, two tile heights:
-    # bf16 activations × bf16 weight shadow → bf16, both operands direct-to-LDS) covering Q/K/V, attention-output, FFN-in/out and
-    # video-embedding projections of the clip encoder (M = 19,200 rows) and the decoder's projections (M = 4,224 rows) — every
-    # launch of that symbol is bracketed, so the average can be checked against rocprofv3's per-kernel average.
+    # Dominant kernel = the forward GEMM of the clip-encoder activation stream: ONE kernel symbol (gemm_glds_pp_kernel<true,true,__bf16>:
+    # bf16 activations × bf16 weight shadow → bf16, both operands direct-to-LDS, 256×256 ping-pong tiles) covering the Q/K/V,
+    # attention-output, FFN-in/out and video-embedding projections of the clip encoder (M = 19,200 rows; 22 launches per step) —
+    # every launch of that symbol is bracketed, so the average can be checked against rocprofv3's per-kernel average.
     rows_enc = args.batch * args.clips * cfg.max_v_len
     bf16_stream = args.precision == "bf16" and ops.bf16_stream_ok(rows_enc, cfg.hidden_size, cfg.video_feature_size)
     glds = bf16_stream and ops.USE_GLDS      # weights come from the optimizer's bf16 shadow → direct-to-LDS kernel
@@ -254,7 +254,7 @@ def main():
 
     def dom_select(d):
         M_, N_, K_, akc, bkc, adt, bdt, cdt = d
-        return akc == 1 and bkc == 1 and (adt, bdt, cdt) == want_dt and (glds or M_ == rows_enc)
+        return akc == 1 and bkc == 1 and (adt, bdt, cdt) == want_dt and M_ == rows_enc
     if graph is None:
         ops.GEMM_TIMER = ops.KernelTimer(select=dom_select)
     if dist is not None:
@@ -286,7 +286,7 @@ def main():
         D_, F_, L_ = cfg.hidden_size, cfg.video_feature_size, cfg.num_hidden_layers
         n_l = max(1, gsum["launches"])
         alg_bytes, alg_flop = gsum["bytes"] / n_l, gsum["work"] / n_l
-        # mean HBM traffic per launch of this symbol from rocprofv3 PMC passes over this very command (profiles/r01_e_pmc_*.csv):
+        # mean HBM traffic per launch of this symbol from rocprofv3 PMC passes over this very command (profiles/r01_i_pmc_*.csv):
         # FETCH_SIZE × 2 (gfx950 reports half of a 16-B/lane stream) + WRITE_SIZE, in KB.  Only valid for the default workload.
         default_cfg = (args.batch, args.clips, L_, D_, F_, args.model_type) == (16, 12, 6, 768, 3072, "vivt") and bf16_stream
         traffic = PMC_TRAFFIC_BYTES if (default_cfg and glds) else None
@@ -303,11 +303,10 @@ def main():
                        "host_enqueue_ms_per_step": host_enqueue_ms,
                        "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (fwd + text-side bwd | clip-encoder bwd beside the text-side all-reduce | remaining all-reduce | optimizer)")
                                  if graph is not None else "eager"},
-            "roofline": {"bound": "mfma", "kernel": "%s — every forward projection of the bf16 activation streams (clip encoder M=%d "
-                                   "rows: Q/K/V, attention-out, FFN, video embedding; decoder M=%d rows)"
-                                   % ("gemm_glds_kernel<true,true,__bf16,3,BM> (bf16·bf16→bf16, direct-to-LDS; BM = 256-row tiles at M=19,200, 128-row at M=4,224)" if glds else
-                                      "gemm_bf16_kernel<128,128,NT,interior,8 waves,%s>" % ("bf16·f32→bf16" if bf16_stream else "f32"),
-                                      rows_enc, args.batch * args.clips * cfg.max_t_len),
+            "roofline": {"bound": "mfma", "kernel": "%s — every forward projection of the clip-encoder activation stream (M=%d rows: "
+                                   "Q/K/V, attention-out, FFN, video embedding)"
+                                   % ("gemm_glds_pp_kernel<true,true,__bf16> (bf16·bf16→bf16, direct-to-LDS, 256x256 ping-pong tiles)" if glds else
+                                      "gemm_bf16_kernel<128,128,NT,interior,8 waves,%s>" % ("bf16·f32→bf16" if bf16_stream else "f32"), rows_enc),
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS[args.precision],
                          "traffic": traffic, "algorithmic_flop_per_launch": alg_flop, "algorithmic_bytes_per_launch": alg_bytes,

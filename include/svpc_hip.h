@@ -85,8 +85,10 @@ int svpc_gemm_bf16(const float* A, int lda, int a_kc, const float* B, int ldb, i
 int svpc_gemm_mx(const void* A, int a_dt, int lda, int a_kc, const void* B, int b_dt, int ldb, int b_kc, void* C, int c_dt, int ldc,
                  void* Z, int M, int N, int K, const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed,
                  int accumulate, float* workspace, size_t workspace_bytes, svpc_stream_t stream);
-/* bf16 × bf16 form with direct-to-LDS operand staging (global_load_lds, 4-deep ring): interior-only shapes; weights come from the
- * optimizer's bf16 shadow arena.  C bf16 (c_dt 1) or fp32 (c_dt 0). */
+/* bf16 × bf16 form with direct-to-LDS operand staging (global_load_lds into an LDS ring, counted vmcnt): any M, N (see
+ * svpc_gemm_glds_supported); weights come from the optimizer's bf16 shadow arena.  C bf16 (c_dt 1) or fp32 (c_dt 0).  Launches of
+ * at least 200 tiles of 256x256 with a k-contiguous operand run on the two-group ping-pong kernel; bf16 outputs are written as whole
+ * 128-byte lines. */
 int svpc_gemm_glds_supported(int a_kc, int b_kc, int lda, int ldb, int M, int N, int K);
 int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int b_kc, void* C, int c_dt, int ldc, void* Z, int M, int N,
                    int K, const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed, int accumulate,
