@@ -580,7 +580,7 @@ int svpc_ln_fwd(const float* x, const int* src_rows, const float* res, const flo
 // workspace: at least svpc_ln_bwd_groups(R) * 2 * D floats
 int svpc_ln_bwd_groups(int R) {
     static int cap = -1;
-    if (cap < 0) { const char* e = getenv("SVPC_LN_GROUPS"); cap = e ? atoi(e) : 512; }
+    if (cap < 0) { const char* e = getenv("SVPC_LN_GROUPS"); cap = e ? atoi(e) : 768; /* three 4-wave workgroups per CU at 12 values per lane (best of 512 / 768 / 1024) */ }
     int g = ceil_div(R, 4);
     return g < 1 ? 1 : (g > cap ? cap : g);
 }
@@ -605,7 +605,10 @@ int svpc_ln_bwd_rows_t(const void* dy, const void* x, int x_dt, int y_dt, const 
         return svpc_check_launch("ln_param_grad");
     }
     if (vec) {
+        static int npl3 = -1;
+        if (npl3 < 0) { const char* e = getenv("SVPC_LN_NPL3"); npl3 = e ? atoi(e) : 1; }
         if (D <= 256) rc = launch_ln_bwd<1, 4>(a, G, x_dt, y_dt, stream);
+        else if (D <= 768 && npl3) rc = launch_ln_bwd<3, 4>(a, G, x_dt, y_dt, stream);     // 12 values per lane: a third fewer registers than <4,4>
         else if (D <= 1024) rc = launch_ln_bwd<4, 4>(a, G, x_dt, y_dt, stream);
         else if (D <= 3072) rc = launch_ln_bwd<12, 4>(a, G, x_dt, y_dt, stream);
         else if (D <= 8192) rc = launch_ln_bwd<32, 4>(a, G, x_dt, y_dt, stream);
