@@ -382,6 +382,78 @@ static int gemm_group_go(const GemmGroupArgs& g, int tiles, hipStream_t stream) 
     return svpc_check_launch("gemm_group");
 }
 
+// ---- "skinny" form for the step-level problems (M ≤ 256 rows: 192 step vectors × 768…2304 features).  These launches are pure
+// latency: a 64² tile with an LDS ring walks 6+ dependent k-tiles per wave.  Here a workgroup owns ONE 32×32 output tile, its 4 waves
+// take every 4th 16-deep k-step, and each wave loads its MFMA fragments STRAIGHT from global memory into registers — up to 12
+// k-steps (192 VGPRs of fp32 operands) are requested before the first is consumed, so K = 768 costs one memory round trip.
+// Partial tiles meet in LDS and are summed in wave order (deterministic); the whole workgroup runs the epilogue.
+// A k-contiguous [M][lda]; B k-contiguous [N][ldb] (B_KC) or k-strided [K][ldb]; K % 16 == 0; rows past an edge are clamped.
+template <bool B_KC>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                          float* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_n) {
+    constexpr int BATCH = 12;
+    __shared__ float part[4][16][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * 32, n0 = tn * 32;
+    const int r = lane & 31, h = lane >> 5;
+    const float* __restrict__ arow = A + (size_t)min(m0 + r, M - 1) * lda + 8 * h;
+    const int bcol = min(n0 + r, N - 1);
+    const float* __restrict__ brow = B_KC ? B + (size_t)bcol * ldb + 8 * h : B + (size_t)(8 * h) * ldb + bcol;
+    const int nsteps = K >> 4;                                  // 16-deep k-steps; this wave takes wave, wave+4, …
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int s0 = wave; s0 < nsteps; s0 += 4 * BATCH) {
+        float4 av[BATCH][2];
+        float bv[BATCH][8];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int s = s0 + 4 * u;
+            if (s < nsteps) {
+                const float* ap = arow + 16 * s;
+                av[u][0] = *reinterpret_cast<const float4*>(ap);
+                av[u][1] = *reinterpret_cast<const float4*>(ap + 4);
+                if (B_KC) {
+                    const float* bp = brow + 16 * s;
+                    const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+                    bv[u][0] = b0.x; bv[u][1] = b0.y; bv[u][2] = b0.z; bv[u][3] = b0.w;
+                    bv[u][4] = b1.x; bv[u][5] = b1.y; bv[u][6] = b1.z; bv[u][7] = b1.w;
+                } else {
+                    const float* bp = brow + (size_t)(16 * s) * ldb;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bv[u][j] = bp[(size_t)j * ldb];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int s = s0 + 4 * u;
+            if (s < nsteps) {
+                bf16x8 af, bf;
+                af[0] = (__bf16)av[u][0].x; af[1] = (__bf16)av[u][0].y; af[2] = (__bf16)av[u][0].z; af[3] = (__bf16)av[u][0].w;
+                af[4] = (__bf16)av[u][1].x; af[5] = (__bf16)av[u][1].y; af[6] = (__bf16)av[u][1].z; af[7] = (__bf16)av[u][1].w;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bf[j] = (__bf16)bv[u][j];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[wave][e][lane] = acc[e];
+    __syncthreads();
+    const u64 seed = epi.p_drop > 0.f ? epi.seed[0] : 0ull;
+    const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
+    const int col = threadIdx.x & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (threadIdx.x >> 5) + 8 * i;             // accumulator element e of lane l holds row (e&3) + 8(e>>2) + 4(l>>5), column l&31
+        const int e = (row & 3) + 4 * (row >> 3), l = col + 32 * ((row >> 2) & 1);
+        const float v = ((part[0][e][l] + part[1][e][l]) + part[2][e][l]) + part[3][e][l];
+        if (m0 + row < M && n0 + col < N) epilogue_store(v, m0 + row, n0 + col, C, ldc, epi, seed, inv_keep);
+    }
+}
+
 extern "C" {
 
 // 1 if the fp32 direct-to-LDS kernel can run this (shape, layout): whole k-tiles, 16-byte aligned chunks, and for a k-strided
@@ -476,6 +548,15 @@ int svpc_gemm_l32(const float* A, int lda, int a_kc, const float* B, int ldb, in
     if (env_tile < 0) { const char* e = getenv("SVPC_L32_TILE"); env_tile = e ? atoi(e) : 0; }      // 128 | 64 (deep ring) | 65 (64, 4 stages)
     if (env_split < 0) { const char* e = getenv("SVPC_L32_SPLITK"); env_split = e ? atoi(e) : 0; }
     if (remap < 0) { const char* e = getenv("SVPC_GEMM_REMAP"); remap = e ? atoi(e) : 1; }
+    static int env_skinny = -1;
+    if (env_skinny < 0) { const char* e = getenv("SVPC_L32_SKINNY"); env_skinny = e ? atoi(e) : 1; }
+    if (env_skinny && a_kc && M <= 256 && N >= 32 && (K & 15) == 0 && (lda & 3) == 0 && (!b_kc || (ldb & 3) == 0)) {
+        const int tn_ = ceil_div(N, 32);
+        dim3 grids(ceil_div(M, 32) * tn_);
+        if (b_kc) hipLaunchKernelGGL(gemm_skinny_kernel<true>, grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_);
+        else hipLaunchKernelGGL(gemm_skinny_kernel<false>, grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_);
+        return svpc_check_launch("gemm_skinny");
+    }
     const int t128 = ceil_div(M, 128) * ceil_div(N, 128), t64 = ceil_div(M, 64) * ceil_div(N, 64);
     // 64² tiles with a 4-stage ring (two workgroups per CU) were the fastest form for every small grid in the sweep; 128² tiles
     // (one workgroup per CU) and the 8-stage ring stay selectable through SVPC_L32_TILE for experiments
