@@ -388,28 +388,26 @@ static int gemm_group_go(const GemmGroupArgs& g, int tiles, hipStream_t stream) 
 // k-steps (192 VGPRs of fp32 operands) are requested before the first is consumed, so K = 768 costs one memory round trip.
 // Partial tiles meet in LDS and are summed in wave order (deterministic); the whole workgroup runs the epilogue.
 // A k-contiguous [M][lda]; B k-contiguous [N][ldb] (B_KC) or k-strided [K][ldb]; K % 16 == 0; rows past an edge are clamped.
-template <bool B_KC>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                          float* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_n) {
+template <bool B_KC, int NW>
+__device__ __forceinline__ void skinny_tile(float (*part)[16][64], const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                            float* __restrict__ C, int ldc, int M, int N, int K, const Epi& epi, int tm, int tn) {
     constexpr int BATCH = 12;
-    __shared__ float part[4][16][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
     const int m0 = tm * 32, n0 = tn * 32;
     const int r = lane & 31, h = lane >> 5;
     const float* __restrict__ arow = A + (size_t)min(m0 + r, M - 1) * lda + 8 * h;
     const int bcol = min(n0 + r, N - 1);
     const float* __restrict__ brow = B_KC ? B + (size_t)bcol * ldb + 8 * h : B + (size_t)(8 * h) * ldb + bcol;
-    const int nsteps = K >> 4;                                  // 16-deep k-steps; this wave takes wave, wave+4, …
+    const int nsteps = K >> 4;                                  // 16-deep k-steps; this wave takes wave, wave+NW, …
     floatx16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (int s0 = wave; s0 < nsteps; s0 += 4 * BATCH) {
+    for (int s0 = wave; s0 < nsteps; s0 += NW * BATCH) {
         float4 av[BATCH][2];
         float bv[BATCH][8];
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int s = s0 + 4 * u;
+            const int s = s0 + NW * u;
             if (s < nsteps) {
                 const float* ap = arow + 16 * s;
                 av[u][0] = *reinterpret_cast<const float4*>(ap);
@@ -428,7 +426,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
         }
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int s = s0 + 4 * u;
+            const int s = s0 + NW * u;
             if (s < nsteps) {
                 bf16x8 af, bf;
                 af[0] = (__bf16)av[u][0].x; af[1] = (__bf16)av[u][0].y; af[2] = (__bf16)av[u][0].z; af[3] = (__bf16)av[u][0].w;
@@ -446,12 +444,33 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
     const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
     const int col = threadIdx.x & 31;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (threadIdx.x >> 5) + 8 * i;             // accumulator element e of lane l holds row (e&3) + 8(e>>2) + 4(l>>5), column l&31
+    for (int i = 0; i < 16 / NW; ++i) {
+        const int row = (threadIdx.x >> 5) + 2 * NW * i;        // accumulator element e of lane l holds row (e&3) + 8(e>>2) + 4(l>>5), column l&31
         const int e = (row & 3) + 4 * (row >> 3), l = col + 32 * ((row >> 2) & 1);
-        const float v = ((part[0][e][l] + part[1][e][l]) + part[2][e][l]) + part[3][e][l];
+        float v = part[0][e][l];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += part[w][e][l];        // wave order: deterministic
         if (m0 + row < M && n0 + col < N) epilogue_store(v, m0 + row, n0 + col, C, ldc, epi, seed, inv_keep);
     }
+}
+template <bool B_KC>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                          float* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_n) {
+    __shared__ float part[4][16][64];
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    skinny_tile<B_KC, 4>(part, A, lda, B, ldb, C, ldc, M, N, K, epi, tm, tn);
+}
+// grouped form (both operands k-contiguous), NW waves per 32×32 tile: 8 for the long reductions of the LSTM dgrad (K = 3072)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_group_skinny_kernel(GemmGroupArgs g) {
+    __shared__ float part[NW][16][64];
+    int pi = 0;
+    while (pi + 1 < g.n && (int)blockIdx.x >= g.p[pi + 1].tile0) ++pi;
+    const GemmProb& q = g.p[pi];
+    const int tile = blockIdx.x - q.tile0;
+    const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
+    Epi epi{nullptr, ACT_NONE, 0.f, 0u, nullptr, g.accumulate, nullptr};
+    skinny_tile<true, NW>(part, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, epi, tm, tn);
 }
 
 extern "C" {
@@ -490,14 +509,28 @@ int svpc_gemm_group(const void* problems, int n, int a_kc, int b_kc, int accumul
     GemmGroupArgs g{};
     g.n = n; g.accumulate = accumulate;
     int tiles = 0;
+    static int env_skinny = -1;
+    if (env_skinny < 0) { const char* e = getenv("SVPC_L32_SKINNY"); env_skinny = e ? atoi(e) : 1; }
+    bool skinny = env_skinny && a_kc && b_kc;       // every problem a few rows tall: 32×32 tiles with register-direct operands
+    int kmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (hp[i].M > 256 || hp[i].N < 32 || (hp[i].K & 15) || (hp[i].lda & 3) || (hp[i].ldb & 3)) skinny = false;
+        if (hp[i].K > kmax) kmax = hp[i].K;
+    }
+    const int T = skinny ? 32 : 64;
     for (int i = 0; i < n; ++i) {
         const HostGemmProblem& h = hp[i];
         SVPC_REQUIRE(svpc_gemm_l32_supported(a_kc, b_kc, h.lda, h.ldb, h.M, h.N, h.K) && ((((uintptr_t)h.A) | ((uintptr_t)h.B)) & 15) == 0,
                      "gemm_group: needs K % 32 == 0 and 16-byte aligned fp32 rows");
         GemmProb& q = g.p[i];
         q.A = h.A; q.B = h.B; q.C = h.C; q.M = h.M; q.N = h.N; q.K = h.K; q.lda = h.lda; q.ldb = h.ldb; q.ldc = h.ldc;
-        q.tile0 = tiles; q.tiles_n = ceil_div(h.N, 64);
-        tiles += ceil_div(h.M, 64) * q.tiles_n;
+        q.tile0 = tiles; q.tiles_n = ceil_div(h.N, T);
+        tiles += ceil_div(h.M, T) * q.tiles_n;
+    }
+    if (skinny) {
+        if (kmax >= 1536) hipLaunchKernelGGL(gemm_group_skinny_kernel<8>, dim3(tiles), dim3(512), 0, stream, g);
+        else hipLaunchKernelGGL(gemm_group_skinny_kernel<4>, dim3(tiles), dim3(256), 0, stream, g);
+        return svpc_check_launch("gemm_group_skinny");
     }
     if (a_kc && b_kc) return gemm_group_go<true, true>(g, tiles, stream);
     if (a_kc) return gemm_group_go<true, false>(g, tiles, stream);
