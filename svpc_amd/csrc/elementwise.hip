@@ -27,6 +27,37 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, 
     }
 }
 
+// 16-byte form for the bf16 streams (8 elements per thread and iteration; n % 8 == 0, 16-byte aligned pointers)
+__global__ __launch_bounds__(256) void act_bwd_bf16x8_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ aux, uint4* __restrict__ dz,
+                                                             size_t n8, int act, float p, uint32_t site, const u64* __restrict__ seed_ptr) {
+    const u64 seed = p > 0.f ? seed_ptr[0] : 0ull;
+    const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n8; q += (size_t)gridDim.x * 256) {
+        const uint4 gv = dy[q], av = aux[q];
+        const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w}, aw[4] = {av.x, av.y, av.z, av.w};
+        uint32_t ow[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float g2[2] = {__uint_as_float(gw[j] << 16), __uint_as_float(gw[j] & 0xffff0000u)};
+            const float a2[2] = {__uint_as_float(aw[j] << 16), __uint_as_float(aw[j] & 0xffff0000u)};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float g = g2[e];
+                if (p > 0.f) g *= drop_scale(seed, site, q * 8 + 2 * j + e, p, ik);
+                const float a = a2[e];
+                if (act == ACT_RELU) g = a > 0.f ? g : 0.f;
+                else if (act == ACT_GELU) g *= gelu_erf_grad(a);
+                else if (act == ACT_SIGMOID) g *= a * (1.0f - a);
+                g2[e] = g;
+            }
+            union { __bf16 h[2]; uint32_t u; } pk;
+            pk.h[0] = (__bf16)g2[0]; pk.h[1] = (__bf16)g2[1];
+            ow[j] = pk.u;
+        }
+        dz[q] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c,
                                                   size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) c[i] = a[i] + b[i];
@@ -496,6 +527,9 @@ int svpc_act_bwd_t(const void* dy, const void* aux, void* dz, int dt, size_t n, 
     SVPC_REQUIRE(p <= 0.f || seed != nullptr, "act_bwd: dropout needs a seed pointer");
     if (dt == 0) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid1d(n)), dim3(256), 0, s, (const float*)dy, (const float*)aux, (float*)dz, n,
                                     act, p, site, seed);
+    else if (n % 8 == 0 && ((((uintptr_t)dy) | ((uintptr_t)aux) | ((uintptr_t)dz)) & 15) == 0)
+        hipLaunchKernelGGL(act_bwd_bf16x8_kernel, dim3(grid1d(n / 8)), dim3(256), 0, s, (const uint4*)dy, (const uint4*)aux, (uint4*)dz, n / 8, act,
+                           p, site, seed);
     else hipLaunchKernelGGL(act_bwd_kernel<__bf16>, dim3(grid1d(n)), dim3(256), 0, s, (const __bf16*)dy, (const __bf16*)aux, (__bf16*)dz, n,
                             act, p, site, seed);
     return svpc_check_launch("act_bwd");
