@@ -76,6 +76,8 @@ def branch_stream(device):
 USE_GROUPED_WGRAD = os.environ.get("SVPC_NO_GROUPED_WGRAD", "") == ""
 GROUP_BF16 = os.environ.get("SVPC_NO_GROUP_BF16", "") == ""      # also the bf16-stream wgrads (one launch, no split-K)
 GROUP_FLUSH_AT = int(os.environ.get("SVPC_GROUP_FLUSH_AT", "16"))
+# packed Q/K/V (432 tiles of 64²) and LSTM (576) weight gradients over K = 192 rows are pure latency as launches of their own
+GROUP_MAX_TILES = int(os.environ.get("SVPC_GROUP_MAX_TILES", "1200"))
 _WQ = []            # (dz, x, wgrad, bgrad)
 
 
@@ -126,7 +128,7 @@ def defer_wgrad(dz, x, wgrad, bgrad):
     if (dz.data_ptr() | x.data_ptr()) % 16 or dz.stride(1) != 1 or x.stride(1) != 1 or not wgrad.is_contiguous():
         return False
     tiles = -(-n_out // 64) * -(-n_in // 64)
-    if tiles > 256:               # a grid of its own fills the chip: nothing to gain from grouping
+    if tiles > GROUP_MAX_TILES:   # a grid of its own fills the chip for long enough: nothing to gain from grouping
         return False
     wp = wgrad.data_ptr()
     if any(q[2].data_ptr() == wp for q in _WQ):
