@@ -579,9 +579,10 @@ int svpc_ln_fwd(const float* x, const int* src_rows, const float* res, const flo
 
 // workspace: at least svpc_ln_bwd_groups(R) * 2 * D floats
 int svpc_ln_bwd_groups(int R) {
-    static int cap = -1;
+    static int cap = -1, rpw = -1;
     if (cap < 0) { const char* e = getenv("SVPC_LN_GROUPS"); cap = e ? atoi(e) : 768; /* three 4-wave workgroups per CU at 12 values per lane (best of 512 / 768 / 1024) */ }
-    int g = ceil_div(R, 4);
+    if (rpw < 0) { const char* e = getenv("SVPC_LN_ROWS_PER_WAVE"); rpw = e ? atoi(e) : 1; }
+    int g = ceil_div(R, 4 * rpw);
     return g < 1 ? 1 : (g > cap ? cap : g);
 }
 
