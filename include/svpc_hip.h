@@ -116,6 +116,10 @@ int svpc_gemm_group_wgrad_max(void);
 /* the same for the bf16 activation streams (dz, x bf16; dw fp32; db must be NULL; n_out % 8 == 0, n_in % 8 == 0, any row count):
  * every 128² tile runs its whole k-loop — no split-K slabs, no reduce launches */
 int svpc_gemm_group_wgrad_bf16(const svpc_wgrad_problem* problems, int n, svpc_stream_t stream);
+/* the same with scratch for load balancing: deep tiles dealt after the first round of workgroups are cut into k-parts that write
+ * fp32 slabs into `workspace`; a second launch adds a tile's slabs in part order into dW (deterministic) */
+int svpc_gemm_group_wgrad_bf16_ws(const svpc_wgrad_problem* problems, int n, float* workspace, size_t workspace_bytes,
+                                  svpc_stream_t stream);
 int svpc_gemm_group_wgrad(const svpc_wgrad_problem* problems, int n, svpc_stream_t stream);
 /* dz = dy · act'(aux) · dropout  (aux = pre-activation for GELU, activated output for ReLU / sigmoid) */
 int svpc_act_bwd(const float* dy, const float* aux, float* dz, size_t n, int act, float p, unsigned site, const svpc_u64* seed,

@@ -541,7 +541,10 @@ __global__ __launch_bounds__(512, (BM == 256 && BN == 256) ? 2 : BM == 256 ? 4 :
 // ---- grouped weight gradients of the bf16 activation streams: up to 48 problems dW_p[n_out, n_in] += dz_pᵀ·x_p (bf16 operands,
 // k-strided, any row count) in ONE launch, every 128² tile running its WHOLE k-loop (no split-K slabs, no reduce launches):
 // the ≈40 wgrads of a step (22 × K = 19,200 rows, 18 × K = 4,224) are ≈2,300 tiles — enough to fill the chip several times over.
-struct G16Prob { const __bf16* dz; const __bf16* x; float* dw; int n_out, n_in, rows, ld_dz, ld_x, ld_dw, tile0, tiles_n; };
+struct G16Prob {
+    const __bf16* dz; const __bf16* x; float* dw; int n_out, n_in, rows, ld_dz, ld_x, ld_dw, tile0, tiles_n;
+    int whole, split, slab0, stile0;      // ping-pong form: leading tiles run whole, the others in `split` k-parts → slabs (see below)
+};
 constexpr int G16_MAX = 48;
 struct G16Args { int n; int total; G16Prob p[G16_MAX]; };
 
@@ -559,17 +562,59 @@ __global__ __launch_bounds__(512) void gemm_group_wgrad16_kernel(G16Args g) {
                                           ((q.rows + GL_BK - 1) / GL_BK) * GL_BK, nullptr);
 }
 
-// the same table on 256×256 ping-pong tiles (problems at least 256 wide both ways); deep problems are dealt first
-__global__ __launch_bounds__(512) void gemm_group_wgrad16_pp_kernel(G16Args g) {
+// the same table on 256×256 ping-pong tiles (problems at least 256 wide both ways); deep problems are dealt first.
+// Balance: with T tiles of very different depth on 256 CUs, whatever starts after the first round of deep tiles decides the
+// makespan (324 tiles of 600 k-tiles: the 68 left over double it).  Tiles dealt after the first round that are still deep
+// are therefore cut into `split` k-parts, each a work item of its own writing a 256×256 fp32 slab; `wgrad16_fixup_kernel`
+// adds a tile's slabs in part order into dW (deterministic, no atomics).  `tile0` counts work items in this form.
+__global__ __launch_bounds__(512) void gemm_group_wgrad16_pp_kernel(G16Args g, float* __restrict__ slabs) {
     __shared__ __attribute__((aligned(1024))) char smem[4 * 4 * GL_OP];
     const int wg = blockIdx.x;
     int pi = 0;
     while (pi + 1 < g.n && wg >= g.p[pi + 1].tile0) ++pi;
     const G16Prob& q = g.p[pi];
-    const int tile = wg - q.tile0;
+    const int item = wg - q.tile0;
+    if (item < q.whole) {
+        const int tm = item / q.tiles_n, tn = item - tm * q.tiles_n;
+        Epi epi{nullptr, ACT_NONE, 0.f, 0u, nullptr, 1, nullptr};
+        glds_tile_pp<false, false, float>(smem, q.dz, q.ld_dz, q.x, q.ld_x, q.dw, q.ld_dw, q.n_out, q.n_in, q.rows, epi, tm, tn);
+        return;
+    }
+    const int st = (item - q.whole) / q.split, part = (item - q.whole) - st * q.split;
+    const int tile = q.whole + st;
     const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
-    Epi epi{nullptr, ACT_NONE, 0.f, 0u, nullptr, 1, nullptr};
-    glds_tile_pp<false, false, float>(smem, q.dz, q.ld_dz, q.x, q.ld_x, q.dw, q.ld_dw, q.n_out, q.n_in, q.rows, epi, tm, tn);
+    const int units = (q.rows + GL_BK - 1) / GL_BK, upp = (units + q.split - 1) / q.split;
+    const int k0 = min(q.rows, part * upp * GL_BK), k1 = min(q.rows, k0 + upp * GL_BK);
+    const int m0 = tm * 256, n0 = tn * 256;
+    Epi epi{nullptr, ACT_NONE, 0.f, 0u, nullptr, 0, nullptr};
+    float* slab = slabs + (size_t)(q.slab0 + st * q.split + part) * 65536;
+    glds_tile_pp<false, false, float>(smem, q.dz + (size_t)k0 * q.ld_dz + m0, q.ld_dz, q.x + (size_t)k0 * q.ld_x + n0, q.ld_x, slab, 256,
+                                      min(256, q.n_out - m0), min(256, q.n_in - n0), k1 - k0, epi, 0, 0);
+}
+__global__ __launch_bounds__(256) void wgrad16_fixup_kernel(G16Args g, const float* __restrict__ slabs) {
+    const int bt = blockIdx.x >> 4, chunk = blockIdx.x & 15;     // 16 workgroups per tile, 16 rows each
+    int pi = 0;
+    while (pi + 1 < g.n && bt >= g.p[pi + 1].stile0) ++pi;
+    const G16Prob& q = g.p[pi];
+    const int st = bt - q.stile0, tile = q.whole + st;
+    const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
+    const float4* sl = reinterpret_cast<const float4*>(slabs + (size_t)(q.slab0 + st * q.split) * 65536);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                             // 16 rows × 64 float4 per workgroup
+        const int i = chunk * 1024 + it * 256 + threadIdx.x;
+        const int row = i >> 6, c4 = i & 63;
+        const int gr = tm * 256 + row, gc = tn * 256 + 4 * c4;
+        if (gr >= q.n_out || gc >= q.n_in) continue;              // n_in % 8 == 0: a float4 is inside or outside as a whole
+        float4 v = sl[i];
+        for (int p = 1; p < q.split; ++p) {
+            const float4 t = sl[(size_t)p * 16384 + i];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        float4* d = reinterpret_cast<float4*>(q.dw + (size_t)gr * q.ld_dw + gc);
+        float4 o = *d;
+        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+        *d = o;
+    }
 }
 
 extern "C" {
@@ -587,7 +632,8 @@ int svpc_gemm_glds_supported(int a_kc, int b_kc, int lda, int ldb, int M, int N,
 
 struct HostWgrad16Problem { const void* dz; const void* x; float* dw; float* db; int n_out, n_in, rows, ld_dz, ld_x, ld_dw; };
 
-int svpc_gemm_group_wgrad_bf16(const void* problems, int n, hipStream_t stream) {
+// workspace (optional): room for the k-part slabs of the balanced ping-pong form; without it every tile runs whole
+int svpc_gemm_group_wgrad_bf16_ws(const void* problems, int n, float* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (n == 0) return 0;
     SVPC_REQUIRE(n > 0 && n <= G16_MAX, "gemm_group_wgrad_bf16: 1..48 problems per launch");
     const HostWgrad16Problem* hp = reinterpret_cast<const HostWgrad16Problem*>(problems);
@@ -597,12 +643,17 @@ int svpc_gemm_group_wgrad_bf16(const void* problems, int n, hipStream_t stream) 
     static int bm_env = -1;
     if (bm_env < 0) { const char* e = getenv("SVPC_GROUP16_BM"); bm_env = e ? atoi(e) : 256; }
     int BMv = bm_env == 128 ? 128 : 256;          // 256-row tiles (wave tile 64×64) unless a problem is narrower than that
-    static int pp_env = -1;
+    static int pp_env = -1, split_env = -1, cus = -1;
     if (pp_env < 0) { const char* e = getenv("SVPC_GROUP16_PP"); pp_env = e ? atoi(e) : 1; }
+    if (split_env < 0) { const char* e = getenv("SVPC_GROUP16_SPLIT"); split_env = e ? atoi(e) : 160; }   // target k-tiles per part; 0 = never split
+    if (cus < 0) {
+        hipDeviceProp_t prop; int dev = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
     bool pp = pp_env != 0;                        // 256×256 ping-pong tiles when every problem is at least that wide
     for (int i = 0; i < n; ++i) {
         if (hp[i].n_out < 256) BMv = 128;
-        if (hp[i].n_out < 256 || hp[i].n_in < 256) pp = false;
+        if (hp[i].n_out < 256 || hp[i].n_in < 256 || (hp[i].ld_dw & 3) || (((uintptr_t)hp[i].dw) & 15)) pp = false;
     }
     int order[G16_MAX];
     for (int i = 0; i < n; ++i) order[i] = i;
@@ -613,6 +664,7 @@ int svpc_gemm_group_wgrad_bf16(const void* problems, int n, hipStream_t stream) 
             while (j >= 0 && hp[order[j]].rows < hp[v].rows) { order[j + 1] = order[j]; --j; }
             order[j + 1] = v;
         }
+    int items = 0, slabs = 0, stiles = 0, seen = 0;          // seen = tiles dealt so far (in order)
     for (int ii = 0; ii < n; ++ii) {
         const int i = ii;
         const HostWgrad16Problem& h = hp[order[ii]];
@@ -621,14 +673,38 @@ int svpc_gemm_group_wgrad_bf16(const void* problems, int n, hipStream_t stream) 
                      "gemm_group_wgrad_bf16: n_out % 8, n_in % 8, 16-byte aligned bf16 rows; no bias output");
         G16Prob& q = g.p[i];
         q.dz = (const __bf16*)h.dz; q.x = (const __bf16*)h.x; q.dw = h.dw; q.n_out = h.n_out; q.n_in = h.n_in; q.rows = h.rows;
-        q.ld_dz = h.ld_dz; q.ld_x = h.ld_x; q.ld_dw = h.ld_dw; q.tile0 = tiles; q.tiles_n = ceil_div(h.n_in, pp ? 256 : GL_BN);
-        tiles += ceil_div(h.n_out, BMv) * q.tiles_n;
+        q.ld_dz = h.ld_dz; q.ld_x = h.ld_x; q.ld_dw = h.ld_dw; q.tiles_n = ceil_div(h.n_in, pp ? 256 : GL_BN);
+        const int tp = ceil_div(h.n_out, BMv) * q.tiles_n;
+        if (!pp) { q.tile0 = tiles; tiles += tp; continue; }
+        // tiles of this problem that still belong to the first round run whole; later ones are cut when they are deep
+        const int units = ceil_div(h.rows, GL_BK);
+        int split = (split_env > 0 && workspace) ? units / split_env : 1;
+        if (split > 8) split = 8;
+        if (split < 2) split = 1;
+        int whole = tp;
+        if (split > 1) whole = seen >= cus ? 0 : (cus - seen < tp ? cus - seen : tp);
+        if (split > 1 && (size_t)(slabs + (tp - whole) * split) * 65536 * sizeof(float) > workspace_bytes) { split = 1; whole = tp; }
+        if (whole == tp) split = 1;
+        q.whole = whole; q.split = split; q.slab0 = slabs; q.stile0 = stiles; q.tile0 = items;
+        items += whole + (tp - whole) * split;
+        if (split > 1) { slabs += (tp - whole) * split; stiles += tp - whole; }
+        seen += tp;
+    }
+    if (pp) {
+        g.total = items;
+        hipLaunchKernelGGL(gemm_group_wgrad16_pp_kernel, dim3(items), dim3(512), 0, stream, g, workspace);
+        int rc = svpc_check_launch("gemm_group_wgrad_bf16");
+        if (rc || stiles == 0) return rc;
+        hipLaunchKernelGGL(wgrad16_fixup_kernel, dim3(stiles * 16), dim3(256), 0, stream, g, (const float*)workspace);
+        return svpc_check_launch("gemm_group_wgrad_bf16 fix-up");
     }
     g.total = tiles;
-    if (pp) hipLaunchKernelGGL(gemm_group_wgrad16_pp_kernel, dim3(tiles), dim3(512), 0, stream, g);
-    else if (BMv == 256) hipLaunchKernelGGL(gemm_group_wgrad16_kernel<256>, dim3(tiles), dim3(512), 0, stream, g);
+    if (BMv == 256) hipLaunchKernelGGL(gemm_group_wgrad16_kernel<256>, dim3(tiles), dim3(512), 0, stream, g);
     else hipLaunchKernelGGL(gemm_group_wgrad16_kernel<128>, dim3(tiles), dim3(512), 0, stream, g);
     return svpc_check_launch("gemm_group_wgrad_bf16");
+}
+int svpc_gemm_group_wgrad_bf16(const void* problems, int n, hipStream_t stream) {
+    return svpc_gemm_group_wgrad_bf16_ws(problems, n, nullptr, 0, stream);
 }
 
 // A, B bf16; C bf16 (c_dt = 1) or fp32 (c_dt = 0); Z (optional pre-activation copy) has C's type.

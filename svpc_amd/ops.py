@@ -146,7 +146,8 @@ def flush_wgrads(bf16=True):
         for i, (dz, x, wg, _) in enumerate(_WQ16):
             probs[i] = _WgradProblem(dz.data_ptr(), x.data_ptr(), wg.data_ptr(), None, dz.shape[1], x.shape[1], dz.shape[0],
                                      dz.stride(0), x.stride(0), wg.stride(0))
-        _lib.call("gemm_group_wgrad_bf16", ctypes.addressof(probs), len(_WQ16), _stream())
+        ws = _ws(_WQ16[0][0].device)
+        _lib.call("gemm_group_wgrad_bf16_ws", ctypes.addressof(probs), len(_WQ16), _p(ws), ws.numel() * 4, _stream())
         done = list(_WQ16)
         del _WQ16[:]
         for _, _, wg, _ in done:

@@ -600,6 +600,12 @@ def test_grouped_weight_gradients_bf16_pingpong_tiles(bf16_mode):
     _grouped_wgrad_bf16_case([(4230, 768, 768), (19200, 768, 768), (1000, 264, 776), (4224, 2304, 768), (40, 256, 256), (1537, 768, 3072)])
 
 
+def test_grouped_weight_gradients_bf16_balanced_tail(bf16_mode):
+    """more 256×256 tiles than CUs with deep reductions: the tiles dealt after the first round are cut into k-parts (slabs in the
+    workspace) and added in part order by the fix-up launch; ragged rows (zero-sourced k tail inside the last part) and tile edges"""
+    _grouped_wgrad_bf16_case([(10270, 2296, 3064), (10272, 2304, 3072), (10272, 2304, 3072), (4224, 768, 768)])
+
+
 def _grouped_wgrad_bf16_case(shapes):
     import ctypes
     g = torch.Generator().manual_seed(9)
@@ -611,7 +617,8 @@ def _grouped_wgrad_bf16_case(shapes):
         dw = dw0.clone()
         keep.append((dz, x, dw0, dw))
         probs[i] = O._WgradProblem(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), None, n_out, n_in, rows, dz.stride(0), x.stride(0), dw.stride(0))
-    O._lib.call("gemm_group_wgrad_bf16", ctypes.addressof(probs), len(shapes), O._stream())
+    ws = O._ws(torch.device(DEV))
+    O._lib.call("gemm_group_wgrad_bf16_ws", ctypes.addressof(probs), len(shapes), ws.data_ptr(), ws.numel() * 4, O._stream())
     torch.cuda.synchronize()
     for (rows, n_out, n_in), (dz, x, dw0, dw) in zip(shapes, keep):
         ref = dw0.double() + dz.double().t() @ x.double()
