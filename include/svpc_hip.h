@@ -93,6 +93,11 @@ int svpc_gemm_glds_supported(int a_kc, int b_kc, int lda, int ldb, int M, int N,
 int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int b_kc, void* C, int c_dt, int ldc, void* Z, int M, int N,
                    int K, const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed, int accumulate,
                    float* workspace, size_t workspace_bytes, svpc_stream_t stream);
+/* the same with an addend R of C's type and leading dimension: C = epi(A·B) + R.  Lets the dgrad of a sub-layer's first projection
+ * absorb the residual-path gradient (reference: the `+` of model.py:229-233 / :285-289 in backward) instead of a separate add kernel */
+int svpc_gemm_glds_r(const void* A, int lda, int a_kc, const void* B, int ldb, int b_kc, void* C, int c_dt, int ldc, void* Z, const void* R,
+                     int M, int N, int K, const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed, int accumulate,
+                     float* workspace, size_t workspace_bytes, svpc_stream_t stream);
 /* fp32-operand form with direct-to-LDS staging (deep LDS ring, operands rounded to bf16 when the MFMA fragments are built): the
  * latency-bound GEMMs of the decoder :620-694, step-wise encoder :594-617, simulators :742-823, BiLSTM :1017-1025, LM head
  * :697-739 and their dgrad/wgrad.  Any M, N (edges clamped); K % 32 == 0; k-strided operands need rows % 4 == 0. */

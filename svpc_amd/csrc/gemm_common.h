@@ -7,6 +7,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 struct Epi {
     const float* bias; int act; float p_drop; uint32_t site; const u64* seed; int accumulate;
     float* Z;   // optional pre-activation output (same ldc)
+    const void* R;   // optional bf16 addend with C's layout, C = act(acc + bias) + R (a residual-path gradient joining a dgrad): only the
+                     // 16-byte row-store epilogues of gemm_glds.hip apply it — the launcher refuses R where they cannot run
 };
 
 __device__ __forceinline__ void epilogue_store(float v, int row, int col, float* __restrict__ C, int ldc, const Epi& e,

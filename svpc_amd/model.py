@@ -206,11 +206,12 @@ class BertLayerNoMemoryUntied(nn.Module):
         ctx = ops.attention(qkv, qkv, (0, D, 2 * D), D, cx.H, seq, key_mask=key_mask, causal=False, drop=cx.drop(cx.p_a))
         so = self.attention.output
         ao = ops.linear(ctx, so.dense.weight, so.dense.bias)
-        x1 = ops.layernorm(ao, so.LayerNorm.weight, so.LayerNorm.bias, cx.eps, residual=h, pre_drop=cx.drop(cx.p_h))
+        # sink=True: h / x1 are consumed by exactly one projection besides the residual path; its dgrad absorbs the residual gradient
+        x1 = ops.layernorm(ao, so.LayerNorm.weight, so.LayerNorm.bias, cx.eps, residual=h, pre_drop=cx.drop(cx.p_h), sink=True)
         it = ops.linear(x1, self.hidden_intermediate.dense.weight, self.hidden_intermediate.dense.bias, act=ACT_GELU)
         o = ops.linear(it, self.output.dense.weight, self.output.dense.bias)
         return ops.layernorm(o, self.output.LayerNorm.weight, self.output.LayerNorm.bias, cx.eps,
-                             residual=x1, pre_drop=cx.drop(cx.p_h))
+                             residual=x1, pre_drop=cx.drop(cx.p_h), sink=True)
 
 
     def run_rows(self, h, sel_rows, seq_sel, key_mask, cx):
@@ -279,7 +280,7 @@ class BertDecoderLayerNoMemoryUntied(nn.Module):
         qkv = ops.linear(x, w, b, wgrad=wg, bgrad=bg, w16=w16)
         sa = ops.attention(qkv, qkv, (0, D, 2 * D), D, cx.H, seq_self, key_mask=text_mask, causal=True,
                            drop=cx.drop(cx.p_a))
-        x1 = ops.layernorm(sa, self.norm1.weight, self.norm1.bias, cx.eps, residual=x)
+        x1 = ops.layernorm(sa, self.norm1.weight, self.norm1.bias, cx.eps, residual=x, sink=True)
         ca_m = self.dec_enc_attention
         qc = ops.linear(x1, ca_m.query.weight, ca_m.query.bias)
         wkv, bkv, wg, bg, w16 = ca_m.packed("kv")
@@ -287,10 +288,10 @@ class BertDecoderLayerNoMemoryUntied(nn.Module):
         if kvc.dtype != qc.dtype:          # the few memory rows stay fp32 in HBM; the attention core wants one operand type
             kvc = kvc.to(qc.dtype)
         ca = ops.attention(qc, kvc, (0, 0, D), D, cx.H, seq_cross, key_mask=mem_mask, causal=False, drop=cx.drop(cx.p_a))
-        x2 = ops.layernorm(ca, self.norm2.weight, self.norm2.bias, cx.eps, residual=x1)
+        x2 = ops.layernorm(ca, self.norm2.weight, self.norm2.bias, cx.eps, residual=x1, sink=True)
         o = ops.linear(x2, self.output.dense.weight, self.output.dense.bias)
         return ops.layernorm(o, self.output.LayerNorm.weight, self.output.LayerNorm.bias, cx.eps,
-                             residual=x2, pre_drop=cx.drop(cx.p_h))
+                             residual=x2, pre_drop=cx.drop(cx.p_h), sink=True)
 
 
     def memory_kv(self, mem):

@@ -250,6 +250,11 @@ def join_side():
     flush_wgrads()
     flush_finalizes()
     _JOIN_QUEUED[0] = False
+    if _RES_SINK:
+        n_left = len(_RES_SINK)
+        _RES_SINK.clear()
+        raise _lib.SvpcKernelError("residual-gradient hand-over: %d parked gradient(s) were never absorbed by a projection's dgrad "
+                                   "(layernorm(..., sink=True) without a consuming ops.linear)" % n_left)
     if _SIDE_DIRTY:
         cur = torch.cuda.current_stream()
         for st in _SIDE_DIRTY:
@@ -434,7 +439,8 @@ def bf16_stream_ok(rows, *dims):
     return rows % 128 == 0 and all(d % 128 == 0 for d in dims)
 
 
-def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NONE, p=0.0, site=0, seed=None, accumulate=0):
+def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NONE, p=0.0, site=0, seed=None, accumulate=0, R=None):
+    """C = epi(A·B) (+ R: an addend of C's type and layout, only on the bf16 direct-to-LDS path; other paths add it afterwards)"""
     ws = _ws(C.device)
     ev = (GEMM_TIMER.bracket(2.0 * M * N * K, (M, N, K, a_kc, b_kc, _dt(A), _dt(B), _dt(C)))
           if GEMM_TIMER is not None else None)
@@ -442,8 +448,9 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NON
         ev[0].record()
     if _PRECISION == "bf16" and USE_GLDS and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and \
             (A.data_ptr() | B.data_ptr()) % 16 == 0 and _lib.load().svpc_gemm_glds_supported(a_kc, b_kc, lda, ldb, M, N, K) == 1:
-        _lib.call("gemm_glds", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), _dt(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
-                  _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+        _lib.call("gemm_glds_r", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), _dt(C), C.stride(0), _p(Z), _p(R), M, N, K, _p(bias), act, p,
+                  site, _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+        R = None
     elif _PRECISION == "bf16" and USE_L32 and A.dtype == B.dtype == C.dtype == torch.float32 and \
             (A.data_ptr() | B.data_ptr()) % 16 == 0 and _lib.load().svpc_gemm_l32_preferred(a_kc, b_kc, lda, ldb, M, N, K) == 1:
         _lib.call("gemm_l32", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
@@ -455,6 +462,8 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NON
     else:
         _lib.call("gemm_f32", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
                   _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+    if R is not None:
+        C.add_(R)
     if ev:
         ev[1].record()
 
@@ -502,6 +511,16 @@ def _shadow(w):
     return s
 
 
+# Residual-gradient hand-over.  In `y = LayerNorm(sub(h) + h)` the gradient of h has two parts: the LayerNorm's dh (residual path)
+# and the dgrad of sub's first projection.  Autograd would add them with a separate kernel (≈30 per step on the bf16 streams);
+# instead a LayerNorm called with sink=True parks its dh here, keyed by h's address, and returns no residual gradient, and the
+# backward of the projection that consumes h adds the parked tensor in its dgrad epilogue (C = dz·W + R).  The caller promises
+# that exactly one ops.linear consumes h and needs its input gradient; join_side() fails loudly if a parked gradient is left over.
+USE_RES_SINK = os.environ.get("SVPC_RES_SINK", "1") != "0"
+_RES_SINK = {}
+SINK_STATS = [0, 0]        # parked by LayerNorm backwards / absorbed by dgrad epilogues (since import)
+
+
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, act, trans_w, drop, wgrad, bgrad, w16):
@@ -535,7 +554,12 @@ class _Linear(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=x.dtype, device=dy.device)
-            _gemm(dz, N, 1, w, w.stride(0), 1 if trans_w else 0, dx, M, K, N)
+            parked = _RES_SINK.pop(x.data_ptr(), None) if _RES_SINK else None
+            if parked is not None:
+                SINK_STATS[1] += 1
+            if parked is not None and (parked.shape != dx.shape or parked.dtype != dx.dtype):
+                raise _lib.SvpcKernelError("residual-gradient hand-over: parked gradient does not match the projection's input")
+            _gemm(dz, N, 1, w, w.stride(0), 1 if trans_w else 0, dx, M, K, N, R=parked)
         wgrad, bgrad = ctx.direct
         w_done = False
         if wgrad is not None and not trans_w and (not has_b or bgrad is not None):
@@ -598,8 +622,9 @@ def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgr
 class _LayerNorm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, add2, eps, src_rows, pad_row, pre_drop, post_drop, add1, add1_mod, add2_idx,
-                out_bf16=False):
+                out_bf16=False, sink=False):
         _need_gpu(x)
+        ctx.sink = bool(sink)
         ctx.direct = (_direct(gamma), _direct(beta), _direct(x) if src_rows is not None else None,
                       _direct(add2) if add2 is not None else None)
         x = _c(x)
@@ -669,13 +694,21 @@ class _LayerNorm(Function):
                 _ready(a2_dir)
             else:
                 dadd2 = _colsum(dy, add2_idx, k_add2)
-        return dx, dgamma, dbeta, (dh if need_res else None), dadd2, None, None, None, None, None, None, None, None, None
+        dres = dh if need_res else None
+        if need_res and ctx.sink and USE_RES_SINK and dh.dtype == torch.bfloat16:
+            _RES_SINK[residual.data_ptr()] = dh       # joins the dgrad of the projection that consumes the residual tensor
+            SINK_STATS[0] += 1
+            _queue_end_of_backward_join()
+            dres = None
+        return dx, dgamma, dbeta, dres, dadd2, None, None, None, None, None, None, None, None, None, None
 
 
 def layernorm(x, gamma, beta, eps, residual=None, src_rows=None, pad_row=-1, pre_drop=None, post_drop=None,
-              add1=None, add1_mod=0, add2=None, add2_idx=None, out_bf16=False):
+              add1=None, add1_mod=0, add2=None, add2_idx=None, out_bf16=False, sink=False):
+    """sink=True: the residual tensor's only other consumer is an ops.linear whose backward will absorb this LayerNorm's
+    residual-path gradient in its dgrad epilogue (see _RES_SINK)."""
     return _LayerNorm.apply(x, gamma, beta, residual, add2, eps, src_rows, pad_row, pre_drop, post_drop, add1, add1_mod,
-                            add2_idx, out_bf16)
+                            add2_idx, out_bf16, sink)
 
 
 # ------------------------------------------------------------------------------------------------ attention

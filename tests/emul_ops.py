@@ -56,7 +56,7 @@ def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgr
 
 
 def layernorm(x, gamma, beta, eps, residual=None, src_rows=None, pad_row=-1, pre_drop=None, post_drop=None,
-              add1=None, add1_mod=0, add2=None, add2_idx=None, out_bf16=False):
+              add1=None, add1_mod=0, add2=None, add2_idx=None, out_bf16=False, sink=False):
     h = x if src_rows is None else x[src_rows.long()]
     h = _apply_drop(h, pre_drop)
     if residual is not None:

@@ -531,6 +531,58 @@ def test_glds_pingpong_tiles(bf16_mode, M, N, K, a_kc, b_kc):
     assert (C.double() - (C0.double() + ref)).abs().max().item() <= 1.2e-2 * max(scale, C0.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(19200, 768, 768), (4224, 768, 2304), (18000, 760, 768)])
+def test_glds_addend_epilogue(bf16_mode, M, N, K):
+    """C = A·B + R in the 16-byte row-store epilogues (ping-pong tiles through the LDS image at M = 19,200 / 18,000, direct row
+    pieces of the 128² tiles at M = 4,224): the dgrad that absorbs a residual-path gradient — against fp64"""
+    g = torch.Generator().manual_seed(M + N)
+    bf = torch.bfloat16
+    A = torch.randn(M, K, generator=g).to(bf).to(DEV)
+    B = (0.05 * torch.randn(K, N, generator=g)).to(bf).to(DEV)
+    R = torch.randn(M, N, generator=g).to(bf).to(DEV)
+    C = torch.empty(M, N, device=DEV, dtype=bf)
+    O._gemm(A, K, 1, B, N, 0, C, M, N, K, R=R)
+    ref = A.double() @ B.double() + R.double()
+    assert (C.double() - ref).abs().max().item() <= 6e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_residual_gradient_hand_over(bf16_mode):
+    """layernorm(sub(h) + h, sink=True): the LayerNorm parks its residual-path gradient and the projection consuming h adds it in its
+    dgrad epilogue — same gradients as autograd's separate add (within bf16 rounding); a parked gradient nobody absorbs fails loudly"""
+    torch.manual_seed(0)
+    rows, D = 512, 128
+    h0 = (0.5 * torch.randn(rows, D, device=DEV)).bfloat16()
+    w = (0.1 * torch.randn(D, D, device=DEV)).requires_grad_(True)
+    b = torch.zeros(D, device=DEV, requires_grad=True)
+    gamma, beta = torch.ones(D, device=DEV, requires_grad=True), torch.zeros(D, device=DEV, requires_grad=True)
+    wt = torch.randn(rows, D, device=DEV)
+    grads = []
+    keep = O.USE_RES_SINK
+    try:
+        for use in (True, False):
+            O.USE_RES_SINK = use
+            h = h0.clone().requires_grad_(True)
+            for t in (w, b, gamma, beta):
+                t.grad = None
+            before = O.SINK_STATS[1]
+            y = O.layernorm(O.linear(h, w, b), gamma, beta, 1e-12, residual=h, sink=True)
+            (y.float() * wt).sum().backward()
+            torch.cuda.synchronize()
+            assert (O.SINK_STATS[1] - before) == (1 if use else 0)
+            grads.append((h.grad.float().clone(), w.grad.clone()))
+        assert torch.allclose(grads[0][0], grads[1][0], rtol=2e-2, atol=2e-2 * grads[1][0].abs().max().item())
+        assert torch.allclose(grads[0][1], grads[1][1], rtol=2e-2, atol=2e-2 * grads[1][1].abs().max().item())
+        # no projection consumes h: the parked gradient is reported at the end of backward, not dropped
+        O.USE_RES_SINK = True
+        h = h0.clone().requires_grad_(True)
+        y = O.layernorm(h * 2.0, gamma, beta, 1e-12, residual=h, sink=True)
+        with pytest.raises(Exception, match="hand-over"):
+            (y.float() * wt).sum().backward()
+    finally:
+        O.USE_RES_SINK = keep
+        O._RES_SINK.clear()
+
+
 def test_grouped_weight_gradients(bf16_mode):
     """svpc_gemm_group_wgrad: several independent dW += dzᵀ·x (+ db += Σ dz) problems of different shapes in one launch, against
     fp64 on the bf16-rounded operands (weights) and an fp32 column sum (bias); accumulation into non-zero targets."""
