@@ -786,22 +786,17 @@ int svpc_gemm_glds_r(const void* A, int lda, int a_kc, const void* B, int ldb, i
     static int ppdbg = -1;
     if (ppdbg < 0) { const char* e = getenv("SVPC_PP_DBG"); ppdbg = e ? atoi(e) : 0; }
     dim3 grid(tiles * splitk), block(512);
-    static int ns = -1;
-    if (ns < 0) { const char* e = getenv("SVPC_GLDS_NS"); ns = e ? atoi(e) : 3; }   // 3 stages = 48 KiB → 3 workgroups per CU (measured best)
+    // 3 stages = 48 KiB → 3 workgroups per CU (measured best of 3 / 4)
 #define GL_LAUNCH1(AK, BKC, TC, NSV, BMV)                                                                                            \
     hipLaunchKernelGGL((gemm_glds_kernel<AK, BKC, TC, NSV, BMV>), grid, block, 0, stream, (const __bf16*)A, lda, (const __bf16*)B, ldb,   \
                        (TC*)C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, workspace, remap)
 #define GL_LAUNCH(AK, BKC, TC)                                                                                                       \
     do {                                                                                                                             \
-        if (big && big_env == 2)                                                                                                     \
-            hipLaunchKernelGGL((gemm_glds_kernel<AK, BKC, TC, 4, 256, 256>), grid, block, 0, stream, (const __bf16*)A, lda,          \
-                               (const __bf16*)B, ldb, (TC*)C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, workspace, remap); \
-        else if (big)                                                                                                                \
+        if (big)                                                                                                                     \
             hipLaunchKernelGGL((gemm_glds_pp_kernel<AK, BKC, TC>), grid, block, 0, stream, (const __bf16*)A, lda, (const __bf16*)B,  \
                                ldb, (TC*)C, ldc, M, N, K, epi, tiles_m, tiles_n, remap, nullptr);                                    \
         else if (BMv == 256) GL_LAUNCH1(AK, BKC, TC, 3, 256);                                                                          \
-        else if (ns == 3) GL_LAUNCH1(AK, BKC, TC, 3, 128);                                                                           \
-        else GL_LAUNCH1(AK, BKC, TC, 4, 128);                                                                                        \
+        else GL_LAUNCH1(AK, BKC, TC, 3, 128);                                                                                        \
     } while (0)
     if (big && (ppdbg & 8) && c_dt == 1 && a_kc && b_kc && workspace) {      // development aid: stamped instance, stamps → workspace
         hipLaunchKernelGGL((gemm_glds_pp_kernel<true, true, __bf16, true>), grid, block, 0, stream, (const __bf16*)A, lda, (const __bf16*)B,
