@@ -246,6 +246,11 @@ int svpc_lstm_pair_fwd(const float* const* gx, const int* const* rows, const flo
 int svpc_lstm_pair_bwd(const float* const* dh_out, const float* const* dh_rec, const float* const* dc, const float* const* gates,
                        const float* const* c_prev, const float* active, float* const* dgates, float* const* dc_prev,
                        float* const* dh_prev, int N, int D, svpc_stream_t stream);
+/* the same when the recurrent dgrad dgates·W_hh of the previous time step was computed in n_parts k-parts (more workgroups pulling
+ * the weight): dh_parts[z] = n_parts slabs of N·D floats, added to dh_rec in part order */
+int svpc_lstm_pair_bwd_parts(const float* const* dh_out, const float* const* dh_rec, const float* const* dh_parts, int n_parts,
+                             const float* const* dc, const float* const* gates, const float* const* c_prev, const float* active,
+                             float* const* dgates, float* const* dc_prev, float* const* dh_prev, int N, int D, svpc_stream_t stream);
 /* greedy decoding step: argmax with the UNK column suppressed + OOV→UNK remap, src/translator.py:104-112 */
 int svpc_greedy_pick(const float* scores, int ld, const int* row_c, const int* row_x, int n_sent, int lt, int pos, int unk,
                      int* next_ext, int* next_model, svpc_stream_t stream);

@@ -441,6 +441,7 @@ struct LstmPair {
     float* h[2]; float* c[2]; float* gates[2];
     // backward
     const float* dh_out[2]; const float* dh_rec[2]; const float* dc[2]; float* dgates[2]; float* dc_prev[2]; float* dh_prev[2];
+    const float* dh_parts[2]; int n_parts;      // optional k-parts of the recurrent dgrad (n_parts slabs of N·D floats per direction)
 };
 __global__ __launch_bounds__(256) void lstm_pair_fwd_kernel(LstmPair a, int N, int D) {
     const int i = blockIdx.x * 256 + threadIdx.x, z = blockIdx.y;
@@ -470,7 +471,8 @@ __global__ __launch_bounds__(256) void lstm_pair_bwd_kernel(LstmPair a, int N, i
     const float* ga = a.gates[z];
     const float gi = ga[g0], gf = ga[g0 + D], gg = ga[g0 + 2 * D], go = ga[g0 + 3 * D];
     const float act = a.active[n];
-    const float dht = a.dh_out[z][i] + a.dh_rec[z][i];
+    float dht = a.dh_out[z][i] + a.dh_rec[z][i];
+    for (int p = 0; p < a.n_parts; ++p) dht += a.dh_parts[z][(size_t)p * N * D + i];       // part order: deterministic
     const float dci = a.dc[z][i], cp = a.c_prev[z][i];
     const float dhn = act * dht, dcn_in = act * dci;
     const float cn = gf * cp + gi * gg;
@@ -690,11 +692,22 @@ int svpc_lstm_pair_fwd(const float* const* gx, const int* const* rows, const flo
     hipLaunchKernelGGL(lstm_pair_fwd_kernel, dim3(ceil_div(N * D, 256), 2), dim3(256), 0, s, a, N, D);
     return svpc_check_launch("lstm_pair_fwd");
 }
+int svpc_lstm_pair_bwd_parts(const float* const* dh_out, const float* const* dh_rec, const float* const* dh_parts, int n_parts,
+                             const float* const* dc, const float* const* gates, const float* const* c_prev, const float* active,
+                             float* const* dgates, float* const* dc_prev, float* const* dh_prev, int N, int D, hipStream_t s);
 int svpc_lstm_pair_bwd(const float* const* dh_out, const float* const* dh_rec, const float* const* dc, const float* const* gates,
                        const float* const* c_prev, const float* active, float* const* dgates, float* const* dc_prev,
                        float* const* dh_prev, int N, int D, hipStream_t s) {
+    return svpc_lstm_pair_bwd_parts(dh_out, dh_rec, nullptr, 0, dc, gates, c_prev, active, dgates, dc_prev, dh_prev, N, D, s);
+}
+// the same with the recurrent dgrad of the previous launch arriving as n_parts k-part slabs per direction (dh_parts[z]: n_parts × N·D)
+int svpc_lstm_pair_bwd_parts(const float* const* dh_out, const float* const* dh_rec, const float* const* dh_parts, int n_parts,
+                             const float* const* dc, const float* const* gates, const float* const* c_prev, const float* active,
+                             float* const* dgates, float* const* dc_prev, float* const* dh_prev, int N, int D, hipStream_t s) {
     if (N == 0) return 0;
     LstmPair a{};
+    a.n_parts = dh_parts ? n_parts : 0;
+    for (int z = 0; z < 2 && a.n_parts; ++z) a.dh_parts[z] = dh_parts[z];
     for (int z = 0; z < 2; ++z) {
         a.dh_out[z] = dh_out[z]; a.dh_rec[z] = dh_rec[z]; a.dc[z] = dc[z]; a.gates[z] = const_cast<float*>(gates[z]);
         a.c_prev[z] = c_prev[z]; a.dgates[z] = dgates[z]; a.dc_prev[z] = dc_prev[z]; a.dh_prev[z] = dh_prev[z];

@@ -1190,6 +1190,9 @@ def _ptr2(a, b):
     return ctypes.addressof(arr), arr          # keep `arr` alive until the call returns
 
 
+LSTM_DGRAD_PARTS = int(os.environ.get("SVPC_LSTM_DGRAD_PARTS", "4"))
+
+
 class _BiLstmSeq(Function):
     """Both directions of the BiLSTM recurrence as ONE autograd node advancing in lockstep: per time step one grouped GEMM (the two
     recurrent projections) and one cell launch (both directions) forward, one cell launch and one grouped dgrad GEMM backward —
@@ -1245,11 +1248,30 @@ class _BiLstmSeq(Function):
         dh2, dc2 = [mk(N, D) for _ in range(2)], [mk(N, D) for _ in range(2)]
         wt = [w[z].t().contiguous() for z in range(2)]        # (D, 4D): k-contiguous operand of the per-step dgrad
         st = _stream()
+        # the per-step dgrad (N × D over K = 4D) is bound by how fast ONE workgroup can pull its weight columns: cut K into
+        # LSTM_DGRAD_PARTS k-parts (separate problems of the grouped launch, each writing a slab) that the next cell launch adds
+        P = LSTM_DGRAD_PARTS if (4 * D) % (32 * LSTM_DGRAD_PARTS) == 0 else 1
+        Kp = 4 * D // P
+        slabs = [mk(P, N, D) for _ in range(2)] if P > 1 else None
+        have_parts = False
         for t in range(S - 1, -1, -1):
             a = [_ptr2(dhs[0][t], dhs[1][t]), _ptr2(dh[0], dh[1]), _ptr2(dc[0], dc[1]), _ptr2(gates[0][t], gates[1][t]),
                  _ptr2(c_all[0][t], c_all[1][t]), None, _ptr2(dG[0][t], dG[1][t]), _ptr2(dc2[0], dc2[1]), _ptr2(dh2[0], dh2[1])]
-            _lib.call("lstm_pair_bwd", a[0][0], a[1][0], a[2][0], a[3][0], a[4][0], _p(active_t[t]), a[6][0], a[7][0], a[8][0], N, D, st)
-            _gemm_pair([dG[0][t], dG[1][t]], wt, dh2, N, D, 4 * D, accumulate=1)      # dh_{t-1} = pass-through + dgates · W_hh
+            if P > 1:
+                sp = _ptr2(slabs[0], slabs[1])
+                _lib.call("lstm_pair_bwd_parts", a[0][0], a[1][0], sp[0] if have_parts else None, P if have_parts else 0, a[2][0], a[3][0],
+                          a[4][0], _p(active_t[t]), a[6][0], a[7][0], a[8][0], N, D, st)
+                if t > 0:
+                    probs = (_GemmProblem * (2 * P))()
+                    for z in range(2):
+                        for k in range(P):
+                            probs[z * P + k] = _GemmProblem(dG[z][t].data_ptr() + 4 * k * Kp, wt[z].data_ptr() + 4 * k * Kp,
+                                                            slabs[z][k].data_ptr(), N, D, Kp, 4 * D, 4 * D, D)
+                    _lib.call("gemm_group", ctypes.addressof(probs), 2 * P, 1, 1, 0, st)
+                    have_parts = True
+            else:
+                _lib.call("lstm_pair_bwd", a[0][0], a[1][0], a[2][0], a[3][0], a[4][0], _p(active_t[t]), a[6][0], a[7][0], a[8][0], N, D, st)
+                _gemm_pair([dG[0][t], dG[1][t]], wt, dh2, N, D, 4 * D, accumulate=1)      # dh_{t-1} = pass-through + dgates · W_hh
             dh, dh2 = dh2, dh
             dc, dc2 = dc2, dc
         dws, dgx = [None, None], [None, None]
