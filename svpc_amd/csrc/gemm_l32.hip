@@ -171,11 +171,11 @@ __global__ __launch_bounds__(256) void gemm_l32_kernel(const float* __restrict__
 // bytes in flight per CU — these launches are bound by the memory round trip per k-tile, nothing else.
 // `asum` (optional): += Σ_k A(m, k) for the tile's 64 rows m — the bias gradient of a wgrad (A = dz, k-strided) — taken from the
 // fp32 LDS image (not the bf16-rounded fragments) by the workgroups of the first tile column.
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int NS = 2>
 __device__ __forceinline__ void l32w_tile(char* l32_smem, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                           float* __restrict__ C, int ldc, int M, int N, int K, const Epi& epi, int tm, int tn,
                                           float* __restrict__ asum) {
-    constexpr int T = 64, OP = T * L32_BK * 4, STAGE = 2 * OP, NS = 2, PIECES = OP / 1024;      // 8 pieces of 1 KiB per operand tile
+    constexpr int T = 64, OP = T * L32_BK * 4, STAGE = 2 * OP, PIECES = OP / 1024;      // 8 pieces of 1 KiB per operand tile; NS stages per wave
     const int m0 = tm * T, n0 = tn * T;
     const bool want_asum = !A_KC && asum != nullptr && tn == 0;
     float bsum = 0.f;
@@ -204,7 +204,7 @@ __device__ __forceinline__ void l32w_tile(char* l32_smem, const float* __restric
 
 #define L32W_ISSUE(t)                                                                                                       \
     do {                                                                                                                    \
-        char* st = ring + ((t) & 1) * STAGE;                                                                                \
+        char* st = ring + ((t) % NS) * STAGE;                                                                               \
         _Pragma("unroll") for (int i = 0; i < PIECES; ++i) {                                                                \
             __builtin_amdgcn_global_load_lds((l32_gptr)ga[i], (l32_lptr)(st + i * 1024), 16, 0, 0);                         \
             __builtin_amdgcn_global_load_lds((l32_gptr)gb[i], (l32_lptr)(st + OP + i * 1024), 16, 0, 0);                    \
@@ -212,16 +212,19 @@ __device__ __forceinline__ void l32w_tile(char* l32_smem, const float* __restric
         }                                                                                                                   \
     } while (0)
 
-    if (nk > 0) L32W_ISSUE(0);
+    if (NS == 2 && nk > 0) L32W_ISSUE(0);
     for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) {
+        if (NS == 1) {                             // one stage per wave (half the LDS → two workgroups per CU): load, wait, multiply
+            L32W_ISSUE(t);
+            l32_wait_vmcnt<0>();
+        } else if (t + 1 < nk) {
             L32W_ISSUE(t + 1);
             l32_wait_vmcnt<2 * PIECES>();          // tile t landed; tile t+1 (16 pieces) may still be in flight
         } else {
             l32_wait_vmcnt<0>();
         }
         __builtin_amdgcn_wave_barrier();
-        const char* sa = ring + (t & 1) * STAGE;
+        const char* sa = ring + (t % NS) * STAGE;
         const char* sb = sa + OP;
         if (want_asum) {                                    // k-strided image: [32 k-rows][64 columns] fp32, lane = column
             const float* img = reinterpret_cast<const float*>(sa);
@@ -295,6 +298,7 @@ struct GProb { const float* dz; const float* x; float* dw; float* db; int n_out,
 constexpr int GROUP_MAX = 48;
 struct GArgs { int n; GProb p[GROUP_MAX]; };
 
+template <int NS>
 __global__ __launch_bounds__(256) void gemm_group_wgrad_kernel(GArgs g) {
     extern __shared__ __attribute__((aligned(1024))) char l32_smem[];
     int pi = 0;
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(256) void gemm_group_wgrad_kernel(GArgs g) {
     const int tile = blockIdx.x - q.tile0;
     const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
     Epi epi{nullptr, ACT_NONE, 0.f, 0u, nullptr, 1, nullptr};
-    l32w_tile<false, false>(l32_smem, q.dz, q.ld_dz, q.x, q.ld_x, q.dw, q.ld_dw, q.n_out, q.n_in, q.rows, epi, tm, tn, q.db);
+    l32w_tile<false, false, NS>(l32_smem, q.dz, q.ld_dz, q.x, q.ld_x, q.dw, q.ld_dw, q.n_out, q.n_in, q.rows, epi, tm, tn, q.db);
 }
 
 
@@ -555,15 +559,23 @@ int svpc_gemm_group_wgrad(const void* problems, int n, hipStream_t stream) {
         q.ld_x = h.ld_x; q.ld_dw = h.ld_dw; q.tile0 = tiles; q.tiles_n = ceil_div(h.n_in, 64);
         tiles += ceil_div(h.n_out, 64) * q.tiles_n;
     }
-    constexpr int LDS = 4 * 2 * 2 * 64 * L32_BK * 4;
+    constexpr int LDS2 = 4 * 2 * 2 * 64 * L32_BK * 4, LDS1 = 4 * 64 * 64 * 4 + 1024;      // one stage per wave: the partial-tile area sets the size
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_group_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_group_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           LDS2);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_group_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
         if (e != hipSuccess) { svpc_set_error("gemm_group_wgrad: cannot raise the dynamic LDS limit"); return (int)e; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_group_wgrad_kernel, dim3(tiles), dim3(256), LDS, stream, g);
+    // one stage per wave halves the LDS and lets two workgroups share a CU: these launches are thousands of 64² tiles with short
+    // reductions (192 … 576 rows: ≤ 5 k-tiles per wave), one per CU at a time with the two-stage ring (measured: 1 < auto < 2)
+    static int ns_env = -1;
+    if (ns_env < 0) { const char* e = getenv("SVPC_GROUP_WGRAD_NS"); ns_env = e ? atoi(e) : 1; }
+    const bool one_stage = ns_env != 2;
+    if (one_stage) hipLaunchKernelGGL(gemm_group_wgrad_kernel<1>, dim3(tiles), dim3(256), LDS1, stream, g);
+    else hipLaunchKernelGGL(gemm_group_wgrad_kernel<2>, dim3(tiles), dim3(256), LDS2, stream, g);
     return svpc_check_launch("gemm_group_wgrad");
 }
 
