@@ -758,11 +758,13 @@ int svpc_gemm_glds_r(const void* A, int lda, int a_kc, const void* B, int ldb, i
     if (!a_kc && !b_kc && M >= 256 && wgrad_bm == 256) BMv = 256;      // wgrad: split-K supplies the parallelism
     if (bm_env == 128 || bm_env == 256) BMv = bm_env;
     // 256×256 tiles (wave tile 128×64, 4-stage ring of 32 KiB stages = 128 KiB, one workgroup per CU): half the LDS reads and
-    // half the L2→LDS bytes per MFMA of the 256×128 tile; taken when such tiles alone fill most of the chip
+    // half the L2→LDS bytes per MFMA of the 256×128 tile; taken when such tiles alone fill most of the chip (≥ 150 of them)
     static int big_env = -1;
     if (big_env < 0) { const char* e = getenv("SVPC_GLDS_BIG"); big_env = e ? atoi(e) : 1; }
     const int t_big = ceil_div(M, 256) * ceil_div(N, 256);
-    const bool big = big_env && (a_kc || b_kc) && t_big >= 200;
+    static int big_min = -1;
+    if (big_min < 0) { const char* e = getenv("SVPC_GLDS_BIG_MIN"); big_min = e ? atoi(e) : 150; }   // measured on 13 / 10 / 8-video batches: 183 tiles win, ≤ 141 lose
+    const bool big = big_env && (a_kc || b_kc) && t_big >= big_min;
     const int BNv = big ? 256 : GL_BN;
     if (big) BMv = 256;
     const int tiles_m = ceil_div(M, BMv), tiles_n = ceil_div(N, BNv), tiles = tiles_m * tiles_n;

@@ -20,6 +20,7 @@ typedef const void __attribute__((address_space(1))) * l32_gptr;
 typedef void __attribute__((address_space(3))) * l32_lptr;
 
 constexpr int L32_BK = 32;
+__device__ __attribute__((aligned(16))) const float l32_zeros[4] = {0.f, 0.f, 0.f, 0.f};     // source of k-rows past K (wgrad tails)
 
 template <int N> __device__ __forceinline__ void l32_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -180,8 +181,12 @@ __device__ __forceinline__ void l32w_tile(char* l32_smem, const float* __restric
     const bool want_asum = !A_KC && asum != nullptr && tn == 0;
     float bsum = 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nk_all = K / L32_BK;
+    // both operands k-strided (a weight gradient: K = the row count of the activations, arbitrary): the last k-tile may be partial,
+    // its k-rows past K are fetched from a block of zeros; otherwise K is a multiple of the tile depth (host check)
+    constexpr bool TAIL = !A_KC && !B_KC;
+    const int nk_all = TAIL ? (K + L32_BK - 1) / L32_BK : K / L32_BK;
     const int nk = (nk_all - wave + 3) / 4;                 // k-tiles wave, wave+4, wave+8, …
+    const int krow0 = wave * L32_BK + lane / (T / 4);       // k-row of this lane in piece 0 of the wave's first tile (k-strided operands)
     char* const ring = l32_smem + wave * (NS * STAGE);
 
     const float* ga[PIECES];
@@ -206,8 +211,9 @@ __device__ __forceinline__ void l32w_tile(char* l32_smem, const float* __restric
     do {                                                                                                                    \
         char* st = ring + ((t) % NS) * STAGE;                                                                               \
         _Pragma("unroll") for (int i = 0; i < PIECES; ++i) {                                                                \
-            __builtin_amdgcn_global_load_lds((l32_gptr)ga[i], (l32_lptr)(st + i * 1024), 16, 0, 0);                         \
-            __builtin_amdgcn_global_load_lds((l32_gptr)gb[i], (l32_lptr)(st + OP + i * 1024), 16, 0, 0);                    \
+            const bool z_ = TAIL && krow0 + (t) * 4 * L32_BK + i * (256 / T) >= K;     /* piece i = k-rows i·(256/T) … of the tile */ \
+            __builtin_amdgcn_global_load_lds((l32_gptr)(z_ ? l32_zeros : ga[i]), (l32_lptr)(st + i * 1024), 16, 0, 0);      \
+            __builtin_amdgcn_global_load_lds((l32_gptr)(z_ ? l32_zeros : gb[i]), (l32_lptr)(st + OP + i * 1024), 16, 0, 0); \
             ga[i] += stepA; gb[i] += stepB;                                                                                 \
         }                                                                                                                   \
     } while (0)
@@ -551,9 +557,9 @@ int svpc_gemm_group_wgrad(const void* problems, int n, hipStream_t stream) {
     int tiles = 0;
     for (int i = 0; i < n; ++i) {
         const HostWgradProblem& h = hp[i];
-        SVPC_REQUIRE(svpc_gemm_l32_supported(0, 0, h.ld_dz, h.ld_x, h.n_out, h.n_in, h.rows) && h.rows >= L32_BK &&
+        SVPC_REQUIRE(h.rows > 0 && h.n_out > 0 && h.n_in > 0 && h.n_out % 4 == 0 && h.n_in % 4 == 0 && h.ld_dz % 4 == 0 && h.ld_x % 4 == 0 &&
                          ((((uintptr_t)h.dz) | ((uintptr_t)h.x)) & 15) == 0,
-                     "gemm_group_wgrad: rows % 32, n_out % 4, n_in % 4 and 16-byte alignment required");
+                     "gemm_group_wgrad: n_out % 4, n_in % 4 and 16-byte aligned rows required (any row count)");
         GProb& q = g.p[i];
         q.dz = h.dz; q.x = h.x; q.dw = h.dw; q.db = h.db; q.n_out = h.n_out; q.n_in = h.n_in; q.rows = h.rows; q.ld_dz = h.ld_dz;
         q.ld_x = h.ld_x; q.ld_dw = h.ld_dw; q.tile0 = tiles; q.tiles_n = ceil_div(h.n_in, 64);

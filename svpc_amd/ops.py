@@ -123,7 +123,7 @@ def defer_wgrad(dz, x, wgrad, bgrad):
         return False
     rows, n_out = dz.shape
     n_in = x.shape[1]
-    if rows % 32 or rows < 32 or n_out % 4 or n_in % 4 or dz.stride(0) % 4 or x.stride(0) % 4 or wgrad.stride(0) % 4:
+    if rows < 1 or n_out % 4 or n_in % 4 or dz.stride(0) % 4 or x.stride(0) % 4 or wgrad.stride(0) % 4:      # any row count: k tail zero-sourced
         return False
     if (dz.data_ptr() | x.data_ptr()) % 16 or dz.stride(1) != 1 or x.stride(1) != 1 or not wgrad.is_contiguous():
         return False

@@ -588,7 +588,9 @@ def test_grouped_weight_gradients(bf16_mode):
     fp64 on the bf16-rounded operands (weights) and an fp32 column sum (bias); accumulation into non-zero targets."""
     import ctypes
     shapes = [(192, 768, 768, True), (576, 1536, 768, True), (192, 64, 300, False), (4224, 768, 768, True), (32, 8, 4, True),
-              (192, 3072, 768, True), (96, 100, 60, False)]
+              (192, 3072, 768, True), (96, 100, 60, False),
+              # ragged row counts (T = Σ S_b steps is arbitrary): the partial last k-tile is fetched from a block of zeros
+              (156, 768, 768, True), (7, 64, 300, True), (468, 1536, 768, False), (3432, 768, 768, True), (33, 2304, 768, True)]
     g = torch.Generator().manual_seed(5)
     keep, probs = [], (O._WgradProblem * len(shapes))()
     for i, (rows, n_out, n_in, with_b) in enumerate(shapes):
