@@ -108,7 +108,8 @@ int svpc_gemm_l32(const float* A, int lda, int a_kc, const float* B, int ldb, in
                   size_t workspace_bytes, svpc_stream_t stream);
 /* grouped weight (+ bias) gradients of up to svpc_gemm_group_wgrad_max() independent linears in one launch:
  *   dw[n_out, n_in] += dzᵀ · x,   db[n_out] += Σ_rows dz   (db may be NULL)       — the wgrad half of every nn.Linear backward
- * `problems` is a HOST array of svpc_wgrad_problem; rows % 32 == 0, n_out % 4 == 0, n_in % 4 == 0, 16-byte aligned operands */
+ * `problems` is a HOST array of svpc_wgrad_problem; any row count (the partial last k-tile is zero-sourced), n_out % 4 == 0, n_in % 4 == 0,
+ * 16-byte aligned operands */
 /* grouped small GEMMs of one layout in one launch (fp32 operands, bf16 MFMA): C_p = (accumulate ? C_p : 0) + Σ_k A_p(m,k)·B_p(n,k);
  * `problems` is a HOST array, at most 32 entries, K % 32 == 0 — e.g. the recurrent projections of both LSTM directions at one step */
 typedef struct svpc_gemm_problem { const float* A; const float* B; float* C; int M, N, K, lda, ldb, ldc; } svpc_gemm_problem;
