@@ -1,18 +1,23 @@
-// bf16 × bf16 GEMM for the clip-encoder activation stream with DIRECT-TO-LDS operand staging (global_load_lds_dwordx4):
-// no staging registers, no conversion, no ds_write — the loads of three k-tiles stay in flight behind a counted vmcnt while the
-// matrix cores work on the current one (4-deep LDS ring, one raw s_barrier per k-tile).
+// bf16 × bf16 GEMM for the bf16 activation streams with DIRECT-TO-LDS operand staging (global_load_lds_dwordx4): no staging
+// registers, no conversion, no ds_write — the loads of the next k-tiles stay in flight behind a counted vmcnt while the matrix
+// cores work on the current one (LDS ring, raw s_barrier).
 //
 //   C[M,N] = epi( sum_k A(m,k) · B(n,k) ),  A: a_kc ? [M][lda] : [K][lda],  B: b_kc ? [N][ldb] : [K][ldb]   (bf16)
 // Any M, N: rows past the edge are clamped to the last valid row / 16-byte chunk (their products are never stored).  K: whole
 // 32-deep tiles for a k-contiguous operand (K is a feature width there); for a k-strided operand (wgrad: K = the row count of the
 // activation stream, arbitrary) the k-rows past K are fetched from a block of zeros instead.
 //
-// Tile 128×128×32, 512 threads = 8 waves (2×4), each wave 64×32 as two 32×32 v_mfma_f32_32x32x16_bf16 tiles.
-// One k-tile of one operand is 8 KiB = 8 wave-instructions of 1 KiB (64 lanes × 16 B, LDS destination = wave-uniform base
-// + lane·16); wave w issues instruction w of A and of B.  The LDS image is linear in that order; bank conflicts are removed by
+// Three tile forms, 512 threads = 8 waves each, MFMA v_mfma_f32_32x32x16_bf16:
+//   128×128×32  waves 2×4, wave tile 64×32, 3-stage ring (48 KiB, three workgroups per CU)      — the decoder's 4,224-row launches
+//   256×128×32  waves 4×2, wave tile 64×64, 3-stage ring (72 KiB, two per CU)                    — mid-sized grids
+//   256×256×32  two wave groups in ping-pong, wave tile 128×64, 4-stage ring (128 KiB, one per CU) — ≥ 150 such tiles: every
+//               19,200-row forward / dgrad launch and the grouped weight gradients (glds_tile_pp below)
+// One k-tile of one 128-row operand image is 8 KiB = 8 wave-instructions of 1 KiB (64 lanes × 16 B, LDS destination = wave-uniform
+// base + lane·16); wave w issues instruction w of every image.  The LDS image is linear in that order; bank conflicts are removed by
 // permuting the 16-byte chunks on the SOURCE side (per-lane global address) and applying the same XOR on the read side:
 //   k-contiguous operand: [128 rows][64 B], chunk c of row r stored at c ^ ((r>>2)&3)      → ds_read_b128 fragments, conflict-free
 //   k-strided operand:    [32 k-rows][256 B], chunk c of k-row q stored at c ^ ((q&3)<<2)  → ds_read_b64_tr_b16 fragments
+// bf16 outputs are accumulated transposed (a row on a lane) and leave as 16-byte row pieces / whole 128-byte lines (glds_store_*).
 // Weights come from the bf16 shadow arena the fused optimizer maintains next to the fp32 masters.
 #include "gemm_common.h"
 #include <stdlib.h>
