@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-videos", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=8)      # ≈ 12 s of CPU work (1 warm-up + 8 timed 2-video steps)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
 
