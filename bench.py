@@ -6,32 +6,134 @@ A step = {zero_grad, forward, backward, gradient all-reduce (N>1), global clip 1
 is already resident in HBM (reference: src/train.py:125-147 without EMA/logging).
 
   python bench.py --gpus 1 --steps 10 --warmup 3
+  python bench.py --gpus N ...            # WORLD_SIZE unset: this process starts N fresh rank processes itself (before any GPU
+                                          # call) and relays rank 0's JSON line; non-zero exit if any rank fails
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (metric/value/… + "roofline" for the dominant kernel + "cpu_baseline").
+Prints ONE JSON line on rank 0: metric/value/… + "roofline" (dominant kernel) + "cpu_baseline" + "secondary" (config 5:
+greedy decode) + "parity_mode" (the fp32 ≤1e-4-parity arithmetic timed on the same workload) + "ceilings" (vendor GEMM / copy).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from svpc_amd import StateAwareRecursiveTransformer, make_batch, make_config  # noqa: E402
-from svpc_amd import ops, synthetic as syn  # noqa: E402
-from svpc_amd.graph import backward_all
-from svpc_amd.optim import FusedBertAdam, GradReducer  # noqa: E402
-
-PMC_TRAFFIC_BYTES = 119381333   # (2·FETCH_SIZE + WRITE_SIZE)·1024, means per launch of the dominant kernel: profiles/r01_i_pmc_bench_dominant_gemm.csv
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense peaks (f32-in MFMA; bf16 MFMA)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "dominant_gemm_traffic.json")
+DOMINANT_SOURCES = ("svpc_amd/csrc/gemm_glds.hip", "svpc_amd/csrc/gemm_common.h", "svpc_amd/csrc/common.h")
 
 
-def build(args, device):
-    cfg = make_config(model_type=args.model_type, hidden_size=args.hidden, num_hidden_layers=args.layers,
+def dominant_kernel_sha():
+    h = hashlib.sha256()
+    for rel in DOMINANT_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes recorded in profiles/ (tools/pmc_traffic.py
+    writes the file, stamped with the hash of the kernel's sources); None when the sources changed since that measurement."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    if rec.get("kernel_sources_sha16") != dominant_kernel_sha():
+        return None, "stale: %s was measured on other kernel sources" % os.path.basename(TRAFFIC_FILE)
+    return rec.get("traffic_bytes_per_launch"), rec.get("source")
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model-type", default="vivt")
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--clips", type=int, default=12)
+    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--hidden", type=int, default=768)
+    ap.add_argument("--heads", type=int, default=12)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+                    help="arithmetic type of the GEMM / attention operands (accumulation, statistics and parameters are fp32 either way)")
+    ap.add_argument("--decode", action="store_true", help="only the secondary metric: greedy-decode captions/s (BASELINE config 5: 64 videos)")
+    ap.add_argument("--decode-videos", type=int, default=64)
+    ap.add_argument("--decode-full", action="store_true", help="decode with the reference-shaped loop (all Lt positions every iteration)")
+    ap.add_argument("--decode-eager", action="store_true", help="launch the decode kernels eagerly instead of replaying the batch structure's hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU rehearsals)")
+    ap.add_argument("--rehearse-dp", action="store_true",
+                    help="run the data-parallel code path (process group, three graphs, bucketed all-reduce) even with one rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the decode / parity-mode / ceilings legs (N=1 only legs)")
+    ap.add_argument("--cpu-videos", type=int, default=16, help="videos per CPU-baseline step (16 = the stated configuration)")
+    ap.add_argument("--cpu-warmup", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=3)      # ≈ 40 s of CPU work at 16 videos (BASELINE.md §3's 3+5 protocol: --cpu-warmup 3 --cpu-steps 5)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--parity-steps", type=int, default=5)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher/rendezvous check without a GPU: every rank joins the process group, SUM-all-reduces a small CPU "
+                         "gradient arena through GradReducer and rank 0 prints the JSON line (tests/test_bench_launcher.py)")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="(with --dry-run) this rank exits 3 after the rendezvous")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ parent: start N ranks
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """``--gpus N`` without a launcher: start N fresh rank processes (this process has made no GPU call and makes none), wait for
+    all of them, relay rank 0's JSON line.  Exit code = first non-zero rank exit code."""
+    import tempfile
+    port = _free_port()
+    procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None))
+    # wait for all; a rank that dies must not leave the others blocked in a collective for ever: after the first failure the
+    # remaining ranks get 20 s, then exactly these child PIDs are killed
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > 20.0:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.2)
+    codes = [p.returncode for p in procs]
+    out0.seek(0)
+    sys.stdout.write(out0.read())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print("[bench] rank(s) failed: %s" % bad, file=sys.stderr)
+        sys.exit(bad[0][1] if bad[0][1] > 0 else 1)
+
+
+# ------------------------------------------------------------------------------------------------ worker
+def build(args, device, model_type=None):
+    import torch
+    from svpc_amd import StateAwareRecursiveTransformer, make_config
+    mt = model_type or args.model_type
+    cfg = make_config(model_type=mt, hidden_size=args.hidden, num_hidden_layers=args.layers,
                       num_attention_heads=args.heads)
     torch.manual_seed(2019)
     model = StateAwareRecursiveTransformer(cfg)
@@ -40,15 +142,17 @@ def build(args, device):
     verb = 0.4 * torch.randn(cfg.action_vocab_size, cfg.word_vec_size, generator=g)
     model.ingredient_embeddings.set_pretrained_embedding(glove.clone(), freeze=False)
     model.text_embeddings.set_pretrained_embedding(glove.clone(), freeze=False)
-    if args.model_type in ("vivt", "viv"):
+    if mt in ("vivt", "viv"):
         model.reasoner.set_pretrained_embedding(verb.clone(), freeze=False)
-    if args.model_type == "vivt":
+    if mt == "vivt":
         model.recipe_reasoner.set_pretrained_embedding(verb.clone(), freeze=False)
     return cfg, model.to(device)
 
 
-def device_batch(cfg, args, device, seed):
-    b = make_batch(cfg, n_videos=args.batch, max_steps=args.clips, n_ingr=10, n_oov=0, seed=seed, full_clips=True)
+def device_batch(cfg, args, device, seed, n_videos=None):
+    import torch
+    from svpc_amd import make_batch
+    b = make_batch(cfg, n_videos=n_videos or args.batch, max_steps=args.clips, n_ingr=10, n_oov=0, seed=seed, full_clips=True)
     feats = torch.stack(b["video_features_list"]).to(device)           # one (S, N, L, F) buffer: consumed in place
     b["video_features_list"] = [feats[s] for s in range(feats.shape[0])]
     for k, v in list(b.items()):
@@ -62,9 +166,11 @@ def device_batch(cfg, args, device, seed):
 
 
 def cpu_baseline(cfg, model, args):
-    """The CPU oracle (a port of the reference path, pinned to it by tests/golden) timed on this host's cores on a
-    bounded sample of the same workload; reported next to the GPU number, never the target."""
+    """The CPU oracle (a port of the reference path, pinned to it by tests/golden) timed on this host's cores; reported next
+    to the GPU number, never the target.  Default: the stated configuration (all 16 videos of a step), median of the timed steps."""
+    import torch
     from oracle import svpc_oracle as orc
+    from svpc_amd import make_batch, synthetic as syn
     n_vid = args.cpu_videos
     torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
     b = make_batch(cfg, n_videos=n_vid, max_steps=args.clips, n_ingr=10, n_oov=0, seed=7, full_clips=True)
@@ -73,6 +179,8 @@ def cpu_baseline(cfg, model, args):
     state = {}
     wd = {n: (0.0 if any(t in n for t in ("bias", "LayerNorm.bias", "LayerNorm.weight")) else 0.01) for n in names}
 
+    step_no = [0]
+
     def one_step():
         for n in names:
             P[n].requires_grad_(True)
@@ -80,27 +188,43 @@ def cpu_baseline(cfg, model, args):
         total, _, _, _ = orc.forward(P, cfg, *syn.forward_args(b), training=True)
         total.backward()
         grads = {n: P[n].grad for n in names if P[n].grad is not None}
-        gn = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values()))
-        coef = float(min(1.0, 1.0 / (gn + 1e-6)))
         with torch.no_grad():
             for n in names:
                 P[n].requires_grad_(False)
-            orc.bert_adam_step({n: P[n] for n in grads}, {n: g * coef for n, g in grads.items()}, state, 1e-4, wd=wd)
-    one_step()
-    t0 = time.time()
-    k = 0
-    while k < args.cpu_steps:
+            # global clip 1.0 → BertAdam (warm-up-linear lr) in the reference's order; pinned by tests/golden/optim.npz
+            orc.train_tail_step({n: P[n] for n in grads}, grads, state, None, step_no[0], 1e-4, 0.1, 100000, grad_clip=1.0, wd=wd)
+        step_no[0] += 1
+    for _ in range(max(0, args.cpu_warmup)):
         one_step()
-        k += 1
-    dt = (time.time() - t0) / k
+    times = []
+    for _ in range(max(1, args.cpu_steps)):
+        t0 = time.time()
+        one_step()
+        times.append(time.time() - t0)
+    dt = sorted(times)[len(times) // 2]
     steps_per_s = (n_vid / float(args.batch)) / dt
+    cpu_model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    scaled = "" if n_vid == args.batch else ", scaled by %d/%d (a lower bound: the CPU's GEMMs are %dx smaller than at the stated batch)" % (
+        n_vid, args.batch, args.batch // max(1, n_vid))
     return {"value": steps_per_s, "unit": "steps/s (16-video steps)", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d of %d videos per step (S=%d, L=%d, same model), %d timed steps of fwd+bwd+clip+BertAdam on torch-CPU fp32, "
-                      "%.2f s/step, scaled by %d/%d" % (n_vid, args.batch, args.clips, args.layers, k, dt, n_vid, args.batch)}
+            "cpu": "%s, %d logical cpus on the box" % (cpu_model, os.cpu_count() or 0),
+            "sample": "%d of %d videos per step (S=%d, L=%d, same model and step definition: fwd+bwd+global clip+BertAdam, torch-CPU "
+                      "fp32, dropout on), %d warm-up + %d timed steps, median %.2f s/step%s"
+                      % (n_vid, args.batch, args.clips, args.layers, args.cpu_warmup, len(times), dt, scaled)}
 
 
-def decode_bench(cfg, model, args, device, world, rank, dist):
+def run_decode(cfg, model, args, device, world, rank, dist, steps, warmup):
     """captions/s of Translator.translate_batch (greedy) on synthetic clips, videos sharded over ranks (replicas only)."""
+    import torch
+    from svpc_amd import make_batch, synthetic as syn
     from svpc_amd.translator import Translator
     n_vid = args.decode_videos
     b = make_batch(cfg, n_videos=n_vid, max_steps=args.clips, n_ingr=10, n_oov=0, seed=2019 + rank, full_clips=True)
@@ -111,13 +235,13 @@ def decode_bench(cfg, model, args, device, world, rank, dist):
             b[k] = v.to(device)
     tr = Translator(type("O", (), {"cuda": True})(), {"model_cfg": cfg, "model": model.state_dict()}, model=model,
                     incremental=not args.decode_full, graph=not args.decode_eager)
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, warmup)):
         tr.translate_batch(syn.translate_inputs(b))
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out, _ = tr.translate_batch(syn.translate_inputs(b))
     if dist is not None:
         dist.barrier()
@@ -127,114 +251,71 @@ def decode_bench(cfg, model, args, device, world, rank, dist):
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if rank == 0:
-        caps = world * args.steps * n_vid * args.clips
-        print(json.dumps({"metric": "greedy-decode captions/sec (vivt, 64 videos)", "value": caps / elapsed, "unit": "captions/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-                          "config": {"workload": "MODEL_TYPE=%s translate_batch greedy: %d videos/GPU x %d clips, Lt=%d, L=%d; %s, batched "
-                                                 "over videos, on-device pick"
-                                                 % (args.model_type, n_vid, args.clips, cfg.max_t_len, cfg.num_hidden_layers,
-                                                    "full decoder re-run per position (reference loop shape)" if args.decode_full
-                                                    else "KV-cached incremental decoder (one new token per sentence and iteration)"),
-                                     "launch": "eager" if args.decode_eager else "hipGraph replay per batch structure (inputs copied into the captured buffers)"}}))
-    if dist is not None:
-        dist.destroy_process_group()
+    caps = world * steps * n_vid * args.clips
+    return {"metric": "greedy-decode captions/sec (vivt, 64 videos)", "value": caps / elapsed, "unit": "captions/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1000.0 * elapsed / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "MODEL_TYPE=%s translate_batch greedy: %d videos/GPU x %d clips, Lt=%d, L=%d; %s, batched "
+                                   "over videos, on-device pick"
+                                   % (args.model_type, n_vid, args.clips, cfg.max_t_len, cfg.num_hidden_layers,
+                                      "full decoder re-run per position (reference loop shape)" if args.decode_full
+                                      else "KV-cached incremental decoder (one new token per sentence and iteration)"),
+                       "launch": "eager" if args.decode_eager else "hipGraph replay per batch structure (inputs copied into the captured buffers)"}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model-type", default="vivt")
-    ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--clips", type=int, default=12)
-    ap.add_argument("--layers", type=int, default=6)
-    ap.add_argument("--hidden", type=int, default=768)
-    ap.add_argument("--heads", type=int, default=12)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
-                    help="arithmetic type of the GEMM operands (accumulation and storage are fp32 either way)")
-    ap.add_argument("--decode", action="store_true", help="secondary metric: greedy-decode captions/s (BASELINE config 5: 64 videos)")
-    ap.add_argument("--decode-videos", type=int, default=64)
-    ap.add_argument("--decode-full", action="store_true", help="decode with the reference-shaped loop (all Lt positions every iteration)")
-    ap.add_argument("--decode-eager", action="store_true", help="launch the decode kernels eagerly instead of replaying the batch structure's hipGraph")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU rehearsals)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-videos", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=8)      # ≈ 12 s of CPU work (1 warm-up + 8 timed 2-video steps)
-    ap.add_argument("--cpu-threads", type=int, default=16)
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        n_dev = torch.cuda.device_count()
-        dev_index = local_rank % max(1, n_dev)
-        torch.cuda.set_device(dev_index)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(args.backend)
-    else:
-        dev_index = 0
-        torch.cuda.set_device(0)
-    device = torch.device("cuda", dev_index)
-
-    ops.set_precision(args.precision)
+def run_train(args, precision, device, world, rank, dist, steps, warmup, instrument=True):
+    """Build model + optimizer in ``precision``, warm up, capture, time ``steps`` steps.  → dict (rank-0 view)."""
+    import torch
+    from svpc_amd import ops, synthetic as syn
+    from svpc_amd.graph import GraphedTrainStep, backward_all
+    from svpc_amd.optim import FusedBertAdam, GradReducer
+    ops.set_precision(precision)
     cfg, model = build(args, device)
-    if args.decode:
-        return decode_bench(cfg, model, args, device, world, rank, dist)
     model.train()
     batch = device_batch(cfg, args, device, seed=2019 + rank)
     fargs = syn.forward_args(batch)
     opt = FusedBertAdam(list(model.named_parameters()), lr=1e-4, warmup=0.1, t_total=100000, grad_clip=1.0, ema_decay=-1.0)
-    reducer = None
+    exchange_on = world > 1 or args.rehearse_dp
+    state = {"reducer": None}
 
     def step():
-        nonlocal reducer
         opt.zero_grad()
         loss = model(*fargs)[0]
         backward_all(model, loss)
         arena = opt.ensure_built()
-        if world > 1:
-            if reducer is None:
-                # graph mode: the exchange runs between two captured graphs (no hooks); eager mode: overlapped with backward
-                reducer = GradReducer(arena, overlap=args.no_graph)
-                reducer.reset()
-                for bi in range(len(reducer.buckets)):   # first step: hooks were not installed during this backward
-                    reducer.launched[bi] = False
-            reducer.finish()
+        if exchange_on:
+            if state["reducer"] is None:
+                # graph mode: the exchange runs between captured graphs (no hooks); eager mode: overlapped with backward
+                state["reducer"] = GradReducer(arena, overlap=args.no_graph, force=args.rehearse_dp)
+                state["reducer"].mark_all_unlaunched()   # first step: hooks were not installed during this backward
+            state["reducer"].finish()
         opt.step()
         return loss
 
-    for _ in range(max(args.warmup, 2)):
+    for _ in range(max(warmup, 2)):
         loss = step()
     torch.cuda.synchronize()
+    reducer = state["reducer"]
 
-    # ---- capture the step in hipGraphs: ≈1,100 launches per step would otherwise make it host-bound.  One GPU: one graph
-    # (zero_grad → forward → backward → clip+BertAdam).  N GPUs: {zero_grad, forward, backward} and {clip+BertAdam} with the
-    # bucketed RCCL all-reduce issued eagerly in between.  Falls back to eager (overlapped exchange) on failure.
-    graph = None
+    # ---- capture the step in hipGraphs: ≈600 launches per step would otherwise make it host-bound.  One GPU: one graph
+    # (zero_grad → forward → backward → clip+BertAdam).  N GPUs: three graphs with the bucketed RCCL all-reduce issued
+    # eagerly in between (svpc_amd/graph.py).  A failed capture is reported in config.degraded, never silently.
+    graph, degraded = None, None
+    eager_step = step
     if not args.no_graph:
         try:
-            from svpc_amd.graph import GraphedTrainStep
             loss = None          # drop the last eager autograd graph before capture
-            graph = GraphedTrainStep(model, opt, fargs, warmup=2, exchange=(reducer if world > 1 else None))
-            eager_step = step
+            graph = GraphedTrainStep(model, opt, fargs, warmup=2, exchange=reducer if exchange_on else None)
             step = graph
             for _ in range(2):
                 step()
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
-            print("[bench] hipGraph capture failed (%s: %s) - running eagerly" % (type(e).__name__, e), file=sys.stderr)
+            degraded = "hipGraph capture failed (%s: %s)" % (type(e).__name__, str(e)[:200])
+            print("[bench] %s - running eagerly" % degraded, file=sys.stderr)
             graph = None
+            step = eager_step
             torch.cuda.synchronize()
     # host-side enqueue cost of one step (GPU idle at start, no sync at the end): tells whether the step is launch-bound
     th = time.perf_counter()
@@ -243,83 +324,229 @@ def main():
     torch.cuda.synchronize()
     # roofline leg: HIP events around every launch of the dominant kernel symbol.  Eager mode: inside the timed region.  Graph
     # mode: events cannot be recorded inside a replay, so the same kernels are bracketed in instrumented eager steps right after it.
-    # Dominant kernel = the forward GEMM of the clip-encoder activation stream: ONE kernel symbol (gemm_glds_pp_kernel<true,true,__bf16>:
-    # bf16 activations × bf16 weight shadow → bf16, both operands direct-to-LDS, 256×256 ping-pong tiles) covering the Q/K/V,
-    # attention-output, FFN-in/out and video-embedding projections of the clip encoder (M = 19,200 rows; 22 launches per step) —
-    # every launch of that symbol is bracketed, so the average can be checked against rocprofv3's per-kernel average.
     rows_enc = args.batch * args.clips * cfg.max_v_len
-    bf16_stream = args.precision == "bf16" and ops.bf16_stream_ok(rows_enc, cfg.hidden_size, cfg.video_feature_size)
+    bf16_stream = precision == "bf16" and ops.bf16_stream_ok(rows_enc, cfg.hidden_size, cfg.video_feature_size)
     glds = bf16_stream and ops.USE_GLDS      # weights come from the optimizer's bf16 shadow → direct-to-LDS kernel
     want_dt = ((1, 1, 1) if glds else (1, 0, 1)) if bf16_stream else (0, 0, 0)
 
     def dom_select(d):
         M_, N_, K_, akc, bkc, adt, bdt, cdt = d
         return akc == 1 and bkc == 1 and (adt, bdt, cdt) == want_dt and M_ == rows_enc
-    if graph is None:
+    if graph is None and instrument:
         ops.GEMM_TIMER = ops.KernelTimer(select=dom_select)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if graph is not None:
-        ops.GEMM_TIMER = ops.KernelTimer(select=dom_select)
-        for _ in range(3):
-            eager_step()
-        torch.cuda.synchronize()
-    timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    gsum = timer.summary()
     final_loss = float(loss.item())
+    # exposed exchange time: the same steps with the all-reduce calls skipped (gradients stay local — timing only, after the
+    # timed region); difference of the two = what the exchange adds to a step after overlap
+    no_exchange_ms = None
+    if exchange_on and reducer is not None and world > 1:
+        reducer.skip = True
+        for _ in range(2):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        no_exchange_ms = 1000.0 * (time.perf_counter() - t1) / steps
+        reducer.skip = False
+    gsum = None
+    if instrument:
+        if graph is not None:
+            ops.GEMM_TIMER = ops.KernelTimer(select=dom_select)
+            with torch.cuda.stream(graph.stream):      # the stream every AccumulateGrad node of this model is bound to
+                for _ in range(3):
+                    eager_step()
+            torch.cuda.synchronize()
+        timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
+        gsum = timer.summary()
+    ms = 1000.0 * elapsed / steps
+    launch = ("hipGraph replay" if not exchange_on else
+              "hipGraph replay (fwd + text-side bwd | clip-encoder bwd beside the text-side all-reduce | remaining all-reduce | optimizer)") \
+        if graph is not None else ("eager (capture failed: see config.degraded)" if degraded else "eager")
+    res = dict(cfg=cfg, model=model, ms=ms, elapsed=elapsed, final_loss=final_loss, host_enqueue_ms=host_enqueue_ms, launch=launch,
+               degraded=degraded, gsum=gsum, glds=glds, bf16_stream=bf16_stream, rows_enc=rows_enc, no_exchange_ms=no_exchange_ms,
+               allreduce_bytes=(reducer.bytes_per_step() if reducer is not None else 0),
+               n_buckets=(len(reducer.buckets) if reducer is not None else 0))
+    return res
 
+
+def dry_run(args):
+    """No GPU: rendezvous + one bucketed SUM all-reduce of a CPU arena through the product's GradReducer (gloo)."""
+    import torch
+    import torch.distributed as dist
+    from svpc_amd.optim import GradArena, GradReducer
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank == args.dry_run_fail_rank:
+        sys.exit(3)
+    params = [("w%d" % i, torch.nn.Parameter(torch.zeros(64, 33))) for i in range(5)]
+    for i, (_, p) in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    arena = GradArena(params)
+    red = GradReducer(arena, bucket_bytes=8 << 10, overlap=False)
+    red.finish()
+    want = sum(r + 1 for r in range(world))
+    ok = all(float(p.grad.min()) == float(p.grad.max()) == want * (i + 1) for i, (_, p) in enumerate(params))
+    joined = dist.get_world_size()
+    dist.barrier()
     if rank == 0:
-        ms = 1000.0 * elapsed / args.steps
-        achieved = gsum["work"] / (gsum["ms"] * 1e-3) / 1e12 if gsum["ms"] > 0 else 0.0
-        D_, F_, L_ = cfg.hidden_size, cfg.video_feature_size, cfg.num_hidden_layers
-        n_l = max(1, gsum["launches"])
-        alg_bytes, alg_flop = gsum["bytes"] / n_l, gsum["work"] / n_l
-        # mean HBM traffic per launch of this symbol from rocprofv3 PMC passes over this very command (profiles/r01_i_pmc_*.csv):
-        # FETCH_SIZE × 2 (gfx950 reports half of a 16-B/lane stream) + WRITE_SIZE, in KB.  Only valid for the default workload.
-        default_cfg = (args.batch, args.clips, L_, D_, F_, args.model_type) == (16, 12, 6, 768, 3072, "vivt") and bf16_stream
-        traffic = PMC_TRAFFIC_BYTES if (default_cfg and glds) else None
-        out = {
-            "metric": "train steps/sec (vivt, batch=16, clip_seq=12)", "value": world * args.steps / elapsed,
-            "unit": "steps/s (one step = 16 clip-sequences per GPU; whole-job aggregate)", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "MODEL_TYPE=%s train step: N=%d videos/GPU x S=%d clips x Lv=%d frames x F=%d, Lt=%d, D=%d, H=%d, "
-                                   "L=%d (enc+step-enc+dec), V=%d, A=%d, E=10; dropout .1/.1/.4; fwd+bwd+allreduce+clip+BertAdam"
-                                   % (args.model_type, args.batch, args.clips, cfg.max_v_len, cfg.video_feature_size, cfg.max_t_len,
-                                      cfg.hidden_size, cfg.num_attention_heads, cfg.num_hidden_layers, cfg.vocab_size, cfg.action_vocab_size),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": final_loss,
-                       "host_enqueue_ms_per_step": host_enqueue_ms,
-                       "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (fwd + text-side bwd | clip-encoder bwd beside the text-side all-reduce | remaining all-reduce | optimizer)")
-                                 if graph is not None else "eager"},
-            "roofline": {"bound": "mfma", "kernel": "%s — every forward projection of the clip-encoder activation stream (M=%d rows: "
-                                   "Q/K/V, attention-out, FFN, video embedding)"
-                                   % ("gemm_glds_pp_kernel<true,true,__bf16> (bf16·bf16→bf16, direct-to-LDS, 256x256 ping-pong tiles)" if glds else
-                                      "gemm_bf16_kernel<128,128,NT,interior,8 waves,%s>" % ("bf16·f32→bf16" if bf16_stream else "f32"), rows_enc),
-                         "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_PEAK_TFLOPS[args.precision],
-                         "traffic": traffic, "algorithmic_flop_per_launch": alg_flop, "algorithmic_bytes_per_launch": alg_bytes,
-                         "launches": gsum["launches"], "avg_launch_ms": gsum["ms"] / max(1, gsum["launches"]),
-                         "event_pair_overhead_ms": gsum["event_overhead_ms"],
-                         "measured": "HIP events on the launch stream (net of the calibrated empty event-pair time), " + ("3 instrumented eager steps after the timed graph replays"
-                                                                            if graph is not None else "inside the timed region")},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, model, args)
-        print(json.dumps(out))
+        print(json.dumps({"metric": "dry-run (launcher + rendezvous + bucketed SUM all-reduce on CPU)", "value": 0.0, "n_gpus": joined,
+                          "rccl_ranks": joined, "config": {"gpus_requested": args.gpus, "buckets": len(red.buckets),
+                                                            "allreduce_bytes_per_step": red.bytes_per_step(), "sum_ok": ok}}))
+    dist.destroy_process_group()
+    if not ok:
+        sys.exit(4)
+
+
+def worker(args):
+    if args.dry_run:
+        return dry_run(args)
+    import torch
+    from svpc_amd import ops
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1 or args.rehearse_dp:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        n_dev = torch.cuda.device_count()
+        dev_index = local_rank % max(1, n_dev)
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
+        joined = dist.get_world_size()
+    else:
+        dev_index = 0
+        torch.cuda.set_device(0)
+        joined = 1
+    device = torch.device("cuda", dev_index)
+    # everything (eager warm-up, capture, instrumented steps) runs on ONE non-default stream: autograd's AccumulateGrad nodes
+    # are bound to the stream of the first backward, and a captured graph must not depend on the legacy default stream
+    main_stream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(main_stream):
+        if args.decode:
+            ops.set_precision(args.precision)
+            cfg, model = build(args, device)
+            out = run_decode(cfg, model, args, device, world, rank, dist if world > 1 else None, args.steps, args.warmup)
+            if rank == 0:
+                print(json.dumps(out))
+        else:
+            _train_main(args, device, world, rank, dist if (world > 1 or args.rehearse_dp) else None, joined)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _train_main(args, device, world, rank, dist, joined):
+    import torch
+    from svpc_amd import ops
+    r = run_train(args, args.precision, device, world, rank, dist, args.steps, args.warmup)
+    cfg, gsum = r["cfg"], r["gsum"]
+    extras = {}
+    if world == 1 and not args.no_secondary and not args.rehearse_dp:
+        # N=1-only legs, all after the timed region: config 5 (greedy decode), the fp32 parity arithmetic on the same workload,
+        # and the two same-box ceilings (vendor GEMM, copy bandwidth)
+        try:
+            ops.set_precision(args.precision)
+            d = run_decode(cfg, r["model"], args, device, 1, 0, None, steps=3, warmup=2)
+            extras["secondary"] = {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config")}
+        except Exception as e:  # noqa: BLE001
+            extras["secondary"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        if args.precision == "bf16":
+            try:
+                p = run_train(args, "fp32", device, 1, 0, None, args.parity_steps, 2, instrument=False)
+                extras["parity_mode"] = {"precision": "fp32 (v_mfma_f32_32x32x2_f32 GEMMs, fp32 attention and storage: the arithmetic "
+                                                      "of the <=1e-4 parity tests)", "ms_per_step": p["ms"], "steps_per_s": 1000.0 / p["ms"],
+                                         "steps": args.parity_steps, "launch": p["launch"], "final_loss": p["final_loss"],
+                                         "degraded": p["degraded"]}
+                del p
+            except Exception as e:  # noqa: BLE001
+                extras["parity_mode"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            ops.set_precision(args.precision)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import ceilings
+            extras["ceilings"] = ceilings.measure(device, quick=True)
+        except Exception as e:  # noqa: BLE001
+            extras["ceilings"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    if rank != 0:
+        return
+    ms, elapsed = r["ms"], r["elapsed"]
+    precision = args.precision
+    achieved = gsum["work"] / (gsum["ms"] * 1e-3) / 1e12 if gsum["ms"] > 0 else 0.0
+    D_, F_, L_ = cfg.hidden_size, cfg.video_feature_size, cfg.num_hidden_layers
+    n_l = max(1, gsum["launches"])
+    alg_bytes, alg_flop = gsum["bytes"] / n_l, gsum["work"] / n_l
+    default_cfg = (args.batch, args.clips, L_, D_, F_, args.model_type) == (16, 12, 6, 768, 3072, "vivt") and r["bf16_stream"]
+    traffic, traffic_src = measured_traffic() if (default_cfg and r["glds"]) else (None, None)
+    out = {
+        "metric": "train steps/sec (vivt, batch=16, clip_seq=12)", "value": joined * args.steps / elapsed,
+        "unit": "steps/s (one step = 16 clip-sequences per GPU; whole-job aggregate)", "n_gpus": joined, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": "MODEL_TYPE=%s train step: N=%d videos/GPU x S=%d clips x Lv=%d frames x F=%d, Lt=%d, D=%d, H=%d, "
+                               "L=%d (enc+step-enc+dec), V=%d, A=%d, E=10; dropout .1/.1/.4; fwd+bwd+allreduce+clip+BertAdam"
+                               % (args.model_type, args.batch, args.clips, cfg.max_v_len, cfg.video_feature_size, cfg.max_t_len,
+                                  cfg.hidden_size, cfg.num_attention_heads, cfg.num_hidden_layers, cfg.vocab_size, cfg.action_vocab_size),
+                   "global_batch": args.batch * joined, "parallelism": "dp%d" % joined, "final_loss": r["final_loss"],
+                   "host_enqueue_ms_per_step": r["host_enqueue_ms"], "launch": r["launch"], "degraded": r["degraded"],
+                   "gpus_requested": args.gpus},
+        "roofline": {"bound": "mfma", "kernel": "%s — every forward projection of the clip-encoder activation stream (M=%d rows: "
+                               "Q/K/V, attention-out, FFN, video embedding)"
+                               % ("gemm_glds_pp_kernel<true,true,__bf16> (bf16·bf16→bf16, direct-to-LDS, 256x256 ping-pong tiles)" if r["glds"] else
+                                  "gemm_bf16_kernel<128,128,NT,interior,8 waves,%s>" % ("bf16·f32→bf16" if r["bf16_stream"] else "f32"), r["rows_enc"]),
+                     "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[precision], "unit": "TFLOP/s",
+                     "frac": achieved / MFMA_PEAK_TFLOPS[precision],
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_flop_per_launch": alg_flop, "algorithmic_bytes_per_launch": alg_bytes,
+                     "launches": gsum["launches"], "avg_launch_ms": gsum["ms"] / max(1, gsum["launches"]),
+                     "event_pair_overhead_ms": gsum["event_overhead_ms"],
+                     "measured": "HIP events on the launch stream (net of the calibrated empty event-pair time), " +
+                                 ("3 instrumented EAGER steps right after the timed graph replays (events cannot be recorded inside a replay; "
+                                  "rocprofv3's average over the replays is kept in profiles/ as the cross-check)"
+                                  if r["launch"].startswith("hipGraph") else "inside the timed region")},
+    }
+    if dist is not None:
+        out["rccl_ranks"] = joined
+        out["exchange"] = {"backend": args.backend, "allreduce_bytes_per_step": r["allreduce_bytes"], "buckets": r["n_buckets"],
+                           "op": "SUM over the fp32 gradient arena, before the global clip (src/train.py:140-143)",
+                           "ms_per_step_without_exchange": r["no_exchange_ms"],
+                           "exposed_exchange_ms": (ms - r["no_exchange_ms"]) if r["no_exchange_ms"] is not None else None}
+    out.update(extras)
+    if world == 1 and not args.no_cpu_baseline and not args.rehearse_dp:
+        out["cpu_baseline"] = cpu_baseline(cfg, r["model"], args)
+    print(json.dumps(out))
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -18,3 +18,19 @@ def case_config_and_batch(case, model_type, device="cpu"):
     cfg_kw, batch_kw = CASES[case]
     cfg = syn.make_config(model_type=model_type, **cfg_kw)
     return cfg, syn.make_batch(cfg, device=device, **batch_kw)
+
+
+# ---- optimizer fixture (oracle/make_golden_optim.py ↔ tests/test_optimizer_golden.py) -------------------------------------------
+OPTIM_CASE = dict(steps=4, lr=1e-3, warmup=0.1, t_total=20, grad_clip=1.0, ema_decay=0.9999, weight_decay=0.01)
+OPTIM_GRAD_SCALE = (1.0, 1.7, 0.6, 2e-4)    # last step: global norm < 1 → neither the global nor the per-tensor clip engages
+
+
+def optim_step_gradient(base, name, t):
+    """Gradient of parameter ``name`` at step ``t`` of the optimizer fixture: the tiny vivt reference gradient (``base``, a numpy
+    array from tests/golden/tiny_vivt.npz) rescaled and perturbed by a name/step-seeded pattern — data both sides rebuild."""
+    import zlib
+    import numpy as np
+    rs = np.random.RandomState((zlib.crc32(name.encode()) + 7919 * t) & 0x7FFFFFFF)
+    amp = float(np.abs(base).max()) if base.size else 0.0
+    g = OPTIM_GRAD_SCALE[t] * (base.astype(np.float64) + 0.25 * amp * rs.standard_normal(base.shape))
+    return g.astype(np.float32)

@@ -407,3 +407,32 @@ def bert_adam_step(params, grads, state, lr, step_frac_lr=1.0, b1=0.9, b2=0.999,
         if wd and wd.get(n, 0.0) > 0:
             upd = upd + wd[n] * p
         p.sub_(lr * step_frac_lr * upd)
+
+
+def warmup_linear(progress, warmup):
+    """src/rtransformer/optimization.py:162-171 (WarmupLinearSchedule.get_lr_)."""
+    if progress < warmup:
+        return progress / warmup
+    return max((progress - 1.0) / (warmup - 1.0), 0.0)
+
+
+def global_clip_coef(grads, max_norm=1.0):
+    """nn.utils.clip_grad_norm_(model.parameters(), max_norm) as src/train.py:141-142 calls it → (total norm, scale factor)."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    return total, torch.clamp(max_norm / (total + 1e-6), max=1.0)
+
+
+def ema_update(shadow, params, step, decay):
+    """src/rtransformer/optimization.py:196-203: shadow ← (1−d)·θ + d·shadow with d = min(decay, (1+step)/(10+step))."""
+    d = min(decay, (1.0 + step) / (10.0 + step))
+    for n, p in params.items():
+        shadow[n] = (1.0 - d) * p + d * shadow[n]
+
+
+def train_tail_step(params, grads, state, shadow, step, lr, warmup, t_total, grad_clip=1.0, ema_decay=-1.0, wd=None):
+    """One training-step tail in the reference's order (src/train.py:140-147): global clip → BertAdam.step → EMA."""
+    _, coef = global_clip_coef(grads, grad_clip) if grad_clip and grad_clip > 0 else (None, 1.0)
+    sched = warmup_linear(step / t_total, warmup) if t_total > 0 else 1.0
+    bert_adam_step(params, {n: g * coef for n, g in grads.items()}, state, lr, step_frac_lr=sched, wd=wd)
+    if ema_decay >= 0:
+        ema_update(shadow, params, step, ema_decay)

@@ -3,10 +3,12 @@
 reference: src/train.py:401-405 writes ``{"model": state_dict, "model_cfg": EasyDict, "opt": EasyDict, "epoch": int}`` with
 ``torch.save``; src/translator.py:33-38 / src/translate.py read ``checkpoint["model_cfg"]`` and ``checkpoint["model"]``.
 
-``save_checkpoint`` writes the same four keys (configs as plain dicts with attribute access, so the file needs no third-party
-class to load).  ``load_checkpoint`` also opens files written by the reference: their ``model_cfg`` / ``opt`` are pickled
-``easydict.EasyDict`` objects — a package this image does not have — so that one class name is mapped onto ``ModelConfig``
-while unpickling; nothing else is remapped.
+``save_checkpoint`` writes the same four keys.  The two configs are pickled as ``easydict.EasyDict`` when that package is
+importable (what the reference's loaders expect: they use attribute access on ``checkpoint["model_cfg"]``), otherwise as plain
+``dict``s — never as a class of this package, so the file opens with a bare ``torch.load`` wherever it is read (a reference
+process without easydict-typed configs needs one line, ``EasyDict(ckpt["model_cfg"])``).  ``load_checkpoint``
+turns either form into ``ModelConfig`` and also opens files written by the reference on a box without easydict: that one class
+name is mapped onto ``ModelConfig`` while unpickling; nothing else is remapped.
 """
 from __future__ import annotations
 
@@ -35,7 +37,11 @@ def save_checkpoint(path, model, opt=None, epoch=0, state_dict=None):
     """``state_dict`` overrides ``model.state_dict()`` (e.g. the EMA weights, as train.py:401 saves them)."""
     sd = state_dict if state_dict is not None else model.state_dict()
     sd = {k: v.detach().cpu().clone() for k, v in sd.items()}
-    ckpt = {"model": sd, "model_cfg": ModelConfig(dict(model.config)), "opt": ModelConfig(dict(opt)) if opt is not None else None,
+    try:
+        from easydict import EasyDict as _cfg_type       # the reference's own container, when the environment has it
+    except ImportError:
+        _cfg_type = dict
+    ckpt = {"model": sd, "model_cfg": _cfg_type(dict(model.config)), "opt": _cfg_type(dict(opt)) if opt is not None else None,
             "epoch": int(epoch)}
     torch.save(ckpt, path)
     return ckpt

@@ -230,18 +230,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
     }
 }
 
-static int set_lds(const void* fn, size_t bytes) {
-    // raised once per kernel to the device maximum (never inside a stream capture after the first call)
-    static const void* done[16]; static int n_done = 0;
-    for (int i = 0; i < n_done; ++i) if (done[i] == fn) return 0;
-    if (n_done < 16) done[n_done++] = fn;
-    bytes = 160 * 1024;
-    if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) { svpc_set_error("attention: cannot raise dynamic LDS limit"); return (int)e; }
-    }
-    return 0;
-}
+static int set_lds(const void* fn, size_t bytes) { return svpc_raise_lds_once(fn, "attention"); }   // once per kernel symbol, process-wide table (api.cpp)
 
 // ---- single-query attention (incremental decoding: one new token per sentence attends to its cached keys; translator.py:88-100
 // under the causal mask).  One wave per (sequence, head), lane = head dimension; the keys/values of up to 32 positions are

@@ -443,18 +443,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
     }
 }
 
-static int mattn_set_lds(const void* fn, size_t bytes) {
-    // raised once per kernel to the device maximum (never inside a stream capture after the first call)
-    static const void* done[16]; static int n_done = 0;
-    for (int i = 0; i < n_done; ++i) if (done[i] == fn) return 0;
-    if (n_done < 16) done[n_done++] = fn;
-    bytes = 160 * 1024;
-    if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) { svpc_set_error("attn_mfma: cannot raise dynamic LDS limit"); return (int)e; }
-    }
-    return 0;
-}
+static int mattn_set_lds(const void* fn, size_t bytes) { return svpc_raise_lds_once(fn, "attn_mfma"); }   // once per kernel symbol, process-wide table (api.cpp)
 static bool mattn_ok(int dh, int max_q, int max_k, int ldq, int ldk, int ldv, const void* Q, const void* K, const void* V, int dt) {
     const int al = dt ? 8 : 16;   // 4 elements per staging unit
     return (dh == 64 || dh == 32) && max_q <= AT_MAX && max_k <= AT_MAX && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 &&

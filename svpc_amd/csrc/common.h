@@ -9,6 +9,7 @@ typedef unsigned long long u64;
 
 // ---- status plumbing for the C-ABI -------------------------------------------------------------
 extern "C" void svpc_set_error(const char* msg);
+extern "C" int svpc_raise_lds_once(const void* fn, const char* who);   // api.cpp
 static inline int svpc_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -333,15 +333,7 @@ __global__ __launch_bounds__(256) void gumbel_emb_grad_kernel(const float* __res
     for (int c = threadIdx.x; c < W; c += 256) atomicAdd(&demb[(size_t)t * W + c], coef * dbow[(size_t)r * W + c]);
 }
 
-static int ptr_set_lds(const void* fn) {
-    // raised once per kernel to the device maximum (never inside a stream capture after the first call)
-    static const void* done[8]; static int n_done = 0;
-    for (int i = 0; i < n_done; ++i) if (done[i] == fn) return 0;
-    if (n_done < 8) done[n_done++] = fn;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { svpc_set_error("ptr_attn: cannot raise dynamic LDS limit"); return (int)e; }
-    return 0;
-}
+static int ptr_set_lds(const void* fn) { return svpc_raise_lds_once(fn, "ptr_attn"); }   // once per kernel symbol, process-wide table (api.cpp)
 
 extern "C" {
 

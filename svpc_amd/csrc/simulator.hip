@@ -280,18 +280,7 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
     }
 }
 
-static int sim_set_lds(const void* fn, size_t bytes) {
-    // raised once per kernel to the device maximum (never inside a stream capture after the first call)
-    static const void* done[64]; static int n_done = 0;
-    for (int i = 0; i < n_done; ++i) if (done[i] == fn) return 0;
-    if (n_done < 64) done[n_done++] = fn;
-    bytes = 160 * 1024;
-    if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) { svpc_set_error("sim_recur: cannot raise dynamic LDS limit"); return (int)e; }
-    }
-    return 0;
-}
+static int sim_set_lds(const void* fn, size_t bytes) { return svpc_raise_lds_once(fn, "sim_recur"); }   // once per kernel symbol, process-wide table (api.cpp)
 
 extern "C" {
 

@@ -22,6 +22,19 @@ import gc
 import torch
 
 
+_STREAMS = {}
+
+
+def ops_stream(device=None):
+    """The one warm-up / capture stream of this process per device (a fresh stream per captured object would pin a 256 MB
+    kernel workspace each: svpc_amd.ops._ws is per (device, stream))."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    st = _STREAMS.get(dev)
+    if st is None:
+        st = _STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def backward_all(model, loss):
     """``loss.backward()`` plus, when the model cut its autograd graph at the [CLS] rows (``model.split_backward``), the second
     phase through the clip encoder."""
@@ -37,19 +50,24 @@ class GraphedTrainStep:
         self.model, self.opt, self.args = model, optimizer, forward_args
         self.exchange = exchange
         assert optimizer.arena is not None, "run at least one eager step first (the gradient arena is built lazily)"
-        gc.collect()     # stale autograd graphs keep AccumulateGrad nodes bound to the default stream
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        gc.collect()     # stale autograd graphs keep AccumulateGrad nodes bound to the stream of an earlier backward
+        # ONE stream for warm-up, capture and any later eager step of this model: autograd binds a leaf's AccumulateGrad node to the
+        # stream of the backward that created it, so eager steps on another stream (the legacy default stream above all) make
+        # the engine insert cross-stream syncs ("AccumulateGrad node's stream does not match …") that a capture cannot contain.
+        # A caller already running on a non-default stream (bench.py does) keeps it; otherwise a dedicated one is made.
+        cur = torch.cuda.current_stream()
+        self.stream = cur if cur != torch.cuda.default_stream() else ops_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 self._eager()
-        torch.cuda.current_stream().wait_stream(side)
+        cur.wait_stream(self.stream)
         torch.cuda.synchronize()
         gc.collect()
         self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None
         if exchange is None:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=self.stream):
                 optimizer.zero_grad()
                 self.loss = model(*forward_args)[0]
                 self.loss.backward()
@@ -58,18 +76,18 @@ class GraphedTrainStep:
             from . import ops
             model.split_backward = True
             # other threads (the collective library's watchdog) keep making driver calls: only this thread's are policed
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                 optimizer.zero_grad()
                 self.loss = model(*forward_args)[0]
                 self.loss.backward()
                 ops.join_side()
             self.graph_clip = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_clip, pool=self.graph.pool(), capture_error_mode="thread_local"):
+            with torch.cuda.graph(self.graph_clip, pool=self.graph.pool(), stream=self.stream, capture_error_mode="thread_local"):
                 out, cut = model.split_boundary
                 out.backward(cut.grad)
                 ops.join_side()
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), capture_error_mode="thread_local"):
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), stream=self.stream, capture_error_mode="thread_local"):
                 optimizer.launch()
         self._versions = optimizer.weights.versions()
 

@@ -687,16 +687,19 @@ class StateAwareRecursiveTransformer(nn.Module):
         return p
 
     def _spans_for(self, ingr_sep_masks):
-        """[SEP]-span table of the batch.  The mask lives on the device; reading it is the one host sync of a step, so the
-        result is cached on (storage, version): a resident batch (bench, graph replay) never syncs again."""
-        key = (ingr_sep_masks.data_ptr(), tuple(ingr_sep_masks.shape), ingr_sep_masks._version)
+        """[SEP]-span table of the batch.  The mask lives on the device; reading it is the one host sync of a step, so the result
+        is cached for a RESIDENT batch (bench, graph replay): the entry holds a reference to the very tensor object it was read
+        from — its storage therefore cannot be freed and handed to another batch — and is valid only for that object at the same
+        version counter.  A fresh tensor per step (a real loader's ``.to(device)``) is a different object and is always re-read."""
+        key = id(ingr_sep_masks)
         hit = self._span_cache.get(key)
-        if hit is None:
-            if len(self._span_cache) > 16:
-                self._span_cache.clear()
-            hit = self.ingredient_embeddings.spans(ingr_sep_masks.cpu())
-            self._span_cache[key] = hit
-        return hit
+        if hit is not None and hit[0] is ingr_sep_masks and hit[1] == ingr_sep_masks._version:
+            return hit[2]
+        if len(self._span_cache) >= 4:
+            self._span_cache.clear()
+        spans = self.ingredient_embeddings.spans(ingr_sep_masks.cpu())
+        self._span_cache[key] = (ingr_sep_masks, ingr_sep_masks._version, spans)
+        return spans
 
     @staticmethod
     def _stacked(tensors):

@@ -245,21 +245,30 @@ def flush_finalizes():
             _ready(o1)
 
 
-def join_side():
-    """Make the current stream wait for every side stream that has gradient work in flight."""
+def flush_pending():
+    """Launch every queued gradient tail (grouped wgrads, column sums, finalizers) and make the current stream wait for the side
+    streams that carry gradient work.  Safe at any point of a backward pass: parked residual gradients (``_RES_SINK``) are left
+    alone — LayerNorm backwards legitimately keep one parked until the consuming projection's dgrad runs."""
     flush_wgrads()
     flush_finalizes()
+    if _SIDE_DIRTY:
+        cur = torch.cuda.current_stream()
+        for st in _SIDE_DIRTY:
+            cur.wait_stream(st)
+        del _SIDE_DIRTY[:]
+
+
+def join_side():
+    """End of a backward pass (autograd callback) / before the optimizer kernels: ``flush_pending`` + the leftover check of the
+    residual-gradient hand-over.  NOT for use in the middle of backward (a gradient bucket released by a hook calls
+    ``flush_pending``): a parked gradient is normal there."""
+    flush_pending()
     _JOIN_QUEUED[0] = False
     if _RES_SINK:
         n_left = len(_RES_SINK)
         _RES_SINK.clear()
         raise _lib.SvpcKernelError("residual-gradient hand-over: %d parked gradient(s) were never absorbed by a projection's dgrad "
                                    "(layernorm(..., sink=True) without a consuming ops.linear)" % n_left)
-    if _SIDE_DIRTY:
-        cur = torch.cuda.current_stream()
-        for st in _SIDE_DIRTY:
-            cur.wait_stream(st)
-        del _SIDE_DIRTY[:]
 
 
 class _side_of:

@@ -299,10 +299,13 @@ class GradReducer:
     backward; ``finish()`` waits before the clip/optimizer kernels read the arena.  SUM (not mean) keeps the reference's
     sum-over-videos loss semantics (model.py:1110-1115, :1188): N ranks × 16 videos ≡ one process with 16·N videos."""
 
-    def __init__(self, arena, process_group=None, bucket_bytes=64 << 20, overlap=True):
+    def __init__(self, arena, process_group=None, bucket_bytes=64 << 20, overlap=True, force=False):
         import torch.distributed as dist
         self.dist, self.arena, self.pg = dist, arena, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force: issue the collectives even with one rank (rehearsal of the data-parallel code path on a one-GPU box)
+        self.active = self.world > 1 or (force and dist.is_initialized())
+        self.skip = False          # timing aid (bench.py): walk the whole protocol but do not call all_reduce
         self.buckets = []          # (start, end, [param indices])
         cur, cur_start, cur_bytes = [], 0, 0
         # parameters are registered in forward order, so backward finishes them roughly last-to-first:
@@ -317,7 +320,7 @@ class GradReducer:
         if cur:
             self._close(cur)
         self.pending, self.works = [], []
-        self.overlap = overlap and self.world > 1
+        self.overlap = overlap and self.active
         self._handles = []
         if self.overlap:
             from . import ops
@@ -353,14 +356,34 @@ class GradReducer:
         self.pending = [len(m) for _, _, m in self.buckets]
         self.works = []
         self.launched = [False] * len(self.buckets)
+        self.ready = [False] * len(self.buckets)
+        self._next = 0
         self._count = {}
+
+    def mark_all_unlaunched(self):
+        """first step after construction: the hooks were not installed during the backward that has just run"""
+        self.reset()
+
+    def bytes_per_step(self):
+        return sum((e - s) * 4 for s, e, _ in self.buckets)
 
     def _launch(self, bi):
         from . import ops
-        ops.join_side()        # the bucket's gradients may still be in flight on a side stream
+        ops.flush_pending()    # the bucket's gradients may still sit in a deferred-tail queue or on a side stream
         s, e, _ = self.buckets[bi]
         self.launched[bi] = True
+        if self.skip:
+            return
         self.works.append(self.dist.all_reduce(self.arena.flat[s:e], op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _release(self, bi):
+        """Bucket ``bi`` is complete.  Collectives are issued strictly in bucket-index order (bucket i waits for 0..i-1): ranks
+        whose backward completes buckets in a different order would otherwise pair mismatched all-reduces."""
+        self.ready[bi] = True
+        while self._next < len(self.buckets) and (self.ready[self._next] or self.launched[self._next]):
+            if not self.launched[self._next]:
+                self._launch(self._next)
+            self._next += 1
 
     def _ready_ptr(self, ptr, numel=None, kind=None):
         """a kernel has just finished (enqueued) writing the arena gradient at ``ptr``"""
@@ -376,21 +399,22 @@ class GradReducer:
         for bi in ids:
             self.pending[bi] -= 1
             if self.pending[bi] == 0 and not self.launched[bi]:
-                self._launch(bi)
+                self._release(bi)
 
     def _make_hook(self, bi):
         def hook(param):
             self.pending[bi] -= 1
             if self.pending[bi] == 0 and not self.launched[bi]:
-                self._launch(bi)
+                self._release(bi)
         return hook
 
     CLIP_SIDE = ("video_embeddings.", "encoder.", "token_type_embeddings.")
 
     def start_early(self):
         """Two-phase backward (svpc_amd/graph.py): launch, without waiting, every bucket none of whose members belongs to the clip
-        encoder — their gradients are final once the text-side backward has been enqueued."""
-        if self.world <= 1:
+        encoder — their gradients are final once the text-side backward has been enqueued.  (Index order within the subset; every
+        rank selects the same subset from the same arena layout.)"""
+        if not self.active:
             return
         for bi, (_, _, members) in enumerate(self.buckets):
             if self.launched[bi]:
@@ -400,12 +424,25 @@ class GradReducer:
 
     def finish(self):
         """Launch whatever has not been launched (tensors without a gradient this step never fire a hook) and wait."""
-        if self.world > 1:
+        recalibrate = False
+        if self.overlap and not self._calibrating and self._count != self._expected:
+            # a gradient was written more (or fewer) times than on the calibration step: a bucket may have been exchanged while
+            # kernels were still accumulating into it.  Repair: sum is linear, so exchanging the ranks' late contributions is
+            # not possible after the fact — refuse loudly rather than train on a wrong gradient.
+            late = [k for k, c in self._count.items() if c > self._expected.get(k, 1)]
+            if late:
+                self.reset()
+                self._calibrating, self._expected = True, {}
+                raise _lib.SvpcKernelError("GradReducer: %d gradient(s) were written more often than on the calibration step; their "
+                                           "bucket may have been all-reduced early.  The write counts are re-calibrated on the next "
+                                           "step — re-run this batch." % len(late))
+            recalibrate = True       # fewer writes than expected: those buckets simply launch here, late but complete
+        if self.active:
             for bi in range(len(self.buckets)):
                 if not self.launched[bi]:
                     self._launch(bi)
             for w in self.works:
                 w.wait()
-        if self._calibrating and self._count:
+        if (self._calibrating or recalibrate) and self._count:
             self._expected, self._calibrating = dict(self._count), False
         self.reset()

@@ -106,3 +106,21 @@ def test_load_checkpoint_written_with_easydict(tmp_path):
     assert ck["opt"].lr == 3e-4 and ck["epoch"] == 7
     for (n1, p1), (n2, p2) in zip(model.state_dict().items(), model2.state_dict().items()):
         assert n1 == n2 and torch.equal(p1, p2)
+
+
+def test_saved_checkpoint_opens_without_this_package(tmp_path):
+    """The file must not pickle any class of svpc_amd: a fresh interpreter that cannot import the package reads it with a bare
+    ``torch.load`` (the reference's side of the interchange, src/translator.py:33-38)."""
+    import subprocess
+    cfg, model = _tiny_model()
+    path = str(tmp_path / "plain.chkpt")
+    CK.save_checkpoint(path, model, opt=syn.ModelConfig(lr=1e-4), epoch=1)
+    code = ("import sys, torch\n"
+            "sys.modules['svpc_amd'] = None\n"                       # any 'import svpc_amd…' inside the unpickler would raise
+            "ck = torch.load(%r, weights_only=False)\n"
+            "assert type(ck['model_cfg']) is dict and type(ck['opt']) is dict, (type(ck['model_cfg']), type(ck['opt']))\n"
+            "assert ck['model_cfg']['hidden_size'] == 32 and ck['epoch'] == 1\n"
+            "assert all(isinstance(v, torch.Tensor) for v in ck['model'].values())\n"
+            "print('ok')\n" % path)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), timeout=240)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

@@ -37,8 +37,10 @@ def test_tiny_forward_backward_vs_reference_golden(golden_dir, mt):
         refg = z[k]
         scale = max(1e-6, float(np.abs(refg).max()))
         assert p.grad is not None, name
-        # key biases have an analytically zero gradient (softmax shift invariance): only an absolute floor applies
-        err = float(np.abs(p.grad.cpu().numpy() - refg).max()) / (scale + 2e-3)
+        # key biases have an analytically zero gradient (softmax shift invariance; the reference's own values are rounding noise
+        # ≲1e-6): only there an absolute floor applies.  Every other tensor is held to 2e-3 of its own max magnitude.
+        floor = 2e-3 if name.endswith(".key.bias") else 0.0
+        err = float(np.abs(p.grad.cpu().numpy() - refg).max()) / (scale + floor)
         worst = max(worst, (err, name))
         n += 1
     assert n > 20
