@@ -319,32 +319,33 @@ class GradReducer:
                 cur, cur_bytes = [], 0
         if cur:
             self._close(cur)
-        self.pending, self.works = [], []
+        self.works = []
         self.overlap = overlap and self.active
         self._handles = []
+        self._by_pack = {}
         if self.overlap:
             from . import ops
             bucket_of = {}
             for bi, (s, e, members) in enumerate(self.buckets):
                 for i in members:
                     bucket_of[i] = bi
-                    self._handles.append(arena.params[i].register_post_accumulate_grad_hook(self._make_hook(bi)))
-            # gradients written in place by the kernels never pass through AccumulateGrad: ops report them by pointer
-            self._by_ptr = {}
+                    self._handles.append(arena.params[i].register_post_accumulate_grad_hook(self._make_hook(i, bi)))
+            # Readiness signals.  (1) The post-accumulate hook of a parameter: autograd runs a leaf's AccumulateGrad node once, after
+            # EVERY consumer of the leaf has run its backward — also when those backwards wrote the gradient in place (or queued
+            # the write) and handed autograd no tensor (the hook fires on an undefined gradient too; tests/test_dp_gloo.py pins
+            # that) — so it is the "last write has been enqueued or queued" signal, multi-use parameters included; the queues are
+            # flushed before a bucket is exchanged (``_launch``).  (2) Packed Q/K/V (K/V) projections use views of the weight
+            # store that have no autograd edge to their member parameters: their in-place writes are reported by pointer
+            # (``ops._ready`` → ``_ready_ptr``), one write per view and step.
             for i, p in enumerate(arena.params):
-                self._by_ptr.setdefault(p.grad.data_ptr(), []).append(bucket_of[i])
                 packed = getattr(p, "_svpc_packed", None)
                 if packed is not None:
                     for which, (wg, bg) in packed.items():
                         mem = p._svpc_packed_members[which]
                         half = len(mem) // 2
-                        self._by_ptr[("w", wg.data_ptr(), wg.numel())] = [bucket_of[j] for j in mem[:half]]
-                        self._by_ptr[("b", bg.data_ptr(), bg.numel())] = [bucket_of[j] for j in mem[half:]]
+                        self._by_pack[("w", wg.data_ptr(), wg.numel())] = [(j, bucket_of[j]) for j in mem[:half]]
+                        self._by_pack[("b", bg.data_ptr(), bg.numel())] = [(j, bucket_of[j]) for j in mem[half:]]
             ops.GRAD_READY_HOOK = self._ready_ptr
-        # a parameter may be written by several kernels per step (LSTM recurrent weights: once per time step; the word table:
-        # text embedding + re-simulation).  The first step after construction only COUNTS the in-place writes per gradient;
-        # from then on a bucket is released when every member has received its full count.
-        self._expected, self._count, self._calibrating = {}, {}, True
         self.reset()
 
     def _close(self, members):
@@ -353,12 +354,12 @@ class GradReducer:
         self.buckets.append((lo, hi, list(members)))
 
     def reset(self):
-        self.pending = [len(m) for _, _, m in self.buckets]
+        self.left = [set(m) for _, _, m in self.buckets]
         self.works = []
         self.launched = [False] * len(self.buckets)
         self.ready = [False] * len(self.buckets)
         self._next = 0
-        self._count = {}
+        self._releasing = False
 
     def mark_all_unlaunched(self):
         """first step after construction: the hooks were not installed during the backward that has just run"""
@@ -367,11 +368,20 @@ class GradReducer:
     def bytes_per_step(self):
         return sum((e - s) * 4 for s, e, _ in self.buckets)
 
+    def close(self):
+        """remove the hooks (tests; a reducer normally lives as long as the model)"""
+        from . import ops
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+        if ops.GRAD_READY_HOOK == self._ready_ptr:
+            ops.GRAD_READY_HOOK = None
+
     def _launch(self, bi):
         from . import ops
-        ops.flush_pending()    # the bucket's gradients may still sit in a deferred-tail queue or on a side stream
+        self.launched[bi] = True     # first: flushing the queues below reports more gradients ready (re-entrant)
+        ops.flush_pending()          # the bucket's gradients may still sit in a deferred-tail queue or on a side stream
         s, e, _ = self.buckets[bi]
-        self.launched[bi] = True
         if self.skip:
             return
         self.works.append(self.dist.all_reduce(self.arena.flat[s:e], op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True))
@@ -380,32 +390,32 @@ class GradReducer:
         """Bucket ``bi`` is complete.  Collectives are issued strictly in bucket-index order (bucket i waits for 0..i-1): ranks
         whose backward completes buckets in a different order would otherwise pair mismatched all-reduces."""
         self.ready[bi] = True
-        while self._next < len(self.buckets) and (self.ready[self._next] or self.launched[self._next]):
-            if not self.launched[self._next]:
-                self._launch(self._next)
-            self._next += 1
+        if self._releasing:          # called from inside a launch's queue flush: the outer loop picks the bucket up
+            return
+        self._releasing = True
+        try:
+            while self._next < len(self.buckets) and (self.ready[self._next] or self.launched[self._next]):
+                if not self.launched[self._next]:
+                    self._launch(self._next)
+                self._next += 1
+        finally:
+            self._releasing = False
+
+    def _done(self, i, bi):
+        left = self.left[bi]
+        if i in left:
+            left.discard(i)
+            if not left and not self.launched[bi]:
+                self._release(bi)
 
     def _ready_ptr(self, ptr, numel=None, kind=None):
-        """a kernel has just finished (enqueued) writing the arena gradient at ``ptr``"""
-        key = (kind, ptr, numel)
-        ids = self._by_ptr.get(key) if kind is not None else None
-        if ids is None:
-            key = ptr
-            ids = self._by_ptr.get(ptr, ())
-        c = self._count.get(key, 0) + 1
-        self._count[key] = c
-        if self._calibrating or c != self._expected.get(key, 1):
-            return
-        for bi in ids:
-            self.pending[bi] -= 1
-            if self.pending[bi] == 0 and not self.launched[bi]:
-                self._release(bi)
+        """a kernel has just finished (enqueued) writing the arena gradient view at ``ptr`` — only packed views are tracked here"""
+        for i, bi in self._by_pack.get((kind, ptr, numel), ()):
+            self._done(i, bi)
 
-    def _make_hook(self, bi):
+    def _make_hook(self, i, bi):
         def hook(param):
-            self.pending[bi] -= 1
-            if self.pending[bi] == 0 and not self.launched[bi]:
-                self._release(bi)
+            self._done(i, bi)
         return hook
 
     CLIP_SIDE = ("video_embeddings.", "encoder.", "token_type_embeddings.")
@@ -424,25 +434,10 @@ class GradReducer:
 
     def finish(self):
         """Launch whatever has not been launched (tensors without a gradient this step never fire a hook) and wait."""
-        recalibrate = False
-        if self.overlap and not self._calibrating and self._count != self._expected:
-            # a gradient was written more (or fewer) times than on the calibration step: a bucket may have been exchanged while
-            # kernels were still accumulating into it.  Repair: sum is linear, so exchanging the ranks' late contributions is
-            # not possible after the fact — refuse loudly rather than train on a wrong gradient.
-            late = [k for k, c in self._count.items() if c > self._expected.get(k, 1)]
-            if late:
-                self.reset()
-                self._calibrating, self._expected = True, {}
-                raise _lib.SvpcKernelError("GradReducer: %d gradient(s) were written more often than on the calibration step; their "
-                                           "bucket may have been all-reduced early.  The write counts are re-calibrated on the next "
-                                           "step — re-run this batch." % len(late))
-            recalibrate = True       # fewer writes than expected: those buckets simply launch here, late but complete
         if self.active:
             for bi in range(len(self.buckets)):
                 if not self.launched[bi]:
                     self._launch(bi)
             for w in self.works:
                 w.wait()
-        if (self._calibrating or recalibrate) and self._count:
-            self._expected, self._calibrating = dict(self._count), False
         self.reset()

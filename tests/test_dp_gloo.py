@@ -119,3 +119,27 @@ def test_two_rank_sum_allreduce_equals_full_batch_gradient(golden_dir, overlap):
         assert np.abs(g - ref).max() <= 3e-4 * max(1e-6, np.abs(ref).max()) + 1e-6, name
         n += 1
     assert n > 20
+
+
+def test_post_accumulate_hook_fires_without_a_gradient_tensor():
+    """GradReducer's readiness signal: a leaf's post-accumulate hook runs once per backward, after all of its consumers, even when
+    their backward returned no gradient tensor for it (the in-place arena write of the HIP ops) — torch behaviour the overlap
+    logic relies on (svpc_amd/optim.py)."""
+    class F(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            w.grad += x.t() @ g          # "kernel writes in place"
+            return g @ w.t(), None
+    w = torch.nn.Parameter(torch.randn(3, 3))
+    w.grad = torch.zeros(3, 3)
+    x = torch.randn(2, 3, requires_grad=True)
+    fired = []
+    w.register_post_accumulate_grad_hook(lambda p: fired.append(float(p.grad.abs().sum())))
+    (F.apply(x, w).sum() + F.apply(2 * x, w).sum()).backward()
+    assert len(fired) == 1 and fired[0] > 0          # once, after BOTH uses have written

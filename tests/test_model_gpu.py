@@ -39,7 +39,13 @@ def test_tiny_forward_backward_vs_reference_golden(golden_dir, mt):
         assert p.grad is not None, name
         # key biases have an analytically zero gradient (softmax shift invariance; the reference's own values are rounding noise
         # ≲1e-6): only there an absolute floor applies.  Every other tensor is held to 2e-3 of its own max magnitude.
-        floor = 2e-3 if name.endswith(".key.bias") else 0.0
+        # Likewise the cross-attention query/key projections of MODEL_TYPE=v: its memory holds ONE row per step, the softmax over a
+        # single key is the constant 1, so those gradients are exactly zero in exact arithmetic.
+        # And the pointer's Wing.bias: r[e] = <Wing·B[e] + b, d> — the bias adds the same <b, d> to every entity's score and the
+        # softmax over entities is shift-invariant (model.py:899-903).
+        zero_in_theory = (name.endswith(".key.bias") or name == "Wing.bias" or
+                          (mt == "v" and ("dec_enc_attention.query" in name or "dec_enc_attention.key" in name)))
+        floor = 2e-3 if zero_in_theory else 0.0
         err = float(np.abs(p.grad.cpu().numpy() - refg).max()) / (scale + floor)
         worst = max(worst, (err, name))
         n += 1
@@ -447,3 +453,51 @@ def test_edge_shapes_forward_backward_match_oracle(mt, steps, n_ingr, n_oov):
         assert (p.grad.cpu() - rg).abs().max().item() <= 3e-3 * scale + floor, n
         checked += 1
     assert checked > 20
+
+
+def test_overlapped_reducer_with_bf16_sink_mid_backward():
+    """a gradient bucket released by a hook in the MIDDLE of backward must not trip the residual-gradient
+    hand-over's leftover check — a parked LayerNorm gradient is legitimately pending there.  One rank (gloo; SUM over one rank is
+    the identity) through the real overlap machinery (post-accumulate hooks + pointer notifications + ordered bucket launch) in
+    bf16 mode with the sink engaged: three steps, gradients equal to the plain backward's."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from svpc_amd import ops
+    from svpc_amd.optim import FusedBertAdam, GradReducer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    ops.set_precision("bf16")
+    red = None
+    try:
+        cfg, model, batch = _stream_model(n_videos=4, steps=4, max_t_len=8)
+        fargs = syn.forward_args(batch)
+        opt = FusedBertAdam(list(model.named_parameters()), lr=0.0, grad_clip=-1.0, max_grad_norm=-1.0)
+        opt.zero_grad(); model(*fargs)[0].backward(); arena = opt.ensure_built()
+        opt.zero_grad(); model(*fargs)[0].backward(); ops.join_side()
+        ref = arena.flat.clone()
+        parked0 = ops.SINK_STATS[0]
+        red = GradReducer(arena, bucket_bytes=64 << 10, overlap=True, force=True)
+        assert red.active and red.overlap and len(red.buckets) > 4
+        scale = float(ref.abs().max())
+        for it in range(3):           # buckets are released from inside backward, in index order
+            opt.zero_grad()
+            model(*fargs)[0].backward()
+            n_mid = sum(red.launched)
+            red.finish()
+            torch.cuda.synchronize()
+            # the grouped weight-gradient launches are cut at other points than in the reference run (a bucket release flushes the
+            # queue), which changes the fp32 summation order of the split tiles: compare against the tensor's scale
+            err = float((arena.flat - ref).abs().max())
+            assert err <= 2e-5 * scale, (it, err, scale)
+            assert n_mid > 0, "no bucket was released during backward"
+        assert ops.SINK_STATS[0] > parked0, "the residual-gradient sink was not engaged"
+    finally:
+        ops.set_precision("fp32")
+        if red is not None:
+            red.close()
+        if created:
+            dist.destroy_process_group()
