@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense peaks (f32-in MFMA; bf16 MFMA)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "dominant_gemm_traffic.json")
-DOMINANT_SOURCES = ("svpc_amd/csrc/gemm_glds.hip", "svpc_amd/csrc/gemm_common.h", "svpc_amd/csrc/common.h")
+DOMINANT_SOURCES = ("svpc_amd/csrc/gemm_p8.hip", "svpc_amd/csrc/gemm_common.h", "svpc_amd/csrc/common.h")
 
 
 def dominant_kernel_sha():
@@ -516,7 +516,8 @@ def _train_main(args, device, world, rank, dist, joined):
                    "gpus_requested": args.gpus},
         "roofline": {"bound": "mfma", "kernel": "%s — every forward projection of the clip-encoder activation stream (M=%d rows: "
                                "Q/K/V, attention-out, FFN, video embedding)"
-                               % ("gemm_glds_pp_kernel<true,true,__bf16> (bf16·bf16→bf16, direct-to-LDS, 256x256 ping-pong tiles)" if r["glds"] else
+                               % ("gemm_p8_kernel (bf16·bf16→bf16, both operands direct-to-LDS, 256x256x64 tiles, 8 phases per pair of k-tiles, "
+                                  "v_mfma_f32_16x16x32_bf16)" if r["glds"] else
                                   "gemm_bf16_kernel<128,128,NT,interior,8 waves,%s>" % ("bf16·f32→bf16" if r["bf16_stream"] else "f32"), r["rows_enc"]),
                      "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[precision], "unit": "TFLOP/s",
                      "frac": achieved / MFMA_PEAK_TFLOPS[precision],

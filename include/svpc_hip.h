@@ -98,6 +98,12 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
 int svpc_gemm_glds_r(const void* A, int lda, int a_kc, const void* B, int ldb, int b_kc, void* C, int c_dt, int ldc, void* Z, const void* R,
                      int M, int N, int K, const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed, int accumulate,
                      float* workspace, size_t workspace_bytes, svpc_stream_t stream);
+/* the 8-phase 256x256x64 form of the same product for the FORWARD projections of a bf16 activation stream (both operands
+ * k-contiguous bf16, bf16 output, optional bias / ReLU / GELU / pre-activation copy Z; K % 64 == 0, N % 8 == 0, 16-byte aligned rows):
+ * C = act(A[M,K]·B[N,K]^T + bias).  svpc_gemm_glds routes its stream-sized forward launches here; the direct entry exists for tests
+ * and tools.  reference: every nn.Linear of the clip encoder / decoder forward (model.py:195-197,230,259,281,551). */
+int svpc_gemm_p8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* Z, int M, int N, int K, const float* bias, int act,
+                 svpc_stream_t stream);
 /* fp32-operand form with direct-to-LDS staging (deep LDS ring, operands rounded to bf16 when the MFMA fragments are built): the
  * latency-bound GEMMs of the decoder :620-694, step-wise encoder :594-617, simulators :742-823, BiLSTM :1017-1025, LM head
  * :697-739 and their dgrad/wgrad.  Any M, N (edges clamped); K % 32 == 0; k-strided operands need rows % 4 == 0. */

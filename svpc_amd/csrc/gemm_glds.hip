@@ -637,6 +637,12 @@ __global__ __launch_bounds__(256) void wgrad16_fixup_kernel(G16Args g, const flo
     }
 }
 
+// gemm_p8.hip: the 8-phase 256×256×64 form for forward projections (both operands k-contiguous, bf16 output, plain epilogue)
+bool glds_p8_supported(int a_kc, int b_kc, int c_dt, int lda, int ldb, int ldc, int M, int N, int K, const Epi& epi, const void* A,
+                       const void* B, const void* C);
+int glds_p8_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const Epi& epi, int remap,
+                   hipStream_t stream);
+
 extern "C" {
 
 // 1 if (shape, layout) can run on the direct-to-LDS kernel: bf16 A and B with 16-byte aligned rows; any M and N (even N) for
@@ -792,6 +798,10 @@ int svpc_gemm_glds_r(const void* A, int lda, int a_kc, const void* B, int ldb, i
     if (remap < 0) { const char* e = getenv("SVPC_GEMM_REMAP"); remap = e ? atoi(e) : 1; }
     static int ppdbg = -1;
     if (ppdbg < 0) { const char* e = getenv("SVPC_PP_DBG"); ppdbg = e ? atoi(e) : 0; }
+    static int p8_env = -1;
+    if (p8_env < 0) { const char* e = getenv("SVPC_P8"); p8_env = e ? atoi(e) : 1; }
+    if (big && p8_env && glds_p8_supported(a_kc, b_kc, c_dt, lda, ldb, ldc, M, N, K, epi, A, B, C))
+        return glds_p8_launch(A, lda, B, ldb, C, ldc, M, N, K, epi, remap, stream);
     dim3 grid(tiles * splitk), block(512);
     // 3 stages = 48 KiB → 3 workgroups per CU (measured best of 3 / 4)
 #define GL_LAUNCH1(AK, BKC, TC, NSV, BMV)                                                                                            \

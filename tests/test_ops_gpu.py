@@ -678,3 +678,39 @@ def _grouped_wgrad_bf16_case(shapes):
         ref = dw0.double() + dz.double().t() @ x.double()
         tol = 2e-6 * math.sqrt(rows) * max(1.0, ref.abs().max().item())
         assert (dw.double() - ref).abs().max().item() <= tol, (rows, n_out, n_in)
+
+
+@pytest.mark.parametrize("M,N,K,act,with_z", [(256, 256, 64, 0, False), (300, 264, 128, 2, True), (1000, 520, 192, 1, False),
+                                              (513, 8, 64, 2, True), (19200, 768, 768, 2, True), (18000, 2304, 768, 0, False),
+                                              (4224, 768, 3072, 1, False)])
+def test_gemm_p8_forward_form(M, N, K, act, with_z):
+    """svpc_gemm_p8 (256×256×64 tiles, 8 phases per pair of k-tiles, 16x16x32 MFMA, both operands direct-to-LDS) through its C-ABI
+    entry: one to 48 k-tiles (prologue-only, odd and even tile counts → both LDS buffers end the loop), ragged M and N edges (clamped
+    rows, guarded 16-byte stores), bias, ReLU / GELU (the kernel's own erf approximation: |error| ≤ 3e-7, below the bf16 rounding of
+    the output) and the exact pre-activation copy — against fp64 of the same bf16 operands."""
+    from svpc_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    bf = torch.bfloat16
+    A = torch.randn(M, K, generator=g).to(bf).to(DEV)
+    B = (0.05 * torch.randn(N, K, generator=g)).to(bf).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    C = torch.full((M + 2, N), 7.0, device=DEV, dtype=bf)          # two guard rows: nothing may be written past row M-1
+    Z = torch.full((M + 2, N), 7.0, device=DEV, dtype=bf) if with_z else None
+    _lib.call("gemm_p8", A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), N, Z.data_ptr() if with_z else None, M, N, K, bias.data_ptr(), act,
+              torch.cuda.current_stream().cuda_stream)
+    zr = A.double() @ B.double().t() + bias.double()
+    ref = torch.relu(zr) if act == 1 else torch.nn.functional.gelu(zr) if act == 2 else zr
+    scale = max(1.0, zr.abs().max().item())
+    assert (C[:M].double() - ref).abs().max().item() <= 6e-3 * scale
+    assert (C[M:] == 7.0).all()
+    if with_z:
+        assert (Z[:M].double() - zr).abs().max().item() <= 6e-3 * scale
+        assert (Z[M:] == 7.0).all()
+
+
+def test_gemm_p8_refuses_what_it_cannot_run():
+    from svpc_amd import _lib
+    bf = torch.bfloat16
+    A = torch.zeros(256, 96, device=DEV, dtype=bf); B = torch.zeros(256, 96, device=DEV, dtype=bf); C = torch.zeros(256, 256, device=DEV, dtype=bf)
+    with pytest.raises(_lib.SvpcKernelError):      # K % 64 != 0
+        _lib.call("gemm_p8", A.data_ptr(), 96, B.data_ptr(), 96, C.data_ptr(), 256, None, 256, 256, 96, None, 0, torch.cuda.current_stream().cuda_stream)

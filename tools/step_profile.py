@@ -5,7 +5,7 @@ import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+top = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 40
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("opt_adam")]
 a, b = idx[-6], idx[-5]                      # a graph replay inside the timed region (the last 3 steps are instrumented eager ones)
@@ -13,6 +13,15 @@ step = rows[a + 1:b + 1]
 t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
 dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 print("kernels %d  span %.3f ms  sum %.3f ms" % (len(step), (t1 - t0) / 1e6, sum(dur(r) for r in step) / 1e6))
+gaps = [int(step[i + 1]["Start_Timestamp"]) - int(step[i]["End_Timestamp"]) for i in range(len(step) - 1)]
+pos = sorted(g_ for g_ in gaps if g_ > 0)
+print("gaps between consecutive kernels: total %.3f ms, median %.2f us, p90 %.2f us, max %.1f us; kernels shorter than 6 us: %d (sum %.3f ms)"
+      % (sum(pos) / 1e6, pos[len(pos) // 2] / 1e3, pos[int(len(pos) * 0.9)] / 1e3, pos[-1] / 1e3,
+         sum(1 for r in step if dur(r) < 6000), sum(dur(r) for r in step if dur(r) < 6000) / 1e6))
+if "--seq" in sys.argv:      # dump the launch sequence (time, duration, gap before, grid, name)
+    for i, r in enumerate(step):
+        print("  %8.3f ms %7.1f us gap %5.1f  grid %7s  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e6, dur(r) / 1e3,
+              (gaps[i - 1] / 1e3 if i else 0.0), r["Grid_Size_X"], r["Kernel_Name"].replace("void ", "")[:90]))
 g = collections.defaultdict(lambda: [0, 0])
 for r in step:
     k = (r["Kernel_Name"].replace("void ", "")[:72], r["Grid_Size_X"])
