@@ -77,17 +77,23 @@ __device__ __forceinline__ void p8_store_pass(const floatx4 (&acc)[8][4], __bf16
         }
         __builtin_amdgcn_sched_barrier(0);              // one row block at a time: keeps the register footprint of the tail small
     }
-    // same wave wrote and reads: LDS operations of a wave complete in order
-    const int chunk = lane & 7, cc = col0 + 8 * chunk;
+    // same wave wrote and reads: LDS operations of a wave complete in order.  Global addresses as ONE 32-bit byte offset per lane
+    // from the uniform base (host check: the output spans < 4 GiB) stepped by a uniform stride — 16 precomputed 64-bit
+    // addresses would not fit beside the 128 accumulator registers the Z pass still needs.
+    const int chunk = lane & 7, cc = col0 + 8 * chunk, r0 = lane >> 3;
+    uint32_t off = ((uint32_t)(row0 + r0) * (uint32_t)ldc + (uint32_t)cc) * 2u;
+    const uint32_t step = 16u * (uint32_t)ldc;                         // 8 rows
+    const bool col_ok = cc + 8 <= N;
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
-        const int r = it * 8 + (lane >> 3), row = row0 + r;
+        const int r = it * 8 + r0;
         const uint4 v = *reinterpret_cast<const uint4*>(wl + r * 128 + ((chunk ^ (r & 7)) << 4));
-        if (row < M && cc + 8 <= N) *reinterpret_cast<uint4*>(C + (size_t)row * ldc + cc) = v;
-        if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four lines in flight: the accumulators stay in registers
+        if (col_ok && row0 + r < M) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(C) + off) = v;
+        off += step;
+        if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four lines in flight
     }
 }
-template <int ACT>
+template <int ACT, bool HASZ>
 __device__ __forceinline__ void p8_store(const floatx4 (&acc)[8][4], __bf16* __restrict__ C, int ldc, __bf16* __restrict__ Z,
                                          const float* __restrict__ bias, int row0, int col0, int M, int N, int lane, char* __restrict__ wl) {
     float4 bb[4];
@@ -96,10 +102,12 @@ __device__ __forceinline__ void p8_store(const floatx4 (&acc)[8][4], __bf16* __r
         const int c = col0 + j * 16 + 4 * (lane >> 4);
         bb[j] = (bias && c + 4 <= N) ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // pre-activation copy first: the activation pass then consumes the sums for the last time and its registers free up as it goes
+    if (HASZ) p8_store_pass<ACT, true>(acc, Z, ldc, bb, row0, col0, M, N, lane, wl);
     p8_store_pass<ACT, false>(acc, C, ldc, bb, row0, col0, M, N, lane, wl);
-    if (Z) p8_store_pass<ACT, true>(acc, Z, ldc, bb, row0, col0, M, N, lane, wl);
 }
 
+template <int ACT, bool HASZ>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B, int ldb,
                                                       __bf16* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_m,
                                                       int tiles_n, int remap) {
@@ -127,6 +135,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const __bf16* __restrict__
     do {                                                                                                                   \
         char* dst_ = my + ((t) & 1) * P8_BUF + (which) * P8_HALF;                                                          \
         const __bf16* src_ = ((which) < 2 ? ga[(which) & 1] : gb[(which) & 1]) + (size_t)(t) * P8_BK;                      \
+        /* (marking the activation loads non-temporal measured 10-25 % slower: the tiles of a tile row share them through L2) */ \
         __builtin_amdgcn_global_load_lds((p8_gptr)(src_), (p8_lptr)(dst_), 16, 0, 0);                                      \
         __builtin_amdgcn_global_load_lds((p8_gptr)(src_ + 32), (p8_lptr)(dst_ + 1024), 16, 0, 0);                          \
     } while (0)
@@ -245,11 +254,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const __bf16* __restrict__
     char* wl = smem + wave * 16384;
     __bf16* Zb = reinterpret_cast<__bf16*>(epi.Z);
     const int row0 = m0 + wr * 128, col0 = n0 + wc * 64;
-    switch (epi.act) {
-        case ACT_RELU: p8_store<ACT_RELU>(acc, C, ldc, Zb, epi.bias, row0, col0, M, N, lane, wl); break;
-        case ACT_GELU: p8_store<ACT_GELU>(acc, C, ldc, Zb, epi.bias, row0, col0, M, N, lane, wl); break;
-        default: p8_store<ACT_NONE>(acc, C, ldc, Zb, epi.bias, row0, col0, M, N, lane, wl); break;
-    }
+    p8_store<ACT, HASZ>(acc, C, ldc, Zb, epi.bias, row0, col0, M, N, lane, wl);
 }
 
 // 1 if this (shape, epilogue) runs on the p8 kernel; the launcher of gemm_glds.hip asks before choosing its own 256×256 form
@@ -257,13 +262,21 @@ bool glds_p8_supported(int a_kc, int b_kc, int c_dt, int lda, int ldb, int ldc, 
                        const void* B, const void* C) {
     return a_kc && b_kc && c_dt == 1 && K >= P8_BK && K % P8_BK == 0 && (N & 7) == 0 && (ldc & 7) == 0 && (lda & 7) == 0 &&
            (ldb & 7) == 0 && epi.p_drop <= 0.f && !epi.accumulate && epi.R == nullptr && epi.act != ACT_SIGMOID &&
+           (unsigned long long)M * (unsigned long long)ldc * 2ull < (1ull << 32) &&
            ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)epi.Z) | ((uintptr_t)epi.bias)) & 15) == 0;
 }
 int glds_p8_launch(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const Epi& epi, int remap,
                    hipStream_t stream) {
     const int tiles_m = ceil_div(M, 256), tiles_n = ceil_div(N, 256);
-    hipLaunchKernelGGL(gemm_p8_kernel, dim3(tiles_m * tiles_n), dim3(512), 0, stream, (const __bf16*)A, lda, (const __bf16*)B, ldb,
-                       (__bf16*)C, ldc, M, N, K, epi, tiles_m, tiles_n, remap);
+    // one instantiation per (activation, pre-activation copy): each epilogue is register-allocated on its own
+#define P8_GO(ACTV, ZV)                                                                                                         \
+    hipLaunchKernelGGL((gemm_p8_kernel<ACTV, ZV>), dim3(tiles_m * tiles_n), dim3(512), 0, stream, (const __bf16*)A, lda, (const __bf16*)B, \
+                       ldb, (__bf16*)C, ldc, M, N, K, epi, tiles_m, tiles_n, remap)
+    const bool z = epi.Z != nullptr;
+    if (epi.act == ACT_GELU) { if (z) P8_GO(ACT_GELU, true); else P8_GO(ACT_GELU, false); }
+    else if (epi.act == ACT_RELU) { if (z) P8_GO(ACT_RELU, true); else P8_GO(ACT_RELU, false); }
+    else { if (z) P8_GO(ACT_NONE, true); else P8_GO(ACT_NONE, false); }
+#undef P8_GO
     return svpc_check_launch("gemm_p8");
 }
 
