@@ -153,10 +153,13 @@ def device_batch(cfg, args, device, seed, n_videos=None):
     import torch
     from svpc_amd import make_batch
     b = make_batch(cfg, n_videos=n_videos or args.batch, max_steps=args.clips, n_ingr=10, n_oov=0, seed=seed, full_clips=True)
-    feats = torch.stack(b["video_features_list"]).to(device)           # one (S, N, L, F) buffer: consumed in place
-    b["video_features_list"] = [feats[s] for s in range(feats.shape[0])]
+    # one (S, N, ...) buffer per per-step list (what svpc_amd.input_pipeline builds on the device): the model consumes them in place
+    stacked = ("video_features_list", "input_ids_list", "input_masks_list", "input_labels_list", "token_type_ids_list")
+    for k in stacked:
+        buf = torch.stack(b[k]).to(device)
+        b[k] = [buf[s] for s in range(buf.shape[0])]
     for k, v in list(b.items()):
-        if k == "video_features_list":
+        if k in stacked:
             continue
         if isinstance(v, list) and v and isinstance(v[0], torch.Tensor):
             b[k] = [t.to(device) for t in v]

@@ -221,6 +221,17 @@ int svpc_asl_rows_fwd(const float* p, const float* y, const float* active, float
                       float clip, float eps, svpc_stream_t stream);
 int svpc_asl_rows_bwd(const float* dout, const float* p, const float* y, const float* active, float* dp, int R, int C, float gneg,
                       float gpos, float clip, float eps, svpc_stream_t stream);
+/* The whole loss sum in one launch (and its backward in one): total = sum(cap_rows) + [sum_r BCE(e_p[r], align[r]; first widths[r]
+ * columns) + sum_{r: any(act[r] == 1)} ASL(a_p[r], act[r])] + lambda * [the same for the re-simulator's r_e / r_a] — reference
+ * model.py:1110-1115 (per-video BCE-sum / ASL), :1168-1188 (re-simulation terms weighted by lambda_, total).  Any of e_p / a_p / r_e /
+ * r_a may be NULL (modes without a simulator).  out5 = {total, caption, entity, action, re-simulation}.  Deterministic. */
+int svpc_loss_tail_fwd(const float* cap_rows, int n_cap, const float* e_p, const float* align, const int* widths, int R, int Ce,
+                       const float* a_p, const float* act, int Ca, const float* r_e, const float* r_a, float lambda, float gneg,
+                       float gpos, float clip, float eps, float* out5, svpc_stream_t stream);
+int svpc_loss_tail_bwd(const float* dout, int n_cap, const float* e_p, const float* align, const int* widths, int R, int Ce,
+                       const float* a_p, const float* act, int Ca, const float* r_e, const float* r_a, float lambda, float gneg,
+                       float gpos, float clip, float eps, float* d_cap, float* de_p, float* da_p, float* dr_e, float* dr_a,
+                       svpc_stream_t stream);
 int svpc_row_any_eq1(const float* x, float* out, int R, int C, svpc_stream_t stream);
 int svpc_clamp_labels(const int* in, int* out, int n, int vocab, int unk, svpc_stream_t stream); /* model.py:1013 */
 int svpc_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, const float* h_prev, const float* active, float* h,

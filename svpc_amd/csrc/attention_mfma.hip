@@ -14,6 +14,7 @@
 // No atomics, no HBM intermediates.  Bound: HBM (AI ≈ 25–50 FLOP/B): algorithmic bytes per (sequence, head) forward =
 // (2·Lq + 2·Lk)·dh·4.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -270,6 +271,144 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
         store_tile<T>((T*)a.O + (size_t)q_off * a.ldo + h * DH, a.ldo, q0, q_len, 32 * dt, acc[dt], 1.0f, lane);
 }
 
+// ---- forward for the bf16 activation streams with more than 32 rows per sequence (the clip encoder: 100 × 100 × 64).  Same
+// arithmetic as attn_mfma_fwd_kernel, restructured for occupancy and wide memory operations — the kernel is latency-bound (one
+// memory round trip, ≈50 KB per (sequence, head)), so what counts is how many pairs a CU has in flight and how few instructions
+// each needs:
+//   * Q never goes through LDS: a wave needs only its own 32 queries, and their MFMA operand fragments are exactly 16-byte row
+//     pieces — loaded straight into registers (scaled there; 1/√64 is a power of two, so the bf16 values are the same).
+//     LDS holds K and V only: 37 KB → FOUR workgroups per CU instead of two.
+//   * K / V rows are staged with 16-byte loads and LDS stores (half the instructions of the 8-byte form).
+//   * O is accumulated TRANSPOSED (Oᵀ = Vᵀ·P̃ᵀ: the V fragment in the A slot) so a lane owns one query row; two
+//     v_permlane32_swap per pair of 4-column runs give it 8 consecutive head columns → four 16-byte stores per lane instead of
+//     sixteen shuffled dword stores.
+template <int DH>
+__global__ __launch_bounds__(256, 4) void attn_stream_fwd_kernel(MAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int AT = 128, RS = AImg<DH>::RS, IB = AT * RS, NTL = AT / 32, UPR = DH / 8, NIT = AT * UPR / 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5, tid = threadIdx.x;
+    char* Ks = smem; char* Vs = smem + IB;
+    float* mterm = reinterpret_cast<float*>(smem + 2 * IB);
+    const int sh = blockIdx.x;
+    const int s = sh / a.H, h = sh - s * a.H;
+    const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
+    const int q0 = 32 * wave;
+    const __bf16* Kp = (const __bf16*)a.K + (size_t)k_off * a.ldk + h * DH;
+    const __bf16* Vp = (const __bf16*)a.V + (size_t)k_off * a.ldv + h * DH;
+    uint4 kraw[NIT], vraw[NIT];
+    bf16x8 qf[DH / 16];
+    {   // every global load of the prologue in flight at once
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int u = tid + 256 * it, row = u / UPR, c8 = u - row * UPR;
+            kraw[it] = vraw[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (row < k_len) {
+                kraw[it] = *reinterpret_cast<const uint4*>(Kp + (size_t)row * a.ldk + 8 * c8);
+                vraw[it] = *reinterpret_cast<const uint4*>(Vp + (size_t)row * a.ldv + 8 * c8);
+            }
+        }
+        const int qr = min(q0 + l31, q_len - 1);        // rows past the sequence repeat its last query (never stored)
+        const __bf16* Qp = (const __bf16*)a.Q + (size_t)(q_off + max(qr, 0)) * a.ldq + h * DH + 8 * lhi;
+#pragma unroll
+        for (int ds = 0; ds < DH / 16; ++ds) qf[ds] = *reinterpret_cast<const bf16x8*>(Qp + 16 * ds);
+        for (int j = tid; j < AT; j += 256)
+            mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int u = tid + 256 * it, row = u / UPR, c8 = u - row * UPR;
+            *reinterpret_cast<uint4*>(Ks + row * RS + c8 * 16) = kraw[it];
+            *reinterpret_cast<uint4*>(Vs + row * RS + c8 * 16) = vraw[it];
+        }
+#pragma unroll
+        for (int ds = 0; ds < DH / 16; ++ds)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[ds][j] = (__bf16)((float)qf[ds][j] * a.scale);
+    }
+    __syncthreads();
+    if (q0 >= q_len) return;
+    const int nkt = (k_len + 31) >> 5;
+
+    floatx16 st[NTL];
+#pragma unroll
+    for (int jt = 0; jt < NTL; ++jt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[jt][e] = 0.f;
+        if (jt < nkt) {
+#pragma unroll
+            for (int ds = 0; ds < DH / 16; ++ds)
+                st[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(Ks, 32 * jt, ds, lane), qf[ds], st[jt], 0, 0, 0);
+        }
+    }
+    const int q = q0 + l31;                 // this lane's query
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < NTL; ++jt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = 32 * jt + acc_row(e, lane);
+            float t = mterm[key];
+            const float v = st[jt][e] + t;
+            st[jt][e] = v;
+            mx = fmaxf(mx, v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NTL; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const float p = __expf(st[jt][e] - mx); st[jt][e] = p; sum += p; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (lane < 32 && q < q_len && a.LSE) a.LSE[((size_t)s * a.H + h) * a.max_q + q] = mx + logf(sum);
+    const DropCtx dctx(a.seed, a.site, a.p_drop, (u64)a.n_seq * a.H * a.max_q * a.max_k);
+    const u64 row_base = ((u64)(s * a.H + h) * a.max_q + q) * a.max_k;
+    floatx16 acc[DH / 32];      // Oᵀ: rows = head columns 32·dt + acc_row(e), column = this lane's query
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[dt][e] = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NTL; ++jt) {
+        if (jt < nkt) {
+            float pv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pv[e] = st[jt][e] * inv;
+            if (a.p_drop > 0.f) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) pv[e] *= dctx.mul(row_base, 32 * jt + acc_row(e, lane));
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pb = pack8(&pv[8 * s2]);
+#pragma unroll
+                for (int dt = 0; dt < DH / 32; ++dt)
+                    acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<DH>(Vs, 32 * jt + 16 * s2, 32 * dt, lane), pb, acc[dt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // one key tile at a time: the dropout hashes of later tiles must not be hoisted (registers)
+    }
+    __bf16* Op = (__bf16*)a.O + (size_t)(q_off + q) * a.ldo + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+        for (int k = 0; k < 4; k += 2) {            // runs k and k+1 of 4 columns → the 8-column chunks k (lanes 0-31) and k+1 (lanes 32-63)
+            uint32_t y[4];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int e = 4 * (k + g);
+                union { __bf16 hh[2]; uint32_t u; } p0, p1;
+                p0.hh[0] = (__bf16)acc[dt][e]; p0.hh[1] = (__bf16)acc[dt][e + 1];
+                p1.hh[0] = (__bf16)acc[dt][e + 2]; p1.hh[1] = (__bf16)acc[dt][e + 3];
+                y[2 * g] = p0.u; y[2 * g + 1] = p1.u;
+            }
+            auto r0 = __builtin_amdgcn_permlane32_swap(y[0], y[2], false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(y[1], y[3], false, false);
+            if (q < q_len) *reinterpret_cast<uint4*>(Op + 32 * dt + 8 * (k + lhi)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+}
+
 template <int DH, typename T, int AT, bool PERWAVE>
 __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   // 2 waves/SIMD: ≤ 256 registers, 2 workgroups per CU
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
@@ -469,9 +608,23 @@ static int mattn_bwd_go(const MAttnArgs& a, int n_pairs, hipStream_t stream) {
     return svpc_check_launch("attn_mfma_bwd");
 }
 // image height: 32 rows when every sequence has ≤ 32 queries and keys (decoder, step encoder, memory slots), else 128
+template <int DH>
+static int mattn_stream_fwd_go(const MAttnArgs& a, int n_pairs, hipStream_t stream) {
+    const size_t lds = 2 * (size_t)128 * AImg<DH>::RS + 128 * sizeof(float);
+    hipLaunchKernelGGL((attn_stream_fwd_kernel<DH>), dim3(n_pairs), dim3(256), lds, stream, a);
+    return svpc_check_launch("attn_stream_fwd");
+}
+static bool mattn_stream_ok(const MAttnArgs& a) {       // 16-byte row pieces everywhere
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SVPC_ATTN_STREAM"); on = e ? atoi(e) : 1; }
+    return on && a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 8 == 0 &&
+           ((((uintptr_t)a.Q) | ((uintptr_t)a.K) | ((uintptr_t)a.V) | ((uintptr_t)a.O)) & 15) == 0;
+}
 template <typename T>
 static int mattn_fwd_launch(const MAttnArgs& a, int dh, int n_blocks, hipStream_t stream) {
     const bool small = a.max_q <= 32 && a.max_k <= 32;
+    if (sizeof(T) == 2 && !small && !a.causal && mattn_stream_ok(a))      // (the causal decoder sequences take the 32-row form)
+        return dh == 64 ? mattn_stream_fwd_go<64>(a, n_blocks, stream) : mattn_stream_fwd_go<32>(a, n_blocks, stream);
     if (dh == 64) return small ? mattn_fwd_go<T, 64, 32>(a, n_blocks, stream) : mattn_fwd_go<T, 64, 128>(a, n_blocks, stream);
     return small ? mattn_fwd_go<T, 32, 32>(a, n_blocks, stream) : mattn_fwd_go<T, 32, 128>(a, n_blocks, stream);
 }

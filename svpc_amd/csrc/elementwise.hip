@@ -264,6 +264,113 @@ __global__ __launch_bounds__(256) void row_any_eq1_kernel(const float* __restric
     f = wave_max(f);
     if (lane == 0) out[r] = f;
 }
+// ---- loss tail: the whole sum of the training loss in ONE launch (and its backward in one) -----------------------------------
+// total = Σ cap_rows + [Σ_r BCE(e_p[r], align[r]) + Σ_{r: any(act[r]==1)} ASL(a_p[r], act[r])] + λ·[the same two sums for the
+// re-simulator's r_e / r_a]   (reference: model.py:1110-1115 per-video sums, :1168-1188 total; BCE :869, ASL losses.py:15-50).
+// The eager form was 15 launches forward (row kernels, five sum_all, adds) and ≈10 backward on a launch-bound chain.
+// Forward: one workgroup of 16 waves, a wave per row (rows w, w+16, …), per-wave partials combined in wave order → deterministic.
+struct LossTailArgs {
+    const float* cap_rows; int n_cap;
+    const float* e_p; const float* align; const int* widths; int R, Ce;
+    const float* a_p; const float* act; int Ca;
+    const float* r_e; const float* r_a; float lambda;
+    float gneg, gpos, clip, eps;
+    float* out;            // out[0] total, out[1] caption, out[2] entity, out[3] action, out[4] re-simulation (unweighted)
+    const float* dout;     // backward: upstream gradient of the total (device scalar)
+    float* d_cap; float* de_p; float* da_p; float* dr_e; float* dr_a;
+};
+__device__ __forceinline__ float bce_row_sum(const float* __restrict__ p, const float* __restrict__ y, int wdt, int lane) {
+    float s = 0.f;
+    for (int c = lane; c < wdt; c += 64) {
+        const float pp = p[c], yy = y[c];
+        s -= yy * fmaxf(logf(pp), -100.f) + (1.f - yy) * fmaxf(logf(1.f - pp), -100.f);
+    }
+    return wave_sum(s);
+}
+__device__ __forceinline__ float asl_row_sum(const float* __restrict__ p, const float* __restrict__ y, int C, int lane, const LossTailArgs& a) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        float l, d;
+        asl_terms(p[c], y[c], a.gneg, a.gpos, a.clip, a.eps, l, d);
+        s += l;
+    }
+    return wave_sum(s);
+}
+__device__ __forceinline__ bool row_has_one(const float* __restrict__ y, int C, int lane) {
+    float f = 0.f;
+    for (int c = lane; c < C; c += 64) f = fmaxf(f, y[c] == 1.0f ? 1.f : 0.f);
+    return wave_max(f) != 0.f;
+}
+__global__ __launch_bounds__(1024) void loss_tail_fwd_kernel(LossTailArgs a) {
+    __shared__ float part[16][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float cap = 0.f, ent = 0.f, actl = 0.f, re = 0.f;
+    for (int i = threadIdx.x; i < a.n_cap; i += 1024) cap += a.cap_rows[i];
+    cap = wave_sum(cap);
+    for (int r = wave; r < a.R; r += 16) {
+        const int wdt = a.widths[r];
+        const float* yr = a.align + (size_t)r * a.Ce;
+        const float* ar = a.act + (size_t)r * a.Ca;
+        const bool on = row_has_one(ar, a.Ca, lane);
+        if (a.e_p) ent += bce_row_sum(a.e_p + (size_t)r * a.Ce, yr, wdt, lane);
+        if (a.a_p && on) actl += asl_row_sum(a.a_p + (size_t)r * a.Ca, ar, a.Ca, lane, a);
+        if (a.r_e) re += bce_row_sum(a.r_e + (size_t)r * a.Ce, yr, wdt, lane);
+        if (a.r_a && on) re += asl_row_sum(a.r_a + (size_t)r * a.Ca, ar, a.Ca, lane, a);
+    }
+    if (lane == 0) { part[wave][0] = cap; part[wave][1] = ent; part[wave][2] = actl; part[wave][3] = re; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < 16; ++w)
+            for (int k = 0; k < 4; ++k) t[k] += part[w][k];
+        a.out[1] = t[0]; a.out[2] = t[1]; a.out[3] = t[2]; a.out[4] = t[3];
+        a.out[0] = ((t[0] + t[1]) + t[2]) + a.lambda * t[3];          // the reference's order of additions (model.py:1188)
+    }
+}
+// backward: blocks [0, ceil(R/4)) — one wave per row writes every probability gradient of its row; the remaining blocks fill d_cap
+__global__ __launch_bounds__(256) void loss_tail_bwd_kernel(LossTailArgs a, int row_blocks) {
+    const float g = a.dout[0];
+    if ((int)blockIdx.x >= row_blocks) {
+        const int i = ((int)blockIdx.x - row_blocks) * 256 + threadIdx.x;
+        if (a.d_cap && i < a.n_cap) a.d_cap[i] = g;
+        return;
+    }
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.R) return;
+    const int wdt = a.widths[r];
+    const float* yr = a.align + (size_t)r * a.Ce;
+    const float* ar = a.act + (size_t)r * a.Ca;
+    const bool on = row_has_one(ar, a.Ca, lane);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const float* p = which ? a.r_e : a.e_p;
+        float* dp = which ? a.dr_e : a.de_p;
+        const float go = which ? g * a.lambda : g;
+        if (!p || !dp) continue;
+        for (int c = lane; c < a.Ce; c += 64) {
+            float v = 0.f;
+            if (c < wdt) {
+                const float pp = p[(size_t)r * a.Ce + c], yy = yr[c];
+                const float x0 = logf(pp) > -100.f ? -yy / pp : 0.f;
+                const float x1 = logf(1.f - pp) > -100.f ? (1.f - yy) / (1.f - pp) : 0.f;
+                v = go * (x0 + x1);
+            }
+            dp[(size_t)r * a.Ce + c] = v;
+        }
+    }
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const float* p = which ? a.r_a : a.a_p;
+        float* dp = which ? a.dr_a : a.da_p;
+        const float go = on ? (which ? g * a.lambda : g) : 0.f;
+        if (!p || !dp) continue;
+        for (int c = lane; c < a.Ca; c += 64) {
+            float l, d = 0.f;
+            if (go != 0.f) asl_terms(p[(size_t)r * a.Ca + c], ar[c], a.gneg, a.gpos, a.clip, a.eps, l, d);
+            dp[(size_t)r * a.Ca + c] = go * d;
+        }
+    }
+}
 __global__ __launch_bounds__(256) void clamp_labels_kernel(const int* __restrict__ in, int* __restrict__ out, int n, int vocab, int unk) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = in[i] >= vocab ? unk : in[i];
@@ -616,6 +723,34 @@ int svpc_asl_rows_bwd(const float* dout, const float* p, const float* y, const f
     if (R == 0) return 0;
     hipLaunchKernelGGL(asl_rows_bwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, dout, p, y, active, dp, R, C, gneg, gpos, clip, eps);
     return svpc_check_launch("asl_rows_bwd");
+}
+static LossTailArgs loss_tail_args(const float* cap_rows, int n_cap, const float* e_p, const float* align, const int* widths, int R, int Ce,
+                                   const float* a_p, const float* act, int Ca, const float* r_e, const float* r_a, float lambda,
+                                   float gneg, float gpos, float clip, float eps) {
+    LossTailArgs a{};
+    a.cap_rows = cap_rows; a.n_cap = n_cap; a.e_p = e_p; a.align = align; a.widths = widths; a.R = R; a.Ce = Ce; a.a_p = a_p; a.act = act;
+    a.Ca = Ca; a.r_e = r_e; a.r_a = r_a; a.lambda = lambda; a.gneg = gneg; a.gpos = gpos; a.clip = clip; a.eps = eps;
+    return a;
+}
+int svpc_loss_tail_fwd(const float* cap_rows, int n_cap, const float* e_p, const float* align, const int* widths, int R, int Ce,
+                       const float* a_p, const float* act, int Ca, const float* r_e, const float* r_a, float lambda, float gneg,
+                       float gpos, float clip, float eps, float* out5, hipStream_t s) {
+    SVPC_REQUIRE(R == 0 || (align && act && widths), "loss_tail: targets missing");
+    LossTailArgs a = loss_tail_args(cap_rows, n_cap, e_p, align, widths, R, Ce, a_p, act, Ca, r_e, r_a, lambda, gneg, gpos, clip, eps);
+    a.out = out5;
+    hipLaunchKernelGGL(loss_tail_fwd_kernel, dim3(1), dim3(1024), 0, s, a);
+    return svpc_check_launch("loss_tail_fwd");
+}
+int svpc_loss_tail_bwd(const float* dout, int n_cap, const float* e_p, const float* align, const int* widths, int R, int Ce,
+                       const float* a_p, const float* act, int Ca, const float* r_e, const float* r_a, float lambda, float gneg,
+                       float gpos, float clip, float eps, float* d_cap, float* de_p, float* da_p, float* dr_e, float* dr_a,
+                       hipStream_t s) {
+    LossTailArgs a = loss_tail_args(nullptr, n_cap, e_p, align, widths, R, Ce, a_p, act, Ca, r_e, r_a, lambda, gneg, gpos, clip, eps);
+    a.dout = dout; a.d_cap = d_cap; a.de_p = de_p; a.da_p = da_p; a.dr_e = dr_e; a.dr_a = dr_a;
+    const int row_blocks = ceil_div(R, 4), cap_blocks = d_cap ? ceil_div(n_cap, 256) : 0;
+    if (row_blocks + cap_blocks == 0) return 0;
+    hipLaunchKernelGGL(loss_tail_bwd_kernel, dim3(row_blocks + cap_blocks), dim3(256), 0, s, a, row_blocks);
+    return svpc_check_launch("loss_tail_bwd");
 }
 int svpc_row_any_eq1(const float* x, float* out, int R, int C, hipStream_t s) {
     if (R == 0) return 0;

@@ -285,7 +285,7 @@ class BertDecoderLayerNoMemoryUntied(nn.Module):
         qc = ops.linear(x1, ca_m.query.weight, ca_m.query.bias)
         wkv, bkv, wg, bg, w16 = ca_m.packed("kv")
         kvc = ops.linear(mem, wkv, bkv, wgrad=wg, bgrad=bg, w16=w16)
-        if kvc.dtype != qc.dtype:          # the few memory rows stay fp32 in HBM; the attention core wants one operand type
+        if kvc.dtype != qc.dtype:          # (memory rows handed over in another storage type than the sentence stream)
             kvc = kvc.to(qc.dtype)
         ca = ops.attention(qc, kvc, (0, 0, D), D, cx.H, seq_cross, key_mask=mem_mask, causal=False, drop=cx.drop(cx.p_a))
         x2 = ops.layernorm(ca, self.norm2.weight, self.norm2.bias, cx.eps, residual=x1, sink=True)
@@ -330,6 +330,10 @@ class BertDecoderNoMemoryUntied(nn.Module):
         stream_bf16 = x.dtype == torch.float32 and ops.bf16_stream_ok(x.shape[0], x.shape[1], self.config.intermediate_size)
         if stream_bf16:
             x = x.to(torch.bfloat16)
+            # the memory rows join the stream once, not per layer: each layer's K|V projection then reads bf16 and writes bf16
+            # (one cast instead of six casts forward and six backward; its weight gradients join the grouped bf16 launch)
+            if mem.dtype == torch.float32 and ops.bf16_stream_ok(mem.shape[0], mem.shape[1], 2 * mem.shape[1]):
+                mem = mem.to(torch.bfloat16)
         for layer in self.layer:
             x = layer.run(x, text_mask, mem, seq_self, seq_cross, mem_mask, cx)
         return x.float() if stream_bf16 else x
@@ -821,9 +825,10 @@ class StateAwareRecursiveTransformer(nn.Module):
         T = plan.T
 
         feats = self._stacked(video_features_list).reshape(S_pad * N * L, F)
-        ids_all = torch.stack(input_ids_list).reshape(-1).to(torch.int32)
-        masks_all = torch.stack(input_masks_list).reshape(-1).float()
-        labels_all = torch.stack(input_labels_list).reshape(-1).to(torch.int32)
+        # (zero-copy when the per-step tensors are consecutive slices of one buffer: the input pipeline and bench.py hand them so)
+        ids_all = self._stacked(input_ids_list).reshape(-1).to(torch.int32)
+        masks_all = self._stacked(input_masks_list).reshape(-1).float()
+        labels_all = self._stacked(input_labels_list).reshape(-1).to(torch.int32)
 
         # (1) entity initial states, compact (ΣE, D)
         ents = self.ingredient_embeddings.run(ingr_input_ids.reshape(-1).to(torch.int32), spans, cx)
@@ -877,18 +882,14 @@ class StateAwareRecursiveTransformer(nn.Module):
         pl = self._ptr_plan(ingr_id_dict if mode != "video" else [{}] * N, c_list, Lt, plan.step_ne, plan.row_vid)
         row_c = pl["row_c"]
         P, cap_rows = self._lm_probs(dec, bank, pl, cx, labels=labels)
-        caption_loss = ops.sum_all(cap_rows)
-
-        # (7) simulator losses and the textual re-simulator
-        total = caption_loss
+        # (7) simulator losses, the textual re-simulator, and the sum of all terms (one launch: ops.loss_tail)
         ent_list, act_list, mem_list = [], [], []
-        if sim_out is not None:
+        if sim_out is None:
+            total = ops.sum_all(cap_rows)
+        else:
             align = self._pad_cat(alignments, plan.e_max)
             act_t = torch.cat(list(actions), 0)
-            any_act = ops.row_any_eq1(act_t)
-            ent_loss = ops.sum_all(ops.bce_rows(e_p, align, plan.step_ne))
-            act_loss = ops.sum_all(ops.asl_rows(a_p, act_t, any_act))
-            total = total + ent_loss + act_loss
+            r_e = r_a = None
             if mode == "full":
                 noise = None
                 if self.gumbel_noise is not None:
@@ -898,9 +899,8 @@ class StateAwareRecursiveTransformer(nn.Module):
                 pooled = ops.span_mean(bow, plan.text_starts, plan.text_lens, weights=text_mask)
                 seq_vec = self._bilstm(pooled, plan)
                 r_e, r_a, _, r_all, _ = self.recipe_reasoner.run(seq_vec, ents, plan.sim, cx)
-                re_ent = ops.sum_all(ops.bce_rows(r_e, align, plan.step_ne))
-                re_act = ops.sum_all(ops.asl_rows(r_a, act_t, any_act))
-                total = total + cfg.lambda_ * (re_ent + re_act)
+            # caption + entity BCE + action ASL (rows with a detected action) + lambda·(the same two for the re-simulation)
+            total = ops.loss_tail(cap_rows, e_p, a_p, r_e, r_a, align, act_t, plan.step_ne, cfg.lambda_ if mode == "full" else 0.0)
 
         # (8) per-video views for the reference's return contract
         prediction_scores_list = []

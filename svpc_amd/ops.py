@@ -1217,9 +1217,10 @@ class _BiLstmSeq(Function):
         D = w[0].shape[1]
         dev = gx_f.device
         mk = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
-        h_all, c_all = [mk(S + 1, N, D) for _ in range(2)], [mk(S + 1, N, D) for _ in range(2)]
-        for z in range(2):
-            h_all[z][0].zero_(); c_all[z][0].zero_()
+        # states of both directions in ONE buffer (direction, h|c, time, N, D) with the four initial states adjacent: one fill
+        state = mk(2, 2, S + 1, N, D)
+        state[:, :, 0].zero_()
+        h_all, c_all = [state[0, 0], state[1, 0]], [state[0, 1], state[1, 1]]
         gates = [mk(S, N, 4 * D) for _ in range(2)]
         gh = [mk(N, 4 * D) for _ in range(2)]
         st = _stream()
@@ -1245,15 +1246,19 @@ class _BiLstmSeq(Function):
         S, N, D = ctx.cfg
         dev = g0.device
         mk = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        # every zero-initialised buffer of the backward in ONE allocation (one fill): the scattered output gradients of both
+        # directions (2·S·N rows) and the four running state gradients (4·N rows)
+        zeros = torch.zeros(2 * S * N + 4 * N, D, dtype=torch.float32, device=dev)
         dhs = []
         for z, d in enumerate((dout_f, dout_b)):
-            t_ = torch.zeros(S * N, D, dtype=torch.float32, device=dev)
+            t_ = zeros[z * S * N:(z + 1) * S * N]
             if d is not None:
                 t_.index_copy_(0, picks[z].long(), _c(d))
             dhs.append(t_.view(S, N, D))
         dG = [mk(S, N, 4 * D) for _ in range(2)]
-        dh = [torch.zeros(N, D, dtype=torch.float32, device=dev) for _ in range(2)]
-        dc = [torch.zeros(N, D, dtype=torch.float32, device=dev) for _ in range(2)]
+        tail = zeros[2 * S * N:].view(4, N, D)
+        dh = [tail[0], tail[1]]
+        dc = [tail[2], tail[3]]
         dh2, dc2 = [mk(N, D) for _ in range(2)], [mk(N, D) for _ in range(2)]
         wt = [w[z].t().contiguous() for z in range(2)]        # (D, 4D): k-contiguous operand of the per-step dgrad
         st = _stream()
@@ -1360,6 +1365,47 @@ class _AslRows(Function):
 
 def asl_rows(p, y, row_active, gamma_neg=4.0, gamma_pos=1.0, clip=0.05, eps=1e-8):
     return _AslRows.apply(p, y, row_active, float(gamma_neg), float(gamma_pos), float(clip), float(eps))
+
+
+class _LossTail(Function):
+    """total = Σ cap_rows + Σ BCE(e_p) + Σ ASL(a_p) + λ·(Σ BCE(r_e) + Σ ASL(r_a)) in one launch; backward in one launch."""
+
+    @staticmethod
+    def forward(ctx, cap_rows, e_p, a_p, r_e, r_a, align, act, widths, lam, gneg, gpos, clip, eps):
+        _need_gpu(cap_rows)
+        cap_rows = _c(cap_rows)
+        e_p, a_p, r_e, r_a = [(_c(t) if t is not None else None) for t in (e_p, a_p, r_e, r_a)]
+        align, act = _c(align), _c(act)
+        dev = cap_rows.device
+        R, Ce = align.shape
+        Ca = act.shape[1]
+        w = widths.dev(dev)
+        out = torch.empty(5, dtype=torch.float32, device=dev)
+        _lib.call("loss_tail_fwd", _p(cap_rows), cap_rows.numel(), _p(e_p), _p(align), _p(w), R, Ce, _p(a_p), _p(act), Ca, _p(r_e), _p(r_a),
+                  float(lam), gneg, gpos, clip, eps, _p(out), _stream())
+        ctx.save_for_backward(e_p, a_p, r_e, r_a, align, act, w)
+        ctx.cfg = (cap_rows.numel(), R, Ce, Ca, float(lam), gneg, gpos, clip, eps)
+        ctx.parts = out
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dout):
+        e_p, a_p, r_e, r_a, align, act, w = ctx.saved_tensors
+        n_cap, R, Ce, Ca, lam, gneg, gpos, clip, eps = ctx.cfg
+        dev = align.device
+        need = ctx.needs_input_grad
+        mk = lambda t, on: torch.empty_like(t) if (t is not None and on) else None
+        d_cap = torch.empty(n_cap, dtype=torch.float32, device=dev) if need[0] else None
+        de, da, dre, dra = mk(e_p, need[1]), mk(a_p, need[2]), mk(r_e, need[3]), mk(r_a, need[4])
+        _lib.call("loss_tail_bwd", _p(_c(dout)), n_cap, _p(e_p), _p(align), _p(w), R, Ce, _p(a_p), _p(act), Ca, _p(r_e), _p(r_a), lam, gneg,
+                  gpos, clip, eps, _p(d_cap), _p(de), _p(da), _p(dre), _p(dra), _stream())
+        return d_cap, de, da, dre, dra, None, None, None, None, None, None, None, None
+
+
+def loss_tail(cap_rows, e_p, a_p, r_e, r_a, align, act, widths, lam, gamma_neg=4.0, gamma_pos=1.0, clip=0.05, eps=1e-8):
+    """Scalar training loss from the caption-loss rows and the (re-)simulator probabilities; e_p / a_p / r_e / r_a may be None."""
+    return _LossTail.apply(cap_rows, e_p, a_p, r_e, r_a, align, act, as_idx(widths), float(lam), float(gamma_neg), float(gamma_pos),
+                           float(clip), float(eps))
 
 
 def greedy_pick(scores, row_c, row_x, lt, pos, unk):

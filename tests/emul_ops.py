@@ -286,6 +286,21 @@ def sum_all(x):
     return x.sum()
 
 
+def loss_tail(cap_rows, e_p, a_p, r_e, r_a, align, act, widths, lam, gamma_neg=4.0, gamma_pos=1.0, clip=0.05, eps=1e-8):
+    on = row_any_eq1(act)
+    total = cap_rows.sum()
+    if e_p is not None:
+        total = total + bce_rows(e_p, align, widths).sum()
+    if a_p is not None:
+        total = total + asl_rows(a_p, act, on, gamma_neg, gamma_pos, clip, eps).sum()
+    re = 0.0
+    if r_e is not None:
+        re = re + bce_rows(r_e, align, widths).sum()
+    if r_a is not None:
+        re = re + asl_rows(r_a, act, on, gamma_neg, gamma_pos, clip, eps).sum()
+    return total + lam * re
+
+
 def take_rows(x, idx):
     return x[idx.long()]
 

@@ -714,3 +714,31 @@ def test_gemm_p8_refuses_what_it_cannot_run():
     A = torch.zeros(256, 96, device=DEV, dtype=bf); B = torch.zeros(256, 96, device=DEV, dtype=bf); C = torch.zeros(256, 256, device=DEV, dtype=bf)
     with pytest.raises(_lib.SvpcKernelError):      # K % 64 != 0
         _lib.call("gemm_p8", A.data_ptr(), 96, B.data_ptr(), 96, C.data_ptr(), 256, None, 256, 256, 96, None, 0, torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("with_resim,with_sim", [(True, True), (False, True)])
+def test_loss_tail_matches_separate_terms(with_resim, with_sim):
+    """ops.loss_tail (all loss terms + their sum in one launch, backward in one) against the per-term torch statement: ragged
+    entity widths, rows without any detected action (excluded from the ASL, model.py:1112-1114), probabilities at the BCE clamp."""
+    g = torch.Generator().manual_seed(5)
+    R, Ce, Ca, n_cap = 37, 7, 45, 531
+    widths = [int(v) for v in torch.randint(1, Ce + 1, (R,), generator=g)]
+    mk = lambda *sh: torch.rand(*sh, generator=g).clamp(1e-4, 1 - 1e-4)
+    e_p, a_p, r_e, r_a = mk(R, Ce), mk(R, Ca), mk(R, Ce), mk(R, Ca)
+    e_p[0, 0] = 0.0; e_p[1, 0] = 1.0                       # log clamped at -100 (nn.BCELoss)
+    align = (torch.rand(R, Ce, generator=g) < 0.3).float()
+    act = (torch.rand(R, Ca, generator=g) < 0.05).float()
+    act[3] = 0.0; act[11] = 0.0                            # rows without a detected action
+    cap = torch.rand(n_cap, generator=g) * 5
+    outs = {}
+    for name, mod, dev in (("hip", O, DEV), ("ref", E, "cpu")):
+        t = [x.clone().to(dev).requires_grad_(True) for x in (cap, e_p, a_p, r_e, r_a)]
+        tot = mod.loss_tail(t[0], t[1], t[2], t[3] if with_resim else None, t[4] if with_resim else None, align.to(dev), act.to(dev),
+                            Idx(widths), 0.5 if with_resim else 0.0)
+        (tot * 1.7).backward()
+        outs[name] = (tot.detach().cpu(), [x.grad.cpu() if x.grad is not None else None for x in t])
+    assert torch.allclose(outs["hip"][0], outs["ref"][0], rtol=2e-6)
+    for a, b in zip(outs["hip"][1], outs["ref"][1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.allclose(a, b, rtol=2e-5, atol=1e-6)
