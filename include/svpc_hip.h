@@ -224,10 +224,13 @@ int svpc_asl_rows_bwd(const float* dout, const float* p, const float* y, const f
 /* The whole loss sum in one launch (and its backward in one): total = sum(cap_rows) + [sum_r BCE(e_p[r], align[r]; first widths[r]
  * columns) + sum_{r: any(act[r] == 1)} ASL(a_p[r], act[r])] + lambda * [the same for the re-simulator's r_e / r_a] — reference
  * model.py:1110-1115 (per-video BCE-sum / ASL), :1168-1188 (re-simulation terms weighted by lambda_, total).  Any of e_p / a_p / r_e /
- * r_a may be NULL (modes without a simulator).  out5 = {total, caption, entity, action, re-simulation}.  Deterministic. */
+ * r_a may be NULL (modes without a simulator).  out5 = {total, caption, entity, action, re-simulation}.  Deterministic (row
+ * partials in `workspace`, svpc_loss_tail_ws_floats() floats, summed in index order by the last workgroup; `counter`: one int zeroed
+ * once by the caller, left at zero by every launch). */
+int svpc_loss_tail_ws_floats(int n_cap, int R);
 int svpc_loss_tail_fwd(const float* cap_rows, int n_cap, const float* e_p, const float* align, const int* widths, int R, int Ce,
                        const float* a_p, const float* act, int Ca, const float* r_e, const float* r_a, float lambda, float gneg,
-                       float gpos, float clip, float eps, float* out5, svpc_stream_t stream);
+                       float gpos, float clip, float eps, float* out5, float* workspace, int* counter, svpc_stream_t stream);
 int svpc_loss_tail_bwd(const float* dout, int n_cap, const float* e_p, const float* align, const int* widths, int R, int Ce,
                        const float* a_p, const float* act, int Ca, const float* r_e, const float* r_a, float lambda, float gneg,
                        float gpos, float clip, float eps, float* d_cap, float* de_p, float* da_p, float* dr_e, float* dr_a,

@@ -268,7 +268,6 @@ __global__ __launch_bounds__(256) void row_any_eq1_kernel(const float* __restric
 // total = Σ cap_rows + [Σ_r BCE(e_p[r], align[r]) + Σ_{r: any(act[r]==1)} ASL(a_p[r], act[r])] + λ·[the same two sums for the
 // re-simulator's r_e / r_a]   (reference: model.py:1110-1115 per-video sums, :1168-1188 total; BCE :869, ASL losses.py:15-50).
 // The eager form was 15 launches forward (row kernels, five sum_all, adds) and ≈10 backward on a launch-bound chain.
-// Forward: one workgroup of 16 waves, a wave per row (rows w, w+16, …), per-wave partials combined in wave order → deterministic.
 struct LossTailArgs {
     const float* cap_rows; int n_cap;
     const float* e_p; const float* align; const int* widths; int R, Ce;
@@ -301,30 +300,67 @@ __device__ __forceinline__ bool row_has_one(const float* __restrict__ y, int C, 
     for (int c = lane; c < C; c += 64) f = fmaxf(f, y[c] == 1.0f ? 1.f : 0.f);
     return wave_max(f) != 0.f;
 }
-__global__ __launch_bounds__(1024) void loss_tail_fwd_kernel(LossTailArgs a) {
-    __shared__ float part[16][4];
+// Forward in ONE launch on many workgroups: blocks [0, ceil(R/4)) — a wave per row writes that row's three sums into `partial`;
+// the remaining blocks sum 1,024 caption rows each.  The workgroup that draws the last ticket (agent-scope release / acquire around
+// a relaxed counter, cdna_hip_programming.md Guideline 16) adds the partials in index order — deterministic — writes out[0..4] and
+// resets the counter for the next launch (the counter lives in a buffer the caller zeroed once).
+__global__ __launch_bounds__(256) void loss_tail_fwd_kernel(LossTailArgs a, int row_blocks, float* __restrict__ partial, int* __restrict__ counter) {
+    __shared__ float red[4];
+    __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float cap = 0.f, ent = 0.f, actl = 0.f, re = 0.f;
-    for (int i = threadIdx.x; i < a.n_cap; i += 1024) cap += a.cap_rows[i];
-    cap = wave_sum(cap);
-    for (int r = wave; r < a.R; r += 16) {
-        const int wdt = a.widths[r];
-        const float* yr = a.align + (size_t)r * a.Ce;
-        const float* ar = a.act + (size_t)r * a.Ca;
-        const bool on = row_has_one(ar, a.Ca, lane);
-        if (a.e_p) ent += bce_row_sum(a.e_p + (size_t)r * a.Ce, yr, wdt, lane);
-        if (a.a_p && on) actl += asl_row_sum(a.a_p + (size_t)r * a.Ca, ar, a.Ca, lane, a);
-        if (a.r_e) re += bce_row_sum(a.r_e + (size_t)r * a.Ce, yr, wdt, lane);
-        if (a.r_a && on) re += asl_row_sum(a.r_a + (size_t)r * a.Ca, ar, a.Ca, lane, a);
+    float* prow = partial;                                   // [R][3]
+    float* pcap = partial + (size_t)3 * a.R;                 // [cap blocks]
+    if ((int)blockIdx.x < row_blocks) {
+        const int r = blockIdx.x * 4 + wave;
+        if (r < a.R) {
+            const int wdt = a.widths[r];
+            const float* yr = a.align + (size_t)r * a.Ce;
+            const float* ar = a.act + (size_t)r * a.Ca;
+            const bool on = row_has_one(ar, a.Ca, lane);
+            float ent = 0.f, actl = 0.f, re = 0.f;
+            if (a.e_p) ent = bce_row_sum(a.e_p + (size_t)r * a.Ce, yr, wdt, lane);
+            if (a.a_p && on) actl = asl_row_sum(a.a_p + (size_t)r * a.Ca, ar, a.Ca, lane, a);
+            if (a.r_e) re = bce_row_sum(a.r_e + (size_t)r * a.Ce, yr, wdt, lane);
+            if (a.r_a && on) re += asl_row_sum(a.r_a + (size_t)r * a.Ca, ar, a.Ca, lane, a);
+            if (lane == 0) { prow[3 * r] = ent; prow[3 * r + 1] = actl; prow[3 * r + 2] = re; }
+        }
+    } else {
+        const int cb = blockIdx.x - row_blocks;
+        float c = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = cb * 1024 + k * 256 + threadIdx.x;
+            if (i < a.n_cap) c += a.cap_rows[i];
+        }
+        c = block_sum_256(c, red);
+        if (threadIdx.x == 0) pcap[cb] = c;
     }
-    if (lane == 0) { part[wave][0] = cap; part[wave][1] = ent; part[wave][2] = actl; part[wave][3] = re; }
+    // ---- publish, draw a ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        float t[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int w = 0; w < 16; ++w)
-            for (int k = 0; k < 4; ++k) t[k] += part[w][k];
-        a.out[1] = t[0]; a.out[2] = t[1]; a.out[3] = t[2]; a.out[4] = t[3];
-        a.out[0] = ((t[0] + t[1]) + t[2]) + a.lambda * t[3];          // the reference's order of additions (model.py:1188)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, tc = 0.f;
+    for (int r = lane; r < a.R; r += 64) { t0 += prow[3 * r]; t1 += prow[3 * r + 1]; t2 += prow[3 * r + 2]; }
+    const int ncb = (int)gridDim.x - row_blocks;
+    for (int i = lane; i < ncb; i += 64) tc += pcap[i];
+    t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2); tc = wave_sum(tc);
+    if (lane == 0) {
+        a.out[1] = tc; a.out[2] = t0; a.out[3] = t1; a.out[4] = t2;
+        a.out[0] = ((tc + t0) + t1) + a.lambda * t2;          // the reference's order of additions (model.py:1188)
+        __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 // backward: blocks [0, ceil(R/4)) — one wave per row writes every probability gradient of its row; the remaining blocks fill d_cap
@@ -732,13 +768,17 @@ static LossTailArgs loss_tail_args(const float* cap_rows, int n_cap, const float
     a.Ca = Ca; a.r_e = r_e; a.r_a = r_a; a.lambda = lambda; a.gneg = gneg; a.gpos = gpos; a.clip = clip; a.eps = eps;
     return a;
 }
+int svpc_loss_tail_ws_floats(int n_cap, int R) { return 3 * R + ceil_div(n_cap > 0 ? n_cap : 1, 1024) + 4; }
+// workspace: svpc_loss_tail_ws_floats() floats of scratch; counter: one int the caller zeroed ONCE (the kernel leaves it at zero)
 int svpc_loss_tail_fwd(const float* cap_rows, int n_cap, const float* e_p, const float* align, const int* widths, int R, int Ce,
                        const float* a_p, const float* act, int Ca, const float* r_e, const float* r_a, float lambda, float gneg,
-                       float gpos, float clip, float eps, float* out5, hipStream_t s) {
+                       float gpos, float clip, float eps, float* out5, float* workspace, int* counter, hipStream_t s) {
     SVPC_REQUIRE(R == 0 || (align && act && widths), "loss_tail: targets missing");
+    SVPC_REQUIRE(workspace && counter, "loss_tail: workspace and counter required");
     LossTailArgs a = loss_tail_args(cap_rows, n_cap, e_p, align, widths, R, Ce, a_p, act, Ca, r_e, r_a, lambda, gneg, gpos, clip, eps);
     a.out = out5;
-    hipLaunchKernelGGL(loss_tail_fwd_kernel, dim3(1), dim3(1024), 0, s, a);
+    const int row_blocks = ceil_div(R, 4), cap_blocks = ceil_div(n_cap > 0 ? n_cap : 1, 1024);
+    hipLaunchKernelGGL(loss_tail_fwd_kernel, dim3(row_blocks + cap_blocks), dim3(256), 0, s, a, row_blocks, workspace, counter);
     return svpc_check_launch("loss_tail_fwd");
 }
 int svpc_loss_tail_bwd(const float* dout, int n_cap, const float* e_p, const float* align, const int* widths, int R, int Ce,

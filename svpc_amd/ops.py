@@ -1367,6 +1367,9 @@ def asl_rows(p, y, row_active, gamma_neg=4.0, gamma_pos=1.0, clip=0.05, eps=1e-8
     return _AslRows.apply(p, y, row_active, float(gamma_neg), float(gamma_pos), float(clip), float(eps))
 
 
+_TICKETS = {}
+
+
 class _LossTail(Function):
     """total = Σ cap_rows + Σ BCE(e_p) + Σ ASL(a_p) + λ·(Σ BCE(r_e) + Σ ASL(r_a)) in one launch; backward in one launch."""
 
@@ -1381,8 +1384,12 @@ class _LossTail(Function):
         Ca = act.shape[1]
         w = widths.dev(dev)
         out = torch.empty(5, dtype=torch.float32, device=dev)
+        scratch = torch.empty(_lib.load().svpc_loss_tail_ws_floats(cap_rows.numel(), R), dtype=torch.float32, device=dev)
+        counter = _TICKETS.get(dev)
+        if counter is None:       # zeroed once; every launch leaves it at zero
+            counter = _TICKETS[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
         _lib.call("loss_tail_fwd", _p(cap_rows), cap_rows.numel(), _p(e_p), _p(align), _p(w), R, Ce, _p(a_p), _p(act), Ca, _p(r_e), _p(r_a),
-                  float(lam), gneg, gpos, clip, eps, _p(out), _stream())
+                  float(lam), gneg, gpos, clip, eps, _p(out), _p(scratch), _p(counter), _stream())
         ctx.save_for_backward(e_p, a_p, r_e, r_a, align, act, w)
         ctx.cfg = (cap_rows.numel(), R, Ce, Ca, float(lam), gneg, gpos, clip, eps)
         ctx.parts = out

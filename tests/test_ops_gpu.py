@@ -741,4 +741,6 @@ def test_loss_tail_matches_separate_terms(with_resim, with_sim):
     for a, b in zip(outs["hip"][1], outs["ref"][1]):
         assert (a is None) == (b is None)
         if a is not None:
-            assert torch.allclose(a, b, rtol=2e-5, atol=1e-6)
+            ok = torch.isfinite(b)        # torch's own BCE statement differentiates log(0)·0 to NaN at the clamp; the kernel gives 0 there
+            assert torch.isfinite(a).all() and torch.allclose(a[ok], b[ok], rtol=2e-5, atol=1e-6)
+            assert (a[~ok] == 0).all()
