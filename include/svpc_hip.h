@@ -112,6 +112,11 @@ int svpc_gemm_l32_preferred(int a_kc, int b_kc, int lda, int ldb, int M, int N, 
 int svpc_gemm_l32(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, int M, int N, int K,
                   const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed, int accumulate, float* workspace,
                   size_t workspace_bytes, svpc_stream_t stream);
+/* the same with an fp32 addend R of C's leading dimension, C = epi(A·B) + R (fp32 twin of svpc_gemm_glds_r: the residual-path
+ * gradient of a LayerNorm joins the dgrad of the projection that consumes the residual tensor — step-wise encoder, model.py:565-591) */
+int svpc_gemm_l32_r(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,
+                    int N, int K, const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed, int accumulate,
+                    float* workspace, size_t workspace_bytes, svpc_stream_t stream);
 /* grouped weight (+ bias) gradients of up to svpc_gemm_group_wgrad_max() independent linears in one launch:
  *   dw[n_out, n_in] += dzᵀ · x,   db[n_out] += Σ_rows dz   (db may be NULL)       — the wgrad half of every nn.Linear backward
  * `problems` is a HOST array of svpc_wgrad_problem; any row count (the partial last k-tile is zero-sourced), n_out % 4 == 0, n_in % 4 == 0,

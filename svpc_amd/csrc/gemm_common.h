@@ -7,8 +7,9 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 struct Epi {
     const float* bias; int act; float p_drop; uint32_t site; const u64* seed; int accumulate;
     float* Z;   // optional pre-activation output (same ldc)
-    const void* R;   // optional bf16 addend with C's layout, C = act(acc + bias) + R (a residual-path gradient joining a dgrad): only the
-                     // 16-byte row-store epilogues of gemm_glds.hip apply it — the launcher refuses R where they cannot run
+    const void* R;   // optional addend of C's type and layout, C = act(acc + bias) + R (a residual-path gradient joining a dgrad).  bf16: only
+                     // the 16-byte row-store epilogues of gemm_glds.hip apply it (the launcher refuses R where they cannot run);
+                     // fp32: the element-wise epilogues below (svpc_gemm_l32_r)
 };
 
 __device__ __forceinline__ void epilogue_store(float v, int row, int col, float* __restrict__ C, int ldc, const Epi& e,
@@ -19,6 +20,7 @@ __device__ __forceinline__ void epilogue_store(float v, int row, int col, float*
     v = apply_act(v, e.act);
     if (e.p_drop > 0.f) v *= drop_scale(seed, e.site, o, e.p_drop, inv_keep);
     if (e.accumulate) v += C[o];
+    if (e.R) v += reinterpret_cast<const float*>(e.R)[o];
     C[o] = v;
 }
 
@@ -33,6 +35,7 @@ __device__ __forceinline__ void epilogue_store_t(float v, int row, int col, TC* 
     v = apply_act(v, e.act);
     if (e.p_drop > 0.f) v *= drop_scale(seed, e.site, o, e.p_drop, inv_keep);
     if (e.accumulate) v += (float)C[o];
+    if (sizeof(TC) == 4 && e.R) v += reinterpret_cast<const float*>(e.R)[o];      // (bf16 addends: gemm_glds.hip's row-store epilogues)
     C[o] = (TC)v;
 }
 

@@ -587,14 +587,25 @@ int svpc_gemm_group_wgrad(const void* problems, int n, hipStream_t stream) {
 
 // Same contract as svpc_gemm_mx with fp32 A, B, C (reference: every nn.Linear / matmul of model.py that is not on the
 // clip-encoder bf16 stream — e.g. :620-663 decoder, :594-617 step-wise encoder, :742-823 simulator, :1017-1025 BiLSTM).
+int svpc_gemm_l32_r(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,
+                    int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
+                    float* workspace, size_t workspace_bytes, hipStream_t stream);
 int svpc_gemm_l32(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, int M, int N, int K,
                   const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate, float* workspace,
                   size_t workspace_bytes, hipStream_t stream) {
+    return svpc_gemm_l32_r(A, lda, a_kc, B, ldb, b_kc, C, ldc, Z, nullptr, M, N, K, bias, act, p_drop, site, seed, accumulate, workspace,
+                           workspace_bytes, stream);
+}
+// R (optional): fp32 addend with C's leading dimension, C = epi(A·B) + R — the residual-path gradient joining the dgrad of the
+// projection that consumes the residual tensor (fp32 twin of svpc_gemm_glds_r)
+int svpc_gemm_l32_r(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,
+                    int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
+                    float* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (M == 0 || N == 0) return 0;
     SVPC_REQUIRE(svpc_gemm_l32_supported(a_kc, b_kc, lda, ldb, M, N, K) && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0,
                  "gemm_l32: needs K % 32 == 0 and 16-byte aligned fp32 rows");
     SVPC_REQUIRE(p_drop <= 0.f || seed != nullptr, "gemm: dropout needs a seed pointer");
-    Epi epi{bias, act, p_drop, site, seed, accumulate, Z};
+    Epi epi{bias, act, p_drop, site, seed, accumulate, Z, R};
     static int env_tile = -1, env_split = -1, remap = -1;
     if (env_tile < 0) { const char* e = getenv("SVPC_L32_TILE"); env_tile = e ? atoi(e) : 0; }      // 128 | 64 (deep ring) | 65 (64, 4 stages)
     if (env_split < 0) { const char* e = getenv("SVPC_L32_SPLITK"); env_split = e ? atoi(e) : 0; }

@@ -462,7 +462,11 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NON
         R = None
     elif _PRECISION == "bf16" and USE_L32 and A.dtype == B.dtype == C.dtype == torch.float32 and \
             (A.data_ptr() | B.data_ptr()) % 16 == 0 and _lib.load().svpc_gemm_l32_preferred(a_kc, b_kc, lda, ldb, M, N, K) == 1:
-        _lib.call("gemm_l32", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
+        if R is not None and not (R.dtype == torch.float32 and R.is_contiguous() and R.shape == C.shape and C.is_contiguous()):
+            Rk = None
+        else:
+            Rk, R = R, None       # absorbed by the epilogue
+        _lib.call("gemm_l32_r", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), _p(Rk), M, N, K, _p(bias), act, p, site,
                   _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
     elif _PRECISION == "bf16":
         dt = lambda t: 1 if t.dtype == torch.bfloat16 else 0
@@ -704,7 +708,7 @@ class _LayerNorm(Function):
             else:
                 dadd2 = _colsum(dy, add2_idx, k_add2)
         dres = dh if need_res else None
-        if need_res and ctx.sink and USE_RES_SINK and dh.dtype == torch.bfloat16:
+        if need_res and ctx.sink and USE_RES_SINK and (dh.dtype == torch.bfloat16 or (_PRECISION == "bf16" and USE_L32)):
             _RES_SINK[residual.data_ptr()] = dh       # joins the dgrad of the projection that consumes the residual tensor
             SINK_STATS[0] += 1
             _queue_end_of_backward_join()
