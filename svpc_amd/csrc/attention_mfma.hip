@@ -57,43 +57,38 @@ template <int DH> struct AImg { static constexpr int RS = DH * 2 + 16; };
 // ``stage_pair`` keeps two matrices in flight at once.
 template <int DH, typename T, int AT, int NT = 256>
 struct RowStage {
-    static constexpr int UPR = DH / 4, NIT = AT * UPR / NT;
-    float4 raw[NIT];     // fp32: 4 values; bf16: 4 values in .x/.y (8 bytes)
+    static constexpr int EPU = sizeof(T) == 4 ? 4 : 8;          // elements per 16-byte staging unit
+    static constexpr int UPR = DH / EPU, NIT = AT * UPR / NT;
+    float4 raw[NIT];     // 16 bytes: 4 fp32 values or 8 bf16 values
     int tid;
     __device__ __forceinline__ RowStage(int t) : tid(t) {}
     __device__ __forceinline__ void load(const T* __restrict__ src, int ld, int len) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int u = tid + NT * it, row = u / UPR, c4 = u - row * UPR;
+            const int u = tid + NT * it, row = u / UPR, c = u - row * UPR;
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < len) {
-                if (sizeof(T) == 4) t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + 4 * c4);
-                else {
-                    const float2 h = *reinterpret_cast<const float2*>(reinterpret_cast<const __bf16*>(src) + (size_t)row * ld + 4 * c4);
-                    t.x = h.x; t.y = h.y;
-                }
-            }
+            if (row < len) t = *reinterpret_cast<const float4*>(src + (size_t)row * ld + EPU * c);
             raw[it] = t;
         }
     }
     __device__ __forceinline__ void store(char* __restrict__ img, float scale) const {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int u = tid + NT * it, row = u / UPR, c4 = u - row * UPR;
-            bf16x4 b;
+            const int u = tid + NT * it, row = u / UPR, c = u - row * UPR;
             if (sizeof(T) == 4) {
+                bf16x4 b;
                 b[0] = (__bf16)(raw[it].x * scale); b[1] = (__bf16)(raw[it].y * scale);
                 b[2] = (__bf16)(raw[it].z * scale); b[3] = (__bf16)(raw[it].w * scale);
+                *reinterpret_cast<bf16x4*>(img + row * AImg<DH>::RS + c * 8) = b;
             } else {
-                union { float2 f; bf16x4 h; } cv;
-                cv.f = make_float2(raw[it].x, raw[it].y);
-                if (scale == 1.0f) b = cv.h;
-                else {
+                union { float4 f; bf16x8 h; } cv;
+                cv.f = raw[it];
+                if (scale != 1.0f) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) b[j] = (__bf16)((float)cv.h[j] * scale);
+                    for (int j = 0; j < 8; ++j) cv.h[j] = (__bf16)((float)cv.h[j] * scale);
                 }
+                *reinterpret_cast<float4*>(img + row * AImg<DH>::RS + c * 16) = cv.f;
             }
-            *reinterpret_cast<bf16x4*>(img + row * AImg<DH>::RS + c4 * 8) = b;
         }
     }
 };
@@ -138,6 +133,28 @@ __device__ __forceinline__ void store_tile(T* __restrict__ base, int ld, int row
             pk.h[0] = (__bf16)(odd ? py : y0); pk.h[1] = (__bf16)(odd ? y1 : py);
             if (r < row_limit) *reinterpret_cast<uint32_t*>(p + (size_t)r * ld + col0 + (l31 & ~1)) = pk.u;
         }
+    }
+}
+// bf16 tile accumulated TRANSPOSED (rows = 32 columns of the matrix in the accumulator's register pattern, lane & 31 = the matrix
+// row): two v_permlane32_swap per pair of 4-column runs give a lane 8 consecutive columns → two 16-byte stores per tile and lane
+// instead of eight shuffled dword stores.  `base` = row 0 of the matrix block, `col0` = first of the 32 columns.
+__device__ __forceinline__ void store_tile_tr(__bf16* __restrict__ base, int ld, int row, int row_limit, int col0, const floatx16& acc,
+                                              float scale, int lane) {
+    const int lhi = lane >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; k += 2) {
+        uint32_t y[4];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int e = 4 * (k + g);
+            union { __bf16 hh[2]; uint32_t u; } p0, p1;
+            p0.hh[0] = (__bf16)(acc[e] * scale); p0.hh[1] = (__bf16)(acc[e + 1] * scale);
+            p1.hh[0] = (__bf16)(acc[e + 2] * scale); p1.hh[1] = (__bf16)(acc[e + 3] * scale);
+            y[2 * g] = p0.u; y[2 * g + 1] = p1.u;
+        }
+        auto r0 = __builtin_amdgcn_permlane32_swap(y[0], y[2], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(y[1], y[3], false, false);
+        if (row < row_limit) *reinterpret_cast<uint4*>(base + (size_t)row * ld + col0 + 8 * (k + lhi)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
     }
 }
 // MFMA operand fragment: 32 image rows starting at row0, 16 columns starting at 16·ds (lane = (row, half) → 8 columns)
@@ -412,6 +429,7 @@ __global__ __launch_bounds__(256, 4) void attn_stream_fwd_kernel(MAttnArgs a) {
 template <int DH, typename T, int AT, bool PERWAVE>
 __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   // 2 waves/SIMD: ≤ 256 registers, 2 workgroups per CU
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    constexpr bool TRS = sizeof(T) == 2;        // bf16 gradients: tiles accumulated transposed, a matrix row per lane (16-byte stores)
     constexpr int IB = AT * AImg<DH>::RS;
     constexpr int GROUP_BYTES = 4 * IB + 3 * AT * (int)sizeof(float), NT = PERWAVE ? 64 : 256;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31;
@@ -522,15 +540,25 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
                 const bf16x8 pa = pack8(&pt[8 * s2]), da = pack8(&dsv[8 * s2]);
 #pragma unroll
                 for (int dt = 0; dt < DH / 32; ++dt) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<DH>(Ds, 32 * qt + 16 * s2, 32 * dt, lane), dv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_tr<DH>(Qs, 32 * qt + 16 * s2, 32 * dt, lane), dk[dt], 0, 0, 0);
+                    if (TRS) {      // transposed tiles (head columns in registers, this lane's key = the matrix row): 16-byte row stores
+                        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<DH>(Ds, 32 * qt + 16 * s2, 32 * dt, lane), pa, dv[dt], 0, 0, 0);
+                        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<DH>(Qs, 32 * qt + 16 * s2, 32 * dt, lane), da, dk[dt], 0, 0, 0);
+                    } else {
+                        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr<DH>(Ds, 32 * qt + 16 * s2, 32 * dt, lane), dv[dt], 0, 0, 0);
+                        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_tr<DH>(Qs, 32 * qt + 16 * s2, 32 * dt, lane), dk[dt], 0, 0, 0);
+                    }
                 }
             }
         }
 #pragma unroll
         for (int dt = 0; dt < DH / 32; ++dt) {
-            store_tile<T>((T*)a.dV + (size_t)k_off * a.lddv + h * DH, a.lddv, k0, k_len, 32 * dt, dv[dt], 1.0f, lane);
-            store_tile<T>((T*)a.dK + (size_t)k_off * a.lddk + h * DH, a.lddk, k0, k_len, 32 * dt, dk[dt], 1.0f, lane);   // Qs carries 1/sqrt(dh)
+            if (TRS) {
+                store_tile_tr((__bf16*)a.dV + (size_t)k_off * a.lddv + h * DH, a.lddv, key, k_len, 32 * dt, dv[dt], 1.0f, lane);
+                store_tile_tr((__bf16*)a.dK + (size_t)k_off * a.lddk + h * DH, a.lddk, key, k_len, 32 * dt, dk[dt], 1.0f, lane);
+            } else {
+                store_tile<T>((T*)a.dV + (size_t)k_off * a.lddv + h * DH, a.lddv, k0, k_len, 32 * dt, dv[dt], 1.0f, lane);
+                store_tile<T>((T*)a.dK + (size_t)k_off * a.lddk + h * DH, a.lddk, k0, k_len, 32 * dt, dk[dt], 1.0f, lane);   // Qs carries 1/sqrt(dh)
+            }
         }
     }
     // ---------------- pass 2: wave = query tile → dQ (transposed layout: query on lane, keys in registers)
@@ -573,19 +601,21 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
                 const bf16x8 da = pack8(&dsv[8 * s2]);
 #pragma unroll
                 for (int dt = 0; dt < DH / 32; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_tr<DH>(Ks, 32 * kt + 16 * s2, 32 * dt, lane), dq[dt], 0, 0, 0);
+                    dq[dt] = TRS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<DH>(Ks, 32 * kt + 16 * s2, 32 * dt, lane), da, dq[dt], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_tr<DH>(Ks, 32 * kt + 16 * s2, 32 * dt, lane), dq[dt], 0, 0, 0);
             }
         }
 #pragma unroll
         for (int dt = 0; dt < DH / 32; ++dt)
-            store_tile<T>((T*)a.dQ + (size_t)q_off * a.lddq + h * DH, a.lddq, q0, q_len, 32 * dt, dq[dt], a.scale, lane);
+            if (TRS) store_tile_tr((__bf16*)a.dQ + (size_t)q_off * a.lddq + h * DH, a.lddq, q, q_len, 32 * dt, dq[dt], a.scale, lane);
+            else store_tile<T>((T*)a.dQ + (size_t)q_off * a.lddq + h * DH, a.lddq, q0, q_len, 32 * dt, dq[dt], a.scale, lane);
     }
 }
 
 static int mattn_set_lds(const void* fn, size_t bytes) { return svpc_raise_lds_once(fn, "attn_mfma"); }   // once per kernel symbol, process-wide table (api.cpp)
 static bool mattn_ok(int dh, int max_q, int max_k, int ldq, int ldk, int ldv, const void* Q, const void* K, const void* V, int dt) {
-    const int al = dt ? 8 : 16;   // 4 elements per staging unit
-    return (dh == 64 || dh == 32) && max_q <= AT_MAX && max_k <= AT_MAX && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 &&
+    const int al = 16, lm = dt ? 8 : 4;   // 16-byte staging units: 8 bf16 or 4 fp32 elements
+    return (dh == 64 || dh == 32) && max_q <= AT_MAX && max_k <= AT_MAX && ldq % lm == 0 && ldk % lm == 0 && ldv % lm == 0 &&
            (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & (al - 1)) == 0;
 }
 
@@ -672,7 +702,8 @@ int svpc_attn_mfma_bwd_t(const void* Q, int ldq, const void* K, int ldk, const v
                  "attn_mfma: unsupported shape/alignment");
     SVPC_REQUIRE(ldo % (dt ? 8 : 4) == 0 && lddo % (dt ? 8 : 4) == 0 && (((uintptr_t)O | (uintptr_t)dO) & 15) == 0,
                  "attn_mfma: O and dO rows must be 16-byte aligned");
-    SVPC_REQUIRE(dt == 0 || (lddq % 2 == 0 && lddk % 2 == 0 && lddv % 2 == 0), "attn_mfma: bf16 gradients need even row strides");
+    SVPC_REQUIRE(dt == 0 || (lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0 && (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 15) == 0),
+                 "attn_mfma: bf16 gradients need 16-byte aligned rows");
     MAttnArgs a{};
     a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = const_cast<void*>(O); a.ldo = ldo;
     a.LSE = const_cast<float*>(LSE); a.seq = seq; a.n_seq = n_seq; a.H = H; a.max_q = max_q; a.max_k = max_k; a.key_mask = key_mask;

@@ -741,7 +741,7 @@ class _Attention(Function):
         tbl = seq.table if seq.table.device == qt.device else seq.table.to(qt.device)
         es = qt.element_size()
         qp, kp, vp = qt.data_ptr() + cols[0] * es, kvt_c.data_ptr() + cols[1] * es, kvt_c.data_ptr() + cols[2] * es
-        mfma = (_PRECISION == "bf16" and ((qp | kp | vp) & (4 * es - 1)) == 0 and
+        mfma = (_PRECISION == "bf16" and ((qp | kp | vp) & 15) == 0 and
                 _lib.load().svpc_attn_mfma_supported(dh, seq.max_q, seq.max_k, qt.stride(0), kvt_c.stride(0), kvt_c.stride(0)) == 1)
         if (not torch.is_grad_enabled() and seq.max_q == 1 and p <= 0.0 and not causal and qt.dtype == torch.float32 and dh <= 64
                 and not (qt.requires_grad or kvt_c.requires_grad)):

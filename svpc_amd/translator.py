@@ -186,21 +186,32 @@ class Translator(object):
         is tied to the batch structure (step / ingredient / OOV counts: ``_prepare``'s key): the first batch of a structure runs
         eagerly twice (warm-up: index tables reach the device, kernels set their attributes) and is then captured; later batches of
         the same structure copy their tensors into the captured inputs and replay."""
+        # a captured graph holds raw pointers: it is valid only while the parameters (and, on the bf16 path, their shadow) live where
+        # they lived at capture time — a weight store built later (optimizer start, WeightStore.for_model) re-points them
+        from . import ops as _ops
+        sig = (tuple(p.data_ptr() for p in list(model.parameters())[:8]), _ops.get_precision(),
+               id(getattr(model, "_svpc_weight_store", None)))
         g = prep["graph"]
+        if g is not None and g[3] != sig:
+            g = prep["graph"] = None
         if g is None:
             self._decode_core(model, prep, feats, ids_all, masks_all, ingr_flat)
             static = [feats.clone(), ids_all.clone(), masks_all.clone(), ingr_flat.clone()]
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
+            # warm-up and capture on the process's one capture stream (svpc_amd.graph.ops_stream): a fresh stream per batch
+            # structure would pin another 256 MB kernel workspace each (ops._ws is per (device, stream))
+            from .graph import ops_stream
+            cur = torch.cuda.current_stream()
+            side = cur if cur != torch.cuda.default_stream() else ops_stream()
+            side.wait_stream(cur)
             with torch.cuda.stream(side):
                 self._decode_core(model, prep, *static)
-            torch.cuda.current_stream().wait_stream(side)
+            cur.wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=side):
                 out = self._decode_core(model, prep, *static)
-            g = prep["graph"] = (graph, static, out)
-        graph, static, out = g
+            g = prep["graph"] = (graph, static, out, sig)
+        graph, static, out, _ = g
         for dst, src in zip(static, (feats, ids_all, masks_all, ingr_flat)):
             dst.copy_(src)
         graph.replay()
