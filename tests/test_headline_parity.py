@@ -43,8 +43,11 @@ GRAD_NAMES = [
 ]
 
 # stated tolerances: (loss rel, probability abs, gradient-norm rel, gradient cosine ≥)
-TOL = {"fp32": dict(loss=1e-4, prob=5e-5, gnorm=2e-3, cos=0.99999, argmax=0.9999),
-       "bf16": dict(loss=4e-3, prob=0.25, gnorm=6e-2, cos=0.985, argmax=0.98)}
+# bf16: measured 3e-4 … 2.4e-3 (loss), 0.987 … 0.992 (argmax agreement), ≤ 5.2e-2 (gradient norms), ≥ 0.9925 (cosines) on the four
+# headline cases (profiles/r02_c_headline_parity.json); the single worst probability entry moves by up to 0.24 where the pointer's
+# softmax over ≤ 10 entities is nearly tied ("What the bf16 mode costs in accuracy"), hence a mean criterion beside the max.
+TOL = {"fp32": dict(loss=1e-4, prob=5e-5, prob_mean=1e-6, gnorm=2e-3, cos=0.99999, argmax=0.9999),
+       "bf16": dict(loss=4e-3, prob=0.5, prob_mean=1e-4, gnorm=8e-2, cos=0.985, argmax=0.98)}
 
 _REPORT = {}
 
@@ -110,6 +113,7 @@ def _compare(tag, precision, loss, probs, grads, ref, names):
     rep = {"loss": loss, "ref_loss": ref["loss"], "loss_rel": abs(loss - ref["loss"]) / abs(ref["loss"])}
     perr = max(float((p.detach().cpu() - r).abs().max()) for p, r in zip(probs, ref["probs"]))
     rep["prob_abs_max"] = perr
+    rep["prob_abs_mean"] = float(np.mean([float((p.detach().cpu() - r).abs().mean()) for p, r in zip(probs, ref["probs"])]))
     agree = np.mean([float((p.detach().cpu().argmax(-1) == r.argmax(-1)).float().mean()) for p, r in zip(probs, ref["probs"])])
     rep["argmax_agreement"] = float(agree)
     rep["grads"] = {}
@@ -127,6 +131,7 @@ def _compare(tag, precision, loss, probs, grads, ref, names):
         json.dump(_REPORT, f, indent=1)
     assert rep["loss_rel"] <= tol["loss"], (tag, rep["loss"], rep["ref_loss"], rep["loss_rel"])
     assert perr <= tol["prob"], (tag, perr)
+    assert rep["prob_abs_mean"] <= tol["prob_mean"], (tag, rep["prob_abs_mean"])
     assert rep["argmax_agreement"] >= tol["argmax"], (tag, rep["argmax_agreement"])
     assert len(rep["grads"]) >= 12
     for n, d in rep["grads"].items():
