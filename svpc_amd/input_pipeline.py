@@ -212,3 +212,27 @@ class _Null:
 
     def __exit__(self, *a):
         return False
+
+
+def balance_by_steps(step_counts, world_size):
+    """Assign the videos of a GLOBAL batch to data-parallel ranks so that every rank gets the same number of videos and nearly the
+    same number of clips (work ∝ Σ S_b: valid clips are the rows every stage runs over; padded steps cost nothing here).
+
+    The reference batches whatever the sampler yields (``recursive_caption_dataset.py:528-576`` pads every video to the longest of
+    the batch); real YouCook2 videos have 3-16 steps, so with one process per GPU an unlucky rank would hold the step's long videos and
+    every other rank would wait for it at the gradient all-reduce ("sort/bucket by S if real data is used").
+    Longest-processing-time greedy with a per-rank capacity: videos in decreasing S, each to the rank with the fewest clips so far
+    that still has room.  → list of ``world_size`` index lists (positions into ``step_counts``), each of len(step_counts)//world_size.
+    Deterministic (ties by index), so every rank computes the same assignment from the same global list."""
+    n = len(step_counts)
+    if world_size <= 0 or n % world_size:
+        raise ValueError("balance_by_steps: %d videos cannot be split evenly over %d ranks" % (n, world_size))
+    cap = n // world_size
+    order = sorted(range(n), key=lambda i: (-int(step_counts[i]), i))
+    ranks = [[] for _ in range(world_size)]
+    load = [0] * world_size
+    for i in order:
+        r = min((r for r in range(world_size) if len(ranks[r]) < cap), key=lambda r: (load[r], r))
+        ranks[r].append(i)
+        load[r] += int(step_counts[i])
+    return [sorted(v) for v in ranks]
