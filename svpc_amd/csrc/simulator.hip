@@ -31,18 +31,42 @@ __global__ __launch_bounds__(1024) void sim_recur_fwd_kernel(SimArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NT = blockDim.x, NW = blockDim.x >> 6;
     for (int i = threadIdx.x; i < E * D; i += NT) Es[i] = a.E0[(size_t)e0 * D + i];
     if (threadIdx.x < SIM_EMAX) prev[threadIdx.x] = 0.f;
+    // The recurrence is a chain of dependent steps on ONE workgroup per video: what a step costs is its exposed latency.  The step
+    // vector q_t (and c_t, w_t) do not depend on the state, so the values of step t+1 are requested at the top of step t and land under
+    // its arithmetic (D <= 768: 12 values per lane; wider rows read q in the loop as before).
+    constexpr int QN = 12;
+    const bool pre = D <= 64 * QN;
+    float qn[QN], cn0 = 0.f, cn1 = 0.f, wn = 0.f;
+    auto fetch = [&](int jn) {
+        const float* qp = a.q + (size_t)jn * D;
+#pragma unroll
+        for (int k = 0; k < QN; ++k) qn[k] = (lane + 64 * k) < D ? qp[lane + 64 * k] : 0.f;
+        cn0 = a.c[(size_t)jn * 3]; cn1 = a.c[(size_t)jn * 3 + 1]; wn = a.w4f[jn];
+    };
+    if (pre && S > 0) fetch(s0);
     __syncthreads();
     for (int t = 0; t < S; ++t) {
         const int j = s0 + t;
         const float* qj = a.q + (size_t)j * D;
+        float qc[QN];
+#pragma unroll
+        for (int k = 0; k < QN; ++k) qc[k] = qn[k];
+        const float pc0 = cn0, pc1 = cn1, pw = wn;
+        if (pre && t + 1 < S) fetch(j + 1);
         for (int e = wave; e < E; e += NW) {
             float dot = 0.f;
-            for (int d = lane; d < D; d += 64) dot += Es[(size_t)e * D + d] * qj[d];
+            if (pre) {
+#pragma unroll
+                for (int k = 0; k < QN; ++k)
+                    if (lane + 64 * k < D) dot += Es[(size_t)e * D + lane + 64 * k] * qc[k];
+            } else {
+                for (int d = lane; d < D; d += 64) dot += Es[(size_t)e * D + d] * qj[d];
+            }
             dot = wave_sum(dot);
             if (lane == 0) ev[e] = sigmoidf_(dot);
         }
         __syncthreads();
-        const float c0 = a.c[(size_t)j * 3], c1 = a.c[(size_t)j * 3 + 1];
+        const float c0 = pre ? pc0 : a.c[(size_t)j * 3], c1 = pre ? pc1 : a.c[(size_t)j * 3 + 1];
         if (threadIdx.x < SIM_EMAX) {
             const int e = threadIdx.x;
             al[e] = e < E ? c0 * ev[e] + c1 * prev[e] : 0.f;
@@ -52,7 +76,7 @@ __global__ __launch_bounds__(1024) void sim_recur_fwd_kernel(SimArgs a) {
         float Z = 0.f;
         for (int e = 0; e < E; ++e) Z += al[e];
         const float invZ = 1.0f / Z;
-        const float w = a.w4f[j];
+        const float w = pre ? pw : a.w4f[j];
         for (int d = threadIdx.x; d < D; d += NT) {
             float eb = 0.f;
             for (int e = 0; e < E; ++e) eb += al[e] * Es[(size_t)e * D + d];
@@ -127,6 +151,22 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
         if (a.deall) sim_dma<NT>(a.deall + (size_t)(s0 + S - 1) * em * D, Ubuf, E * D, wave, lane);
     }
 
+    // Per-step operands that do not depend on the recurrence (c_t, w_t, the saved e rows, ē_t, q_t, the upstream gradients of e and ē):
+    // the values of step t-1 are requested at the top of step t and land under its arithmetic — the chain of S_b dependent steps
+    // is what this kernel costs, so no load may sit on it.
+    float n_c0 = 0.f, n_c1 = 0.f, n_w = 0.f, n_eb[CPT], n_deb[CPT], n_q[CPT];     // (the 3·E saved-e scalars too: spills at 168 VGPRs, measured slower)
+    auto fetch = [&](int tt) {
+        const int jj = s0 + tt;
+        n_c0 = a.c[(size_t)jj * 3]; n_c1 = a.c[(size_t)jj * 3 + 1]; n_w = a.w4f[jj];
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int d = threadIdx.x + NT * u;
+            n_eb[u] = d < D ? a.ebar[(size_t)jj * D + d] : 0.f;
+            n_deb[u] = (d < D && a.debar) ? a.debar[(size_t)jj * D + d] : 0.f;
+            n_q[u] = d < D ? a.q[(size_t)jj * D + d] : 0.f;
+        }
+    };
+    if (S > 0) fetch(S - 1);
     for (int t = S - 1; t >= 0; --t) {
         const int j = s0 + t;
         const int cur = DMA ? ((S - 1 - t) & 1) : 0;
@@ -148,17 +188,20 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
             }
             __syncthreads();
         }
-        const float c0 = a.c[(size_t)j * 3], c1 = a.c[(size_t)j * 3 + 1];
-        const float w = a.w4f[j];
-        float al[EM], evv[EM], pv[EM];
+        const float c0 = n_c0, c1 = n_c1, w = n_w;
+        float al[EM], evv[EM], pv[EM], dev[EM], ebv[CPT], debv[CPT], qv[CPT];
         float Z = 0.f;
 #pragma unroll
         for (int e = 0; e < EM; ++e) {
             evv[e] = e < E ? a.e_out[(size_t)j * em + e] : 0.f;
             pv[e] = (e < E && t > 0) ? a.e_out[(size_t)(j - 1) * em + e] : 0.f;
+            dev[e] = (e < E && a.de) ? a.de[(size_t)j * em + e] : 0.f;
             al[e] = e < E ? c0 * evv[e] + c1 * pv[e] : 0.f;
             Z += al[e];
         }
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) { ebv[u] = n_eb[u]; debv[u] = n_deb[u]; qv[u] = n_q[u]; }
+        if (t > 0) fetch(t - 1);
         const float invZ = 1.0f / Z;
         // per-thread partials of A1[e], dab[e], dw
         float pA[EM], pB[EM];
@@ -171,7 +214,7 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
             const int d = threadIdx.x + NT * u;
             debar_l[u] = 0.f; kq[u] = 0.f;
             if (d < D) {
-                const float eb = a.ebar[(size_t)j * D + d];
+                const float eb = ebv[u];
                 const float k = fmaxf(w * eb, 0.f);
                 float dk = 0.f;
 #pragma unroll
@@ -187,7 +230,7 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
                 }
                 const float dpre = k > 0.f ? dk : 0.f;
                 pw += dpre * eb;
-                const float deb = dpre * w + (a.debar ? a.debar[(size_t)j * D + d] : 0.f);
+                const float deb = dpre * w + debv[u];
                 debar_l[u] = deb;
 #pragma unroll
                 for (int e = 0; e < EM; ++e) {
@@ -196,7 +239,7 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
                         dE[e][u] += al[e] * invZ * deb;
                     }
                 }
-                kq[u] = a.q[(size_t)j * D + d];
+                kq[u] = qv[u];
             }
         }
         // block reduction of 2E+1 scalars
@@ -238,7 +281,7 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
                 dal[e] = A1 + (dab[e] - mix) * invZ;
                 dc0 += dal[e] * evv[e];
                 dc1 += dal[e] * pv[e];
-                const float de_tot = c0 * dal[e] + (a.de ? a.de[(size_t)j * em + e] : 0.f) + dprev[e];
+                const float de_tot = c0 * dal[e] + dev[e] + dprev[e];
                 dsv[e] = de_tot * evv[e] * (1.f - evv[e]);
             }
         }
