@@ -221,9 +221,15 @@ __device__ __forceinline__ void asl_terms(float p, float y, float gneg, float gp
     const float dpt = y + dpn * (1.f - y);
     const float gam = gpos * y + gneg * (1.f - y);
     const float base = 1.f - pt;
-    const float w = powf(base, gam);
+    // base^gam and base^(gam-1): gamma is 1 (positives) or 4 (negatives) in the reference's loss (losses.py:15-22), which a
+    // product does in 3 multiplies where the general powf costs ≈100 instructions — per element, twice, in a kernel that sits on
+    // the step's dependent chain; other exponents take the general route
+    float w, wm1;
+    if (gam == 1.f) { w = base; wm1 = 1.f; }
+    else if (gam == 4.f) { const float b2 = base * base; w = b2 * b2; wm1 = b2 * base; }
+    else { w = powf(base, gam); wm1 = gam == 0.f ? 0.f : powf(base, gam - 1.f); }
     // d/dp base^gam = -gam * base^(gam-1) * dpt   (torch.pow backward; 0 where gam == 0)
-    const float dw = gam == 0.f ? 0.f : -gam * powf(base, gam - 1.f) * dpt;
+    const float dw = gam == 0.f ? 0.f : -gam * wm1 * dpt;
     loss = -(ce * w);
     dldp = -(dce * w + ce * dw);
 }
@@ -278,6 +284,7 @@ struct LossTailArgs {
     const float* dout;     // backward: upstream gradient of the total (device scalar)
     float* d_cap; float* de_p; float* da_p; float* dr_e; float* dr_a;
 };
+constexpr int LT_CH = 8;      // columns per lane held in registers by the loss-tail kernels (action vocabulary ≤ 512)
 __device__ __forceinline__ float bce_row_sum(const float* __restrict__ p, const float* __restrict__ y, int wdt, int lane) {
     float s = 0.f;
     for (int c = lane; c < wdt; c += 64) {
@@ -316,12 +323,44 @@ __global__ __launch_bounds__(256) void loss_tail_fwd_kernel(LossTailArgs a, int 
             const int wdt = a.widths[r];
             const float* yr = a.align + (size_t)r * a.Ce;
             const float* ar = a.act + (size_t)r * a.Ca;
-            const bool on = row_has_one(ar, a.Ca, lane);
             float ent = 0.f, actl = 0.f, re = 0.f;
-            if (a.e_p) ent = bce_row_sum(a.e_p + (size_t)r * a.Ce, yr, wdt, lane);
-            if (a.a_p && on) actl = asl_row_sum(a.a_p + (size_t)r * a.Ca, ar, a.Ca, lane, a);
-            if (a.r_e) re = bce_row_sum(a.r_e + (size_t)r * a.Ce, yr, wdt, lane);
-            if (a.r_a && on) re += asl_row_sum(a.r_a + (size_t)r * a.Ca, ar, a.Ca, lane, a);
+            if (a.Ca <= 64 * LT_CH) {
+                // every load of the row in flight at once (targets, both probability rows): the row test, then the sums, otherwise
+                // form a chain of dependent memory round trips
+                float yv[LT_CH], pv[LT_CH], rv[LT_CH];
+#pragma unroll
+                for (int k = 0; k < LT_CH; ++k) {
+                    const int c = lane + 64 * k;
+                    const bool in = c < a.Ca;
+                    yv[k] = in ? ar[c] : 0.f;
+                    pv[k] = (in && a.a_p) ? a.a_p[(size_t)r * a.Ca + c] : 0.5f;
+                    rv[k] = (in && a.r_a) ? a.r_a[(size_t)r * a.Ca + c] : 0.5f;
+                }
+                if (a.e_p) ent = bce_row_sum(a.e_p + (size_t)r * a.Ce, yr, wdt, lane);
+                if (a.r_e) re = bce_row_sum(a.r_e + (size_t)r * a.Ce, yr, wdt, lane);
+                float f = 0.f;
+#pragma unroll
+                for (int k = 0; k < LT_CH; ++k) f = fmaxf(f, yv[k] == 1.0f ? 1.f : 0.f);
+                if (wave_max(f) != 0.f) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < LT_CH; ++k) {
+                        if (lane + 64 * k < a.Ca) {
+                            float l, d;
+                            if (a.a_p) { asl_terms(pv[k], yv[k], a.gneg, a.gpos, a.clip, a.eps, l, d); s1 += l; }
+                            if (a.r_a) { asl_terms(rv[k], yv[k], a.gneg, a.gpos, a.clip, a.eps, l, d); s2 += l; }
+                        }
+                    }
+                    actl = wave_sum(s1);
+                    re += wave_sum(s2);
+                }
+            } else {
+                const bool on = row_has_one(ar, a.Ca, lane);
+                if (a.e_p) ent = bce_row_sum(a.e_p + (size_t)r * a.Ce, yr, wdt, lane);
+                if (a.a_p && on) actl = asl_row_sum(a.a_p + (size_t)r * a.Ca, ar, a.Ca, lane, a);
+                if (a.r_e) re = bce_row_sum(a.r_e + (size_t)r * a.Ce, yr, wdt, lane);
+                if (a.r_a && on) re += asl_row_sum(a.r_a + (size_t)r * a.Ca, ar, a.Ca, lane, a);
+            }
             if (lane == 0) { prow[3 * r] = ent; prow[3 * r + 1] = actl; prow[3 * r + 2] = re; }
         }
     } else {
@@ -363,20 +402,7 @@ __global__ __launch_bounds__(256) void loss_tail_fwd_kernel(LossTailArgs a, int 
         __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-// backward: blocks [0, ceil(R/4)) — one wave per row writes every probability gradient of its row; the remaining blocks fill d_cap
-__global__ __launch_bounds__(256) void loss_tail_bwd_kernel(LossTailArgs a, int row_blocks) {
-    const float g = a.dout[0];
-    if ((int)blockIdx.x >= row_blocks) {
-        const int i = ((int)blockIdx.x - row_blocks) * 256 + threadIdx.x;
-        if (a.d_cap && i < a.n_cap) a.d_cap[i] = g;
-        return;
-    }
-    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= a.R) return;
-    const int wdt = a.widths[r];
-    const float* yr = a.align + (size_t)r * a.Ce;
-    const float* ar = a.act + (size_t)r * a.Ca;
-    const bool on = row_has_one(ar, a.Ca, lane);
+__device__ __forceinline__ void loss_tail_bce_bwd(const LossTailArgs& a, int r, int wdt, const float* __restrict__ yr, float g, int lane) {
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
         const float* p = which ? a.r_e : a.e_p;
@@ -394,6 +420,50 @@ __global__ __launch_bounds__(256) void loss_tail_bwd_kernel(LossTailArgs a, int 
             dp[(size_t)r * a.Ce + c] = v;
         }
     }
+}
+// backward: blocks [0, ceil(R/4)) — one wave per row writes every probability gradient of its row; the remaining blocks fill d_cap
+__global__ __launch_bounds__(256) void loss_tail_bwd_kernel(LossTailArgs a, int row_blocks) {
+    const float g = a.dout[0];
+    if ((int)blockIdx.x >= row_blocks) {
+        const int i = ((int)blockIdx.x - row_blocks) * 256 + threadIdx.x;
+        if (a.d_cap && i < a.n_cap) a.d_cap[i] = g;
+        return;
+    }
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.R) return;
+    const int wdt = a.widths[r];
+    const float* yr = a.align + (size_t)r * a.Ce;
+    const float* ar = a.act + (size_t)r * a.Ca;
+    if (a.Ca <= 64 * LT_CH) {       // all loads of the row first (see the forward)
+        float yv[LT_CH], pv[LT_CH], rv[LT_CH];
+#pragma unroll
+        for (int k = 0; k < LT_CH; ++k) {
+            const int c = lane + 64 * k;
+            const bool in = c < a.Ca;
+            yv[k] = in ? ar[c] : 0.f;
+            pv[k] = (in && a.a_p && a.da_p) ? a.a_p[(size_t)r * a.Ca + c] : 0.5f;
+            rv[k] = (in && a.r_a && a.dr_a) ? a.r_a[(size_t)r * a.Ca + c] : 0.5f;
+        }
+        loss_tail_bce_bwd(a, r, wdt, yr, g, lane);
+        float f = 0.f;
+#pragma unroll
+        for (int k = 0; k < LT_CH; ++k) f = fmaxf(f, yv[k] == 1.0f ? 1.f : 0.f);
+        const bool on = wave_max(f) != 0.f;
+#pragma unroll
+        for (int k = 0; k < LT_CH; ++k) {
+            const int c = lane + 64 * k;
+            if (c < a.Ca) {
+                float l, d1 = 0.f, d2 = 0.f;
+                if (on && a.a_p && a.da_p) asl_terms(pv[k], yv[k], a.gneg, a.gpos, a.clip, a.eps, l, d1);
+                if (on && a.r_a && a.dr_a) asl_terms(rv[k], yv[k], a.gneg, a.gpos, a.clip, a.eps, l, d2);
+                if (a.a_p && a.da_p) a.da_p[(size_t)r * a.Ca + c] = g * d1;
+                if (a.r_a && a.dr_a) a.dr_a[(size_t)r * a.Ca + c] = g * a.lambda * d2;
+            }
+        }
+        return;
+    }
+    const bool on = row_has_one(ar, a.Ca, lane);
+    loss_tail_bce_bwd(a, r, wdt, yr, g, lane);
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
         const float* p = which ? a.r_a : a.a_p;

@@ -26,18 +26,20 @@ __device__ __forceinline__ void ptr_stage(float* __restrict__ dst, const float* 
     const int n4 = n_floats >> 2;
     const float4* s4 = reinterpret_cast<const float4*>(src);
     float4* d4 = reinterpret_cast<float4*>(dst);
+    const int NT = blockDim.x;
     int i = threadIdx.x;
-    for (; i + 768 < n4; i += 1024) {
-        const float4 a = s4[i], b = s4[i + 256], c = s4[i + 512], d = s4[i + 768];
-        d4[i] = a; d4[i + 256] = b; d4[i + 512] = c; d4[i + 768] = d;
+    for (; i + 3 * NT < n4; i += 4 * NT) {
+        const float4 a = s4[i], b = s4[i + NT], c = s4[i + 2 * NT], d = s4[i + 3 * NT];
+        d4[i] = a; d4[i + NT] = b; d4[i + 2 * NT] = c; d4[i + 3 * NT] = d;
     }
-    for (; i < n4; i += 256) d4[i] = s4[i];
+    for (; i < n4; i += NT) d4[i] = s4[i];
 }
 // sc[t*32 + e0+e] = <rows_t[t], ent[e]> for t < lt, e < ec, both operands in LDS (one wave per dot, lanes over D)
 __device__ __forceinline__ void ptr_dots(const float* __restrict__ rows_t, const float* __restrict__ ent, float* __restrict__ sc, int lt,
                                          int ec, int e0, int D) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int pe = wave; pe < lt * ec; pe += 4) {
+    const int NW = blockDim.x >> 6;
+    for (int pe = wave; pe < lt * ec; pe += NW) {
         const int t = pe / ec, e = pe - t * ec;
         float dot = 0.f;
         for (int d = lane; d < D; d += 64) dot += rows_t[(size_t)t * D + d] * ent[(size_t)e * D + d];
@@ -47,7 +49,9 @@ __device__ __forceinline__ void ptr_dots(const float* __restrict__ rows_t, const
 }
 
 // LDS: lt·D (decoder rows) + PTR_EC·D (entity chunk) + lt·32 (scores/pi) floats
-__global__ __launch_bounds__(256) void ptr_attn_fwd_kernel(const float* __restrict__ dec, const float* __restrict__ proj,
+// (NT = blockDim.x threads: 768 at D = 768 — one column per thread in the column phases, 12 waves on the row·entity dot products;
+// one workgroup per step and one round of workgroups, so the time of a launch is the latency of ONE workgroup)
+__global__ __launch_bounds__(768) void ptr_attn_fwd_kernel(const float* __restrict__ dec, const float* __restrict__ proj,
                                                            const float* __restrict__ bank, const int* __restrict__ step_ne,
                                                            float* __restrict__ pi, float* __restrict__ att, int lt, int em, int D) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(256) void ptr_attn_fwd_kernel(const float* __restri
         ptr_dots(rows, ent, sc, lt, ec, e0, D);
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < lt; t += 256) {
+    for (int t = threadIdx.x; t < lt; t += blockDim.x) {
         float m = -INFINITY;
         for (int e = 0; e < E; ++e) m = fmaxf(m, sc[t * PTR_EMAX + e]);
         float s = 0.f;
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void ptr_attn_fwd_kernel(const float* __restri
     }
     __syncthreads();
     // att[t][d] = Σ_e pi[t][e]·bank[e][d]: a thread owns column d, the E bank values of the column sit in registers
-    for (int d = threadIdx.x; d < D; d += 256) {
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
         float bv[PTR_EMAX];
 #pragma unroll
         for (int e = 0; e < PTR_EMAX; ++e) bv[e] = e < E ? bj[(size_t)e * D + d] : 0.f;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void ptr_attn_fwd_kernel(const float* __restri
 
 // dproj/dbank are (T, em, D) and fully written (zeros for e ≥ E); ddec (T*lt, D) fully written.
 // LDS: lt·D (datt rows) + PTR_EC·D (entity chunk) + 2·lt·32 floats
-__global__ __launch_bounds__(256) void ptr_attn_bwd_kernel(const float* __restrict__ dec, const float* __restrict__ proj,
+__global__ __launch_bounds__(768) void ptr_attn_bwd_kernel(const float* __restrict__ dec, const float* __restrict__ proj,
                                                            const float* __restrict__ bank, const int* __restrict__ step_ne,
                                                            const float* __restrict__ pi, const float* __restrict__ dpi,
                                                            const float* __restrict__ datt, float* __restrict__ ddec,
@@ -119,20 +123,20 @@ __global__ __launch_bounds__(256) void ptr_attn_bwd_kernel(const float* __restri
         ptr_dots(rows, ent, dsc, lt, ec, e0, D);      // datt[t]·bank[e]
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < lt * E; i += 256) {
+    for (int i = threadIdx.x; i < lt * E; i += blockDim.x) {
         const int t = i / E, e = i - t * E;
         const size_t o = ((size_t)j * lt + t) * em + e;
         dsc[t * PTR_EMAX + e] += dpi ? dpi[o] : 0.f;
         pis[t * PTR_EMAX + e] = pi[o];
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < lt; t += 256) {
+    for (int t = threadIdx.x; t < lt; t += blockDim.x) {
         float mix = 0.f;
         for (int e = 0; e < E; ++e) mix += pis[t * PTR_EMAX + e] * dsc[t * PTR_EMAX + e];
         for (int e = 0; e < E; ++e) dsc[t * PTR_EMAX + e] = pis[t * PTR_EMAX + e] * (dsc[t * PTR_EMAX + e] - mix);
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < D; d += 256) {
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
         // ddec[t][d] = Σ_e dsc[t][e]·proj[e][d]
         float pv[PTR_EMAX];
 #pragma unroll
@@ -346,7 +350,8 @@ int svpc_ptr_attn_fwd(const float* dec, const float* proj, const float* bank, co
     SVPC_REQUIRE(lds <= 150 * 1024, "ptr_attn: sentence rows do not fit LDS");
     int rc = ptr_set_lds((const void*)ptr_attn_fwd_kernel);
     if (rc) return rc;
-    hipLaunchKernelGGL(ptr_attn_fwd_kernel, dim3(T), dim3(256), lds, s, dec, proj, bank, step_ne, pi, att, lt, e_max, D);
+    const int nt = D >= 768 ? 768 : (D >= 512 ? 512 : 256);
+    hipLaunchKernelGGL(ptr_attn_fwd_kernel, dim3(T), dim3(nt), lds, s, dec, proj, bank, step_ne, pi, att, lt, e_max, D);
     return svpc_check_launch("ptr_attn_fwd");
 }
 int svpc_ptr_attn_bwd(const float* dec, const float* proj, const float* bank, const int* step_ne, const float* pi, const float* dpi,
@@ -359,7 +364,8 @@ int svpc_ptr_attn_bwd(const float* dec, const float* proj, const float* bank, co
     SVPC_REQUIRE(lds <= 150 * 1024, "ptr_attn: sentence rows do not fit LDS");
     int rc = ptr_set_lds((const void*)ptr_attn_bwd_kernel);
     if (rc) return rc;
-    hipLaunchKernelGGL(ptr_attn_bwd_kernel, dim3(T), dim3(256), lds, s, dec, proj, bank, step_ne, pi, dpi, datt, ddec, dproj, dbank, lt,
+    const int nt = D >= 768 ? 768 : (D >= 512 ? 512 : 256);
+    hipLaunchKernelGGL(ptr_attn_bwd_kernel, dim3(T), dim3(nt), lds, s, dec, proj, bank, step_ne, pi, dpi, datt, ddec, dproj, dbank, lt,
                        e_max, D);
     return svpc_check_launch("ptr_attn_bwd");
 }
