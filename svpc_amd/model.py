@@ -274,7 +274,8 @@ class BertDecoderLayerNoMemoryUntied(nn.Module):
         self.norm2 = BertLayerNorm(config.hidden_size, eps=config.layer_norm_eps)
         self.output = BertOutput(config)
 
-    def run(self, x, text_mask, mem, seq_self, seq_cross, mem_mask, cx):
+    def run(self, x, text_mask, mem, seq_self, seq_cross, mem_mask, cx, kvc=None):
+        """``kvc``: this layer's K|V rows of the memory when the stack has projected them for all layers at once."""
         D = x.shape[1]
         w, b, wg, bg, w16 = self.self_attention.packed()
         qkv = ops.linear(x, w, b, wgrad=wg, bgrad=bg, w16=w16)
@@ -283,8 +284,9 @@ class BertDecoderLayerNoMemoryUntied(nn.Module):
         x1 = ops.layernorm(sa, self.norm1.weight, self.norm1.bias, cx.eps, residual=x, sink=True)
         ca_m = self.dec_enc_attention
         qc = ops.linear(x1, ca_m.query.weight, ca_m.query.bias)
-        wkv, bkv, wg, bg, w16 = ca_m.packed("kv")
-        kvc = ops.linear(mem, wkv, bkv, wgrad=wg, bgrad=bg, w16=w16)
+        if kvc is None:
+            wkv, bkv, wg, bg, w16 = ca_m.packed("kv")
+            kvc = ops.linear(mem, wkv, bkv, wgrad=wg, bgrad=bg, w16=w16)
         if kvc.dtype != qc.dtype:          # (memory rows handed over in another storage type than the sentence stream)
             kvc = kvc.to(qc.dtype)
         ca = ops.attention(qc, kvc, (0, 0, D), D, cx.H, seq_cross, key_mask=mem_mask, causal=False, drop=cx.drop(cx.p_a))
@@ -325,6 +327,21 @@ class BertDecoderNoMemoryUntied(nn.Module):
         self.config = config
         self.layer = nn.ModuleList([BertDecoderLayerNoMemoryUntied(config) for _ in range(config.num_hidden_layers)])
 
+    def stacked_memory_kv(self):
+        """[Wk0 Wv0 Wk1 Wv1 …] (L·2D, D), its bias, the gradient views and the bf16 shadow — available once the parameters live in
+        a ``WeightStore`` / ``GradArena``, whose layout keeps the cross-attention key / value projections of the stack together."""
+        a = self.layer[0].dec_enc_attention.key.weight
+        sw = getattr(a, "_svpc_stack_w", None)
+        sg = getattr(a, "_svpc_stack", None)
+        if sw is None or (sg is None and torch.is_grad_enabled()):
+            return None
+        if sw[0].shape[0] != 2 * len(self.layer) * a.shape[0]:
+            return None
+        for p in a._svpc_stack_w_members:
+            ops._shadow(p)
+        wg, bg = sg if sg is not None else (None, None)
+        return sw[0], sw[1], wg, bg, sw[2]
+
     def run(self, x, text_mask, mem, seq_self, seq_cross, mem_mask, cx):
         # interior-only row counts in bf16 precision: the sentence activations (and their gradients) stream through HBM as bf16
         stream_bf16 = x.dtype == torch.float32 and ops.bf16_stream_ok(x.shape[0], x.shape[1], self.config.intermediate_size)
@@ -334,8 +351,16 @@ class BertDecoderNoMemoryUntied(nn.Module):
             # (one cast instead of six casts forward and six backward; its weight gradients join the grouped bf16 launch)
             if mem.dtype == torch.float32 and ops.bf16_stream_ok(mem.shape[0], mem.shape[1], 2 * mem.shape[1]):
                 mem = mem.to(torch.bfloat16)
-        for layer in self.layer:
-            x = layer.run(x, text_mask, mem, seq_self, seq_cross, mem_mask, cx)
+        # Every layer projects the SAME memory rows to its keys and values (reference model.py:643-651): one (R, D) x (D, L·2D)
+        # projection for the stack instead of L, each layer reads its 2D columns in place; backward likewise gathers the L
+        # key / value gradients in one buffer and runs one dgrad (contraction L·2D) and one wgrad.
+        kvs = [None] * len(self.layer)
+        st = self.stacked_memory_kv() if mem.dtype == x.dtype else None
+        if st is not None:
+            w, b, wg, bg, w16 = st
+            kvs = ops.split_cols(ops.linear(mem, w, b, wgrad=wg, bgrad=bg, w16=w16), len(self.layer))
+        for layer, kvc in zip(self.layer, kvs):
+            x = layer.run(x, text_mask, mem, seq_self, seq_cross, mem_mask, cx, kvc=kvc)
         return x.float() if stream_bf16 else x
 
     def forward(self, dec_hidden_states, dec_mask, enc_outputs, enc_mask, diagonal_mask=True,

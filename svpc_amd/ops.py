@@ -760,6 +760,7 @@ class _Attention(Function):
                       dh, seq.max_q, seq.max_k, _p(key_mask), 1 if causal else 0, 1.0 / math.sqrt(dh), p, site, _p(seed), _stream())
         ctx.save_for_backward(qt, kvt_c, out, lse, key_mask, seed, tbl)
         ctx.cfg = (cols, D, H, seq.n, seq.max_q, seq.max_k, causal, p, site, same)
+        ctx.kv_into = None if same else getattr(kvt, "_svpc_grad_into", None)     # a column block of a shared gradient buffer
         ctx.mfma = mfma
         ctx.n_k_rows = seq.n_k_rows
         return out
@@ -781,7 +782,11 @@ class _Attention(Function):
             dkv_t = dq_t
         else:
             dq_t = covered(qt, D, n_q_rows)
-            dkv_t = covered(kvt, 2 * D, n_k_rows)
+            into = ctx.kv_into
+            if into is not None and into.shape == kvt.shape and into.dtype == kvt.dtype and kvt.shape == (n_k_rows, 2 * D):
+                dkv_t = into                 # every element is written by the kernel below
+            else:
+                dkv_t = covered(kvt, 2 * D, n_k_rows)
         es = qt.element_size()
         if ctx.mfma:
             _lib.call("attn_mfma_bwd_t", qt.data_ptr() + cols[0] * es, qt.stride(0), kvt.data_ptr() + cols[1] * es, kvt.stride(0),
@@ -801,6 +806,43 @@ class _Attention(Function):
 
 def attention(qt, kvt, cols, D, n_heads, seq, key_mask=None, causal=False, drop=None):
     return _Attention.apply(qt, kvt, cols, D, n_heads, seq, key_mask, causal, drop)
+
+
+class _SplitCols(Function):
+    """One wide projection output (R, n·w) handed out as n column blocks (views, row stride n·w).  The gradient of the wide
+    tensor is ONE buffer allocated up front: a consumer that finds ``_svpc_grad_into`` on its block (ops.attention does) writes
+    its gradient straight into that block's columns and returns the view, so backward neither concatenates nor adds."""
+
+    @staticmethod
+    def forward(ctx, wide, n, gbuf):
+        w = wide.shape[1] // n
+        ctx.gbuf, ctx.n, ctx.w = gbuf, n, w
+        return tuple(wide[:, i * w:(i + 1) * w] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        g, w = ctx.gbuf, ctx.w
+        for i, gi in enumerate(grads):
+            blk = g[:, i * w:(i + 1) * w]
+            if gi is None:
+                blk.zero_()
+            elif gi.data_ptr() != blk.data_ptr() or gi.stride() != blk.stride():
+                blk.copy_(gi)
+        ctx.gbuf = None
+        return g, None, None
+
+
+def split_cols(wide, n):
+    """→ n column blocks of ``wide`` (R, n·w) whose gradients are gathered in place (see _SplitCols)."""
+    if not (torch.is_grad_enabled() and wide.requires_grad):
+        w = wide.shape[1] // n
+        return tuple(wide[:, i * w:(i + 1) * w] for i in range(n))
+    gbuf = torch.empty_like(wide)
+    outs = _SplitCols.apply(wide, n, gbuf)
+    w = wide.shape[1] // n
+    for i, o in enumerate(outs):
+        o._svpc_grad_into = gbuf[:, i * w:(i + 1) * w]
+    return outs
 
 
 # ------------------------------------------------------------------------------------------------ spans / rows

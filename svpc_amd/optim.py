@@ -12,6 +12,7 @@ post-accumulate hooks), and clip + Adam + EMA three kernel launches over a chunk
 from __future__ import annotations
 
 import ctypes
+import re
 
 import torch
 
@@ -36,11 +37,21 @@ class _Meta(ctypes.Structure):
 _QKV = {"query.weight": 0, "key.weight": 1, "value.weight": 2, "query.bias": 3, "key.bias": 4, "value.bias": 5}
 
 
+_MEMKV = re.compile(r"^(.*\.layer\.)(\d+)\.dec_enc_attention\.(key|value)\.(weight|bias)$")
+
+
 def _ordered(named_params):
     """Keep registration order, but lay each attention block out as [Wq Wk Wv | bq bk bv] so the packed projection
-    ((3D, D) / (2D, D)) — weight, bf16 shadow and gradient alike — is one contiguous region a GEMM can use in place."""
+    ((3D, D) / (2D, D)) — weight, bf16 shadow and gradient alike — is one contiguous region a GEMM can use in place.
+    The cross-attention key / value projections of a decoder stack all read the same memory rows (model.py:643-651), so
+    they are laid out across the layers as [Wk0 Wv0 Wk1 Wv1 … | bk0 bv0 bk1 bv1 …]: one (L·2D, D) projection for the stack."""
     first, keyed = {}, []
     for i, (n, p) in enumerate(named_params):
+        m = _MEMKV.match(n)
+        if m is not None:
+            first.setdefault(m.group(1), i)
+            keyed.append(((first[m.group(1)], 0 if m.group(4) == "weight" else 1, int(m.group(2)), 0 if m.group(3) == "key" else 1), n, p))
+            continue
         for suf, k in _QKV.items():
             if n.endswith("." + suf):
                 pre = n[:-len(suf)]
@@ -64,8 +75,13 @@ def _layout(named_params):
     return names, params, offsets, off
 
 
+def _run(ids):
+    return ids == list(range(ids[0], ids[0] + len(ids)))
+
+
 def _packed_groups(names, params, offsets):
-    """→ [(query weight parameter, [6 member indices])] for every attention block laid out contiguously."""
+    """→ [(query weight parameter, [6 member indices], kinds)] for every attention block; ``kinds`` ⊆ {"qkv", "kv", "q"} are
+    the packed projections whose members are contiguous in this layout."""
     idx = {n: i for i, n in enumerate(names)}
     out = []
     for n in names:
@@ -76,23 +92,57 @@ def _packed_groups(names, params, offsets):
         if not all(k in idx for k in need):
             continue
         ids = [idx[k] for k in need]
-        if ids != list(range(ids[0], ids[0] + 6)):
-            continue
         D_out, D_in = params[ids[0]].shape
         if (D_out * D_in) % 8 or D_out % 8:
             continue
-        out.append((params[ids[0]], ids))
+        kinds = ["q"]
+        if _run(ids[:3]) and _run(ids[3:]):
+            kinds.append("qkv")
+        if _run(ids[1:3]) and _run(ids[4:]):
+            kinds.append("kv")
+        out.append((params[ids[0]], ids, kinds))
     return out
 
 
-def _packed_views(flat, offsets, ids, D_out, D_in):
+def _packed_views(flat, offsets, ids, D_out, D_in, kinds=("qkv", "kv", "q")):
     ow, ob = offsets[ids[0]], offsets[ids[3]]
-    return {
-        "qkv": (flat[ow:ow + 3 * D_out * D_in].view(3 * D_out, D_in), flat[ob:ob + 3 * D_out]),
-        "kv": (flat[offsets[ids[1]]:offsets[ids[1]] + 2 * D_out * D_in].view(2 * D_out, D_in),
-               flat[offsets[ids[4]]:offsets[ids[4]] + 2 * D_out]),
-        "q": (flat[ow:ow + D_out * D_in].view(D_out, D_in), flat[ob:ob + D_out]),
+    v = {
+        "qkv": lambda: (flat[ow:ow + 3 * D_out * D_in].view(3 * D_out, D_in), flat[ob:ob + 3 * D_out]),
+        "kv": lambda: (flat[offsets[ids[1]]:offsets[ids[1]] + 2 * D_out * D_in].view(2 * D_out, D_in),
+                       flat[offsets[ids[4]]:offsets[ids[4]] + 2 * D_out]),
+        "q": lambda: (flat[ow:ow + D_out * D_in].view(D_out, D_in), flat[ob:ob + D_out]),
     }
+    return {k: v[k]() for k in kinds}
+
+
+def _stack_groups(names, params):
+    """→ [(anchor = layer 0's key weight, weight ids [k0 v0 k1 v1 …], bias ids)] for every decoder stack whose cross-attention
+    key / value projections are contiguous across the layers (see _ordered)."""
+    by_pre = {}
+    for i, n in enumerate(names):
+        m = _MEMKV.match(n)
+        if m is not None:
+            by_pre.setdefault(m.group(1), {})[(m.group(4), int(m.group(2)), m.group(3))] = i
+    out = []
+    for pre, d in by_pre.items():
+        L = 1 + max(k[1] for k in d)
+        try:
+            wi = [d[("weight", l, kv)] for l in range(L) for kv in ("key", "value")]
+            bi = [d[("bias", l, kv)] for l in range(L) for kv in ("key", "value")]
+        except KeyError:
+            continue
+        D_out, D_in = params[wi[0]].shape
+        if L < 2 or not (_run(wi) and _run(bi)) or (D_out * D_in) % 8 or D_out % 8:
+            continue
+        if any(tuple(params[i].shape) != (D_out, D_in) for i in wi):
+            continue
+        out.append((params[wi[0]], wi, bi))
+    return out
+
+
+def _stack_views(flat, offsets, wi, bi, D_out, D_in):
+    n = len(wi)
+    return (flat[offsets[wi[0]]:offsets[wi[0]] + n * D_out * D_in].view(n * D_out, D_in), flat[offsets[bi[0]]:offsets[bi[0]] + n * D_out])
 
 
 class WeightStore:
@@ -117,12 +167,18 @@ class WeightStore:
                 view.copy_(p.detach())
                 p.data = view
                 p._svpc_bf16 = self.shadow[o:o + n].view_as(p)
-        for q, ids in _packed_groups(self.names, self.params, self.offsets):
+        for q, ids, kinds in _packed_groups(self.names, self.params, self.offsets):
             D_out, D_in = q.shape
-            fw = _packed_views(self.flat, self.offsets, ids, D_out, D_in)
-            sw = _packed_views(self.shadow, self.offsets, ids, D_out, D_in)
+            fw = _packed_views(self.flat, self.offsets, ids, D_out, D_in, kinds)
+            sw = _packed_views(self.shadow, self.offsets, ids, D_out, D_in, kinds)
             q._svpc_packed_w = {k: (fw[k][0], fw[k][1], sw[k][0]) for k in fw}
             q._svpc_packed_w_members = [self.params[i] for i in ids]
+        for a, wi, bi in _stack_groups(self.names, self.params):
+            D_out, D_in = a.shape
+            fw = _stack_views(self.flat, self.offsets, wi, bi, D_out, D_in)
+            sw = _stack_views(self.shadow, self.offsets, wi, bi, D_out, D_in)
+            a._svpc_stack_w = (fw[0], fw[1], sw[0])
+            a._svpc_stack_w_members = [self.params[i] for i in wi]
         self.refresh()
 
     @classmethod
@@ -159,10 +215,15 @@ class GradArena:
             p.grad = view
             p._svpc_direct = True       # ops write this parameter's gradient in place from now on
         # packed views for the fused Q/K/V (and K/V) projections
-        for q, ids in _packed_groups(self.names, self.params, self.offsets):
+        for q, ids, kinds in _packed_groups(self.names, self.params, self.offsets):
             D_out, D_in = q.shape
-            q._svpc_packed = _packed_views(self.flat, self.offsets, ids, D_out, D_in)
-            q._svpc_packed_members = {"qkv": ids, "kv": [ids[1], ids[2], ids[4], ids[5]], "q": [ids[0], ids[3]]}
+            q._svpc_packed = _packed_views(self.flat, self.offsets, ids, D_out, D_in, kinds)
+            members = {"qkv": ids, "kv": [ids[1], ids[2], ids[4], ids[5]], "q": [ids[0], ids[3]]}
+            q._svpc_packed_members = {k: members[k] for k in kinds}
+        for a, wi, bi in _stack_groups(self.names, self.params):
+            D_out, D_in = a.shape
+            a._svpc_stack = _stack_views(self.flat, self.offsets, wi, bi, D_out, D_in)
+            a._svpc_stack_members = (wi, bi)
 
     def layout(self):
         return self.names, self.params, self.offsets, self.numel
@@ -345,6 +406,11 @@ class GradReducer:
                         half = len(mem) // 2
                         self._by_pack[("w", wg.data_ptr(), wg.numel())] = [(j, bucket_of[j]) for j in mem[:half]]
                         self._by_pack[("b", bg.data_ptr(), bg.numel())] = [(j, bucket_of[j]) for j in mem[half:]]
+                stack = getattr(p, "_svpc_stack", None)
+                if stack is not None:
+                    wi, bi = p._svpc_stack_members
+                    self._by_pack[("w", stack[0].data_ptr(), stack[0].numel())] = [(j, bucket_of[j]) for j in wi]
+                    self._by_pack[("b", stack[1].data_ptr(), stack[1].numel())] = [(j, bucket_of[j]) for j in bi]
             ops.GRAD_READY_HOOK = self._ready_ptr
         self.reset()
 

@@ -121,7 +121,11 @@ class Translator(object):
             n_mem = mem.shape[0] // T
             layers = model.decoder.layer
             caches = [torch.zeros(T * Lt, 2 * D, dtype=torch.float32, device=dev) for _ in layers]
-            mem_kv = [layer.memory_kv(mem) for layer in layers]
+            st = model.decoder.stacked_memory_kv()
+            if st is not None:                 # one projection of the memory rows for the whole stack; each layer reads its columns
+                mem_kv = ops.split_cols(ops.linear(mem, st[0], st[1]), len(layers))
+            else:
+                mem_kv = [layer.memory_kv(mem) for layer in layers]
             proj = model.bank_projection(bank) if bank is not None else None
             seq_cross = prep["seq_cross"].get(n_mem)
             if seq_cross is None:

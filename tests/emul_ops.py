@@ -305,6 +305,11 @@ def take_rows(x, idx):
     return x[idx.long()]
 
 
+def split_cols(wide, n):
+    w = wide.shape[1] // n
+    return tuple(wide[:, i * w:(i + 1) * w] for i in range(n))
+
+
 def add(a, b):
     return a + b
 

@@ -116,3 +116,50 @@ def test_span_cache_is_not_shared_between_same_shape_batches(monkeypatch):
     b["ingr_sep_masks"].copy_(other)
     sp2 = model._spans_for(b["ingr_sep_masks"])
     assert sp2 is not sp1 and sp2[1].host != sp1[1].host
+
+
+def test_arena_layout_keeps_packed_projections_contiguous():
+    """The gradient arena / weight store lay out (a) every attention block as [Wq Wk Wv | bq bk bv] and (b) the cross-attention
+    key / value projections of the decoder stack across the layers as [Wk0 Wv0 Wk1 Wv1 … | bk0 bv0 …]; the packed views alias
+    exactly the member parameters (reference: one nn.Linear each, model.py:159-172, consumed with the same memory rows by
+    every decoder layer, :643-651)."""
+    from svpc_amd.optim import GradArena, WeightStore
+    cfg = syn.make_config(model_type="vivt", hidden_size=32, num_hidden_layers=3, num_attention_heads=4, video_feature_size=64,
+                          vocab_size=60, word_vec_size=20, action_vocab_size=12, max_v_len=8, max_t_len=6, max_i_len=24)
+    torch.manual_seed(1)
+    model = M.StateAwareRecursiveTransformer(cfg)
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    before = {n: p.detach().clone() for n, p in named}
+    store = WeightStore(named)
+    arena = GradArena(named)
+    for n, p in named:                                     # re-pointing keeps every value
+        assert torch.equal(p.detach(), before[n]), n
+    D, L = cfg.hidden_size, cfg.num_hidden_layers
+    for n, p in named:                                     # a recognisable gradient per tensor
+        p.grad.fill_(float(arena.names.index(n) + 1))
+    dec = model.decoder
+    a = dec.layer[0].dec_enc_attention.key.weight
+    wg, bg = a._svpc_stack
+    w, b, w16 = a._svpc_stack_w
+    assert tuple(wg.shape) == (2 * L * D, D) and tuple(bg.shape) == (2 * L * D,) and w.shape == wg.shape and w16.dtype == torch.bfloat16
+    for l, layer in enumerate(dec.layer):
+        att = layer.dec_enc_attention
+        for j, lin in enumerate((att.key, att.value)):
+            r0 = (2 * l + j) * D
+            assert torch.equal(w[r0:r0 + D], lin.weight.detach()) and torch.equal(b[r0:r0 + D], lin.bias.detach())
+            assert wg[r0:r0 + D].data_ptr() == lin.weight.grad.data_ptr() and bg[r0:r0 + D].data_ptr() == lin.bias.grad.data_ptr()
+            assert torch.equal(wg[r0:r0 + D], lin.weight.grad)
+        # the per-layer K|V view is still there; Q|K|V of this block is no longer contiguous and must not be offered
+        pk = att.query.weight._svpc_packed
+        assert "kv" in pk and "q" in pk and "qkv" not in pk
+        assert pk["kv"][0].data_ptr() == att.key.weight.grad.data_ptr() and tuple(pk["kv"][0].shape) == (2 * D, D)
+        # the self-attention block keeps the full packing
+        sp = layer.self_attention.query.weight._svpc_packed
+        assert set(sp) == {"qkv", "kv", "q"} and sp["qkv"][0].data_ptr() == layer.self_attention.query.weight.grad.data_ptr()
+        assert torch.equal(sp["qkv"][0][D:2 * D], layer.self_attention.key.weight.grad)
+    st = dec.stacked_memory_kv()
+    assert st is not None and st[0].data_ptr() == w.data_ptr() and st[2].data_ptr() == wg.data_ptr()
+    # the fallback concatenation of a block without a contiguous layout still produces the right operand
+    wq, bq, _, _, _ = dec.layer[1].dec_enc_attention.packed("qkv")
+    assert torch.equal(wq[:D], dec.layer[1].dec_enc_attention.query.weight.detach())
+    assert store.numel == arena.numel

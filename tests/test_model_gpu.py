@@ -153,6 +153,42 @@ def test_fused_bert_adam_matches_reference_semantics(golden_dir):
     assert all("memory_intermediate" not in n for n in opt.arena.names)
 
 
+@pytest.mark.parametrize("mt", ["vi", "vivt"])
+def test_stacked_memory_projection_in_arena_mode_matches_golden_gradients(golden_dir, mt):
+    """Once the optimizer owns the parameters the decoder projects the memory rows to the keys / values of ALL layers in one
+    launch and gathers their gradients in one buffer (ops.split_cols): loss and every gradient still equal the reference's."""
+    from svpc_amd import ops
+    from svpc_amd.optim import FusedBertAdam
+    z, cfg, batch, model = build_model("tiny", mt, golden_dir, DEV)
+    opt = FusedBertAdam(list(model.named_parameters()), lr=0.0, warmup=0.1, t_total=20, grad_clip=1.0)
+    calls = []
+    orig = ops.split_cols
+    ops.split_cols = lambda wide, n: (calls.append((tuple(wide.shape), n)), orig(wide, n))[1]
+    try:
+        for it in range(2):             # the first step builds arena + weight store, the second runs on them
+            opt.zero_grad()
+            loss = model(*syn.forward_args(batch))[0]
+            loss.backward()
+            if it == 0:
+                opt.step()
+    finally:
+        ops.split_cols = orig
+    L, D = cfg.num_hidden_layers, cfg.hidden_size
+    assert len(calls) == 1 and calls[0][1] == L and calls[0][0][1] == 2 * L * D, calls
+    ref = float(z["loss"])
+    assert abs(loss.item() - ref) <= 1e-4 * abs(ref), (loss.item(), ref)
+    worst = (0.0, "")
+    for name, p in model.named_parameters():
+        k = "grad/" + name
+        if k not in z.files:
+            continue
+        refg = z[k]
+        zero_in_theory = name.endswith(".key.bias") or name == "Wing.bias"
+        err = float(np.abs(p.grad.cpu().numpy() - refg).max()) / (max(1e-6, float(np.abs(refg).max())) + (2e-3 if zero_in_theory else 0.0))
+        worst = max(worst, (err, name))
+    assert worst[0] <= 2e-3, worst
+
+
 def test_bf16_compute_mode_stays_close_to_reference(golden_dir):
     """Throughput mode: GEMM operands rounded to bf16 (fp32 accumulate, fp32 everything else).  Stated tolerance vs the fp32
     reference: loss ≤ 5e-3 relative at the config-1 shape."""
