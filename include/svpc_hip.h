@@ -98,6 +98,13 @@ int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int
 int svpc_gemm_glds_r(const void* A, int lda, int a_kc, const void* B, int ldb, int b_kc, void* C, int c_dt, int ldc, void* Z, const void* R,
                      int M, int N, int K, const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed, int accumulate,
                      float* workspace, size_t workspace_bytes, svpc_stream_t stream);
+/* … and with an activation-backward factor G (of C's type and leading dimension): C = epi(A·B) ⊙ gact'(G) + R, where G is what the
+ * forward of activation `gact` kept (the pre-activation z for GELU, the output y for ReLU / sigmoid).  The dgrad of the projection
+ * that FOLLOWS an activation (reference: BertOutput.dense after BertIntermediate's gelu, model.py:255-289) writes the gradient of the
+ * pre-activation directly; the separate svpc_act_bwd pass over the stream disappears.  G needs a non-accumulating bf16 output. */
+int svpc_gemm_glds_rg(const void* A, int lda, int a_kc, const void* B, int ldb, int b_kc, void* C, int c_dt, int ldc, void* Z, const void* R,
+                      const void* G, int gact, int M, int N, int K, const float* bias, int act, float p_drop, unsigned site,
+                      const svpc_u64* seed, int accumulate, float* workspace, size_t workspace_bytes, svpc_stream_t stream);
 /* the 8-phase 256x256x64 form of the same product for the FORWARD projections of a bf16 activation stream (both operands
  * k-contiguous bf16, bf16 output, optional bias / ReLU / GELU / pre-activation copy Z; K % 64 == 0, N % 8 == 0, 16-byte aligned rows):
  * C = act(A[M,K]·B[N,K]^T + bias).  svpc_gemm_glds routes its stream-sized forward launches here; the direct entry exists for tests

@@ -116,6 +116,29 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+// The same derivative with the Abramowitz–Stegun 7.1.26 erf (|error| ≤ 1.5e-7, far below the bf16 rounding of what is stored), whose
+// exponential exp(-x²/2) is also the density term: ≈16 instructions instead of erff + expf (≈90).  For GEMM epilogues on bf16
+// streams, where a tile's tail evaluates it tens of thousands of times with nothing left to overlap.
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    const float u = x * 0.70710678118654752f, au = fabsf(u);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, au, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __expf(-au * au);
+    const float cdf = 0.5f * (1.0f + copysignf(fmaf(-p * t, e, 1.0f), u));
+    return fmaf(x * 0.3989422804014327f, e, cdf);
+}
+// act'(.) from what the forward kept: the pre-activation z for GELU, the activated output y for ReLU / sigmoid (as svpc_act_bwd)
+__device__ __forceinline__ float act_grad_from_aux(float aux, int act, bool fast_gelu) {
+    switch (act) {
+        case ACT_RELU: return aux > 0.f ? 1.0f : 0.0f;
+        case ACT_GELU: return fast_gelu ? gelu_grad_fast(aux) : gelu_erf_grad(aux);
+        case ACT_SIGMOID: return aux * (1.0f - aux);
+        default: return 1.0f;
+    }
+}
 __device__ __forceinline__ float apply_act(float z, int act) {
     switch (act) {
         case ACT_RELU: return fmaxf(z, 0.0f);

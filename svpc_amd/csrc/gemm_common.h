@@ -10,6 +10,9 @@ struct Epi {
     const void* R;   // optional addend of C's type and layout, C = act(acc + bias) + R (a residual-path gradient joining a dgrad).  bf16: only
                      // the 16-byte row-store epilogues of gemm_glds.hip apply it (the launcher refuses R where they cannot run);
                      // fp32: the element-wise epilogues below (svpc_gemm_l32_r)
+    const void* G; int gact;   // optional: C = (A·B) ⊙ gact'(G) (+ R) — G of C's type and layout is what the forward of activation `gact` kept
+                               // (z for GELU, y for ReLU / sigmoid): a dgrad whose output feeds an activation's backward applies it.
+                               // Like a bf16 R only in the 16-byte row-store epilogues of gemm_glds.hip (the launcher refuses it elsewhere)
 };
 
 __device__ __forceinline__ void epilogue_store(float v, int row, int col, float* __restrict__ C, int ldc, const Epi& e,

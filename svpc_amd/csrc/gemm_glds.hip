@@ -92,10 +92,19 @@ __device__ __forceinline__ uint32_t add_bf16x2(uint32_t a, uint32_t b) {       /
 __device__ __forceinline__ uint4 add_bf16x8(uint4 a, uint4 b) {
     return make_uint4(add_bf16x2(a.x, b.x), add_bf16x2(a.y, b.y), add_bf16x2(a.z, b.z), add_bf16x2(a.w, b.w));
 }
+__device__ __forceinline__ uint32_t mul_dact_bf16x2(uint32_t v, uint32_t g, int gact) {   // v ⊙ gact'(g), both halves, rounded once
+    return pack_bf16x2(__uint_as_float(v << 16) * act_grad_from_aux(__uint_as_float(g << 16), gact, true),
+                       __uint_as_float(v & 0xffff0000u) * act_grad_from_aux(__uint_as_float(g & 0xffff0000u), gact, true));
+}
+__device__ __forceinline__ uint4 mul_dact_bf16x8(uint4 v, uint4 g, int gact) {
+    return make_uint4(mul_dact_bf16x2(v.x, g.x, gact), mul_dact_bf16x2(v.y, g.y, gact), mul_dact_bf16x2(v.z, g.z, gact),
+                      mul_dact_bf16x2(v.w, g.w, gact));
+}
 template <int TMF, int TNF, int ACT>
 __device__ __forceinline__ void glds_store_rows(const floatx16 (&acc)[TMF][TNF], __bf16* __restrict__ C, int ldc, __bf16* __restrict__ Z,
                                                 const float* __restrict__ bias, int row0, int col0, int M, int N, int lane,
-                                                const __bf16* __restrict__ Radd = nullptr) {
+                                                const __bf16* __restrict__ Radd = nullptr, const __bf16* __restrict__ Gd = nullptr,
+                                                int gact = 0) {
     const int l31 = lane & 31, lhi = lane >> 5;
 #pragma unroll
     for (int j = 0; j < TNF; ++j) {
@@ -130,6 +139,7 @@ __device__ __forceinline__ void glds_store_rows(const floatx16 (&acc)[TMF][TNF],
                 const size_t o = (size_t)row * ldc + cc;
                 if (ok) {
                     uint4 v = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                    if (Gd) v = mul_dact_bf16x8(v, *reinterpret_cast<const uint4*>(Gd + o), gact);
                     if (Radd) v = add_bf16x8(v, *reinterpret_cast<const uint4*>(Radd + o));
                     *reinterpret_cast<uint4*>(C + o) = v;
                 }
@@ -150,7 +160,8 @@ __device__ __forceinline__ void glds_store_rows(const floatx16 (&acc)[TMF][TNF],
 template <int TMF, int ACT, bool PRE>
 __device__ __forceinline__ void glds_store_rows_lds_pass(const floatx16 (&acc)[TMF][2], __bf16* __restrict__ C, int ldc,
                                                          const float* __restrict__ bias, int row0, int col0, int M, int N, int lane,
-                                                         char* __restrict__ wl, const __bf16* __restrict__ Radd = nullptr) {
+                                                         char* __restrict__ wl, const __bf16* __restrict__ Radd = nullptr,
+                                                         const __bf16* __restrict__ Gd = nullptr, int gact = 0) {
     const int l31 = lane & 31, lhi = lane >> 5;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -192,6 +203,7 @@ __device__ __forceinline__ void glds_store_rows_lds_pass(const floatx16 (&acc)[T
         const int r = it * 8 + (lane >> 3), row = row0 + r;
         uint4 v = *reinterpret_cast<const uint4*>(wl + r * 128 + ((chunk ^ (r & 7)) << 4));
         if (row < M && cc + 8 <= N) {
+            if (Gd) v = mul_dact_bf16x8(v, *reinterpret_cast<const uint4*>(Gd + (size_t)row * ldc + cc), gact);
             if (Radd) v = add_bf16x8(v, *reinterpret_cast<const uint4*>(Radd + (size_t)row * ldc + cc));
             *reinterpret_cast<uint4*>(C + (size_t)row * ldc + cc) = v;
         }
@@ -200,8 +212,9 @@ __device__ __forceinline__ void glds_store_rows_lds_pass(const floatx16 (&acc)[T
 template <int TMF, int ACT>
 __device__ __forceinline__ void glds_store_rows_lds(const floatx16 (&acc)[TMF][2], __bf16* __restrict__ C, int ldc, __bf16* __restrict__ Z,
                                                     const float* __restrict__ bias, int row0, int col0, int M, int N, int lane,
-                                                    char* __restrict__ wl, const __bf16* __restrict__ Radd) {
-    glds_store_rows_lds_pass<TMF, ACT, false>(acc, C, ldc, bias, row0, col0, M, N, lane, wl, Radd);
+                                                    char* __restrict__ wl, const __bf16* __restrict__ Radd,
+                                                    const __bf16* __restrict__ Gd = nullptr, int gact = 0) {
+    glds_store_rows_lds_pass<TMF, ACT, false>(acc, C, ldc, bias, row0, col0, M, N, lane, wl, Radd, Gd, gact);
     if (Z) glds_store_rows_lds_pass<TMF, ACT, true>(acc, Z, ldc, bias, row0, col0, M, N, lane, wl);
 }
 // generic element-wise form of the same orientation (dropout, accumulate, split-K slabs, unaligned or ragged-by-less-than-8 outputs)
@@ -231,7 +244,7 @@ __device__ __forceinline__ void glds_store_tr(const floatx16 (&acc)[TMF][TNF], T
                                               int col0, int M, int N, int lane, int splitk, int ks_id, float* __restrict__ slabs,
                                               char* __restrict__ wl = nullptr) {
     const bool fast = splitk == 1 && epi.p_drop <= 0.f && !epi.accumulate && (N & 7) == 0 && (ldc & 7) == 0 &&
-                      ((((uintptr_t)C) | ((uintptr_t)epi.Z) | ((uintptr_t)epi.bias) | ((uintptr_t)epi.R)) & 15) == 0;
+                      ((((uintptr_t)C) | ((uintptr_t)epi.Z) | ((uintptr_t)epi.bias) | ((uintptr_t)epi.R) | ((uintptr_t)epi.G)) & 15) == 0;
     if (!fast) {
         glds_store_rows_generic<TMF, TNF, TC>(acc, C, ldc, epi, row0, col0, M, N, lane, splitk, ks_id, slabs);
         return;
@@ -239,22 +252,24 @@ __device__ __forceinline__ void glds_store_tr(const floatx16 (&acc)[TMF][TNF], T
     __bf16* Cb = reinterpret_cast<__bf16*>(C);
     __bf16* Zb = reinterpret_cast<__bf16*>(epi.Z);
     const __bf16* Rb = reinterpret_cast<const __bf16*>(epi.R);
+    const __bf16* Gb = reinterpret_cast<const __bf16*>(epi.G);
+    const int ga = epi.gact;
     if constexpr (TNF == 2) {
         if (wl) {       // whole-line stores through the wave's LDS image
             switch (epi.act) {
-                case ACT_RELU: glds_store_rows_lds<TMF, ACT_RELU>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, wl, Rb); break;
-                case ACT_GELU: glds_store_rows_lds<TMF, ACT_GELU>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, wl, Rb); break;
-                case ACT_SIGMOID: glds_store_rows_lds<TMF, ACT_SIGMOID>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, wl, Rb); break;
-                default: glds_store_rows_lds<TMF, ACT_NONE>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, wl, Rb); break;
+                case ACT_RELU: glds_store_rows_lds<TMF, ACT_RELU>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, wl, Rb, Gb, ga); break;
+                case ACT_GELU: glds_store_rows_lds<TMF, ACT_GELU>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, wl, Rb, Gb, ga); break;
+                case ACT_SIGMOID: glds_store_rows_lds<TMF, ACT_SIGMOID>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, wl, Rb, Gb, ga); break;
+                default: glds_store_rows_lds<TMF, ACT_NONE>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, wl, Rb, Gb, ga); break;
             }
             return;
         }
     }
     switch (epi.act) {
-        case ACT_RELU: glds_store_rows<TMF, TNF, ACT_RELU>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, Rb); break;
-        case ACT_GELU: glds_store_rows<TMF, TNF, ACT_GELU>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, Rb); break;
-        case ACT_SIGMOID: glds_store_rows<TMF, TNF, ACT_SIGMOID>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, Rb); break;
-        default: glds_store_rows<TMF, TNF, ACT_NONE>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, Rb); break;
+        case ACT_RELU: glds_store_rows<TMF, TNF, ACT_RELU>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, Rb, Gb, ga); break;
+        case ACT_GELU: glds_store_rows<TMF, TNF, ACT_GELU>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, Rb, Gb, ga); break;
+        case ACT_SIGMOID: glds_store_rows<TMF, TNF, ACT_SIGMOID>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, Rb, Gb, ga); break;
+        default: glds_store_rows<TMF, TNF, ACT_NONE>(acc, Cb, ldc, Zb, epi.bias, row0, col0, M, N, lane, Rb, Gb, ga); break;
     }
 }
 
@@ -734,19 +749,27 @@ int svpc_gemm_group_wgrad_bf16(const void* problems, int n, hipStream_t stream) 
 }
 
 // A, B bf16; C bf16 (c_dt = 1) or fp32 (c_dt = 0); Z (optional pre-activation copy) has C's type.
+int svpc_gemm_glds_rg(const void* A, int lda, int a_kc, const void* B, int ldb, int b_kc, void* C, int c_dt, int ldc, void* Z, const void* R,
+                      const void* G, int gact, int M, int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed,
+                      int accumulate, float* workspace, size_t workspace_bytes, hipStream_t stream);
 int svpc_gemm_glds_r(const void* A, int lda, int a_kc, const void* B, int ldb, int b_kc, void* C, int c_dt, int ldc, void* Z, const void* R,
                      int M, int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
-                     float* workspace, size_t workspace_bytes, hipStream_t stream);
+                     float* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return svpc_gemm_glds_rg(A, lda, a_kc, B, ldb, b_kc, C, c_dt, ldc, Z, R, nullptr, 0, M, N, K, bias, act, p_drop, site, seed, accumulate,
+                             workspace, workspace_bytes, stream);
+}
 int svpc_gemm_glds(const void* A, int lda, int a_kc, const void* B, int ldb, int b_kc, void* C, int c_dt, int ldc, void* Z, int M, int N,
                    int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate, float* workspace,
                    size_t workspace_bytes, hipStream_t stream) {
     return svpc_gemm_glds_r(A, lda, a_kc, B, ldb, b_kc, C, c_dt, ldc, Z, nullptr, M, N, K, bias, act, p_drop, site, seed, accumulate, workspace,
                             workspace_bytes, stream);
 }
-// R (optional): addend of C's type and leading dimension, C = epi(A·B) + R — the residual-path gradient joining a dgrad
-int svpc_gemm_glds_r(const void* A, int lda, int a_kc, const void* B, int ldb, int b_kc, void* C, int c_dt, int ldc, void* Z, const void* R,
-                     int M, int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
-                     float* workspace, size_t workspace_bytes, hipStream_t stream) {
+// R (optional): addend of C's type and leading dimension, C = epi(A·B) + R — the residual-path gradient joining a dgrad.
+// G (optional, of C's type and leading dimension): C = epi(A·B) ⊙ gact'(G) (+ R) — what the forward of activation `gact` kept (z for
+// GELU, y for ReLU / sigmoid): the dgrad whose output is that activation's output gradient applies the activation backward itself.
+int svpc_gemm_glds_rg(const void* A, int lda, int a_kc, const void* B, int ldb, int b_kc, void* C, int c_dt, int ldc, void* Z, const void* R,
+                      const void* G, int gact, int M, int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed,
+                      int accumulate, float* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (M == 0 || N == 0) return 0;
     SVPC_REQUIRE(svpc_gemm_glds_supported(a_kc, b_kc, lda, ldb, M, N, K) && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0,
                  "gemm_glds: unsupported shape (see svpc_gemm_glds_supported) or operands not 16-byte aligned");
@@ -754,7 +777,10 @@ int svpc_gemm_glds_r(const void* A, int lda, int a_kc, const void* B, int ldb, i
     SVPC_REQUIRE(R == nullptr || (c_dt == 1 && p_drop <= 0.f && !accumulate && (N & 7) == 0 && (ldc & 7) == 0 &&
                                   ((((uintptr_t)C) | ((uintptr_t)Z) | ((uintptr_t)bias) | ((uintptr_t)R)) & 15) == 0),
                  "gemm_glds: an addend R needs a bf16 output with N % 8 == 0, 16-byte aligned rows, no dropout / accumulate");
-    Epi epi{bias, act, p_drop, site, seed, accumulate, (float*)Z, R};
+    SVPC_REQUIRE(G == nullptr || (c_dt == 1 && p_drop <= 0.f && !accumulate && (N & 7) == 0 && (ldc & 7) == 0 && gact >= ACT_NONE &&
+                                  gact <= ACT_SIGMOID && ((((uintptr_t)C) | ((uintptr_t)Z) | ((uintptr_t)bias) | ((uintptr_t)G)) & 15) == 0),
+                 "gemm_glds: an activation-backward factor G needs a bf16 output with N % 8 == 0, 16-byte aligned rows, no dropout / accumulate");
+    Epi epi{bias, act, p_drop, site, seed, accumulate, (float*)Z, R, G, gact};
     // 256-row tiles when 128-row tiles would need more than one round of resident workgroups and the taller tile fills its rounds
     // better (3 × 48 KiB workgroups per CU vs 2 × 72 KiB)
     static int bm_env = -1;
@@ -784,7 +810,7 @@ int svpc_gemm_glds_r(const void* A, int lda, int a_kc, const void* B, int ldb, i
     if (split_below < 0) { const char* e = getenv("SVPC_GLDS_SPLIT_BELOW"); split_below = e ? atoi(e) : 150; }   // ≥150 tiles already fill most CUs: a split would only add the reduce launch (measured)
     static int split_target = -1;
     if (split_target < 0) { const char* e = getenv("SVPC_GLDS_SPLIT_TARGET"); split_target = e ? atoi(e) : 512; }   // two workgroups per CU (measured best of 128…1024 when the step replays as one linear chain)
-    if (K >= 512 && tiles < split_below && R == nullptr) {
+    if (K >= 512 && tiles < split_below && R == nullptr && G == nullptr) {
         splitk = ceil_div(split_target, tiles);
         const int max_by_k = K / 256;
         if (splitk > max_by_k) splitk = max_by_k;

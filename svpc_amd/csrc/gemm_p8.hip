@@ -261,7 +261,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const __bf16* __restrict__
 bool glds_p8_supported(int a_kc, int b_kc, int c_dt, int lda, int ldb, int ldc, int M, int N, int K, const Epi& epi, const void* A,
                        const void* B, const void* C) {
     return a_kc && b_kc && c_dt == 1 && K >= P8_BK && K % P8_BK == 0 && (N & 7) == 0 && (ldc & 7) == 0 && (lda & 7) == 0 &&
-           (ldb & 7) == 0 && epi.p_drop <= 0.f && !epi.accumulate && epi.R == nullptr && epi.act != ACT_SIGMOID &&
+           (ldb & 7) == 0 && epi.p_drop <= 0.f && !epi.accumulate && epi.R == nullptr && epi.G == nullptr && epi.act != ACT_SIGMOID &&
            (unsigned long long)M * (unsigned long long)ldc * 2ull < (1ull << 32) &&
            ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)epi.Z) | ((uintptr_t)epi.bias)) & 15) == 0;
 }

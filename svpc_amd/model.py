@@ -208,7 +208,8 @@ class BertLayerNoMemoryUntied(nn.Module):
         ao = ops.linear(ctx, so.dense.weight, so.dense.bias)
         # sink=True: h / x1 are consumed by exactly one projection besides the residual path; its dgrad absorbs the residual gradient
         x1 = ops.layernorm(ao, so.LayerNorm.weight, so.LayerNorm.bias, cx.eps, residual=h, pre_drop=cx.drop(cx.p_h), sink=True)
-        it = ops.linear(x1, self.hidden_intermediate.dense.weight, self.hidden_intermediate.dense.bias, act=ACT_GELU)
+        # (fuse_act_bwd: `it` feeds exactly one projection, whose dgrad applies the GELU backward in its epilogue)
+        it = ops.linear(x1, self.hidden_intermediate.dense.weight, self.hidden_intermediate.dense.bias, act=ACT_GELU, fuse_act_bwd=True)
         o = ops.linear(it, self.output.dense.weight, self.output.dense.bias)
         return ops.layernorm(o, self.output.LayerNorm.weight, self.output.LayerNorm.bias, cx.eps,
                              residual=x1, pre_drop=cx.drop(cx.p_h), sink=True)

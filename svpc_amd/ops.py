@@ -448,18 +448,22 @@ def bf16_stream_ok(rows, *dims):
     return rows % 128 == 0 and all(d % 128 == 0 for d in dims)
 
 
-def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NONE, p=0.0, site=0, seed=None, accumulate=0, R=None):
-    """C = epi(A·B) (+ R: an addend of C's type and layout, only on the bf16 direct-to-LDS path; other paths add it afterwards)"""
+def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NONE, p=0.0, site=0, seed=None, accumulate=0, R=None, G=None):
+    """C = epi(A·B) (+ R: an addend of C's type and layout, only on the bf16 direct-to-LDS path; other paths add it afterwards).
+    G = (aux, act): C = (A·B) ⊙ act'(aux) — absorbed only by the bf16 direct-to-LDS path; returns whether it was applied."""
     ws = _ws(C.device)
+    g_done = False
     ev = (GEMM_TIMER.bracket(2.0 * M * N * K, (M, N, K, a_kc, b_kc, _dt(A), _dt(B), _dt(C)))
           if GEMM_TIMER is not None else None)
     if ev:
         ev[0].record()
     if _PRECISION == "bf16" and USE_GLDS and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and \
             (A.data_ptr() | B.data_ptr()) % 16 == 0 and _lib.load().svpc_gemm_glds_supported(a_kc, b_kc, lda, ldb, M, N, K) == 1:
-        _lib.call("gemm_glds_r", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), _dt(C), C.stride(0), _p(Z), _p(R), M, N, K, _p(bias), act, p,
-                  site, _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+        g_ok = G is not None and G[0].dtype == C.dtype and G[0].shape == C.shape and G[0].stride() == C.stride() and not accumulate
+        _lib.call("gemm_glds_rg", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), _dt(C), C.stride(0), _p(Z), _p(R), _p(G[0]) if g_ok else None,
+                  int(G[1]) if g_ok else 0, M, N, K, _p(bias), act, p, site, _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
         R = None
+        g_done = g_ok
     elif _PRECISION == "bf16" and USE_L32 and A.dtype == B.dtype == C.dtype == torch.float32 and \
             (A.data_ptr() | B.data_ptr()) % 16 == 0 and _lib.load().svpc_gemm_l32_preferred(a_kc, b_kc, lda, ldb, M, N, K) == 1:
         if R is not None and not (R.dtype == torch.float32 and R.is_contiguous() and R.shape == C.shape and C.is_contiguous()):
@@ -476,9 +480,12 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NON
         _lib.call("gemm_f32", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
                   _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
     if R is not None:
+        if G is not None and not g_done:
+            raise _lib.SvpcKernelError("gemm: an activation-backward factor and an addend need the direct-to-LDS path")
         C.add_(R)
     if ev:
         ev[1].record()
+    return g_done
 
 
 def _colsum(x2d, idx=None, K=1, out=None, accumulate=0):
@@ -530,13 +537,14 @@ def _shadow(w):
 # backward of the projection that consumes h adds the parked tensor in its dgrad epilogue (C = dz·W + R).  The caller promises
 # that exactly one ops.linear consumes h and needs its input gradient; join_side() fails loudly if a parked gradient is left over.
 USE_RES_SINK = os.environ.get("SVPC_RES_SINK", "1") != "0"
+FUSE_ACT_BWD = os.environ.get("SVPC_FUSE_ACT_BWD", "1") != "0"      # activation backward inside the following projection's dgrad
 _RES_SINK = {}
 SINK_STATS = [0, 0]        # parked by LayerNorm backwards / absorbed by dgrad epilogues (since import)
 
 
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, w, b, act, trans_w, drop, wgrad, bgrad, w16):
+    def forward(ctx, x, w, b, act, trans_w, drop, wgrad, bgrad, w16, tok_out=None, tok_in=None):
         _need_gpu(x)
         x = _rows2d(x)
         w = _c(w if w16 is None else w16)      # bf16 shadow: both GEMM operands stream straight into LDS
@@ -549,6 +557,11 @@ class _Linear(Function):
         ctx.save_for_backward(x, w, z if act == ACT_GELU else (y if act != ACT_NONE else None))
         ctx.cfg = (act, trans_w, p, site, seed, b is not None)
         ctx.direct = (wgrad, bgrad)
+        # activation backward folded into the NEXT projection's dgrad (see linear(): fuse_act_bwd): this node publishes what its
+        # activation's backward needs; the consumer's backward reports the gradient it has already multiplied
+        ctx.tok_out, ctx.tok_in = tok_out, tok_in
+        if tok_out is not None:
+            tok_out["aux"], tok_out["act"] = (z if act == ACT_GELU else y), act
         return y
 
     @staticmethod
@@ -558,7 +571,16 @@ class _Linear(Function):
         M, K = x.shape
         N = w.shape[1] if trans_w else w.shape[0]
         dy = _c(dy)
-        if act != ACT_NONE or p > 0.0:
+        tok = ctx.tok_out
+        premul = tok is not None and tok.get("done") is not None
+        if premul:
+            if tok["done"] != (dy.data_ptr(), tuple(dy.shape)):
+                raise _lib.SvpcKernelError("fused activation backward: the activated tensor has a second consumer (its gradient is not "
+                                           "the one the following projection wrote)")
+            tok["done"] = None
+        if premul:
+            dz = dy                  # the following projection's dgrad has applied act'(.) already
+        elif act != ACT_NONE or p > 0.0:
             dz = torch.empty_like(dy)
             _lib.call("act_bwd_t", _p(dy), _p(aux if aux is not None else dy), _p(dz), _dt(dy), dy.numel(), act, p, site, _p(seed),
                       _stream())
@@ -572,7 +594,10 @@ class _Linear(Function):
                 SINK_STATS[1] += 1
             if parked is not None and (parked.shape != dx.shape or parked.dtype != dx.dtype):
                 raise _lib.SvpcKernelError("residual-gradient hand-over: parked gradient does not match the projection's input")
-            _gemm(dz, N, 1, w, w.stride(0), 1 if trans_w else 0, dx, M, K, N, R=parked)
+            tin = ctx.tok_in
+            G = (tin["aux"], tin["act"]) if (tin is not None and tin.get("aux") is not None and parked is None) else None
+            if _gemm(dz, N, 1, w, w.stride(0), 1 if trans_w else 0, dx, M, K, N, R=parked, G=G):
+                tin["done"] = (dx.data_ptr(), tuple(dx.shape))
         wgrad, bgrad = ctx.direct
         w_done = False
         if wgrad is not None and not trans_w and (not has_b or bgrad is not None):
@@ -580,7 +605,7 @@ class _Linear(Function):
                 if defer_wgrad(dz, x, wgrad, None):           # bf16 stream: grouped wgrad; the bias gradient goes its usual way below
                     w_done = True
             elif defer_wgrad(dz, x, wgrad, bgrad if has_b else None):
-                return dx, None, None, None, None, None, None, None, None
+                return dx, None, None, None, None, None, None, None, None, None, None
         if not w_done and (wgrad is not None or ctx.needs_input_grad[1]):
             acc = 1 if wgrad is not None else 0
             dw = wgrad if wgrad is not None else torch.empty_like(w)
@@ -609,10 +634,15 @@ class _Linear(Function):
                     _ready(bgrad, "b")
             else:
                 db = _colsum(dz).view(-1)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgrad=None, w16=None):
+def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgrad=None, w16=None, fuse_act_bwd=False):
+    """fuse_act_bwd=True (with an activation, no dropout): the caller promises that the returned tensor is consumed by exactly ONE
+    ops.linear; on a bf16 stream that projection's dgrad then writes the gradient of this projection's pre-activation directly
+    (C = dz·W ⊙ act'(z), svpc_gemm_glds_rg) and the separate activation-backward pass over the stream is skipped.  A second consumer
+    is detected in backward and fails loudly."""
+    tok_in = getattr(x, "_svpc_act_tok", None)
     if x.dtype == torch.bfloat16:
         n_out = w.shape[1] if trans_w else w.shape[0]
         if trans_w or drop is not None or not bf16_stream_ok(x.shape[0], x.shape[1], n_out):
@@ -628,7 +658,15 @@ def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgr
             w16 = w.detach().to(torch.bfloat16)
     else:
         w16 = None
-    return _Linear.apply(x, w, b, act, trans_w, drop, wgrad, bgrad, w16)
+    fuse = (fuse_act_bwd and FUSE_ACT_BWD and act != ACT_NONE and drop is None and x.dtype == torch.bfloat16 and USE_GLDS and
+            torch.is_grad_enabled())
+    tok_out = {} if fuse else None
+    if tok_in is not None and (x.dtype != torch.bfloat16 or trans_w or not USE_GLDS):
+        tok_in = None
+    y = _Linear.apply(x, w, b, act, trans_w, drop, wgrad, bgrad, w16, tok_out, tok_in)
+    if tok_out is not None:
+        y._svpc_act_tok = tok_out
+    return y
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm family

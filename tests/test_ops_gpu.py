@@ -546,6 +546,96 @@ def test_glds_addend_epilogue(bf16_mode, M, N, K):
     assert (C.double() - ref).abs().max().item() <= 6e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K,act", [(19200, 768, 768, 2), (4224, 768, 768, 2), (18000, 760, 768, 2), (4224, 768, 768, 1),
+                                        (640, 256, 512, 3)])
+def test_glds_activation_backward_epilogue(bf16_mode, M, N, K, act):
+    """C = (A·B) ⊙ act'(G) in the row-store epilogues (svpc_gemm_glds_rg): the dgrad of the projection that follows an activation writes
+    the pre-activation gradient itself.  Against fp64 with the exact derivative (GELU: Φ(z) + z·φ(z) from the pre-activation; ReLU /
+    sigmoid: from the output), on every tile form: ping-pong + LDS image, 128² row pieces, ragged, element-wise."""
+    g = torch.Generator().manual_seed(M + N + act)
+    bf = torch.bfloat16
+    A = torch.randn(M, K, generator=g).to(bf).to(DEV)
+    B = (0.05 * torch.randn(K, N, generator=g)).to(bf).to(DEV)
+    aux = (1.5 * torch.randn(M, N, generator=g))
+    if act == 1:
+        aux = aux.clamp_min(0.0)
+    elif act == 3:
+        aux = torch.sigmoid(aux)
+    aux = aux.to(bf).to(DEV)
+    C = torch.empty(M, N, device=DEV, dtype=bf)
+    assert O._gemm(A, K, 1, B, N, 0, C, M, N, K, G=(aux, act)) is True
+    a = aux.double()
+    if act == 2:
+        d = 0.5 * (1 + torch.erf(a / 2 ** 0.5)) + a * torch.exp(-0.5 * a * a) / (2 * torch.pi) ** 0.5
+    elif act == 1:
+        d = (a > 0).double()
+    else:
+        d = a * (1 - a)
+    ref = (A.double() @ B.double()) * d
+    # the product is rounded to bf16 before the factor is applied (as the separate pass did) and once after: 2 × 2^-9
+    assert (C.double() - ref).abs().max().item() <= 9e-3 * max(1.0, ref.abs().max().item())
+    # with an addend on top: C = (A·B) ⊙ act'(G) + R
+    R = torch.randn(M, N, generator=g).to(bf).to(DEV)
+    C2 = torch.empty_like(C)
+    assert O._gemm(A, K, 1, B, N, 0, C2, M, N, K, R=R, G=(aux, act)) is True
+    ref2 = ref + R.double()
+    assert (C2.double() - ref2).abs().max().item() <= 9e-3 * max(1.0, ref2.abs().max().item())
+
+
+def test_fused_activation_backward_through_two_linears(bf16_mode):
+    """linear(act, fuse_act_bwd=True) → linear: the second projection's dgrad applies the activation backward (no act_bwd launch);
+    gradients equal the unfused path within bf16 rounding, and a second consumer of the activated tensor fails loudly."""
+    torch.manual_seed(1)
+    rows, D, F = 768, 256, 384
+    x0 = (0.5 * torch.randn(rows, D, device=DEV)).bfloat16()
+    w1 = (0.1 * torch.randn(F, D, device=DEV)).requires_grad_(True)
+    b1 = (0.1 * torch.randn(F, device=DEV)).requires_grad_(True)
+    w2 = (0.1 * torch.randn(D, F, device=DEV)).requires_grad_(True)
+    b2 = torch.zeros(D, device=DEV, requires_grad=True)
+    wt = torch.randn(rows, D, device=DEV)
+    from svpc_amd import _lib
+    res = []
+    keep = O.FUSE_ACT_BWD
+    calls = []
+    orig_call = _lib.call
+    def spy(name, *a):
+        calls.append(name)
+        return orig_call(name, *a)
+    try:
+        for use in (True, False):
+            O.FUSE_ACT_BWD = use
+            x = x0.clone().requires_grad_(True)
+            for t in (w1, b1, w2, b2):
+                t.grad = None
+            del calls[:]
+            _lib.call = spy
+            try:
+                h = O.linear(x, w1, b1, act=2, fuse_act_bwd=True)
+                y = O.linear(h, w2, b2)
+                (y.float() * wt).sum().backward()
+                O.join_side()
+            finally:
+                _lib.call = orig_call
+            torch.cuda.synchronize()
+            assert ("act_bwd_t" in calls) == (not use), calls
+            res.append([t.grad.float().clone() for t in (x, w1, b1, w2, b2)])
+        for a, b in zip(*res):
+            assert torch.allclose(a, b, rtol=2e-2, atol=2e-2 * b.abs().max().item())
+        O.FUSE_ACT_BWD = True
+        x = x0.clone().requires_grad_(True)
+        h = O.linear(x, w1, b1, act=2, fuse_act_bwd=True)
+        y = O.linear(h, w2, b2)
+        with pytest.raises(Exception, match="second consumer"):
+            ((y.float() * wt).sum() + h.float().sum()).backward()
+    finally:
+        O.FUSE_ACT_BWD = keep
+        O._RES_SINK.clear()
+        try:
+            O.join_side()
+        except Exception:
+            pass
+
+
 def test_residual_gradient_hand_over(bf16_mode):
     """layernorm(sub(h) + h, sink=True): the LayerNorm parks its residual-path gradient and the projection consuming h adds it in its
     dgrad epilogue — same gradients as autograd's separate add (within bf16 rounding); a parked gradient nobody absorbs fails loudly"""
