@@ -164,17 +164,21 @@ __device__ __forceinline__ bf16x8 frag_rows(const char* __restrict__ img, int ro
 }
 // transposed fragment for a product that sums over image ROWS r0..r0+15 in the accumulator-permuted order
 // (element j of lane half h ↔ row r0 + 8(j>>2) + 4h + (j&3)); lane ↔ image column c0 + (lane & 31)
-template <int DH>
-__device__ __forceinline__ bf16x8 frag_tr(const char* __restrict__ img, int r0, int c0, int lane) {
+template <int RS>
+__device__ __forceinline__ bf16x8 frag_tr_rs(const char* __restrict__ img, int r0, int c0, int lane) {
     const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, h = g >> 1;
-    const char* a = img + (r0 + 4 * h + q) * AImg<DH>::RS + (c0 + 16 * (g & 1) + 4 * p) * 2;
+    const char* a = img + (r0 + 4 * h + q) * RS + (c0 + 16 * (g & 1) + 4 * p) * 2;
     typedef short4v __attribute__((address_space(3))) * lds_ptr;
     const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a));
-    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 8 * AImg<DH>::RS));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 8 * RS));
     union { short s[8]; bf16x8 v; } u;
     u.s[0] = lo[0]; u.s[1] = lo[1]; u.s[2] = lo[2]; u.s[3] = lo[3];
     u.s[4] = hi[0]; u.s[5] = hi[1]; u.s[6] = hi[2]; u.s[7] = hi[3];
     return u.v;
+}
+template <int DH>
+__device__ __forceinline__ bf16x8 frag_tr(const char* __restrict__ img, int r0, int c0, int lane) {
+    return frag_tr_rs<AImg<DH>::RS>(img, r0, c0, lane);
 }
 __device__ __forceinline__ int acc_row(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
 __device__ __forceinline__ bf16x8 pack8(const float* v) {
@@ -431,7 +435,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     constexpr bool TRS = sizeof(T) == 2;        // bf16 gradients: tiles accumulated transposed, a matrix row per lane (16-byte stores)
     constexpr int IB = AT * AImg<DH>::RS;
-    constexpr int GROUP_BYTES = 4 * IB + 3 * AT * (int)sizeof(float), NT = PERWAVE ? 64 : 256;
+    // dSᵀ image for pass 2 ([key][query] bf16, rows padded by 16 B): written after pass 1 over the V and dO images, which pass 2
+    // does not read (head dim 32 with 128-row images: those two are too small, the image gets LDS of its own)
+    constexpr int TRS_ = AT * 2 + 16, T_BYTES = AT * TRS_, NQT = AT / 32;
+    constexpr bool T_OVER = 2 * IB >= T_BYTES;
+    constexpr int GROUP_BYTES = 4 * IB + 3 * AT * (int)sizeof(float) + (T_OVER ? 0 : T_BYTES), NT = PERWAVE ? 64 : 256;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31;
     const int wave = PERWAVE ? 0 : wv, tid = PERWAVE ? lane : (int)threadIdx.x;
     char* smem = smem_all + (PERWAVE ? wv * GROUP_BYTES : 0);
@@ -439,6 +447,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
     float* mterm = reinterpret_cast<float*>(smem + 4 * IB);
     float* lse = mterm + AT;
     float* delta = lse + AT;
+    char* Ts = T_OVER ? Vs : reinterpret_cast<char*>(delta + AT);
     const int sh = PERWAVE ? (int)blockIdx.x * 4 + wv : (int)blockIdx.x;
     if (PERWAVE && sh >= a.n_seq * a.H) return;
     const int s = sh / a.H, h = sh - s * a.H;
@@ -493,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
     const u64 dbase = (u64)(s * a.H + h) * a.max_q;
     const int nqt = (q_len + 31) >> 5, nkt = (k_len + 31) >> 5;
 
+    bf16x8 keep[NQT][2];                          // this wave's key tile: dS against every query tile, as packed for the dK product
     // ---------------- pass 1: wave = key tile → dV, dK (natural layout: key on lane, queries in registers)
     if (wave < nkt) {
         const int k0 = 32 * wave, key = k0 + l31;
@@ -502,7 +512,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
         for (int dt = 0; dt < DH / 32; ++dt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { dv[dt][e] = 0.f; dk[dt][e] = 0.f; }
-        for (int qt = 0; qt < nqt; ++qt) {
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+            if (qt >= nqt) break;
+            __builtin_amdgcn_sched_barrier(0);    // one query tile at a time (registers)
             floatx16 sc, dp;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { sc[e] = 0.f; dp[e] = 0.f; }
@@ -511,33 +524,35 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
                 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(Qs, 32 * qt, ds, lane), frag_rows<DH>(Ks, k0, ds, lane), sc, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(Ds, 32 * qt, ds, lane), frag_rows<DH>(Vs, k0, ds, lane), dp, 0, 0, 0);
             }
-            // no validity selects: keys ≥ k_len carry t = -inf (p = 0); queries ≥ q_len have zero Q / dO rows and lse = delta = 0,
-            // so whatever finite p they get multiplies zeros in both products
-            float pt[16], dsv[16], dm[16];
+            // keys ≥ k_len carry t = -inf (p = 0).  Queries: accumulator register e holds query 32·qt + 4·(lane>>5) + (e&3) + 8·(e>>2);
+            // a group of four registers whose first query is already ≥ q_len is skipped outright (the last tile of a 100-row
+            // sequence has 4 live rows: 4 of 16 registers) and contributes zeros to both products
+            float pt[16], dsv[16];
             const int qb = 32 * qt + 4 * (lane >> 5);
+            const int nvq = q_len - 32 * qt;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int q = qb + (e & 3) + 8 * (e >> 2);
-                float t = mt;
-                if (a.causal) t = (key > q && key < k_len) ? -10000.0f : t;
-                pt[e] = __expf(sc[e] + t - lse[q]);
-                dm[e] = 1.0f;
-            }
-            if (a.p_drop > 0.f) {
-                const u64 rb = (dbase + qb) * a.max_k;
+            for (int g = 0; g < 4; ++g) {
+                if (8 * g < nvq) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) dm[e] = dctx.mul(rb + (u64)(((e & 3) + 8 * (e >> 2)) * a.max_k), key);
-            }
+                    for (int e = 4 * g; e < 4 * g + 4; ++e) {
+                        const int q = qb + (e & 3) + 8 * (e >> 2);
+                        float t = mt;
+                        if (a.causal) t = (key > q && key < k_len) ? -10000.0f : t;
+                        const float p = __expf(sc[e] + t - lse[q]);
+                        float dm = 1.0f;
+                        if (a.p_drop > 0.f) dm = dctx.mul((dbase + qb) * a.max_k + (u64)(((e & 3) + 8 * (e >> 2)) * a.max_k), key);
+                        pt[e] = p * dm;
+                        dsv[e] = p * (dp[e] * dm - delta[q]);
+                    }
+                } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int q = qb + (e & 3) + 8 * (e >> 2);
-                const float p = pt[e];
-                pt[e] = p * dm[e];
-                dsv[e] = p * (dp[e] * dm[e] - delta[q]);
+                    for (int e = 4 * g; e < 4 * g + 4; ++e) { pt[e] = 0.f; dsv[e] = 0.f; }
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 pa = pack8(&pt[8 * s2]), da = pack8(&dsv[8 * s2]);
+                keep[qt][s2] = da;
 #pragma unroll
                 for (int dt = 0; dt < DH / 32; ++dt) {
                     if (TRS) {      // transposed tiles (head columns in registers, this lane's key = the matrix row): 16-byte row stores
@@ -561,44 +576,36 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
             }
         }
     }
-    // ---------------- pass 2: wave = query tile → dQ (transposed layout: query on lane, keys in registers)
+    // ---------------- dSᵀ → LDS.  Every wave has finished reading the V / dO images (barrier); each key-tile wave then lays its rows
+    // down — lane = key, a run of four consecutive queries per 8-byte store — over those images
+    group_sync<PERWAVE>();
+    if (wave < nkt) {
+        const int krow = 32 * wave + l31;
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+            if (qt >= nqt) break;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                union { bf16x8 v; uint2 h[2]; } u;
+                u.v = keep[qt][g >> 1];
+                *reinterpret_cast<uint2*>(Ts + krow * TRS_ + (32 * qt + 8 * g + 4 * (lane >> 5)) * 2) = u.h[g & 1];
+            }
+        }
+    }
+    group_sync<PERWAVE>();
+    // ---------------- pass 2: wave = query tile → dQᵀ = Kᵀ·dSᵀ (a query on a lane); dS comes back from LDS through the transposing
+    // read in exactly the register order the key fragments use — no second evaluation of S, the softmax or the dropout hash
     if (wave < nqt) {
         const int q0 = 32 * wave, q = q0 + l31;
-        const float lq = lse[q], dq_ = delta[q];
         floatx16 dq[DH / 32];
 #pragma unroll
         for (int dt = 0; dt < DH / 32; ++dt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
         for (int kt = 0; kt < nkt; ++kt) {
-            floatx16 sc, dp;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { sc[e] = 0.f; dp[e] = 0.f; }
-#pragma unroll
-            for (int ds = 0; ds < DH / 16; ++ds) {
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(Ks, 32 * kt, ds, lane), frag_rows<DH>(Qs, q0, ds, lane), sc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(Vs, 32 * kt, ds, lane), frag_rows<DH>(Ds, q0, ds, lane), dp, 0, 0, 0);
-            }
-            float dsv[16], dm[16];
-            const int kb = 32 * kt + 4 * (lane >> 5);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = kb + (e & 3) + 8 * (e >> 2);
-                float t = mterm[key];
-                if (a.causal) t = (key > q && key < k_len) ? -10000.0f : t;
-                dsv[e] = __expf(sc[e] + t - lq);      // keys ≥ k_len: t = -inf → 0; lanes of queries ≥ q_len are never stored
-                dm[e] = 1.0f;
-            }
-            if (a.p_drop > 0.f) {
-                const u64 rb = (dbase + q) * a.max_k;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) dm[e] = dctx.mul(rb, kb + (e & 3) + 8 * (e >> 2));
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) dsv[e] = dsv[e] * (dp[e] * dm[e] - dq_);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 da = pack8(&dsv[8 * s2]);
+                const bf16x8 da = frag_tr_rs<TRS_>(Ts, 32 * kt + 16 * s2, q0, lane);
 #pragma unroll
                 for (int dt = 0; dt < DH / 32; ++dt)
                     dq[dt] = TRS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<DH>(Ks, 32 * kt + 16 * s2, 32 * dt, lane), da, dq[dt], 0, 0, 0)
@@ -631,7 +638,9 @@ static int mattn_fwd_go(const MAttnArgs& a, int n_pairs, hipStream_t stream) {
 template <typename T, int DH, int AT>
 static int mattn_bwd_go(const MAttnArgs& a, int n_pairs, hipStream_t stream) {
     constexpr bool PW = (AT == 32);
-    const size_t lds = (4 * (size_t)AT * AImg<DH>::RS + 3 * AT * sizeof(float)) * (PW ? 4 : 1);
+    constexpr size_t t_bytes = (size_t)AT * (AT * 2 + 16);         // dSᵀ image: lies over the V / dO images when they are large enough
+    const size_t lds = (4 * (size_t)AT * AImg<DH>::RS + 3 * AT * sizeof(float) + (2 * (size_t)AT * AImg<DH>::RS >= t_bytes ? 0 : t_bytes)) *
+                       (PW ? 4 : 1);
     int rc = mattn_set_lds((const void*)attn_mfma_bwd_kernel<DH, T, AT, PW>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((attn_mfma_bwd_kernel<DH, T, AT, PW>), dim3(PW ? ceil_div(n_pairs, 4) : n_pairs), dim3(256), lds, stream, a);
