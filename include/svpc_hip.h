@@ -248,6 +248,11 @@ int svpc_loss_tail_bwd(const float* dout, int n_cap, const float* e_p, const flo
                        float gpos, float clip, float eps, float* d_cap, float* de_p, float* da_p, float* dr_e, float* dr_a,
                        svpc_stream_t stream);
 int svpc_row_any_eq1(const float* x, float* out, int R, int C, svpc_stream_t stream);
+/* token staging: up to 8 segments dst[i] = cast(src[idx ? idx[i] : i]) in one launch.  `segments`: array of
+ *   struct { const void* src; const int* idx; void* dst; int src_dt, dst_dt, n; }   (dtype codes 0 fp32, 1 int64, 2 int32; dst fp32 / int32)
+ * — the clip rows' and sentence rows' ids / masks / labels out of the loader's (step, video) tensors, reference train.py:91-112 +
+ * model.py:1038-1042, 925-1015 (there: slicing inside a Python loop over steps and videos). */
+int svpc_gather_cast_multi(const void* segments, int n, svpc_stream_t stream);
 int svpc_clamp_labels(const int* in, int* out, int n, int vocab, int unk, svpc_stream_t stream); /* model.py:1013 */
 int svpc_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, const float* h_prev, const float* active, float* h,
                        float* c, float* gates_act, int N, int D, svpc_stream_t stream);

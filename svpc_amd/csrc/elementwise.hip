@@ -867,6 +867,48 @@ int svpc_row_any_eq1(const float* x, float* out, int R, int C, hipStream_t s) {
     hipLaunchKernelGGL(row_any_eq1_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, x, out, R, C);
     return svpc_check_launch("row_any_eq1");
 }
+// ---- token staging: up to GC_MAX (gather by int32 row index, or identity) + cast segments in one launch.  The training forward reads
+// ids / masks / labels of all (step, video) rows (int64 or fp32, as the reference's loader hands them: train.py:91-112) and needs the
+// clip rows' ids and masks and the sentence rows' ids, masks and labels as int32 / fp32 (model.py:1038-1042, 925-1015): nine cast and
+// index_select launches otherwise.  dtype codes: 0 fp32, 1 int64, 2 int32.
+constexpr int GC_MAX = 8;
+struct GcSeg { const void* src; const int* idx; void* dst; int src_dt, dst_dt, n, block0; };
+struct GcArgs { int n; GcSeg s[GC_MAX]; };
+__global__ __launch_bounds__(256) void gather_cast_multi_kernel(GcArgs a) {
+    int si = 0;
+    while (si + 1 < a.n && (int)blockIdx.x >= a.s[si + 1].block0) ++si;
+    const GcSeg& g = a.s[si];
+    const int i = ((int)blockIdx.x - g.block0) * 256 + (int)threadIdx.x;
+    if (i >= g.n) return;
+    const size_t j = g.idx ? (size_t)g.idx[i] : (size_t)i;
+    if (g.dst_dt == 0) {
+        const float v = g.src_dt == 0 ? reinterpret_cast<const float*>(g.src)[j]
+                      : g.src_dt == 1 ? (float)reinterpret_cast<const long long*>(g.src)[j] : (float)reinterpret_cast<const int*>(g.src)[j];
+        reinterpret_cast<float*>(g.dst)[i] = v;
+    } else {
+        const int v = g.src_dt == 0 ? (int)reinterpret_cast<const float*>(g.src)[j]
+                    : g.src_dt == 1 ? (int)reinterpret_cast<const long long*>(g.src)[j] : reinterpret_cast<const int*>(g.src)[j];
+        reinterpret_cast<int*>(g.dst)[i] = v;
+    }
+}
+struct HostGcSeg { const void* src; const int* idx; void* dst; int src_dt, dst_dt, n; };
+int svpc_gather_cast_multi(const void* segments, int n, hipStream_t s) {
+    SVPC_REQUIRE(n >= 0 && n <= GC_MAX, "gather_cast_multi: at most 8 segments per launch");
+    const HostGcSeg* h = reinterpret_cast<const HostGcSeg*>(segments);
+    GcArgs a{};
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        SVPC_REQUIRE(h[i].src_dt >= 0 && h[i].src_dt <= 2 && (h[i].dst_dt == 0 || h[i].dst_dt == 2) && h[i].n >= 0,
+                     "gather_cast_multi: dtypes are 0 fp32 / 1 int64 / 2 int32 (destination fp32 or int32)");
+        if (h[i].n == 0) continue;
+        GcSeg& g = a.s[a.n++];
+        g.src = h[i].src; g.idx = h[i].idx; g.dst = h[i].dst; g.src_dt = h[i].src_dt; g.dst_dt = h[i].dst_dt; g.n = h[i].n; g.block0 = blocks;
+        blocks += ceil_div(h[i].n, 256);
+    }
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(gather_cast_multi_kernel, dim3(blocks), dim3(256), 0, s, a);
+    return svpc_check_launch("gather_cast_multi");
+}
 int svpc_clamp_labels(const int* in, int* out, int n, int vocab, int unk, hipStream_t s) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(clamp_labels_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, n, vocab, unk);

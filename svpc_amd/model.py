@@ -852,16 +852,18 @@ class StateAwareRecursiveTransformer(nn.Module):
 
         feats = self._stacked(video_features_list).reshape(S_pad * N * L, F)
         # (zero-copy when the per-step tensors are consecutive slices of one buffer: the input pipeline and bench.py hand them so)
-        ids_all = self._stacked(input_ids_list).reshape(-1).to(torch.int32)
-        masks_all = self._stacked(input_masks_list).reshape(-1).float()
-        labels_all = self._stacked(input_labels_list).reshape(-1).to(torch.int32)
+        # token staging in one launch: the clip rows' ids / masks, the sentence rows' ids / masks / labels, the ingredient ids
+        ids_src, masks_src, labels_src = (self._stacked(l).reshape(-1) for l in (input_ids_list, input_masks_list, input_labels_list))
+        ids_v, mask_v, text_ids, text_mask, labels, ingr_ids = ops.gather_cast_multi([
+            (ids_src, plan.video_rows, torch.int32), (masks_src, plan.video_rows, torch.float32),
+            (ids_src, plan.text_rows, torch.int32), (masks_src, plan.text_rows, torch.float32),
+            (labels_src, plan.text_rows, torch.int32), (ingr_input_ids, None, torch.int32)])
 
         # (1) entity initial states, compact (ΣE, D)
-        ents = self.ingredient_embeddings.run(ingr_input_ids.reshape(-1).to(torch.int32), spans, cx)
+        ents = self.ingredient_embeddings.run(ingr_ids, spans, cx)
 
         # (2) clip encoder over all valid clips at once (reference loops S × forward_step, :1038-1042)
-        cls = self._encode_clips(feats, plan.video_rows, ops.take_rows(ids_all, plan.video_rows),
-                                 ops.take_rows(masks_all, plan.video_rows), plan.seq_enc, cx,
+        cls = self._encode_clips(feats, plan.video_rows, ids_v, mask_v, plan.seq_enc, cx,
                                  cls_only=(plan.cls_rows_dev, plan.seq_enc_cls))                  # (T, D): [CLS] rows only
         # Optional two-phase backward for data parallelism (svpc_amd/graph.py): the [CLS] rows are the ONLY tensor through which
         # the loss reaches the clip encoder, so cutting the autograd graph here lets the caller run the text-side backward,
@@ -877,9 +879,6 @@ class StateAwareRecursiveTransformer(nn.Module):
         g = self.step_wise_encoder.run(x, plan.seq_step, None, cx)
 
         # (4) visual simulator, decoder memory
-        text_ids = ops.take_rows(ids_all, plan.text_rows)
-        text_mask = ops.take_rows(masks_all, plan.text_rows)
-        labels = ops.take_rows(labels_all, plan.text_rows)
         sim_out = None
         if mode in ("full", "reason_copy"):
             e_p, a_p, ebar, eall, fbar = self.reasoner.run(g, ents, plan.sim, cx)

@@ -984,6 +984,36 @@ def take_rows(x, idx):
     return torch.index_select(x, 0, idx)
 
 
+class _GcSeg(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("src_dt", ctypes.c_int),
+                ("dst_dt", ctypes.c_int), ("n", ctypes.c_int)]
+
+
+_GC_CODE = {torch.float32: 0, torch.int64: 1, torch.int32: 2}
+
+
+def gather_cast_multi(items):
+    """items: [(src 1-D tensor, int32 row index or None, torch.float32 | torch.int32)] → [dst]; dst[i] = cast(src[idx[i]]) for all
+    items in ONE launch (data movement only, no gradient) — the token staging of the batched forward."""
+    outs, segs = [], []
+    for src, idx, dt in items:
+        src = _c(src.reshape(-1))
+        if src.dtype not in _GC_CODE:
+            src = src.to(torch.float32 if src.dtype.is_floating_point else torch.int64)
+        n = idx.numel() if idx is not None else src.numel()
+        dst = torch.empty(n, dtype=dt, device=src.device)
+        outs.append(dst)
+        segs.append((src, idx, dst))
+    for k in range(0, len(segs), 8):
+        part = segs[k:k + 8]
+        arr = (_GcSeg * len(part))()
+        for i, (src, idx, dst) in enumerate(part):
+            arr[i] = _GcSeg(src.data_ptr(), idx.data_ptr() if idx is not None else None, dst.data_ptr(), _GC_CODE[src.dtype],
+                            _GC_CODE[dst.dtype], dst.numel())
+        _lib.call("gather_cast_multi", ctypes.addressof(arr), len(part), _stream())
+    return outs
+
+
 def clamp_labels(labels, vocab, unk):
     out = torch.empty_like(labels)
     _lib.call("clamp_labels", _p(labels), _p(out), labels.numel(), int(vocab), int(unk), _stream())

@@ -314,6 +314,10 @@ def add(a, b):
     return a + b
 
 
+def gather_cast_multi(items):
+    return [(src.reshape(-1)[idx.long()] if idx is not None else src.reshape(-1)).to(dt) for src, idx, dt in items]
+
+
 def clamp_labels(labels, vocab, unk):
     return torch.where(labels >= vocab, torch.full_like(labels, unk), labels)
 

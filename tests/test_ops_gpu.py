@@ -834,3 +834,23 @@ def test_loss_tail_matches_separate_terms(with_resim, with_sim):
             ok = torch.isfinite(b)        # torch's own BCE statement differentiates log(0)·0 to NaN at the clamp; the kernel gives 0 there
             assert torch.isfinite(a).all() and torch.allclose(a[ok], b[ok], rtol=2e-5, atol=1e-6)
             assert (a[~ok] == 0).all()
+
+
+def test_gather_cast_multi_token_staging():
+    """dst[i] = cast(src[idx[i]]) for several (source, index, type) segments in one launch: bit-exact against index_select + to()."""
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 5000, (23424,), generator=g).to(DEV)                       # int64, as the loader hands them
+    masks = (torch.rand(23424, generator=g) > 0.3).float().to(DEV)
+    labels = torch.randint(-1, 5000, (23424,), generator=g).to(torch.int32).to(DEV)
+    vrows = torch.randint(0, 23424, (19200,), generator=g).to(torch.int32).to(DEV)
+    trows = torch.randint(0, 23424, (4224,), generator=g).to(torch.int32).to(DEV)
+    ingr = torch.randint(0, 900, (16, 100), generator=g).to(DEV)
+    empty = torch.zeros(0, dtype=torch.int64, device=DEV)
+    items = [(ids, vrows, torch.int32), (masks, vrows, torch.float32), (ids, trows, torch.int32), (masks, trows, torch.float32),
+             (labels, trows, torch.int32), (ingr, None, torch.int32), (empty, None, torch.int32), (masks, None, torch.int32),
+             (ids, trows, torch.float32)]                                               # 9 items: two launches
+    outs = O.gather_cast_multi(items)
+    assert len(outs) == len(items)
+    for (src, idx, dt), o in zip(items, outs):
+        ref = (src.reshape(-1)[idx.long()] if idx is not None else src.reshape(-1)).to(dt)
+        assert o.dtype == dt and o.shape == ref.shape and torch.equal(o, ref)
