@@ -281,6 +281,12 @@ int svpc_lstm_cell_bwd_seq(const float* dh_out, const float* dh_rec, const float
 int svpc_lstm_pair_fwd(const float* const* gx, const int* const* rows, const float* const* gh, const float* const* c_prev,
                        const float* const* h_prev, const float* active, float* const* h, float* const* c, float* const* gates, int N, int D,
                        svpc_stream_t stream);
+/* one time step of both directions with the recurrent projection inside: gates = gx[rows] + h_prev·W_hhᵀ (bf16 MFMA operands, fp32
+ * accumulate) and the cell in ONE launch — a workgroup owns 8 hidden units (their i|f|g|o rows of W_hh), so no (N, 4D) buffer goes
+ * through HBM between a GEMM and a cell launch.  D % 16 == 0.  Arguments as svpc_lstm_pair_fwd (w_hh[z]: (4D, D) row-major). */
+int svpc_lstm_pair_step_fwd(const float* const* h_prev, const float* const* c_prev, const float* const* w_hh, const float* const* gx,
+                            const int* const* rows, const float* active, float* const* h, float* const* c, float* const* gates, int N,
+                            int D, svpc_stream_t stream);
 int svpc_lstm_pair_bwd(const float* const* dh_out, const float* const* dh_rec, const float* const* dc, const float* const* gates,
                        const float* const* c_prev, const float* active, float* const* dgates, float* const* dc_prev,
                        float* const* dh_prev, int N, int D, svpc_stream_t stream);

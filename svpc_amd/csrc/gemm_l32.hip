@@ -398,16 +398,13 @@ static int gemm_group_go(const GemmGroupArgs& g, int tiles, hipStream_t stream) 
 // k-steps (192 VGPRs of fp32 operands) are requested before the first is consumed, so K = 768 costs one memory round trip.
 // Partial tiles meet in LDS and are summed in wave order (deterministic); the whole workgroup runs the epilogue.
 // A k-contiguous [M][lda]; B k-contiguous [N][ldb] (B_KC) or k-strided [K][ldb]; K % 16 == 0; rows past an edge are clamped.
+// the k-loop of one 32×32 tile: this wave's share of the 16-deep k-steps, partial tile → part[wave] (the caller syncs and sums).
+// arow / brow: this lane's operand rows (A row lane&31, B column lane&31) already advanced by 8·(lane>>5) k-elements.
 template <bool B_KC, int NW>
-__device__ __forceinline__ void skinny_tile(float (*part)[16][64], const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                            float* __restrict__ C, int ldc, int M, int N, int K, const Epi& epi, int tm, int tn) {
+__device__ __forceinline__ void skinny_partials(float (*part)[16][64], const float* __restrict__ arow, const float* __restrict__ brow,
+                                                int ldb, int K) {
     constexpr int BATCH = 12;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int m0 = tm * 32, n0 = tn * 32;
-    const int r = lane & 31, h = lane >> 5;
-    const float* __restrict__ arow = A + (size_t)min(m0 + r, M - 1) * lda + 8 * h;
-    const int bcol = min(n0 + r, N - 1);
-    const float* __restrict__ brow = B_KC ? B + (size_t)bcol * ldb + 8 * h : B + (size_t)(8 * h) * ldb + bcol;
     const int nsteps = K >> 4;                                  // 16-deep k-steps; this wave takes wave, wave+NW, …
     floatx16 acc;
 #pragma unroll
@@ -450,6 +447,17 @@ __device__ __forceinline__ void skinny_tile(float (*part)[16][64], const float* 
 #pragma unroll
     for (int e = 0; e < 16; ++e) part[wave][e][lane] = acc[e];
     __syncthreads();
+}
+template <bool B_KC, int NW>
+__device__ __forceinline__ void skinny_tile(float (*part)[16][64], const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                            float* __restrict__ C, int ldc, int M, int N, int K, const Epi& epi, int tm, int tn) {
+    const int lane = threadIdx.x & 63;
+    const int m0 = tm * 32, n0 = tn * 32;
+    const int r = lane & 31, h = lane >> 5;
+    const float* __restrict__ arow = A + (size_t)min(m0 + r, M - 1) * lda + 8 * h;
+    const int bcol = min(n0 + r, N - 1);
+    const float* __restrict__ brow = B_KC ? B + (size_t)bcol * ldb + 8 * h : B + (size_t)(8 * h) * ldb + bcol;
+    skinny_partials<B_KC, NW>(part, arow, brow, ldb, K);
     const u64 seed = epi.p_drop > 0.f ? epi.seed[0] : 0ull;
     const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
     const int col = threadIdx.x & 31;
@@ -483,7 +491,70 @@ __global__ __launch_bounds__(64 * NW) void gemm_group_skinny_kernel(GemmGroupArg
     skinny_tile<true, NW>(part, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, epi, tm, tn);
 }
 
+// ---- one time step of BOTH LSTM directions, recurrent projection and cell in one launch (reference: nn.LSTM inside
+// model.py:1022-1024; per step and direction gates = gx[row] + h_{t-1}·W_hhᵀ, then the cell).  A workgroup owns 8 hidden units of one
+// direction: its 32 tile columns are those units' i | f | g | o gate rows of W_hh, so after the wave-split k-loop (K = D, one memory
+// round trip) the four gate sums of a (video, unit) pair meet in LDS and the cell is evaluated there — no (N, 4D) gate buffer between
+// a GEMM launch and a cell launch.  Inactive videos (sequence ended) carry their state.  Same arithmetic as gemm_group_skinny +
+// lstm_pair_fwd (bf16 MFMA operands rounded from fp32, fp32 accumulate, wave-ordered sums).
+struct LstmStep {
+    const float* h_prev[2]; const float* c_prev[2]; const float* w_hh[2]; const float* gx[2]; const int* rows[2]; const float* active;
+    float* h[2]; float* c[2]; float* gates[2]; int N, D;
+};
+__global__ __launch_bounds__(256) void lstm_pair_step_fwd_kernel(LstmStep a) {
+    __shared__ float part[4][16][64];
+    const int z = blockIdx.y, u0 = blockIdx.x * 8, m0 = blockIdx.z * 32;
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int N = a.N, D = a.D;
+    const float* arow = a.h_prev[z] + (size_t)min(m0 + r, N - 1) * D + 8 * hh;
+    const float* brow = a.w_hh[z] + (size_t)((r >> 3) * D + u0 + (r & 7)) * D + 8 * hh;      // tile column r ↔ gate r>>3 of unit u0 + (r&7)
+    skinny_partials<true, 4>(part, arow, brow, D, D);
+    const int row = threadIdx.x >> 3, j = threadIdx.x & 7, n = m0 + row;
+    if (n >= N) return;
+    float gsum[4];
+    const int e = (row & 3) + 4 * (row >> 3), lb = 32 * ((row >> 2) & 1);      // accumulator element / lane half that hold this row
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int l = g * 8 + j + lb;
+        float v = part[0][e][l];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += part[w][e][l];
+        gsum[g] = v;
+    }
+    const int d = u0 + j;
+    const size_t i = (size_t)n * D + d, g0 = (size_t)n * 4 * D + d;
+    const float* gx = a.gx[z] + (size_t)a.rows[z][n] * 4 * D + d;
+    const float gi = sigmoidf_(gx[0] + gsum[0]);
+    const float gf = sigmoidf_(gx[D] + gsum[1]);
+    const float gg = tanhf(gx[2 * D] + gsum[2]);
+    const float go = sigmoidf_(gx[3 * D] + gsum[3]);
+    float* ga = a.gates[z];
+    ga[g0] = gi; ga[g0 + D] = gf; ga[g0 + 2 * D] = gg; ga[g0 + 3 * D] = go;
+    const float cp = a.c_prev[z][i];
+    const float cn = gf * cp + gi * gg;
+    const float hn = go * tanhf(cn);
+    const float act = a.active[n];
+    a.c[z][i] = act * cn + (1.f - act) * cp;
+    a.h[z][i] = act * hn + (1.f - act) * a.h_prev[z][i];
+}
+
 extern "C" {
+
+int svpc_lstm_pair_step_fwd(const float* const* h_prev, const float* const* c_prev, const float* const* w_hh, const float* const* gx,
+                            const int* const* rows, const float* active, float* const* h, float* const* c, float* const* gates, int N,
+                            int D, hipStream_t stream) {
+    if (N == 0) return 0;
+    SVPC_REQUIRE(D % 16 == 0 && D >= 16, "lstm_pair_step_fwd: hidden size must be a multiple of 16");
+    LstmStep a{};
+    for (int z = 0; z < 2; ++z) {
+        SVPC_REQUIRE(((((uintptr_t)h_prev[z]) | ((uintptr_t)w_hh[z])) & 15) == 0, "lstm_pair_step_fwd: 16-byte aligned state / weight rows");
+        a.h_prev[z] = h_prev[z]; a.c_prev[z] = c_prev[z]; a.w_hh[z] = w_hh[z]; a.gx[z] = gx[z]; a.rows[z] = rows[z];
+        a.h[z] = h[z]; a.c[z] = c[z]; a.gates[z] = gates[z];
+    }
+    a.active = active; a.N = N; a.D = D;
+    hipLaunchKernelGGL(lstm_pair_step_fwd_kernel, dim3(D / 8, 2, ceil_div(N, 32)), dim3(256), 0, stream, a);
+    return svpc_check_launch("lstm_pair_step_fwd");
+}
 
 // 1 if the fp32 direct-to-LDS kernel can run this (shape, layout): whole k-tiles, 16-byte aligned chunks, and for a k-strided
 // operand a row count that is a multiple of 4 (its 16-byte chunks run along the rows)

@@ -88,12 +88,15 @@ class _FcStack(nn.Module):
     def __getitem__(self, i):
         return getattr(self, str(i))
 
-    def run(self, x, eps, src_rows=None, pad_row=-1, drop=None, add1=None, add1_mod=0, add2=None, add2_idx=None, out_bf16=False):
+    def run(self, x, eps, src_rows=None, pad_row=-1, drop=None, add1=None, add1_mod=0, add2=None, add2_idx=None, out_bf16=False,
+            final_bf16=False):
+        """out_bf16: the whole stack runs on a bf16 stream from the first LayerNorm on; final_bf16: only the last LayerNorm writes
+        bf16 (its consumer is a bf16 stream — saves the separate cast)."""
         xn = ops.layernorm(x, self[0].weight, self[0].bias, eps, src_rows=src_rows, pad_row=pad_row, post_drop=drop,
                            out_bf16=out_bf16)
         h = ops.linear(xn, self[2].weight, self[2].bias, act=ACT_RELU)
         return ops.layernorm(h, self[4].weight, self[4].bias, eps, add1=add1, add1_mod=add1_mod,
-                             add2=add2, add2_idx=add2_idx)
+                             add2=add2, add2_idx=add2_idx, out_bf16=final_bf16)
 
 
 class _Seq1(nn.Module):
@@ -343,11 +346,16 @@ class BertDecoderNoMemoryUntied(nn.Module):
         wg, bg = sg if sg is not None else (None, None)
         return sw[0], sw[1], wg, bg, sw[2]
 
+    def streams_bf16(self, rows, width):
+        """whether ``run`` keeps the sentence activations of (rows, width) in bf16"""
+        return ops.bf16_stream_ok(rows, width, self.config.intermediate_size)
+
     def run(self, x, text_mask, mem, seq_self, seq_cross, mem_mask, cx):
         # interior-only row counts in bf16 precision: the sentence activations (and their gradients) stream through HBM as bf16
-        stream_bf16 = x.dtype == torch.float32 and ops.bf16_stream_ok(x.shape[0], x.shape[1], self.config.intermediate_size)
+        stream_bf16 = self.streams_bf16(x.shape[0], x.shape[1])
         if stream_bf16:
-            x = x.to(torch.bfloat16)
+            if x.dtype != torch.bfloat16:      # (the caller may have had the embedding LayerNorm write bf16 already)
+                x = x.to(torch.bfloat16)
             # the memory rows join the stream once, not per layer: each layer's K|V projection then reads bf16 and writes bf16
             # (one cast instead of six casts forward and six backward; its weight gradients join the grouped bf16 launch)
             if mem.dtype == torch.float32 and ops.bf16_stream_ok(mem.shape[0], mem.shape[1], 2 * mem.shape[1]):
@@ -408,10 +416,10 @@ class BertEmbeddingsTextUntied(nn.Module):
         self.word_embeddings = nn.Embedding.from_pretrained(pretrained_embedding, freeze=freeze,
                                                             padding_idx=self.word_embeddings.padding_idx)
 
-    def run(self, ids_flat, lt, cx):
+    def run(self, ids_flat, lt, cx, out_bf16=False):
         return self.word_fc.run(self.word_embeddings.weight, cx.eps, src_rows=ids_flat, pad_row=PAD_ROW,
                                 drop=cx.drop(cx.p_h), add1=self.position_embeddings_text.pe[:lt].contiguous(),
-                                add1_mod=lt)
+                                add1_mod=lt, final_bf16=out_bf16)
 
     def run_at(self, ids, pos, cx):
         """One token per sentence, all at sentence position ``pos`` (incremental decoding)."""
@@ -896,7 +904,7 @@ class StateAwareRecursiveTransformer(nn.Module):
             bank = None
 
         # (5) decoder over all T sentences at once (reference: per video, :1086/:925-1015)
-        xt = self.text_embeddings.run(text_ids, Lt, cx)
+        xt = self.text_embeddings.run(text_ids, Lt, cx, out_bf16=self.decoder.streams_bf16(T * Lt, D))
         dec = self.decoder.run(xt, text_mask, mem, plan.seq_dec_self, plan.seq_dec_cross, None, cx)
 
         # (6) head + pointer-generator + label-smoothed KL

@@ -1314,6 +1314,7 @@ def _ptr2(a, b):
 
 
 LSTM_DGRAD_PARTS = int(os.environ.get("SVPC_LSTM_DGRAD_PARTS", "4"))
+LSTM_FUSED_STEP = os.environ.get("SVPC_LSTM_FUSED_STEP", "1") != "0"      # recurrent projection and cell of a time step in one launch
 
 
 class _BiLstmSeq(Function):
@@ -1338,11 +1339,18 @@ class _BiLstmSeq(Function):
         gates = [mk(S, N, 4 * D) for _ in range(2)]
         gh = [mk(N, 4 * D) for _ in range(2)]
         st = _stream()
+        fused = LSTM_FUSED_STEP and D % 16 == 0 and (w[0].data_ptr() | w[1].data_ptr()) % 16 == 0
+        pw = _ptr2(w[0], w[1])
+        pgx = _ptr2(gx[0], gx[1])
         for t in range(S):
-            _gemm_pair([h_all[0][t], h_all[1][t]], w, gh, N, 4 * D, D)
-            args = [_ptr2(gx[0], gx[1]), _ptr2(rows[0][t], rows[1][t]), _ptr2(gh[0], gh[1]), _ptr2(c_all[0][t], c_all[1][t]),
+            args = [pgx, _ptr2(rows[0][t], rows[1][t]), _ptr2(gh[0], gh[1]), _ptr2(c_all[0][t], c_all[1][t]),
                     _ptr2(h_all[0][t], h_all[1][t]), None, _ptr2(h_all[0][t + 1], h_all[1][t + 1]),
                     _ptr2(c_all[0][t + 1], c_all[1][t + 1]), _ptr2(gates[0][t], gates[1][t])]
+            if fused:       # recurrent projection + cell in one launch per time step
+                _lib.call("lstm_pair_step_fwd", args[4][0], args[3][0], pw[0], args[0][0], args[1][0], _p(active_t[t]), args[6][0],
+                          args[7][0], args[8][0], N, D, st)
+                continue
+            _gemm_pair([h_all[0][t], h_all[1][t]], w, gh, N, 4 * D, D)
             _lib.call("lstm_pair_fwd", args[0][0], args[1][0], args[2][0], args[3][0], args[4][0], _p(active_t[t]), args[6][0],
                       args[7][0], args[8][0], N, D, st)
         outs = [torch.index_select(h_all[z][1:].reshape(S * N, D), 0, pk) for z, pk in enumerate((pick_f, pick_b))]

@@ -703,13 +703,17 @@ def test_grouped_weight_gradients(bf16_mode):
             assert (db.double() - rb).abs().max().item() <= 1e-5 * max(1.0, rb.abs().max().item()), (rows, n_out)
 
 
-def test_bilstm_lockstep_matches_two_direction_nodes(bf16_mode):
-    """Fused two-direction recurrence (grouped GEMM + pair cell kernels) against the per-direction torch statement: outputs and
-    gradients of both input projections and both recurrent weights (bf16 MFMA operands → 2e-2 tolerance), ragged lengths."""
+@pytest.mark.parametrize("N,D,fused", [(3, 32, True), (3, 32, False), (35, 64, True), (16, 768, True)])
+def test_bilstm_lockstep_matches_two_direction_nodes(bf16_mode, N, D, fused):
+    """Fused two-direction recurrence against the per-direction torch statement: outputs and gradients of both input projections and
+    both recurrent weights (bf16 MFMA operands → 2e-2 tolerance), ragged lengths.  fused: recurrent projection + cell in one launch
+    per time step (svpc_lstm_pair_step_fwd; 35 videos = two row tiles, 768 = the headline width) — else grouped GEMM + cell launches."""
     torch.manual_seed(0)
-    N, D, lens = 3, 32, [3, 1, 2]
+    lens = [3, 1, 2] if N == 3 else [1 + (7 * b + 3) % 4 for b in range(N)]
     S, T = max(lens), sum(lens)
-    off = [0, 3, 4]
+    off = [sum(lens[:b]) for b in range(N)]
+    keep_fused = O.LSTM_FUSED_STEP
+    O.LSTM_FUSED_STEP = fused
     mk = lambda f: [torch.tensor([f(b, t) for b in range(N)], dtype=torch.int32, device=DEV) for t in range(S)]
     rows_f = mk(lambda b, t: off[b] + min(t, lens[b] - 1))
     rows_b = mk(lambda b, t: off[b] + max(lens[b] - 1 - t, 0))
@@ -717,7 +721,8 @@ def test_bilstm_lockstep_matches_two_direction_nodes(bf16_mode):
     pick_f = torch.tensor([s_ * N + b for b in range(N) for s_ in range(lens[b])], dtype=torch.int32, device=DEV)
     pick_b = torch.tensor([(lens[b] - 1 - s_) * N + b for b in range(N) for s_ in range(lens[b])], dtype=torch.int32, device=DEV)
     leaves = [torch.randn(T, 4 * D, device=DEV, requires_grad=True), torch.randn(T, 4 * D, device=DEV, requires_grad=True),
-              (0.3 * torch.randn(4 * D, D, device=DEV)).requires_grad_(True), (0.3 * torch.randn(4 * D, D, device=DEV)).requires_grad_(True)]
+              ((0.3 if D <= 64 else 0.04) * torch.randn(4 * D, D, device=DEV)).requires_grad_(True),
+              ((0.3 if D <= 64 else 0.04) * torch.randn(4 * D, D, device=DEV)).requires_grad_(True)]
     wt_f, wt_b = torch.randn(T, D, device=DEV), torch.randn(T, D, device=DEV)
     res = []
     for mod in (O, E):
@@ -727,6 +732,7 @@ def test_bilstm_lockstep_matches_two_direction_nodes(bf16_mode):
         ((of * wt_f).sum() + (ob * wt_b).sum()).backward()
         torch.cuda.synchronize()
         res.append([of.detach().clone(), ob.detach().clone()] + [l.grad.clone() for l in leaves])
+    O.LSTM_FUSED_STEP = keep_fused
     for a, b in zip(res[0], res[1]):
         assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item()), (a - b).abs().max()
 
