@@ -287,11 +287,6 @@ int svpc_lstm_pair_fwd(const float* const* gx, const int* const* rows, const flo
 int svpc_lstm_pair_step_fwd(const float* const* h_prev, const float* const* c_prev, const float* const* w_hh, const float* const* gx,
                             const int* const* rows, const float* active, float* const* h, float* const* c, float* const* gates, int N,
                             int D, svpc_stream_t stream);
-/* … and the backward time step: dh_t = dh_out + dh_rec (pass-through of ended sequences) + dgates[t+1]·W_hh, computed by this launch
- * (dg_next = NULL at the last step; W_hh read in place, no transposed copy), then the cell backward → dgates[t], dc, pass-through dh */
-int svpc_lstm_pair_step_bwd(const float* const* dg_next, const float* const* w_hh, const float* const* dh_out, const float* const* dh_rec,
-                            const float* const* dc, const float* const* gates, const float* const* c_prev, const float* active,
-                            float* const* dgates, float* const* dc_prev, float* const* dh_prev, int N, int D, svpc_stream_t stream);
 int svpc_lstm_pair_bwd(const float* const* dh_out, const float* const* dh_rec, const float* const* dc, const float* const* gates,
                        const float* const* c_prev, const float* active, float* const* dgates, float* const* dc_prev,
                        float* const* dh_prev, int N, int D, svpc_stream_t stream);

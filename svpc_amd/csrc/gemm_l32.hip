@@ -538,70 +538,7 @@ __global__ __launch_bounds__(256) void lstm_pair_step_fwd_kernel(LstmStep a) {
     a.h[z][i] = act * hn + (1.f - act) * a.h_prev[z][i];
 }
 
-// ---- the backward twin: one time step t of both directions.  dh_t = dh_out[t] + (pass-through of the ended sequences) + dgates[t+1]·W_hh
-// — the last term is this launch's k-loop (K = 4D, W_hh read k-strided: no transposed copy of the weights), a workgroup owns 32 hidden
-// units — then the cell backward for those units writes dgates[t], the running dc and the pass-through dh.  One launch per step
-// instead of a cell launch plus a grouped dgrad.  dg_next[z] = null at the last time step (no recurrent term).
-struct LstmStepB {
-    const float* dg_next[2]; const float* w_hh[2]; const float* dh_out[2]; const float* dh_rec[2]; const float* dc[2]; const float* gates[2];
-    const float* c_prev[2]; const float* active; float* dgates[2]; float* dc_prev[2]; float* dh_prev[2]; int N, D;
-};
-__global__ __launch_bounds__(512) void lstm_pair_step_bwd_kernel(LstmStepB a) {
-    __shared__ float part[8][16][64];
-    const int z = blockIdx.y, n0 = blockIdx.x * 32, m0 = blockIdx.z * 32;
-    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-    const int N = a.N, D = a.D;
-    const bool rec = a.dg_next[z] != nullptr;
-    const float* arow = rec ? a.dg_next[z] + (size_t)min(m0 + r, N - 1) * 4 * D + 8 * hh : nullptr;
-    const float* brow = a.w_hh[z] + (size_t)(8 * hh) * D + min(n0 + r, D - 1);              // W_hh[k][d]: k-strided, leading dimension D
-    skinny_partials<false, 8>(part, arow, brow, D, rec ? 4 * D : 0);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int idx = threadIdx.x + 512 * it, row = idx >> 5, col = idx & 31;
-        const int n = m0 + row, d = n0 + col;
-        if (n >= N || d >= D) continue;
-        const int e = (row & 3) + 4 * (row >> 3), l = col + 32 * ((row >> 2) & 1);
-        float v = part[0][e][l];
-#pragma unroll
-        for (int w = 1; w < 8; ++w) v += part[w][e][l];                                    // wave order: deterministic
-        const size_t i = (size_t)n * D + d, g0 = (size_t)n * 4 * D + d;
-        const float* ga = a.gates[z];
-        const float gi = ga[g0], gf = ga[g0 + D], gg = ga[g0 + 2 * D], go = ga[g0 + 3 * D];
-        const float act = a.active[n];
-        const float dht = a.dh_out[z][i] + a.dh_rec[z][i] + v;
-        const float dci = a.dc[z][i], cp = a.c_prev[z][i];
-        const float dhn = act * dht, dcn_in = act * dci;
-        const float cn = gf * cp + gi * gg;
-        const float tc = tanhf(cn);
-        const float dcn = dcn_in + dhn * go * (1.f - tc * tc);
-        float* dg = a.dgates[z];
-        dg[g0] = dcn * gg * gi * (1.f - gi);
-        dg[g0 + D] = dcn * cp * gf * (1.f - gf);
-        dg[g0 + 2 * D] = dcn * gi * (1.f - gg * gg);
-        dg[g0 + 3 * D] = dhn * tc * go * (1.f - go);
-        a.dc_prev[z][i] = dcn * gf + (1.f - act) * dci;
-        a.dh_prev[z][i] = (1.f - act) * dht;
-    }
-}
-
 extern "C" {
-
-int svpc_lstm_pair_step_bwd(const float* const* dg_next, const float* const* w_hh, const float* const* dh_out, const float* const* dh_rec,
-                            const float* const* dc, const float* const* gates, const float* const* c_prev, const float* active,
-                            float* const* dgates, float* const* dc_prev, float* const* dh_prev, int N, int D, hipStream_t stream) {
-    if (N == 0) return 0;
-    SVPC_REQUIRE(D % 16 == 0 && D >= 32, "lstm_pair_step_bwd: hidden size must be a multiple of 16, at least 32");
-    LstmStepB a{};
-    for (int z = 0; z < 2; ++z) {
-        a.dg_next[z] = dg_next ? dg_next[z] : nullptr;
-        SVPC_REQUIRE((((uintptr_t)a.dg_next[z]) & 15) == 0, "lstm_pair_step_bwd: 16-byte aligned gate-gradient rows");
-        a.w_hh[z] = w_hh[z]; a.dh_out[z] = dh_out[z]; a.dh_rec[z] = dh_rec[z]; a.dc[z] = dc[z]; a.gates[z] = gates[z];
-        a.c_prev[z] = c_prev[z]; a.dgates[z] = dgates[z]; a.dc_prev[z] = dc_prev[z]; a.dh_prev[z] = dh_prev[z];
-    }
-    a.active = active; a.N = N; a.D = D;
-    hipLaunchKernelGGL(lstm_pair_step_bwd_kernel, dim3(ceil_div(D, 32), 2, ceil_div(N, 32)), dim3(512), 0, stream, a);
-    return svpc_check_launch("lstm_pair_step_bwd");
-}
 
 int svpc_lstm_pair_step_fwd(const float* const* h_prev, const float* const* c_prev, const float* const* w_hh, const float* const* gx,
                             const int* const* rows, const float* active, float* const* h, float* const* c, float* const* gates, int N,

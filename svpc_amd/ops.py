@@ -1383,25 +1383,14 @@ class _BiLstmSeq(Function):
         dc = [tail[2], tail[3]]
         dh2, dc2 = [mk(N, D) for _ in range(2)], [mk(N, D) for _ in range(2)]
         st = _stream()
-        fused = LSTM_FUSED_STEP and D % 16 == 0 and D >= 32 and (w[0].data_ptr() | w[1].data_ptr()) % 16 == 0
-        if fused:       # one launch per time step: recurrent dgrad (weights read in place) + cell backward
-            pw = _ptr2(w[0], w[1])
-            for t in range(S - 1, -1, -1):
-                a = [_ptr2(dhs[0][t], dhs[1][t]), _ptr2(dh[0], dh[1]), _ptr2(dc[0], dc[1]), _ptr2(gates[0][t], gates[1][t]),
-                     _ptr2(c_all[0][t], c_all[1][t]), None, _ptr2(dG[0][t], dG[1][t]), _ptr2(dc2[0], dc2[1]), _ptr2(dh2[0], dh2[1])]
-                nxt = _ptr2(dG[0][t + 1], dG[1][t + 1]) if t + 1 < S else (None, None)
-                _lib.call("lstm_pair_step_bwd", nxt[0], pw[0], a[0][0], a[1][0], a[2][0], a[3][0], a[4][0], _p(active_t[t]), a[6][0],
-                          a[7][0], a[8][0], N, D, st)
-                dh, dh2 = dh2, dh
-                dc, dc2 = dc2, dc
-        wt = [w[z].t().contiguous() for z in range(2)] if not fused else None     # (D, 4D): k-contiguous operand of the per-step dgrad
+        wt = [w[z].t().contiguous() for z in range(2)]        # (D, 4D): k-contiguous operand of the per-step dgrad
         # the per-step dgrad (N × D over K = 4D) is bound by how fast ONE workgroup can pull its weight columns: cut K into
         # LSTM_DGRAD_PARTS k-parts (separate problems of the grouped launch, each writing a slab) that the next cell launch adds
         P = LSTM_DGRAD_PARTS if (4 * D) % (32 * LSTM_DGRAD_PARTS) == 0 else 1
         Kp = 4 * D // P
         slabs = [mk(P, N, D) for _ in range(2)] if P > 1 else None
         have_parts = False
-        for t in range(S - 1, -1, -1) if not fused else ():
+        for t in range(S - 1, -1, -1):
             a = [_ptr2(dhs[0][t], dhs[1][t]), _ptr2(dh[0], dh[1]), _ptr2(dc[0], dc[1]), _ptr2(gates[0][t], gates[1][t]),
                  _ptr2(c_all[0][t], c_all[1][t]), None, _ptr2(dG[0][t], dG[1][t]), _ptr2(dc2[0], dc2[1]), _ptr2(dh2[0], dh2[1])]
             if P > 1:

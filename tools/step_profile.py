@@ -14,7 +14,7 @@ t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
 dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 print("kernels %d  span %.3f ms  sum %.3f ms" % (len(step), (t1 - t0) / 1e6, sum(dur(r) for r in step) / 1e6))
 gaps = [int(step[i + 1]["Start_Timestamp"]) - int(step[i]["End_Timestamp"]) for i in range(len(step) - 1)]
-pos = sorted(g_ for g_ in gaps if g_ > 0)
+pos = sorted(g_ for g_ in gaps if g_ > 0) or [0]
 print("gaps between consecutive kernels: total %.3f ms, median %.2f us, p90 %.2f us, max %.1f us; kernels shorter than 6 us: %d (sum %.3f ms)"
       % (sum(pos) / 1e6, pos[len(pos) // 2] / 1e3, pos[int(len(pos) * 0.9)] / 1e3, pos[-1] / 1e3,
          sum(1 for r in step if dur(r) < 6000), sum(dur(r) for r in step if dur(r) < 6000) / 1e6))
