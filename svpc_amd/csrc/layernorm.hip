@@ -558,6 +558,9 @@ int svpc_ln_fwd_t(const void* x, int x_dt, const int* src_rows, const void* res,
                      (!res || aligned16(res)) && (!add1 || aligned16(add1)) && (!add2 || aligned16(add2));
     if (vec) {
         if (D <= 256) return launch_ln_fwd<1, 4>(a, x_dt, y_dt, stream);
+        static int npl3 = -1;
+        if (npl3 < 0) { const char* e = getenv("SVPC_LN_FWD_NPL3"); npl3 = e ? atoi(e) : 1; }
+        if (D <= 768 && npl3) return launch_ln_fwd<3, 4>(a, x_dt, y_dt, stream);     // 12 values per lane: no dead quarter of registers
         if (D <= 1024) return launch_ln_fwd<4, 4>(a, x_dt, y_dt, stream);
         if (D <= 3072) return launch_ln_fwd<12, 4>(a, x_dt, y_dt, stream);
         if (D <= 8192) return launch_ln_fwd<32, 4>(a, x_dt, y_dt, stream);
