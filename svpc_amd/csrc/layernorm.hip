@@ -157,9 +157,13 @@ struct LnBwdArgs {
 // workgroups resident per CU the kernel is bound by bytes in flight, not by bandwidth).  dgamma / dbeta partials stay in
 // registers across the wave's rows, are combined over the 4 waves in a fixed order through LDS, and leave as one row of
 // `partial` per workgroup (summed by ln_finalize_kernel) — deterministic, no atomics.
+// LACC (the 12-values-per-lane, two-rows-in-flight instances): gamma and every wave's dgamma / dbeta accumulators live in LDS
+// (lane-private addresses, float4 read-modify-write per row) instead of 36 registers — the kernel waits on memory, so what counts
+// is resident waves: ≤ 128 registers = four waves per SIMD instead of three.
 template <int NPL, int W, typename TX, typename TY, int RU>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
-    extern __shared__ float smem[];  // 2*D floats
+__global__ __launch_bounds__(256, (W == 4 && NPL * W <= 12 && RU == 2) ? 4 : 1) void ln_bwd_kernel(LnBwdArgs a) {
+    constexpr bool LACC = W == 4 && NPL * W <= 12 && RU == 2;
+    extern __shared__ float smem[];  // 2*D floats; LACC: gamma [D] + 4 waves × [dgamma ; dbeta] [2D]
     const TY* __restrict__ dyp = reinterpret_cast<const TY*>(a.dy);
     const TX* __restrict__ xp = reinterpret_cast<const TX*>(a.x);
     const TY* __restrict__ rp = reinterpret_cast<const TY*>(a.res);
@@ -174,13 +178,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     const float ik_post = a.p_post > 0.f ? 1.0f / (1.0f - a.p_post) : 1.0f;
     const float invD = 1.0f / (float)D;
 
-    float g[NPL * W], accg[NPL * W], accb[NPL * W];
+    float g[LACC ? 1 : NPL * W], accg[LACC ? 1 : NPL * W], accb[LACC ? 1 : NPL * W];
+    float* const lg = smem;                                  // LACC: gamma
+    float* const lacc = smem + D + (size_t)wave * 2 * D;     // LACC: this wave's [dgamma ; dbeta]
+    if constexpr (LACC) {
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-        const int col = (lane + 64 * i) * W;
+        for (int i = 0; i < NPL; ++i) {
+            const int col = (lane + 64 * i) * W;
+            if (col < D) {
+                *reinterpret_cast<float4*>(lacc + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(lacc + D + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (wave == 0) *reinterpret_cast<float4*>(lg + col) = *reinterpret_cast<const float4*>(a.gamma + col);
+            }
+        }
+        __syncthreads();
+    } else {
 #pragma unroll
-        for (int j = 0; j < W; ++j) { accg[i * W + j] = 0.f; accb[i * W + j] = 0.f; g[i * W + j] = 0.f; }
-        if (col < D) VecIO<W, float>::load(a.gamma + col, &g[i * W]);
+        for (int i = 0; i < NPL; ++i) {
+            const int col = (lane + 64 * i) * W;
+#pragma unroll
+            for (int j = 0; j < W; ++j) { accg[i * W + j] = 0.f; accb[i * W + j] = 0.f; g[i * W + j] = 0.f; }
+            if (col < D) VecIO<W, float>::load(a.gamma + col, &g[i * W]);
+        }
     }
     const int stride = gridDim.x * 4;
     for (int r0 = blockIdx.x * 4 + wave; r0 < a.R; r0 += stride * RU) {
@@ -229,18 +248,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
             for (int i = 0; i < NPL; ++i) {
                 const int col = (lane + 64 * i) * W;
                 if (col < D) {
+                    float gv[W], ag[W], ab[W];
+                    if constexpr (LACC) {
+                        const float4 t0 = *reinterpret_cast<const float4*>(lg + col), t1 = *reinterpret_cast<const float4*>(lacc + col),
+                                     t2 = *reinterpret_cast<const float4*>(lacc + D + col);
+                        gv[0] = t0.x; gv[1] = t0.y; gv[2] = t0.z; gv[3] = t0.w;
+                        ag[0] = t1.x; ag[1] = t1.y; ag[2] = t1.z; ag[3] = t1.w;
+                        ab[0] = t2.x; ab[1] = t2.y; ab[2] = t2.z; ab[3] = t2.w;
+                    }
 #pragma unroll
                     for (int j = 0; j < W; ++j) {
                         float dy0 = d[u][i * W + j];
                         if (a.p_post > 0.f) dy0 *= drop_scale(seed, a.site_post, orow + col + j, a.p_post, ik_post);
                         const float xhat = (h[u][i * W + j] - mean[u]) * rstd[u];
-                        accg[i * W + j] += dy0 * xhat;
-                        accb[i * W + j] += dy0;
-                        const float t = dy0 * g[i * W + j];
+                        if constexpr (LACC) { ag[j] += dy0 * xhat; ab[j] += dy0; }
+                        else { accg[i * W + j] += dy0 * xhat; accb[i * W + j] += dy0; }
+                        const float t = dy0 * (LACC ? gv[j] : g[i * W + j]);
                         h[u][i * W + j] = xhat;
                         d[u][i * W + j] = t;
                         s1 += t;
                         s2 += t * xhat;
+                    }
+                    if constexpr (LACC) {
+                        *reinterpret_cast<float4*>(lacc + col) = make_float4(ag[0], ag[1], ag[2], ag[3]);
+                        *reinterpret_cast<float4*>(lacc + D + col) = make_float4(ab[0], ab[1], ab[2], ab[3]);
                     }
                 }
             }
@@ -266,6 +297,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
                 }
             }
         }
+    }
+    if constexpr (LACC) {      // the four waves' accumulators are in LDS already: add them in wave order, one partial row per workgroup
+        __syncthreads();
+        float* out = a.partial + (size_t)blockIdx.x * 2 * D;
+        for (int c = threadIdx.x; c < 2 * D; c += 256) {
+            float v = smem[D + c];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) v += smem[D + (size_t)w * 2 * D + c];
+            out[c] = v;
+        }
+        return;
     }
     // workgroup reduce of the gamma/beta partials through LDS: wave 0 stores, waves 1..3 add in order (each lane owns its columns)
 #pragma unroll
@@ -524,10 +566,11 @@ static int launch_ln_fwd(const LnArgs& a, int x_dt, int y_dt, hipStream_t s) {
 template <int NPL, int W>
 static int launch_ln_bwd(const LnBwdArgs& a, int G, int x_dt, int y_dt, hipStream_t s) {
     const dim3 g(G), b(256);
-    const size_t lds = (size_t)2 * a.D * sizeof(float);
     constexpr int RU = (NPL * W <= 16) ? 2 : 1;      // two rows in flight per wave while the registers allow it
+    constexpr bool LACC = W == 4 && NPL * W <= 12 && RU == 2;
     static int ru_env = -1;
     if (ru_env < 0) { const char* e = getenv("SVPC_LN_RU"); ru_env = e ? atoi(e) : 0; }
+    const size_t lds = (size_t)((LACC && ru_env != 1) ? 9 : 2) * a.D * sizeof(float);
     if (ru_env == 1) {
         if (x_dt == 0 && y_dt == 0) hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, float, float, 1>), g, b, lds, s, a);
         else if (x_dt == 0 && y_dt == 1) hipLaunchKernelGGL((ln_bwd_kernel<NPL, W, float, __bf16, 1>), g, b, lds, s, a);
