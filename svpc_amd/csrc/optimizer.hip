@@ -19,7 +19,17 @@ __global__ __launch_bounds__(256) void opt_sumsq_kernel(const TensorMeta* __rest
     const long long s = chunk_start[c];
     const long long e = s + OPT_CHUNK < t.n ? s + OPT_CHUNK : t.n;
     float acc = 0.f;
-    for (long long i = s + threadIdx.x; i < e; i += 256) { const float g = t.g[i]; acc += g * g; }
+    if ((e - s) == OPT_CHUNK && ((((unsigned long long)(t.g + s)) & 15ull) == 0)) {
+        // a whole chunk: 16 independent 16-byte loads per thread, all requested before the first is consumed
+        const float4* g4 = reinterpret_cast<const float4*>(t.g + s);
+        float4 v[OPT_CHUNK / 4 / 256];
+#pragma unroll
+        for (int k = 0; k < OPT_CHUNK / 4 / 256; ++k) v[k] = g4[threadIdx.x + 256 * k];
+#pragma unroll
+        for (int k = 0; k < OPT_CHUNK / 4 / 256; ++k) acc += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+    } else {
+        for (long long i = s + threadIdx.x; i < e; i += 256) { const float g = t.g[i]; acc += g * g; }
+    }
     acc = block_sum_256(acc, red);
     if (threadIdx.x == 0) partial[c] = acc;
 }
