@@ -860,3 +860,30 @@ def test_gather_cast_multi_token_staging():
     for (src, idx, dt), o in zip(items, outs):
         ref = (src.reshape(-1)[idx.long()] if idx is not None else src.reshape(-1)).to(dt)
         assert o.dtype == dt and o.shape == ref.shape and torch.equal(o, ref)
+
+
+def test_split_cols_gathers_block_gradients_in_place():
+    """ops.split_cols: column blocks of a wide projection output whose gradients meet in ONE buffer.  A consumer that honours
+    ``_svpc_grad_into`` (ops.attention) writes its block in place; any other consumer's gradient is copied in; an unused block is zero —
+    the wide tensor's gradient equals what torch.split would give."""
+    torch.manual_seed(4)
+    n_seq, lt, n_mem, H, D = 6, 5, 3, 4, 64
+    wide0 = torch.randn(n_seq * n_mem, 3 * 2 * D, device=DEV)
+    q0 = torch.randn(n_seq * lt, D, device=DEV)
+    seq = O.SeqInfo.uniform(n_seq, lt, n_mem, torch.device(DEV))
+    wt = torch.randn(n_seq * lt, D, device=DEV)
+    res = []
+    for mod in ("split_cols", "torch"):
+        wide = wide0.clone().requires_grad_(True)
+        q = q0.clone().requires_grad_(True)
+        blocks = O.split_cols(wide * 1.0, 3) if mod == "split_cols" else tuple((wide * 1.0).split(2 * D, dim=1))
+        if mod == "split_cols":
+            assert all(getattr(b, "_svpc_grad_into", None) is not None for b in blocks)
+        a0 = O.attention(q, blocks[0], (0, 0, D), D, H, seq)                  # writes its K|V gradient into the shared buffer
+        extra = (blocks[2] * 0.5).sum()                                       # a plain torch consumer: gradient copied in; block 1 unused
+        ((a0 * wt).sum() + extra).backward()
+        torch.cuda.synchronize()
+        res.append((wide.grad.clone(), q.grad.clone()))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-6)
+    assert float(res[0][0][:, 2 * D:4 * D].abs().max()) == 0.0              # the unused block
