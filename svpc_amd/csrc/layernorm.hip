@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
     const TY* __restrict__ rp = reinterpret_cast<const TY*>(a.res);
     TY* __restrict__ yp = reinterpret_cast<TY*>(a.y);
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= a.R) return;
+    const int r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));     // wave-uniform: the row index, its gather
+    if (r >= a.R) return;                                                                  // source and its table rows are scalar loads
     const int D = a.D;
     const size_t xrow = (size_t)(a.src_rows ? a.src_rows[r] : r) * D;
     const size_t orow = (size_t)r * D;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, (W == 4 && NPL * W <= 12 && RU == 2) ? 4 : 1) 
     TY* __restrict__ dhp = reinterpret_cast<TY*>(a.dh);
     TX* __restrict__ dxp = reinterpret_cast<TX*>(a.dx);
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: row indices and per-row statistics are scalar loads
     const int D = a.D;
     const bool any_drop = (a.p_pre > 0.f) || (a.p_post > 0.f);
     const u64 seed = any_drop ? a.seed[0] : 0ull;
