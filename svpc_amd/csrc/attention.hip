@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     float* Vs = Ks + a.max_k * ldr;
     float* qb = Vs + a.max_k * ldr;            // 4 × dh
     float* pb = qb + 4 * dh;                   // 4 × max_k
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i0 = blockIdx.y * QROWS;
     if (i0 >= q_len) return;
     for (int e = threadIdx.x; e < k_len * dh; e += 256) {
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
     float* qb = Vs + a.max_k * ldr;            // 4 × dh (scaled q)
     float* db = qb + 4 * dh;                   // 4 × dh (dO row)
     float* pb = db + 4 * dh;                   // 4 × max_k (dS row)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i0 = blockIdx.y * QROWS;
     if (i0 >= q_len) return;
     for (int e = threadIdx.x; e < k_len * dh; e += 256) {
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
     float* vb = kb + 4 * dh;                   // 4 × dh
     float* pb = vb + 4 * dh;                   // 4 × max_q  (p̃)
     float* sb = pb + 4 * a.max_q;              // 4 × max_q  (dS)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j0 = blockIdx.y * QROWS;
     if (j0 >= k_len) return;
     for (int e = threadIdx.x; e < q_len * dh; e += 256) {
@@ -238,7 +238,7 @@ static int set_lds(const void* fn, size_t bytes) { return svpc_raise_lds_once(fn
 template <int CH>
 __global__ __launch_bounds__(256) void attn_q1_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63;
-    const int sh = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int sh = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (sh >= a.n_seq * a.H) return;
     const int s = sh / a.H, h = sh - s * a.H, dh = a.dh;
     const int q_off = a.seq[s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];

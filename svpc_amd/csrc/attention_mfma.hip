@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     constexpr int IB = AT * AImg<DH>::RS, NTL = AT / 32;
     constexpr int GROUP_BYTES = 3 * IB + AT * (int)sizeof(float), NT = PERWAVE ? 64 : 256;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31;
     const int wave = PERWAVE ? 0 : wv, tid = PERWAVE ? lane : (int)threadIdx.x;
     char* smem = smem_all + (PERWAVE ? wv * GROUP_BYTES : 0);
     char* Qs = smem; char* Ks = smem + IB; char* Vs = smem + 2 * IB;
@@ -307,7 +307,7 @@ template <int DH>
 __global__ __launch_bounds__(256, 4) void attn_stream_fwd_kernel(MAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int AT = 128, RS = AImg<DH>::RS, IB = AT * RS, NTL = AT / 32, UPR = DH / 8, NIT = AT * UPR / 256;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5, tid = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, lhi = lane >> 5, tid = threadIdx.x;
     char* Ks = smem; char* Vs = smem + IB;
     float* mterm = reinterpret_cast<float*>(smem + 2 * IB);
     const int sh = blockIdx.x;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
     constexpr int TRS_ = AT * 2 + 16, T_BYTES = AT * TRS_, NQT = AT / 32;
     constexpr bool T_OVER = 2 * IB >= T_BYTES;
     constexpr int GROUP_BYTES = 4 * IB + 3 * AT * (int)sizeof(float) + (T_OVER ? 0 : T_BYTES), NT = PERWAVE ? 64 : 256;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31;
     const int wave = PERWAVE ? 0 : wv, tid = PERWAVE ? lane : (int)threadIdx.x;
     char* smem = smem_all + (PERWAVE ? wv * GROUP_BYTES : 0);
     char* Qs = smem; char* Ks = smem + IB; char* Vs = smem + 2 * IB; char* Ds = smem + 3 * IB;

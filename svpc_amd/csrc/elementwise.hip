@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ x, size_t
 // ---- rows: one wave per row ------------------------------------------------------------------------------------
 // mode 0: y = a / sum(a)       mode 1: y = softmax(a)
 __global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* __restrict__ a, float* __restrict__ y, int R, int C, int mode) {
-    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (r >= R) return;
     const float* ar = a + (size_t)r * C;
     float* yr = y + (size_t)r * C;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* __restric
 // mode 0: da = (dy - sum(dy*y)) / sum(a)  [y = a/S]      mode 1: da = y (dy - sum(dy*y))
 __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                           const float* __restrict__ a, float* __restrict__ da, int R, int C, int mode) {
-    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (r >= R) return;
     const size_t o = (size_t)r * C;
     float dot = 0.f, s = 0.f;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
 // ---- BCE rows (nn.BCELoss(sum): log clamped at -100) -----------------------------------------------------------
 __global__ __launch_bounds__(256) void bce_rows_fwd_kernel(const float* __restrict__ p, const float* __restrict__ y,
                                                            const int* __restrict__ widths, float* __restrict__ out, int R, int C) {
-    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (r >= R) return;
     const int wdt = widths[r];
     float s = 0.f;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void bce_rows_fwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void bce_rows_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ p,
                                                            const float* __restrict__ y, const int* __restrict__ widths,
                                                            float* __restrict__ dp, int R, int C) {
-    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (r >= R) return;
     const int wdt = widths[r];
     const float go = dout[r];
@@ -236,7 +236,7 @@ __device__ __forceinline__ void asl_terms(float p, float y, float gneg, float gp
 __global__ __launch_bounds__(256) void asl_rows_fwd_kernel(const float* __restrict__ p, const float* __restrict__ y,
                                                            const float* __restrict__ active, float* __restrict__ out, int R, int C,
                                                            float gneg, float gpos, float clip, float eps) {
-    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (r >= R) return;
     float s = 0.f;
     if (active[r] != 0.f) {
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void asl_rows_bwd_kernel(const float* __restri
                                                            const float* __restrict__ y, const float* __restrict__ active,
                                                            float* __restrict__ dp, int R, int C, float gneg, float gpos, float clip,
                                                            float eps) {
-    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (r >= R) return;
     const float go = active[r] != 0.f ? dout[r] : 0.f;
     for (int c = lane; c < C; c += 64) {
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void asl_rows_bwd_kernel(const float* __restri
     }
 }
 __global__ __launch_bounds__(256) void row_any_eq1_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C) {
-    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (r >= R) return;
     float f = 0.f;
     for (int c = lane; c < C; c += 64) f = fmaxf(f, x[(size_t)r * C + c] == 1.0f ? 1.f : 0.f);
@@ -314,7 +314,7 @@ __device__ __forceinline__ bool row_has_one(const float* __restrict__ y, int C, 
 __global__ __launch_bounds__(256) void loss_tail_fwd_kernel(LossTailArgs a, int row_blocks, float* __restrict__ partial, int* __restrict__ counter) {
     __shared__ float red[4];
     __shared__ int s_last;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* prow = partial;                                   // [R][3]
     float* pcap = partial + (size_t)3 * a.R;                 // [cap blocks]
     if ((int)blockIdx.x < row_blocks) {
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void loss_tail_bwd_kernel(LossTailArgs a, int 
         if (a.d_cap && i < a.n_cap) a.d_cap[i] = g;
         return;
     }
-    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (r >= a.R) return;
     const int wdt = a.widths[r];
     const float* yr = a.align + (size_t)r * a.Ce;
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void metric_argmax_kernel(const float* __restr
     const int r = blockIdx.x;
     const long long lab = labels[r];
     if (lab == ignore) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float best = -INFINITY; int bi = 0x7fffffff;
     for (int v = threadIdx.x; v < C; v += 256) {
         const float sc = scores[(size_t)r * ld + v];
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(const float* __restric
     __shared__ int sidx[4];
     const int j = blockIdx.x, r = j * lt + pos;
     const int C = row_c[r], X = row_x[r];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float best = -INFINITY; int bi = 0x7fffffff;
     for (int v = threadIdx.x; v < C; v += 256) {
         const float sc = v == unk ? -1e10f : scores[(size_t)r * ld + v];
