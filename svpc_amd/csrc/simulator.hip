@@ -30,7 +30,8 @@ __global__ __launch_bounds__(1024) void sim_recur_fwd_kernel(SimArgs a) {
     float* al = prev + SIM_EMAX;      // 32
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NT = blockDim.x, NW = blockDim.x >> 6;
     for (int i = threadIdx.x; i < E * D; i += NT) Es[i] = a.E0[(size_t)e0 * D + i];
-    if (threadIdx.x < SIM_EMAX) prev[threadIdx.x] = 0.f;
+    float my_prev = 0.f;              // thread e < 32: e_{t-1}[e] (read and replaced by the same thread: no LDS, no barrier)
+    (void)prev;
     // The recurrence is a chain of dependent steps on ONE workgroup per video: what a step costs is its exposed latency.  The step
     // vector q_t (and c_t, w_t) do not depend on the state, so the values of step t+1 are requested at the top of step t and land under
     // its arithmetic (D <= 768: 12 values per lane; wider rows read q in the loop as before).
@@ -69,8 +70,10 @@ __global__ __launch_bounds__(1024) void sim_recur_fwd_kernel(SimArgs a) {
         const float c0 = pre ? pc0 : a.c[(size_t)j * 3], c1 = pre ? pc1 : a.c[(size_t)j * 3 + 1];
         if (threadIdx.x < SIM_EMAX) {
             const int e = threadIdx.x;
-            al[e] = e < E ? c0 * ev[e] + c1 * prev[e] : 0.f;
-            if (e < em) a.e_out[(size_t)j * em + e] = e < E ? ev[e] : 0.f;
+            const float ev_e = e < E ? ev[e] : 0.f;
+            al[e] = e < E ? c0 * ev_e + c1 * my_prev : 0.f;
+            my_prev = ev_e;
+            if (e < em) a.e_out[(size_t)j * em + e] = ev_e;
         }
         __syncthreads();
         float Z = 0.f;
@@ -92,9 +95,7 @@ __global__ __launch_bounds__(1024) void sim_recur_fwd_kernel(SimArgs a) {
                 a.eall[((size_t)j * em + e) * D + d] = v;
             }
         }
-        __syncthreads();
-        if (threadIdx.x < SIM_EMAX) prev[threadIdx.x] = threadIdx.x < E ? ev[threadIdx.x] : 0.f;
-        __syncthreads();
+        __syncthreads();          // the state is updated (and al / ev read) before the next step's dot products overwrite ev
     }
 }
 
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
     float* red = Ubuf + (MODE == 0 ? 0 : (DMA ? 2 : 1)) * img;       // (2*32+1) × NW wave partials
     float* sc = red + (2 * EM + 1) * NW;     // scalars: ds[32]
     float* dprev = sc + EM;                  // 32: gradient flowing into e_{t-1} through "prev"
+    float* tot = dprev + EM;                 // 2·EM + 1 block totals of the wave partials in `red`
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
     float dE[EM][CPT];
@@ -253,6 +255,16 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
         pw = wave_sum(pw);
         if (lane == 0) red[(2 * EM) * NW + wave] = pw;
         __syncthreads();
+        // 2·EM + 1 threads add the NW wave partials of one scalar each (wave order: deterministic) — every thread then reads 2E + 1
+        // totals instead of (2E + 1)·NW partials: with 12 waves that was 252 LDS reads per thread and step, the longest piece of a step
+        if (threadIdx.x < 2 * EM + 1) {
+            const float* rp = red + threadIdx.x * NW;
+            float t_ = rp[0];
+#pragma unroll
+            for (int w_ = 1; w_ < NW; ++w_) t_ += rp[w_];
+            tot[threadIdx.x] = t_;
+        }
+        __syncthreads();
         // every thread finishes the scalar algebra redundantly (E <= 32)
         float dab[EM], dal[EM];
         float mix = 0.f;
@@ -260,11 +272,7 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
         for (int e = 0; e < EM; ++e) {
             dab[e] = 0.f; dal[e] = 0.f;
             if (e < E) {
-                const float* rb = red + (EM + e) * NW;
-                float t_ = rb[0];
-#pragma unroll
-                for (int w_ = 1; w_ < NW; ++w_) t_ += rb[w_];
-                dab[e] = t_;
+                dab[e] = tot[EM + e];
                 mix += dab[e] * al[e] * invZ;
             }
         }
@@ -274,10 +282,7 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
         for (int e = 0; e < EM; ++e) {
             dsv[e] = 0.f;
             if (e < E) {
-                const float* ra = red + e * NW;
-                float A1 = ra[0];
-#pragma unroll
-                for (int w_ = 1; w_ < NW; ++w_) A1 += ra[w_];
+                const float A1 = tot[e];
                 dal[e] = A1 + (dab[e] - mix) * invZ;
                 dc0 += dal[e] * evv[e];
                 dc1 += dal[e] * pv[e];
@@ -285,11 +290,8 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
                 dsv[e] = de_tot * evv[e] * (1.f - evv[e]);
             }
         }
-        const float* rw = red + (2 * EM) * NW;
-        float dw = rw[0];
-#pragma unroll
-        for (int w_ = 1; w_ < NW; ++w_) dw += rw[w_];
-        __syncthreads();   // all threads have read dprev / red before they are overwritten
+        const float dw = tot[2 * EM];
+        __syncthreads();   // all threads have read dprev / tot before they are overwritten
         if (threadIdx.x < EM) dprev[threadIdx.x] = threadIdx.x < E ? c1 * dal[threadIdx.x] : 0.f;
         if (threadIdx.x == 0) {
             a.dc[(size_t)j * 3] = dc0; a.dc[(size_t)j * 3 + 1] = dc1; a.dc[(size_t)j * 3 + 2] = 0.f;
@@ -354,7 +356,7 @@ int svpc_sim_recur_bwd(const float* q, const float* c, const float* w4f, const f
     const int nt = D > 768 ? 1024 : (D > 512 ? 768 : (D > 256 ? 512 : 256));      // one column per thread up to D = 1024
     const size_t img = (((size_t)e_max * D + 255) / 256) * 256;
     const int EMv = e_max <= 16 ? 16 : 32;
-    const size_t tail = ((2 * EMv + 1) * (nt / 64) + 2 * EMv) * sizeof(float);
+    const size_t tail = ((2 * EMv + 1) * (nt / 64) + 2 * EMv + (2 * EMv + 1)) * sizeof(float);
     const size_t budget = 150 * 1024;
     const bool aligned = ((((uintptr_t)E0) | ((uintptr_t)eall) | ((uintptr_t)deall)) & 15) == 0;
     int mode = 0;
