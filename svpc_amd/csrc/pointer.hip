@@ -81,6 +81,7 @@ __global__ __launch_bounds__(768) void ptr_attn_fwd_kernel(const float* __restri
             if (e < E) sc[t * PTR_EMAX + e] = v;
             pi[((size_t)j * lt + t) * em + e] = v;
         }
+        for (int e = E; e < ((E + 3) & ~3); ++e) sc[t * PTR_EMAX + e] = 0.f;      // the 16-byte reads below cover whole quads
     }
     __syncthreads();
     // att[t][d] = Σ_e pi[t][e]·bank[e][d]: a thread owns column d, the E bank values of the column sit in registers
@@ -88,11 +89,15 @@ __global__ __launch_bounds__(768) void ptr_attn_fwd_kernel(const float* __restri
         float bv[PTR_EMAX];
 #pragma unroll
         for (int e = 0; e < PTR_EMAX; ++e) bv[e] = e < E ? bj[(size_t)e * D + d] : 0.f;
-        for (int t = 0; t < lt; ++t) {
+        for (int t = 0; t < lt; ++t) {       // (the pi row comes in 16-byte LDS reads: every thread reads the same E values)
             float acc = 0.f;
 #pragma unroll
-            for (int e = 0; e < PTR_EMAX; ++e)
-                if (e < E) acc += sc[t * PTR_EMAX + e] * bv[e];
+            for (int q4 = 0; q4 < PTR_EMAX / 4; ++q4) {
+                if (4 * q4 < E) {
+                    const float4 p4 = *reinterpret_cast<const float4*>(sc + t * PTR_EMAX + 4 * q4);     // entries ≥ E meet bv = 0
+                    acc += p4.x * bv[4 * q4] + p4.y * bv[4 * q4 + 1] + p4.z * bv[4 * q4 + 2] + p4.w * bv[4 * q4 + 3];
+                }
+            }
             att[((size_t)j * lt + t) * D + d] = acc;
         }
     }
@@ -110,6 +115,8 @@ __global__ __launch_bounds__(768) void ptr_attn_bwd_kernel(const float* __restri
     float* ent = rows + (size_t)lt * D;        // PTR_EC × D
     float* dsc = ent + (size_t)PTR_EC * D;     // lt × PTR_EMAX
     float* pis = dsc + lt * PTR_EMAX;          // lt × PTR_EMAX
+    float* dscT = pis + lt * PTR_EMAX;         // PTR_EMAX × PTR_LTMAX: the same two, entity-major (the column phase walks t in 16-byte reads)
+    float* pisT = dscT + PTR_EMAX * PTR_LTMAX;
     const int j = blockIdx.x, E = step_ne[j];
     const float* pj = proj + (size_t)j * em * D;
     const float* bj = bank + (size_t)j * em * D;
@@ -133,7 +140,17 @@ __global__ __launch_bounds__(768) void ptr_attn_bwd_kernel(const float* __restri
     for (int t = threadIdx.x; t < lt; t += blockDim.x) {
         float mix = 0.f;
         for (int e = 0; e < E; ++e) mix += pis[t * PTR_EMAX + e] * dsc[t * PTR_EMAX + e];
-        for (int e = 0; e < E; ++e) dsc[t * PTR_EMAX + e] = pis[t * PTR_EMAX + e] * (dsc[t * PTR_EMAX + e] - mix);
+        for (int e = 0; e < E; ++e) {
+            const float v = pis[t * PTR_EMAX + e] * (dsc[t * PTR_EMAX + e] - mix);
+            dsc[t * PTR_EMAX + e] = v;
+            dscT[e * PTR_LTMAX + t] = v;
+            pisT[e * PTR_LTMAX + t] = pis[t * PTR_EMAX + e];
+        }
+        for (int e = E; e < ((E + 3) & ~3); ++e) dsc[t * PTR_EMAX + e] = 0.f;      // the 16-byte reads below cover whole quads
+    }
+    for (int i = threadIdx.x; i < E * PTR_LTMAX; i += blockDim.x) {                  // … and whole quads of t in the transposed copies
+        const int e = i / PTR_LTMAX, t = i - e * PTR_LTMAX;
+        if (t >= lt) { dscT[e * PTR_LTMAX + t] = 0.f; pisT[e * PTR_LTMAX + t] = 0.f; }
     }
     __syncthreads();
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
@@ -151,16 +168,26 @@ __global__ __launch_bounds__(768) void ptr_attn_bwd_kernel(const float* __restri
         for (int t = 0; t < lt; ++t) {
             float acc = 0.f;
 #pragma unroll
-            for (int e = 0; e < PTR_EMAX; ++e)
-                if (e < E) acc += dsc[t * PTR_EMAX + e] * pv[e];
+            for (int q4 = 0; q4 < PTR_EMAX / 4; ++q4) {
+                if (4 * q4 < E) {
+                    const float4 p4 = *reinterpret_cast<const float4*>(dsc + t * PTR_EMAX + 4 * q4);    // entries ≥ E meet pv = 0
+                    acc += p4.x * pv[4 * q4] + p4.y * pv[4 * q4 + 1] + p4.z * pv[4 * q4 + 2] + p4.w * pv[4 * q4 + 3];
+                }
+            }
             ddec[((size_t)j * lt + t) * D + d] = acc;
         }
         for (int e = 0; e < em; ++e) {
             float ap = 0.f, ab = 0.f;
             if (e < E) {
 #pragma unroll
-                for (int t = 0; t < PTR_LTMAX; ++t)
-                    if (t < lt) { ap += dsc[t * PTR_EMAX + e] * dv[t]; ab += pis[t * PTR_EMAX + e] * av[t]; }
+                for (int q4 = 0; q4 < PTR_LTMAX / 4; ++q4) {
+                    if (4 * q4 < lt) {          // (dv / av are zero for t ≥ lt, the copies are zero there too)
+                        const float4 d4 = *reinterpret_cast<const float4*>(dscT + e * PTR_LTMAX + 4 * q4);
+                        const float4 p4 = *reinterpret_cast<const float4*>(pisT + e * PTR_LTMAX + 4 * q4);
+                        ap += d4.x * dv[4 * q4] + d4.y * dv[4 * q4 + 1] + d4.z * dv[4 * q4 + 2] + d4.w * dv[4 * q4 + 3];
+                        ab += p4.x * av[4 * q4] + p4.y * av[4 * q4 + 1] + p4.z * av[4 * q4 + 2] + p4.w * av[4 * q4 + 3];
+                    }
+                }
             }
             dproj[((size_t)j * em + e) * D + d] = ap;
             dbank[((size_t)j * em + e) * D + d] = ab;
@@ -360,7 +387,7 @@ int svpc_ptr_attn_bwd(const float* dec, const float* proj, const float* bank, co
     SVPC_REQUIRE(e_max <= PTR_EMAX, "ptr_attn: at most 32 entities");
     SVPC_REQUIRE(lt <= PTR_LTMAX, "ptr_attn: at most 32 tokens per sentence");
     SVPC_REQUIRE(D % 4 == 0 && ((((uintptr_t)datt) | ((uintptr_t)proj) | ((uintptr_t)bank)) & 15) == 0, "ptr_attn: rows must be 16-byte aligned");
-    const size_t lds = ((size_t)(lt + PTR_EC) * D + (size_t)2 * lt * PTR_EMAX) * sizeof(float);
+    const size_t lds = ((size_t)(lt + PTR_EC) * D + (size_t)2 * lt * PTR_EMAX + (size_t)2 * PTR_EMAX * PTR_LTMAX) * sizeof(float);
     SVPC_REQUIRE(lds <= 150 * 1024, "ptr_attn: sentence rows do not fit LDS");
     int rc = ptr_set_lds((const void*)ptr_attn_bwd_kernel);
     if (rc) return rc;
