@@ -243,13 +243,18 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
 #pragma unroll
     for (int jt = 0; jt < NTL; ++jt) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = 32 * jt + acc_row(e, lane);
-            float t = mterm[key];
-            if (a.causal) t = (key > q && key < k_len) ? -10000.0f : t;     // uniform branch: no per-element selects otherwise
-            const float v = st[jt][e] + t;
-            st[jt][e] = v;
-            mx = fmaxf(mx, v);
+        for (int g = 0; g < 4; ++g) {        // registers 4g..4g+3 ↔ four consecutive keys: their mask terms in one 16-byte LDS read
+            const float4 m4 = *reinterpret_cast<const float4*>(mterm + 32 * jt + 8 * g + 4 * (lane >> 5));
+            const float mt4[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+            for (int e = 4 * g; e < 4 * g + 4; ++e) {
+                const int key = 32 * jt + acc_row(e, lane);
+                float t = mt4[e & 3];
+                if (a.causal) t = (key > q && key < k_len) ? -10000.0f : t;     // uniform branch: no per-element selects otherwise
+                const float v = st[jt][e] + t;
+                st[jt][e] = v;
+                mx = fmaxf(mx, v);
+            }
         }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -365,12 +370,10 @@ __global__ __launch_bounds__(256, 4) void attn_stream_fwd_kernel(MAttnArgs a) {
 #pragma unroll
     for (int jt = 0; jt < NTL; ++jt) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = 32 * jt + acc_row(e, lane);
-            float t = mterm[key];
-            const float v = st[jt][e] + t;
-            st[jt][e] = v;
-            mx = fmaxf(mx, v);
+        for (int g = 0; g < 4; ++g) {        // registers 4g..4g+3 ↔ four consecutive keys: their mask terms in one 16-byte LDS read
+            const float4 m4 = *reinterpret_cast<const float4*>(mterm + 32 * jt + 8 * g + 4 * (lane >> 5));
+            st[jt][4 * g] += m4.x; st[jt][4 * g + 1] += m4.y; st[jt][4 * g + 2] += m4.z; st[jt][4 * g + 3] += m4.w;
+            mx = fmaxf(fmaxf(mx, st[jt][4 * g]), fmaxf(st[jt][4 * g + 1], fmaxf(st[jt][4 * g + 2], st[jt][4 * g + 3])));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -533,16 +536,19 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (8 * g < nvq) {
+                    // the four queries of the group are consecutive: their log-sum-exp and delta terms in one 16-byte LDS read each
+                    const float4 l4 = *reinterpret_cast<const float4*>(lse + qb + 8 * g), d4 = *reinterpret_cast<const float4*>(delta + qb + 8 * g);
+                    const float lq4[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                     for (int e = 4 * g; e < 4 * g + 4; ++e) {
                         const int q = qb + (e & 3) + 8 * (e >> 2);
                         float t = mt;
                         if (a.causal) t = (key > q && key < k_len) ? -10000.0f : t;
-                        const float p = __expf(sc[e] + t - lse[q]);
+                        const float p = __expf(sc[e] + t - lq4[e & 3]);
                         float dm = 1.0f;
                         if (a.p_drop > 0.f) dm = dctx.mul((dbase + qb) * a.max_k + (u64)(((e & 3) + 8 * (e >> 2)) * a.max_k), key);
                         pt[e] = p * dm;
-                        dsv[e] = p * (dp[e] * dm - delta[q]);
+                        dsv[e] = p * (dp[e] * dm - dq4[e & 3]);
                     }
                 } else {
 #pragma unroll
