@@ -354,6 +354,75 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(const float* __restrict
         dP[(size_t)r * c_max + v] = out;
     }
 }
+// The same two with ONE WAVE per row (c_max ≤ 64·NPL): the row's logits stay in registers — no second log / exp pass, no workgroup
+// barrier, four rows per workgroup.  Same arithmetic per element; the row sums add in lane order instead of thread order.
+template <int NPL>
+__global__ __launch_bounds__(256) void gumbel_fwd_row_kernel(const float* __restrict__ P, const float* __restrict__ noise,
+                                                             const int* __restrict__ row_c, const float* __restrict__ emb,
+                                                             float* __restrict__ bow, int* __restrict__ idx_out,
+                                                             float* __restrict__ stats, int R, int c_max, int V, int W, float inv_tau) {
+    const int lane = threadIdx.x & 63;
+    const int r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (r >= R) return;
+    const int C = row_c[r];
+    const float* Pr = P + (size_t)r * c_max;
+    const float* Nr = noise + (size_t)r * c_max;
+    float l[NPL];
+    float best = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int v = lane + 64 * i;
+        l[i] = v < C ? (logf(Pr[v] + 1e-12f) + Nr[v]) * inv_tau : -INFINITY;
+        if (l[i] > best) { best = l[i]; bi = v; }           // ascending v: the first index wins a tie
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i)
+        if (lane + 64 * i < C) s += expf(l[i] - best);
+    s = wave_sum(s);
+    const float ymax = 1.0f / s;                       // soft probability of the arg-max class
+    const float coef = (1.0f - ymax) + ymax;           // hard - y.detach() + y, evaluated like the reference
+    if (lane == 0) { idx_out[r] = bi; stats[2 * r] = best; stats[2 * r + 1] = s; }
+    for (int c = lane; c < W; c += 64) bow[(size_t)r * W + c] = bi < V ? coef * emb[(size_t)bi * W + c] : 0.f;
+}
+template <int NPL>
+__global__ __launch_bounds__(256) void gumbel_bwd_row_kernel(const float* __restrict__ P, const float* __restrict__ noise,
+                                                             const int* __restrict__ row_c, const float* __restrict__ stats,
+                                                             const float* __restrict__ dy, float* __restrict__ dP, int R, int c_max, int V,
+                                                             float inv_tau) {
+    const int lane = threadIdx.x & 63;
+    const int r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (r >= R) return;
+    const int C = row_c[r];
+    const float mx = stats[2 * r], inv = 1.0f / stats[2 * r + 1];
+    const float* Pr = P + (size_t)r * c_max;
+    const float* Nr = noise + (size_t)r * c_max;
+    float y[NPL], pe[NPL], d[NPL];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int v = lane + 64 * i;
+        y[i] = 0.f; pe[i] = 1.f; d[i] = 0.f;
+        if (v < C) {
+            const float p = Pr[v];
+            pe[i] = p + 1e-12f;
+            y[i] = expf((logf(pe[i]) + Nr[v]) * inv_tau - mx) * inv;
+            d[i] = v < V ? dy[(size_t)r * V + v] : 0.f;
+            if (v < V) dot += y[i] * d[i];
+        }
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int v = lane + 64 * i;
+        if (v < c_max) dP[(size_t)r * c_max + v] = v < C ? y[i] * (d[i] - dot) * inv_tau / pe[i] : 0.f;
+    }
+}
 // demb[idx[r]] += coef·dbow[r]
 __global__ __launch_bounds__(256) void gumbel_emb_grad_kernel(const float* __restrict__ dbow, const int* __restrict__ idx,
                                                               const float* __restrict__ stats, float* __restrict__ demb, int V, int W) {
@@ -422,13 +491,21 @@ int svpc_ptr_mix_loss_bwd(const float* logits, const float* g, const float* pi, 
 int svpc_gumbel_fwd(const float* P, const float* noise, const int* row_c, const float* emb, float* bow, int* idx, float* stats, int R,
                     int c_max, int V, int W, float tau, hipStream_t s) {
     if (R == 0) return 0;
-    hipLaunchKernelGGL(gumbel_fwd_kernel, dim3(R), dim3(256), 0, s, P, noise, row_c, emb, bow, idx, stats, c_max, V, W, 1.0f / tau);
+    if (c_max <= 1024)
+        hipLaunchKernelGGL(gumbel_fwd_row_kernel<16>, dim3(ceil_div(R, 4)), dim3(256), 0, s, P, noise, row_c, emb, bow, idx, stats, R, c_max, V,
+                           W, 1.0f / tau);
+    else
+        hipLaunchKernelGGL(gumbel_fwd_kernel, dim3(R), dim3(256), 0, s, P, noise, row_c, emb, bow, idx, stats, c_max, V, W, 1.0f / tau);
     return svpc_check_launch("gumbel_fwd");
 }
 int svpc_gumbel_bwd(const float* P, const float* noise, const int* row_c, const float* stats, const float* dy, float* dP, int R,
                     int c_max, int V, float tau, hipStream_t s) {
     if (R == 0) return 0;
-    hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(R), dim3(256), 0, s, P, noise, row_c, stats, dy, dP, c_max, V, 1.0f / tau);
+    if (c_max <= 1024)
+        hipLaunchKernelGGL(gumbel_bwd_row_kernel<16>, dim3(ceil_div(R, 4)), dim3(256), 0, s, P, noise, row_c, stats, dy, dP, R, c_max, V,
+                           1.0f / tau);
+    else
+        hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(R), dim3(256), 0, s, P, noise, row_c, stats, dy, dP, c_max, V, 1.0f / tau);
     return svpc_check_launch("gumbel_bwd");
 }
 int svpc_gumbel_emb_grad(const float* dbow, const int* idx, const float* stats, float* demb, int R, int V, int W, hipStream_t s) {
