@@ -62,7 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--hidden", type=int, default=768)
     ap.add_argument("--heads", type=int, default=12)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"],
                     help="arithmetic type of the GEMM / attention operands (accumulation, statistics and parameters are fp32 either way)")
     ap.add_argument("--decode", action="store_true", help="only the secondary metric: greedy-decode captions/s (BASELINE config 5: 64 videos)")
     ap.add_argument("--decode-videos", type=int, default=64)
@@ -328,9 +328,11 @@ def run_train(args, precision, device, world, rank, dist, steps, warmup, instrum
     # roofline leg: HIP events around every launch of the dominant kernel symbol.  Eager mode: inside the timed region.  Graph
     # mode: events cannot be recorded inside a replay, so the same kernels are bracketed in instrumented eager steps right after it.
     rows_enc = args.batch * args.clips * cfg.max_v_len
-    bf16_stream = precision == "bf16" and ops.bf16_stream_ok(rows_enc, cfg.hidden_size, cfg.video_feature_size)
+    bf16_stream = precision != "fp32" and ops.bf16_stream_ok(rows_enc, cfg.hidden_size, cfg.video_feature_size)
     glds = bf16_stream and ops.USE_GLDS      # weights come from the optimizer's bf16 shadow → direct-to-LDS kernel
     want_dt = ((1, 1, 1) if glds else (1, 0, 1)) if bf16_stream else (0, 0, 0)
+    if precision == "bf16x3" and bf16_stream:
+        want_dt = (2, 2, 2)                  # split operands and output (gemm_p8x3)
 
     def dom_select(d):
         M_, N_, K_, akc, bkc, adt, bdt, cdt = d

@@ -48,6 +48,18 @@ int svpc_ln_bwd_rows_t(const void* dy, const void* x, int x_dt, int y_dt, const 
                        const float* mean, const float* rstd, void* dh, void* dx, float* partial, int R, int D, float p_pre,
                        unsigned site_pre, float p_post, unsigned site_post, const svpc_u64* seed, svpc_stream_t stream);
 int svpc_ln_param_grads(const float* partial, int R, int D, float* dgamma, float* dbeta, int accumulate, svpc_stream_t stream);
+/* strided / split forms (bf16x3 mode).  dtype code 2 = "split": a row stores an fp32-like value as TWO bf16 planes, hi = bf16(v) at
+ * column c and lo = bf16(v - hi) at column lo + c (hi + lo is exact in fp32, 16-17 significant bits; the bytes of fp32).  ldx / ldr /
+ * ldy: row strides in elements (0 = dense); lox / lor / loy: column offsets of the lo planes.  Forward combinations (x_dt, y_dt):
+ * the typed ones plus (0,2), (2,2), (2,0).  The backward reads the hi planes of split rows in place as dtype 1 with their leading
+ * dimension (ldx, ldr); dy / dh / dx stay dense.  Same reference lines as svpc_ln_fwd_t. */
+int svpc_ln_fwd_s(const void* x, int x_dt, int ldx, int lox, const int* src_rows, const void* res, int ldr, int lor, const float* gamma,
+                  const float* beta, void* y, int y_dt, int ldy, int loy, float* mean, float* rstd, int R, int D, float eps, float p_pre,
+                  unsigned site_pre, float p_post, unsigned site_post, const svpc_u64* seed, const float* add1, int mod1,
+                  const float* add2, const int* idx2, svpc_stream_t stream);
+int svpc_ln_bwd_rows_s(const void* dy, const void* x, int x_dt, int ldx, int y_dt, const int* src_rows, const void* res, int ldr,
+                       const float* gamma, const float* mean, const float* rstd, void* dh, void* dx, float* partial, int R, int D,
+                       float p_pre, unsigned site_pre, float p_post, unsigned site_post, const svpc_u64* seed, svpc_stream_t stream);
 int svpc_bucket_colsum_t(const void* x, int x_dt, int ldx, const int* idx, int R, int C, int K, float* out, int accumulate,
                          float* workspace, svpc_stream_t stream);
 /* deferred reduction tails: the first stage of a plain column sum into a caller-owned partial buffer, and ONE launch that adds the
@@ -111,6 +123,15 @@ int svpc_gemm_glds_rg(const void* A, int lda, int a_kc, const void* B, int ldb, 
  * and tools.  reference: every nn.Linear of the clip encoder / decoder forward (model.py:195-197,230,259,281,551). */
 int svpc_gemm_p8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, void* Z, int M, int N, int K, const float* bias, int act,
                  svpc_stream_t stream);
+/* bf16x3 form of the same projections (the ≤1e-4-parity throughput mode): split operands (see svpc_ln_fwd_s), three-term product
+ *   A·Bᵀ ≈ A_lo·B_hiᵀ + A_hi·B_loᵀ + A_hi·B_hiᵀ   — one bf16 GEMM with a 3K-deep contraction on the svpc_gemm_p8 structure, fp32
+ * accumulate, ≈2⁻¹⁷ per operand instead of 2⁻⁹ at 3× (not 16×, as the f32 MFMA) the bf16 matrix work.  A [M][lda]: hi plane at column
+ * 0, lo plane at column a_lo; B_hi [N][ldb] with B_lo = B_hi + b_lo elements (same layout: the two planes of the weight shadow);
+ * C [M][ldc] written split (hi at column c, lo at c_lo + c); Z (optional, only with an activation): plain bf16 [M][ldz] pre-activation
+ * copy for the bf16 backward.  K % 64 == 0, N % 8 == 0, every plane 16-byte aligned; act in {none, relu, gelu}. */
+int svpc_gemm_p8x3_supported(int lda, int a_lo, int ldb, int ldc, int c_lo, int ldz, int M, int N, int K);
+int svpc_gemm_p8x3(const void* A, int lda, int a_lo, const void* B, int ldb, long long b_lo, void* C, int ldc, int c_lo, void* Z, int ldz,
+                   int M, int N, int K, const float* bias, int act, svpc_stream_t stream);
 /* fp32-operand form with direct-to-LDS staging (deep LDS ring, operands rounded to bf16 when the MFMA fragments are built): the
  * latency-bound GEMMs of the decoder :620-694, step-wise encoder :594-617, simulators :742-823, BiLSTM :1017-1025, LM head
  * :697-739 and their dgrad/wgrad.  Any M, N (edges clamped); K % 32 == 0; k-strided operands need rows % 4 == 0. */
@@ -124,6 +145,11 @@ int svpc_gemm_l32(const float* A, int lda, int a_kc, const float* B, int ldb, in
 int svpc_gemm_l32_r(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,
                     int N, int K, const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed, int accumulate,
                     float* workspace, size_t workspace_bytes, svpc_stream_t stream);
+/* the same contract with bf16x3 products: every fp32 operand value enters as hi + lo bf16 terms when the MFMA fragments are built,
+ * three MFMAs per product — the forward arithmetic of the ≤1e-4-parity throughput mode for every projection in fp32 storage */
+int svpc_gemm_l32_x3(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,
+                     int N, int K, const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed, int accumulate,
+                     float* workspace, size_t workspace_bytes, svpc_stream_t stream);
 /* grouped weight (+ bias) gradients of up to svpc_gemm_group_wgrad_max() independent linears in one launch:
  *   dw[n_out, n_in] += dzᵀ · x,   db[n_out] += Σ_rows dz   (db may be NULL)       — the wgrad half of every nn.Linear backward
  * `problems` is a HOST array of svpc_wgrad_problem; any row count (the partial last k-tile is zero-sourced), n_out % 4 == 0, n_in % 4 == 0,
@@ -132,6 +158,7 @@ int svpc_gemm_l32_r(const float* A, int lda, int a_kc, const float* B, int ldb, 
  * `problems` is a HOST array, at most 32 entries, K % 32 == 0 — e.g. the recurrent projections of both LSTM directions at one step */
 typedef struct svpc_gemm_problem { const float* A; const float* B; float* C; int M, N, K, lda, ldb, ldc; } svpc_gemm_problem;
 int svpc_gemm_group(const svpc_gemm_problem* problems, int n, int a_kc, int b_kc, int accumulate, svpc_stream_t stream);
+int svpc_gemm_group_x3(const svpc_gemm_problem* problems, int n, int a_kc, int b_kc, int accumulate, svpc_stream_t stream); /* bf16x3 products */
 typedef struct svpc_wgrad_problem {
     const float* dz; const float* x; float* dw; float* db;
     int n_out, n_in, rows, ld_dz, ld_x, ld_dw;
@@ -179,6 +206,12 @@ int svpc_attn_mfma_bwd(const float* Q, int ldq, const float* K, int ldk, const f
 int svpc_attn_mfma_fwd_t(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int dt, float* LSE,
                          const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,
                          float scale, float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
+/* bf16x3 forward over split-stored Q / K / V / O (hi planes at the pointers with the rows' leading dimensions, lo planes q_lo / k_lo /
+ * v_lo / o_lo elements behind them): Sᵀ and Oᵀ as three-term split-bf16 products, fp32 softmax, the library's dropout draws; non-causal,
+ * ≤128 rows per sequence, head dim 32 / 64.  The backward is svpc_attn_mfma_bwd_t on the hi planes.  model.py:194-219 (clip encoder). */
+int svpc_attn_stream_x3_fwd(const void* Q, int ldq, int q_lo, const void* K, int ldk, int k_lo, const void* V, int ldv, int v_lo, void* O,
+                            int ldo, int o_lo, float* LSE, const int* seq, int n_seq, int H, int dh, int max_q, int max_k,
+                            const float* key_mask, float scale, float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
 int svpc_attn_mfma_bwd_t(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O, int ldo, int dt,
                          const float* LSE, const void* dO, int lddo, void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv,
                          const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal, float scale,
@@ -287,6 +320,9 @@ int svpc_lstm_pair_fwd(const float* const* gx, const int* const* rows, const flo
 int svpc_lstm_pair_step_fwd(const float* const* h_prev, const float* const* c_prev, const float* const* w_hh, const float* const* gx,
                             const int* const* rows, const float* active, float* const* h, float* const* c, float* const* gates, int N,
                             int D, svpc_stream_t stream);
+int svpc_lstm_pair_step_fwd_x3(const float* const* h_prev, const float* const* c_prev, const float* const* w_hh, const float* const* gx,
+                               const int* const* rows, const float* active, float* const* h, float* const* c, float* const* gates, int N,
+                               int D, svpc_stream_t stream);   /* the same with bf16x3 products */
 int svpc_lstm_pair_bwd(const float* const* dh_out, const float* const* dh_rec, const float* const* dc, const float* const* gates,
                        const float* const* c_prev, const float* active, float* const* dgates, float* const* dc_prev,
                        float* const* dh_prev, int N, int D, svpc_stream_t stream);
@@ -305,8 +341,9 @@ int svpc_dropout_mask(float* out, size_t n, float p, unsigned site, const svpc_u
 int svpc_bump_seed(svpc_u64* seed, svpc_stream_t stream);
 
 /* ---- fused training-step tail: clip_grad_norm_ train.py:141-142, BertAdam optimization.py:284-331, EMA :196-203.
- *      meta = device array of {float* p,g,m,v,ema; long long n; float wd; int pad; bf16* shadow (or NULL)}; chunk tables built by
- *      the host.  shadow[i] = bf16(p[i]) is refreshed by the Adam kernel (operand storage of svpc_gemm_glds). */
+ *      meta = device array of {float* p,g,m,v,ema; long long n; float wd; int pad; bf16* shadow (or NULL); bf16* shadow_lo (or NULL)};
+ *      chunk tables built by the host.  shadow[i] = bf16(p[i]) is refreshed by the Adam kernel (operand storage of svpc_gemm_glds),
+ *      shadow_lo[i] = bf16(p[i] - shadow[i]) likewise (second plane of svpc_gemm_p8x3's B operand). */
 int svpc_opt_chunk(void);
 int svpc_opt_meta_bytes(void);
 int svpc_opt_step(const void* meta, const int* chunk_tid, const long long* chunk_start, const int* tensor_chunk_off, int n_tensors,

@@ -6,7 +6,7 @@
 static thread_local char g_err[512] = "";
 extern "C" void svpc_set_error(const char* msg) { strncpy(g_err, msg, sizeof(g_err) - 1); g_err[sizeof(g_err) - 1] = 0; }
 extern "C" const char* svpc_last_error(void) { return g_err; }
-extern "C" int svpc_abi_version(void) { return 1; }
+extern "C" int svpc_abi_version(void) { return 2; }
 
 // Raise a kernel's dynamic-LDS limit to the 160 KiB of a gfx950 CU, once per kernel symbol for the life of the process: the
 // attribute call must not recur on later launches (it is not capturable into a hipGraph).  One table for every source file;

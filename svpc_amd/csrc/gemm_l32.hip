@@ -60,8 +60,41 @@ __device__ __forceinline__ bf16x8 l32_fragment(const char* __restrict__ img, int
     for (int j = 0; j < 8; ++j) v[j] = (__bf16)f[j];
     return v;
 }
+// bf16x3 arithmetic (the ≤1e-4-parity throughput mode, see gemm_p8x3.hip): an fp32 operand value is split into hi = bf16(v) and
+// lo = bf16(v - hi) when the fragments are built, and a product becomes three MFMAs  lo·hi + hi·lo + hi·hi  (fp32 accumulate; the
+// dropped lo·lo term is ≤ 2⁻¹⁶ relative).  These launches wait on memory round trips, not on the matrix pipe.
+__device__ __forceinline__ void l32_split8(const float* f, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)f[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(f[j] - (float)h);
+    }
+}
+template <int R, bool KC>
+__device__ __forceinline__ void l32_fragment2(const char* __restrict__ img, int row0, int ks, int lane, bf16x8& hi, bf16x8& lo) {
+    float f[8];
+    if (KC) {
+        const int row = row0 + (lane & 31), sw = (row >> 1) & 7;
+        const int c0 = 4 * ks + 2 * (lane >> 5);
+        const float4 a = *reinterpret_cast<const float4*>(img + row * 128 + ((c0 ^ sw) << 4));
+        const float4 b = *reinterpret_cast<const float4*>(img + row * 128 + (((c0 + 1) ^ sw) << 4));
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    } else {
+        const float* p = reinterpret_cast<const float*>(img) + (16 * ks + 8 * (lane >> 5)) * R + row0 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = p[j * R];
+    }
+    l32_split8(f, hi, lo);
+}
+#define L32_MFMA3(ah, al, bh, bl, acc)                                           \
+    do {                                                                         \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);     \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);     \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);     \
+    } while (0)
 
-template <int BM, int BN, bool A_KC, bool B_KC, int NS>
+template <int BM, int BN, bool A_KC, bool B_KC, int NS, bool X3 = false>
 __global__ __launch_bounds__(256) void gemm_l32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                        float* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_m,
                                                        int tiles_n, int splitk, int k_chunk, float* __restrict__ slabs, int remap) {
@@ -133,14 +166,27 @@ __global__ __launch_bounds__(256) void gemm_l32_kernel(const float* __restrict__
         const char* sb = sa + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < L32_BK / 16; ++ks) {
-            bf16x8 bf[TN];
+            if constexpr (X3) {
+                bf16x8 bh[TN], bl[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = l32_fragment<BN, B_KC>(sb, wc * (BN / 2) + j * 32, ks, lane);
+                for (int j = 0; j < TN; ++j) l32_fragment2<BN, B_KC>(sb, wc * (BN / 2) + j * 32, ks, lane, bh[j], bl[j]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const bf16x8 af = l32_fragment<BM, A_KC>(sa, wr * (BM / 2) + i * 32, ks, lane);
+                for (int i = 0; i < TM; ++i) {
+                    bf16x8 ah, al;
+                    l32_fragment2<BM, A_KC>(sa, wr * (BM / 2) + i * 32, ks, lane, ah, al);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) L32_MFMA3(ah, al, bh[j], bl[j], acc[i][j]);
+                }
+            } else {
+                bf16x8 bf[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = l32_fragment<BN, B_KC>(sb, wc * (BN / 2) + j * 32, ks, lane);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const bf16x8 af = l32_fragment<BM, A_KC>(sa, wr * (BM / 2) + i * 32, ks, lane);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[j], acc[i][j], 0, 0, 0);
+                }
             }
         }
     }
@@ -172,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_l32_kernel(const float* __restrict__
 // bytes in flight per CU — these launches are bound by the memory round trip per k-tile, nothing else.
 // `asum` (optional): += Σ_k A(m, k) for the tile's 64 rows m — the bias gradient of a wgrad (A = dz, k-strided) — taken from the
 // fp32 LDS image (not the bf16-rounded fragments) by the workgroups of the first tile column.
-template <bool A_KC, bool B_KC, int NS = 2>
+template <bool A_KC, bool B_KC, int NS = 2, bool X3 = false>
 __device__ __forceinline__ void l32w_tile(char* l32_smem, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                           float* __restrict__ C, int ldc, int M, int N, int K, const Epi& epi, int tm, int tn,
                                           float* __restrict__ asum) {
@@ -239,14 +285,27 @@ __device__ __forceinline__ void l32w_tile(char* l32_smem, const float* __restric
         }
 #pragma unroll
         for (int ks = 0; ks < L32_BK / 16; ++ks) {
-            bf16x8 bf[2];
+            if constexpr (X3) {
+                bf16x8 bh[2], bl[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = l32_fragment<T, B_KC>(sb, j * 32, ks, lane);
+                for (int j = 0; j < 2; ++j) l32_fragment2<T, B_KC>(sb, j * 32, ks, lane, bh[j], bl[j]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const bf16x8 af = l32_fragment<T, A_KC>(sa, i * 32, ks, lane);
+                for (int i = 0; i < 2; ++i) {
+                    bf16x8 ah, al;
+                    l32_fragment2<T, A_KC>(sa, i * 32, ks, lane, ah, al);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) L32_MFMA3(ah, al, bh[j], bl[j], acc[i][j]);
+                }
+            } else {
+                bf16x8 bf[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = l32_fragment<T, B_KC>(sb, j * 32, ks, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bf16x8 af = l32_fragment<T, A_KC>(sa, i * 32, ks, lane);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[j], acc[i][j], 0, 0, 0);
+                }
             }
         }
         // the stage just read is refilled two iterations later by THIS wave (after its own fragment reads): no hazard
@@ -287,14 +346,14 @@ __device__ __forceinline__ void l32w_tile(char* l32_smem, const float* __restric
     }
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool X3 = false>
 __global__ __launch_bounds__(256) void gemm_l32w_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                         float* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_m,
                                                         int tiles_n) {
     extern __shared__ __attribute__((aligned(1024))) char l32_smem[];
     const int tile = blockIdx.x;
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    l32w_tile<A_KC, B_KC>(l32_smem, A, lda, B, ldb, C, ldc, M, N, K, epi, tm, tn, nullptr);
+    l32w_tile<A_KC, B_KC, 2, X3>(l32_smem, A, lda, B, ldb, C, ldc, M, N, K, epi, tm, tn, nullptr);
 }
 
 // ---- grouped weight gradients: up to 48 independent problems  dW_p[n_out, n_in] += dz_pᵀ · x_p  (+ db_p[n_out] += Σ_rows dz_p) in ONE
@@ -317,45 +376,45 @@ __global__ __launch_bounds__(256) void gemm_group_wgrad_kernel(GArgs g) {
 }
 
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool X3 = false>
 static int l32w_launch_one(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
                            int K, Epi epi, int tiles_m, int tiles_n) {
     constexpr int LDS = 4 * 2 * 2 * 64 * L32_BK * 4;      // 4 waves × 2 stages × (A + B) = 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_l32w_kernel<A_KC, B_KC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_l32w_kernel<A_KC, B_KC, X3>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) { svpc_set_error("gemm_l32w: cannot raise the dynamic LDS limit"); return (int)e; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_l32w_kernel<A_KC, B_KC>), grid, dim3(256), LDS, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tiles_m,
+    hipLaunchKernelGGL((gemm_l32w_kernel<A_KC, B_KC, X3>), grid, dim3(256), LDS, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tiles_m,
                        tiles_n);
     return 0;
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int NS>
+template <int BM, int BN, bool A_KC, bool B_KC, int NS, bool X3 = false>
 static int l32_launch_one(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
                           int K, Epi epi, int tiles_m, int tiles_n, int splitk, int k_chunk, float* slabs, int remap) {
     constexpr int LDS = NS * (BM + BN) * L32_BK * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_l32_kernel<BM, BN, A_KC, B_KC, NS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_l32_kernel<BM, BN, A_KC, B_KC, NS, X3>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) { svpc_set_error("gemm_l32: cannot raise the dynamic LDS limit"); return (int)e; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_l32_kernel<BM, BN, A_KC, B_KC, NS>), grid, dim3(256), LDS, stream, A, lda, B, ldb, C, ldc, M, N, K, epi,
+    hipLaunchKernelGGL((gemm_l32_kernel<BM, BN, A_KC, B_KC, NS, X3>), grid, dim3(256), LDS, stream, A, lda, B, ldb, C, ldc, M, N, K, epi,
                        tiles_m, tiles_n, splitk, k_chunk, slabs, remap);
     return 0;
 }
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, bool X3 = false>
 static int l32_launch(int a_kc, int b_kc, dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                       int M, int N, int K, Epi epi, int tiles_m, int tiles_n, int splitk, int k_chunk, float* slabs, int remap) {
 #define L32_ARGS grid, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, slabs, remap
-    if (a_kc && b_kc) return l32_launch_one<BM, BN, true, true, NS>(L32_ARGS);
-    if (a_kc) return l32_launch_one<BM, BN, true, false, NS>(L32_ARGS);
-    if (b_kc) return l32_launch_one<BM, BN, false, true, NS>(L32_ARGS);
-    return l32_launch_one<BM, BN, false, false, NS>(L32_ARGS);
+    if (a_kc && b_kc) return l32_launch_one<BM, BN, true, true, NS, X3>(L32_ARGS);
+    if (a_kc) return l32_launch_one<BM, BN, true, false, NS, X3>(L32_ARGS);
+    if (b_kc) return l32_launch_one<BM, BN, false, true, NS, X3>(L32_ARGS);
+    return l32_launch_one<BM, BN, false, false, NS, X3>(L32_ARGS);
 #undef L32_ARGS
 }
 
@@ -364,7 +423,7 @@ struct GemmProb { const float* A; const float* B; float* C; int M, N, K, lda, ld
 constexpr int GEMM_GROUP_MAX = 32;
 struct GemmGroupArgs { int n; int accumulate; GemmProb p[GEMM_GROUP_MAX]; };
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool X3 = false>
 __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroupArgs g) {
     extern __shared__ __attribute__((aligned(1024))) char l32_smem[];
     int pi = 0;
@@ -373,22 +432,22 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroupArgs g) {
     const int tile = blockIdx.x - q.tile0;
     const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
     Epi epi{nullptr, ACT_NONE, 0.f, 0u, nullptr, g.accumulate, nullptr};
-    l32w_tile<A_KC, B_KC>(l32_smem, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, epi, tm, tn, nullptr);
+    l32w_tile<A_KC, B_KC, 2, X3>(l32_smem, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, epi, tm, tn, nullptr);
 }
 
 struct HostGemmProblem { const float* A; const float* B; float* C; int M, N, K, lda, ldb, ldc; };
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool X3 = false>
 static int gemm_group_go(const GemmGroupArgs& g, int tiles, hipStream_t stream) {
     constexpr int LDS = 4 * 2 * 2 * 64 * L32_BK * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_group_kernel<A_KC, B_KC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_group_kernel<A_KC, B_KC, X3>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) { svpc_set_error("gemm_group: cannot raise the dynamic LDS limit"); return (int)e; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_group_kernel<A_KC, B_KC>), dim3(tiles), dim3(256), LDS, stream, g);
+    hipLaunchKernelGGL((gemm_group_kernel<A_KC, B_KC, X3>), dim3(tiles), dim3(256), LDS, stream, g);
     return svpc_check_launch("gemm_group");
 }
 
@@ -400,7 +459,7 @@ static int gemm_group_go(const GemmGroupArgs& g, int tiles, hipStream_t stream) 
 // A k-contiguous [M][lda]; B k-contiguous [N][ldb] (B_KC) or k-strided [K][ldb]; K % 16 == 0; rows past an edge are clamped.
 // the k-loop of one 32×32 tile: this wave's share of the 16-deep k-steps, partial tile → part[wave] (the caller syncs and sums).
 // arow / brow: this lane's operand rows (A row lane&31, B column lane&31) already advanced by 8·(lane>>5) k-elements.
-template <bool B_KC, int NW>
+template <bool B_KC, int NW, bool X3 = false>
 __device__ __forceinline__ void skinny_partials(float (*part)[16][64], const float* __restrict__ arow, const float* __restrict__ brow,
                                                 int ldb, int K) {
     constexpr int BATCH = 12;
@@ -435,12 +494,20 @@ __device__ __forceinline__ void skinny_partials(float (*part)[16][64], const flo
         for (int u = 0; u < BATCH; ++u) {
             const int s = s0 + NW * u;
             if (s < nsteps) {
-                bf16x8 af, bf;
-                af[0] = (__bf16)av[u][0].x; af[1] = (__bf16)av[u][0].y; af[2] = (__bf16)av[u][0].z; af[3] = (__bf16)av[u][0].w;
-                af[4] = (__bf16)av[u][1].x; af[5] = (__bf16)av[u][1].y; af[6] = (__bf16)av[u][1].z; af[7] = (__bf16)av[u][1].w;
+                if constexpr (X3) {
+                    const float a8[8] = {av[u][0].x, av[u][0].y, av[u][0].z, av[u][0].w, av[u][1].x, av[u][1].y, av[u][1].z, av[u][1].w};
+                    bf16x8 ah, al, bh, bl;
+                    l32_split8(a8, ah, al);
+                    l32_split8(bv[u], bh, bl);
+                    L32_MFMA3(ah, al, bh, bl, acc);
+                } else {
+                    bf16x8 af, bf;
+                    af[0] = (__bf16)av[u][0].x; af[1] = (__bf16)av[u][0].y; af[2] = (__bf16)av[u][0].z; af[3] = (__bf16)av[u][0].w;
+                    af[4] = (__bf16)av[u][1].x; af[5] = (__bf16)av[u][1].y; af[6] = (__bf16)av[u][1].z; af[7] = (__bf16)av[u][1].w;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bf[j] = (__bf16)bv[u][j];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+                    for (int j = 0; j < 8; ++j) bf[j] = (__bf16)bv[u][j];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+                }
             }
         }
     }
@@ -448,7 +515,7 @@ __device__ __forceinline__ void skinny_partials(float (*part)[16][64], const flo
     for (int e = 0; e < 16; ++e) part[wave][e][lane] = acc[e];
     __syncthreads();
 }
-template <bool B_KC, int NW>
+template <bool B_KC, int NW, bool X3 = false>
 __device__ __forceinline__ void skinny_tile(float (*part)[16][64], const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                             float* __restrict__ C, int ldc, int M, int N, int K, const Epi& epi, int tm, int tn) {
     const int lane = threadIdx.x & 63;
@@ -457,7 +524,7 @@ __device__ __forceinline__ void skinny_tile(float (*part)[16][64], const float* 
     const float* __restrict__ arow = A + (size_t)min(m0 + r, M - 1) * lda + 8 * h;
     const int bcol = min(n0 + r, N - 1);
     const float* __restrict__ brow = B_KC ? B + (size_t)bcol * ldb + 8 * h : B + (size_t)(8 * h) * ldb + bcol;
-    skinny_partials<B_KC, NW>(part, arow, brow, ldb, K);
+    skinny_partials<B_KC, NW, X3>(part, arow, brow, ldb, K);
     const u64 seed = epi.p_drop > 0.f ? epi.seed[0] : 0ull;
     const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
     const int col = threadIdx.x & 31;
@@ -471,15 +538,15 @@ __device__ __forceinline__ void skinny_tile(float (*part)[16][64], const float* 
         if (m0 + row < M && n0 + col < N) epilogue_store(v, m0 + row, n0 + col, C, ldc, epi, seed, inv_keep);
     }
 }
-template <bool B_KC>
+template <bool B_KC, bool X3 = false>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                           float* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_n) {
     __shared__ float part[4][16][64];
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
-    skinny_tile<B_KC, 4>(part, A, lda, B, ldb, C, ldc, M, N, K, epi, tm, tn);
+    skinny_tile<B_KC, 4, X3>(part, A, lda, B, ldb, C, ldc, M, N, K, epi, tm, tn);
 }
 // grouped form (both operands k-contiguous), NW waves per 32×32 tile: 8 for the long reductions of the LSTM dgrad (K = 3072)
-template <int NW>
+template <int NW, bool X3 = false>
 __global__ __launch_bounds__(64 * NW) void gemm_group_skinny_kernel(GemmGroupArgs g) {
     __shared__ float part[NW][16][64];
     int pi = 0;
@@ -488,7 +555,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_group_skinny_kernel(GemmGroupArg
     const int tile = blockIdx.x - q.tile0;
     const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
     Epi epi{nullptr, ACT_NONE, 0.f, 0u, nullptr, g.accumulate, nullptr};
-    skinny_tile<true, NW>(part, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, epi, tm, tn);
+    skinny_tile<true, NW, X3>(part, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, epi, tm, tn);
 }
 
 // ---- one time step of BOTH LSTM directions, recurrent projection and cell in one launch (reference: nn.LSTM inside
@@ -501,6 +568,7 @@ struct LstmStep {
     const float* h_prev[2]; const float* c_prev[2]; const float* w_hh[2]; const float* gx[2]; const int* rows[2]; const float* active;
     float* h[2]; float* c[2]; float* gates[2]; int N, D;
 };
+template <bool X3>
 __global__ __launch_bounds__(256) void lstm_pair_step_fwd_kernel(LstmStep a) {
     __shared__ float part[4][16][64];
     const int z = blockIdx.y, u0 = blockIdx.x * 8, m0 = blockIdx.z * 32;
@@ -508,7 +576,7 @@ __global__ __launch_bounds__(256) void lstm_pair_step_fwd_kernel(LstmStep a) {
     const int N = a.N, D = a.D;
     const float* arow = a.h_prev[z] + (size_t)min(m0 + r, N - 1) * D + 8 * hh;
     const float* brow = a.w_hh[z] + (size_t)((r >> 3) * D + u0 + (r & 7)) * D + 8 * hh;      // tile column r ↔ gate r>>3 of unit u0 + (r&7)
-    skinny_partials<true, 4>(part, arow, brow, D, D);
+    skinny_partials<true, 4, X3>(part, arow, brow, D, D);
     const int row = threadIdx.x >> 3, j = threadIdx.x & 7, n = m0 + row;
     if (n >= N) return;
     float gsum[4];
@@ -540,9 +608,9 @@ __global__ __launch_bounds__(256) void lstm_pair_step_fwd_kernel(LstmStep a) {
 
 extern "C" {
 
-int svpc_lstm_pair_step_fwd(const float* const* h_prev, const float* const* c_prev, const float* const* w_hh, const float* const* gx,
-                            const int* const* rows, const float* active, float* const* h, float* const* c, float* const* gates, int N,
-                            int D, hipStream_t stream) {
+static int lstm_pair_step_fwd_x(const float* const* h_prev, const float* const* c_prev, const float* const* w_hh, const float* const* gx,
+                                const int* const* rows, const float* active, float* const* h, float* const* c, float* const* gates, int N,
+                                int D, int x3, hipStream_t stream) {
     if (N == 0) return 0;
     SVPC_REQUIRE(D % 16 == 0 && D >= 16, "lstm_pair_step_fwd: hidden size must be a multiple of 16");
     LstmStep a{};
@@ -552,8 +620,20 @@ int svpc_lstm_pair_step_fwd(const float* const* h_prev, const float* const* c_pr
         a.h[z] = h[z]; a.c[z] = c[z]; a.gates[z] = gates[z];
     }
     a.active = active; a.N = N; a.D = D;
-    hipLaunchKernelGGL(lstm_pair_step_fwd_kernel, dim3(D / 8, 2, ceil_div(N, 32)), dim3(256), 0, stream, a);
+    if (x3) hipLaunchKernelGGL(lstm_pair_step_fwd_kernel<true>, dim3(D / 8, 2, ceil_div(N, 32)), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(lstm_pair_step_fwd_kernel<false>, dim3(D / 8, 2, ceil_div(N, 32)), dim3(256), 0, stream, a);
     return svpc_check_launch("lstm_pair_step_fwd");
+}
+int svpc_lstm_pair_step_fwd(const float* const* h_prev, const float* const* c_prev, const float* const* w_hh, const float* const* gx,
+                            const int* const* rows, const float* active, float* const* h, float* const* c, float* const* gates, int N,
+                            int D, hipStream_t stream) {
+    return lstm_pair_step_fwd_x(h_prev, c_prev, w_hh, gx, rows, active, h, c, gates, N, D, 0, stream);
+}
+// the same with bf16x3 products (≤1e-4-parity throughput mode)
+int svpc_lstm_pair_step_fwd_x3(const float* const* h_prev, const float* const* c_prev, const float* const* w_hh, const float* const* gx,
+                               const int* const* rows, const float* active, float* const* h, float* const* c, float* const* gates, int N,
+                               int D, hipStream_t stream) {
+    return lstm_pair_step_fwd_x(h_prev, c_prev, w_hh, gx, rows, active, h, c, gates, N, D, 1, stream);
 }
 
 // 1 if the fp32 direct-to-LDS kernel can run this (shape, layout): whole k-tiles, 16-byte aligned chunks, and for a k-strided
@@ -583,7 +663,7 @@ struct HostWgradProblem { const float* dz; const float* x; float* dw; float* db;
 int svpc_gemm_group_wgrad_max(void) { return GROUP_MAX; }
 
 // fp32 operands, same layout flags for every problem (a_kc / b_kc as in svpc_gemm_l32), K % 32 == 0, ≤ 32 problems
-int svpc_gemm_group(const void* problems, int n, int a_kc, int b_kc, int accumulate, hipStream_t stream) {
+static int gemm_group_x(const void* problems, int n, int a_kc, int b_kc, int accumulate, int x3, hipStream_t stream) {
     if (n == 0) return 0;
     SVPC_REQUIRE(n > 0 && n <= GEMM_GROUP_MAX, "gemm_group: 1..32 problems per launch");
     const HostGemmProblem* hp = reinterpret_cast<const HostGemmProblem*>(problems);
@@ -609,14 +689,30 @@ int svpc_gemm_group(const void* problems, int n, int a_kc, int b_kc, int accumul
         tiles += ceil_div(h.M, T) * q.tiles_n;
     }
     if (skinny) {
-        if (kmax >= 1536) hipLaunchKernelGGL(gemm_group_skinny_kernel<8>, dim3(tiles), dim3(512), 0, stream, g);
-        else hipLaunchKernelGGL(gemm_group_skinny_kernel<4>, dim3(tiles), dim3(256), 0, stream, g);
+        if (x3) {
+            if (kmax >= 1536) hipLaunchKernelGGL((gemm_group_skinny_kernel<8, true>), dim3(tiles), dim3(512), 0, stream, g);
+            else hipLaunchKernelGGL((gemm_group_skinny_kernel<4, true>), dim3(tiles), dim3(256), 0, stream, g);
+        } else if (kmax >= 1536) hipLaunchKernelGGL((gemm_group_skinny_kernel<8, false>), dim3(tiles), dim3(512), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_group_skinny_kernel<4, false>), dim3(tiles), dim3(256), 0, stream, g);
         return svpc_check_launch("gemm_group_skinny");
+    }
+    if (x3) {
+        if (a_kc && b_kc) return gemm_group_go<true, true, true>(g, tiles, stream);
+        if (a_kc) return gemm_group_go<true, false, true>(g, tiles, stream);
+        if (b_kc) return gemm_group_go<false, true, true>(g, tiles, stream);
+        return gemm_group_go<false, false, true>(g, tiles, stream);
     }
     if (a_kc && b_kc) return gemm_group_go<true, true>(g, tiles, stream);
     if (a_kc) return gemm_group_go<true, false>(g, tiles, stream);
     if (b_kc) return gemm_group_go<false, true>(g, tiles, stream);
     return gemm_group_go<false, false>(g, tiles, stream);
+}
+int svpc_gemm_group(const void* problems, int n, int a_kc, int b_kc, int accumulate, hipStream_t stream) {
+    return gemm_group_x(problems, n, a_kc, b_kc, accumulate, 0, stream);
+}
+// the same with bf16x3 products (≤1e-4-parity throughput mode)
+int svpc_gemm_group_x3(const void* problems, int n, int a_kc, int b_kc, int accumulate, hipStream_t stream) {
+    return gemm_group_x(problems, n, a_kc, b_kc, accumulate, 1, stream);
 }
 
 int svpc_gemm_group_wgrad(const void* problems, int n, hipStream_t stream) {
@@ -658,20 +754,35 @@ int svpc_gemm_group_wgrad(const void* problems, int n, hipStream_t stream) {
 
 // Same contract as svpc_gemm_mx with fp32 A, B, C (reference: every nn.Linear / matmul of model.py that is not on the
 // clip-encoder bf16 stream — e.g. :620-663 decoder, :594-617 step-wise encoder, :742-823 simulator, :1017-1025 BiLSTM).
+static int gemm_l32_x(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,
+                      int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
+                      float* workspace, size_t workspace_bytes, int x3, hipStream_t stream);
 int svpc_gemm_l32_r(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,
                     int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
-                    float* workspace, size_t workspace_bytes, hipStream_t stream);
+                    float* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return gemm_l32_x(A, lda, a_kc, B, ldb, b_kc, C, ldc, Z, R, M, N, K, bias, act, p_drop, site, seed, accumulate, workspace,
+                      workspace_bytes, 0, stream);
+}
+// the same contract with bf16x3 products: every fp32 operand value enters as hi + lo bf16 terms, three MFMAs per product — the
+// arithmetic of the ≤1e-4-parity throughput mode for every projection kept in fp32 storage (text side, step level, simulators, LSTM)
+int svpc_gemm_l32_x3(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,
+                     int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
+                     float* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return gemm_l32_x(A, lda, a_kc, B, ldb, b_kc, C, ldc, Z, R, M, N, K, bias, act, p_drop, site, seed, accumulate, workspace,
+                      workspace_bytes, 1, stream);
+}
 int svpc_gemm_l32(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, int M, int N, int K,
                   const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate, float* workspace,
                   size_t workspace_bytes, hipStream_t stream) {
     return svpc_gemm_l32_r(A, lda, a_kc, B, ldb, b_kc, C, ldc, Z, nullptr, M, N, K, bias, act, p_drop, site, seed, accumulate, workspace,
                            workspace_bytes, stream);
 }
+}  // extern "C"
 // R (optional): fp32 addend with C's leading dimension, C = epi(A·B) + R — the residual-path gradient joining the dgrad of the
 // projection that consumes the residual tensor (fp32 twin of svpc_gemm_glds_r)
-int svpc_gemm_l32_r(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,
-                    int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
-                    float* workspace, size_t workspace_bytes, hipStream_t stream) {
+static int gemm_l32_x(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,
+                      int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
+                      float* workspace, size_t workspace_bytes, int x3, hipStream_t stream) {
     if (M == 0 || N == 0) return 0;
     SVPC_REQUIRE(svpc_gemm_l32_supported(a_kc, b_kc, lda, ldb, M, N, K) && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0,
                  "gemm_l32: needs K % 32 == 0 and 16-byte aligned fp32 rows");
@@ -686,8 +797,11 @@ int svpc_gemm_l32_r(const float* A, int lda, int a_kc, const float* B, int ldb, 
     if (env_skinny && a_kc && M <= 256 && N >= 32 && (K & 15) == 0 && (lda & 3) == 0 && (!b_kc || (ldb & 3) == 0)) {
         const int tn_ = ceil_div(N, 32);
         dim3 grids(ceil_div(M, 32) * tn_);
-        if (b_kc) hipLaunchKernelGGL(gemm_skinny_kernel<true>, grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_);
-        else hipLaunchKernelGGL(gemm_skinny_kernel<false>, grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_);
+        if (x3) {
+            if (b_kc) hipLaunchKernelGGL((gemm_skinny_kernel<true, true>), grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_);
+            else hipLaunchKernelGGL((gemm_skinny_kernel<false, true>), grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_);
+        } else if (b_kc) hipLaunchKernelGGL((gemm_skinny_kernel<true, false>), grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<false, false>), grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_);
         return svpc_check_launch("gemm_skinny");
     }
     const int t128 = ceil_div(M, 128) * ceil_div(N, 128), t64 = ceil_div(M, 64) * ceil_div(N, 64);
@@ -703,7 +817,12 @@ int svpc_gemm_l32_r(const float* A, int lda, int a_kc, const float* B, int ldb, 
         const int tm_ = ceil_div(M, 64), tn_ = ceil_div(N, 64);
         dim3 gridw(tm_ * tn_);
         int rcw;
-        if (a_kc && b_kc) rcw = l32w_launch_one<true, true>(gridw, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tm_, tn_);
+        if (x3) {
+            if (a_kc && b_kc) rcw = l32w_launch_one<true, true, true>(gridw, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tm_, tn_);
+            else if (a_kc) rcw = l32w_launch_one<true, false, true>(gridw, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tm_, tn_);
+            else if (b_kc) rcw = l32w_launch_one<false, true, true>(gridw, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tm_, tn_);
+            else rcw = l32w_launch_one<false, false, true>(gridw, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tm_, tn_);
+        } else if (a_kc && b_kc) rcw = l32w_launch_one<true, true>(gridw, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tm_, tn_);
         else if (a_kc) rcw = l32w_launch_one<true, false>(gridw, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tm_, tn_);
         else if (b_kc) rcw = l32w_launch_one<false, true>(gridw, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tm_, tn_);
         else rcw = l32w_launch_one<false, false>(gridw, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tm_, tn_);
@@ -729,7 +848,10 @@ int svpc_gemm_l32_r(const float* A, int lda, int a_kc, const float* B, int ldb, 
     dim3 grid(tiles * splitk);
     int rc;
 #define L32_ARGS a_kc, b_kc, grid, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tiles_m, tiles_n, splitk, k_chunk, workspace, remap
-    if (mode == 128) rc = l32_launch<128, 128, 4>(L32_ARGS);
+    if (x3) {
+        if (mode == 128) rc = l32_launch<128, 128, 4, true>(L32_ARGS);
+        else rc = l32_launch<64, 64, 4, true>(L32_ARGS);
+    } else if (mode == 128) rc = l32_launch<128, 128, 4>(L32_ARGS);
     else if (mode == 64) rc = l32_launch<64, 64, 8>(L32_ARGS);
     else rc = l32_launch<64, 64, 4>(L32_ARGS);
 #undef L32_ARGS
@@ -742,5 +864,3 @@ int svpc_gemm_l32_r(const float* A, int lda, int a_kc, const float* B, int ldb, 
     }
     return rc;
 }
-
-}  // extern "C"

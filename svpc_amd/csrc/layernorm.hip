@@ -47,11 +47,50 @@ struct VecIO<1, __bf16> {
     static __device__ __forceinline__ void store(__bf16* p, const float* v) { p[0] = (__bf16)v[0]; }
 };
 
+// "split" storage of an fp32-like value as TWO bf16 planes of one row: hi = bf16(v) at column c, lo = bf16(v - hi) at column lo + c
+// (hi + lo is exact in fp32 and carries 16-17 significant bits).  The hi plane alone is an ordinary bf16 tensor with the row's
+// leading dimension — what the bf16 backward kernels read.  Used by the bf16x3 arithmetic mode (three-term split-bf16 products).
+struct split16 { __bf16 v; };
+template <>
+struct VecIO<4, split16> {
+    static __device__ __forceinline__ void load2(const split16* p, int lo, float* v) {
+        const bf16x4_t h = *reinterpret_cast<const bf16x4_t*>(p), l = *reinterpret_cast<const bf16x4_t*>(p + lo);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (float)h[j] + (float)l[j];
+    }
+    static __device__ __forceinline__ void store2(split16* p, int lo, const float* v) {
+        bf16x4_t h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = (__bf16)v[j]; l[j] = (__bf16)(v[j] - (float)h[j]); }
+        *reinterpret_cast<bf16x4_t*>(p) = h;
+        *reinterpret_cast<bf16x4_t*>(p + lo) = l;
+    }
+};
+template <>
+struct VecIO<1, split16> {
+    static __device__ __forceinline__ void load2(const split16* p, int lo, float* v) { v[0] = (float)p[0].v + (float)p[lo].v; }
+    static __device__ __forceinline__ void store2(split16* p, int lo, const float* v) {
+        const __bf16 h = (__bf16)v[0];
+        p[0].v = h; p[lo].v = (__bf16)(v[0] - (float)h);
+    }
+};
+// plane-aware access: the plain types ignore `lo`
+template <typename T> struct IsSplit { static constexpr bool value = false; };
+template <> struct IsSplit<split16> { static constexpr bool value = true; };
+template <int W, typename T> __device__ __forceinline__ void ln_load(const T* p, int lo, float* v) {
+    if constexpr (IsSplit<T>::value) VecIO<W, T>::load2(p, lo, v); else VecIO<W, T>::load(p, v);
+}
+template <int W, typename T> __device__ __forceinline__ void ln_store(T* p, int lo, const float* v) {
+    if constexpr (IsSplit<T>::value) VecIO<W, T>::store2(p, lo, v); else VecIO<W, T>::store(p, v);
+}
+
 struct LnArgs {
     const void* x; const int* src_rows; const void* res; const float* gamma; const float* beta;
     void* y; float* mean; float* rstd; int R; int D; float eps;
     float p_pre; uint32_t site_pre; float p_post; uint32_t site_post; const u64* seed;
     const float* add1; int mod1; const float* add2; const int* idx2;
+    int ldx, ldr, ldy;      // row strides in elements (D for dense tensors)
+    int lox, lor, loy;      // column offset of the lo plane (split16 tensors only)
 };
 
 // TX: element type of x; TY: element type of the residual and of y (float or __bf16; statistics are always fp32)
@@ -64,8 +103,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
     const int r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));     // wave-uniform: the row index, its gather
     if (r >= a.R) return;                                                                  // source and its table rows are scalar loads
     const int D = a.D;
-    const size_t xrow = (size_t)(a.src_rows ? a.src_rows[r] : r) * D;
-    const size_t orow = (size_t)r * D;
+    const size_t xrow = (size_t)(a.src_rows ? a.src_rows[r] : r) * a.ldx;
+    const size_t orow = (size_t)r * D;          // element index base of the dropout draws (independent of the storage strides)
+    const size_t rrow = (size_t)r * a.ldr, yrow = (size_t)r * a.ldy;
     const bool any_drop = (a.p_pre > 0.f) || (a.p_post > 0.f);
     const u64 seed = any_drop ? a.seed[0] : 0ull;
     const float ik_pre = a.p_pre > 0.f ? 1.0f / (1.0f - a.p_pre) : 1.0f;
@@ -77,14 +117,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
     for (int i = 0; i < NPL; ++i) {
         const int col = (lane + 64 * i) * W;
         if (col < D) {
-            VecIO<W, TX>::load(xp + xrow + col, &v[i * W]);
+            ln_load<W, TX>(xp + xrow + col, a.lox, &v[i * W]);
             if (a.p_pre > 0.f) {
 #pragma unroll
                 for (int j = 0; j < W; ++j) v[i * W + j] *= drop_scale(seed, a.site_pre, orow + col + j, a.p_pre, ik_pre);
             }
             if (a.res) {
                 float t[W];
-                VecIO<W, TY>::load(rp + orow + col, t);
+                ln_load<W, TY>(rp + rrow + col, a.lor, t);
 #pragma unroll
                 for (int j = 0; j < W; ++j) v[i * W + j] += t[j];
             }
@@ -138,7 +178,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
 #pragma unroll
                 for (int j = 0; j < W; ++j) o[j] += t[j];
             }
-            VecIO<W, TY>::store(yp + orow + col, o);
+            ln_store<W, TY>(yp + yrow + col, a.loy, o);
         }
     }
 }
@@ -151,6 +191,8 @@ struct LnBwdArgs {
     float* partial; // (gridDim.x, 2, D) per-workgroup [dgamma; dbeta]
     int R; int D;
     float p_pre; uint32_t site_pre; float p_post; uint32_t site_post; const u64* seed;
+    int ldx, ldr;   // row strides (elements) of x and of the residual: D for dense tensors, the split row's leading dimension when the
+                    // saved tensors are the hi planes of split16 rows (bf16x3 mode); dy / dh / dx are always dense
 };
 
 // One wave per row, RU rows per wave in flight (all loads of the RU rows are issued before the first reduction: with ≤2
@@ -210,8 +252,8 @@ __global__ __launch_bounds__(256, (W == 4 && NPL * W <= 12 && RU == 2) ? 4 : 1) 
         for (int u = 0; u < RU; ++u) {
             const int r = r0 + u * stride;
             if (r < a.R) {
-                const size_t xrow = (size_t)(a.src_rows ? a.src_rows[r] : r) * D;
-                const size_t orow = (size_t)r * D;
+                const size_t xrow = (size_t)(a.src_rows ? a.src_rows[r] : r) * a.ldx;
+                const size_t orow = (size_t)r * D, rrow = (size_t)r * a.ldr;
                 mean[u] = a.mean[r]; rstd[u] = a.rstd[r];
 #pragma unroll
                 for (int i = 0; i < NPL; ++i) {
@@ -221,7 +263,7 @@ __global__ __launch_bounds__(256, (W == 4 && NPL * W <= 12 && RU == 2) ? 4 : 1) 
                         VecIO<W, TY>::load(dyp + orow + col, &d[u][i * W]);
                         if (a.res) {
                             float t[W];
-                            VecIO<W, TY>::load(rp + orow + col, t);
+                            VecIO<W, TY>::load(rp + rrow + col, t);
                             if (a.p_pre > 0.f) {
 #pragma unroll
                                 for (int j = 0; j < W; ++j)
@@ -367,20 +409,20 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(LnBwdArgs a, int row
         for (; r + 4 < r1; r += 8) {
             const int ra = r, rb = r + 4;
             float ha[4], hb[4], da[4], db[4], ta[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f};
-            VecIO<4, TX>::load(xp + (size_t)(a.src_rows ? a.src_rows[ra] : ra) * D + c0, ha);
-            VecIO<4, TX>::load(xp + (size_t)(a.src_rows ? a.src_rows[rb] : rb) * D + c0, hb);
+            VecIO<4, TX>::load(xp + (size_t)(a.src_rows ? a.src_rows[ra] : ra) * a.ldx + c0, ha);
+            VecIO<4, TX>::load(xp + (size_t)(a.src_rows ? a.src_rows[rb] : rb) * a.ldx + c0, hb);
             VecIO<4, TY>::load(dyp + (size_t)ra * D + c0, da);
             VecIO<4, TY>::load(dyp + (size_t)rb * D + c0, db);
-            if (a.res) { VecIO<4, TY>::load(rp + (size_t)ra * D + c0, ta); VecIO<4, TY>::load(rp + (size_t)rb * D + c0, tb); }
+            if (a.res) { VecIO<4, TY>::load(rp + (size_t)ra * a.ldr + c0, ta); VecIO<4, TY>::load(rp + (size_t)rb * a.ldr + c0, tb); }
             const float ma = a.mean[ra], sa = a.rstd[ra], mb = a.mean[rb], sb = a.rstd[rb];
             one(ra, ha, da, ta, ma, sa);
             one(rb, hb, db, tb, mb, sb);
         }
         for (; r < r1; r += 4) {
             float h[4], d[4], t[4] = {0.f, 0.f, 0.f, 0.f};
-            VecIO<4, TX>::load(xp + (size_t)(a.src_rows ? a.src_rows[r] : r) * D + c0, h);
+            VecIO<4, TX>::load(xp + (size_t)(a.src_rows ? a.src_rows[r] : r) * a.ldx + c0, h);
             VecIO<4, TY>::load(dyp + (size_t)r * D + c0, d);
-            if (a.res) VecIO<4, TY>::load(rp + (size_t)r * D + c0, t);
+            if (a.res) VecIO<4, TY>::load(rp + (size_t)r * a.ldr + c0, t);
             one(r, h, d, t, a.mean[r], a.rstd[r]);
         }
     }
@@ -560,7 +602,11 @@ static int launch_ln_fwd(const LnArgs& a, int x_dt, int y_dt, hipStream_t s) {
     const dim3 g(ceil_div(a.R, 4)), b(256);
     if (x_dt == 0 && y_dt == 0) hipLaunchKernelGGL((ln_fwd_kernel<NPL, W, float, float>), g, b, 0, s, a);
     else if (x_dt == 0 && y_dt == 1) hipLaunchKernelGGL((ln_fwd_kernel<NPL, W, float, __bf16>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((ln_fwd_kernel<NPL, W, __bf16, __bf16>), g, b, 0, s, a);
+    else if (x_dt == 1 && y_dt == 1) hipLaunchKernelGGL((ln_fwd_kernel<NPL, W, __bf16, __bf16>), g, b, 0, s, a);
+    else if (x_dt == 0 && y_dt == 2) hipLaunchKernelGGL((ln_fwd_kernel<NPL, W, float, split16>), g, b, 0, s, a);
+    else if (x_dt == 2 && y_dt == 2) hipLaunchKernelGGL((ln_fwd_kernel<NPL, W, split16, split16>), g, b, 0, s, a);
+    else if (x_dt == 2 && y_dt == 0) hipLaunchKernelGGL((ln_fwd_kernel<NPL, W, split16, float>), g, b, 0, s, a);
+    else { svpc_set_error("ln_fwd: storage-type combination not instantiated"); return -1; }
     return svpc_check_launch("ln_fwd");
 }
 template <int NPL, int W>
@@ -587,18 +633,26 @@ static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" {
 
-// dtype codes: 0 = fp32, 1 = bf16.  x_dt: x (and dx);  y_dt: residual, y, dy, dh.  Supported: (0,0), (0,1), (1,1).
-int svpc_ln_fwd_t(const void* x, int x_dt, const int* src_rows, const void* res, const float* gamma, const float* beta, void* y,
-                  int y_dt, float* mean, float* rstd, int R, int D, float eps, float p_pre, unsigned site_pre, float p_post,
-                  unsigned site_post, const u64* seed, const float* add1, int mod1, const float* add2, const int* idx2,
-                  hipStream_t stream) {
+// dtype codes: 0 = fp32, 1 = bf16, 2 = split (two bf16 planes per row, see split16).  x_dt: x (and dx);  y_dt: residual, y, dy, dh.
+// Supported: (0,0), (0,1), (1,1) and, forward only, (0,2), (2,2), (2,0).  ldx / ldr / ldy: row strides in elements (0 = dense, D);
+// lox / lor / loy: column offset of the lo plane of a split tensor.
+int svpc_ln_fwd_s(const void* x, int x_dt, int ldx, int lox, const int* src_rows, const void* res, int ldr, int lor, const float* gamma,
+                  const float* beta, void* y, int y_dt, int ldy, int loy, float* mean, float* rstd, int R, int D, float eps, float p_pre,
+                  unsigned site_pre, float p_post, unsigned site_post, const u64* seed, const float* add1, int mod1, const float* add2,
+                  const int* idx2, hipStream_t stream) {
     if (R == 0) return 0;
     SVPC_REQUIRE(!(x_dt == 1 && y_dt == 0), "ln_fwd: bf16 input with fp32 output is not instantiated");
+    if (ldx <= 0) ldx = D;
+    if (ldr <= 0) ldr = D;
+    if (ldy <= 0) ldy = D;
+    SVPC_REQUIRE((x_dt != 2 || (lox >= D && ldx >= lox + D)) && (y_dt != 2 || (loy >= D && ldy >= loy + D && (!res || (lor >= D && ldr >= lor + D)))),
+                 "ln_fwd: a split tensor needs its lo plane inside the row, behind the hi plane");
     LnArgs a{x, src_rows, res, gamma, beta, y, mean, rstd, R, D, eps, p_pre, site_pre, p_post, site_post, seed,
-             add1, mod1, add2, idx2};
+             add1, mod1, add2, idx2, ldx, ldr, ldy, lox, lor, loy};
     SVPC_REQUIRE((p_pre <= 0.f && p_post <= 0.f) || seed != nullptr, "ln_fwd: dropout needs a seed pointer");
     const bool vec = (D % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) &&
-                     (!res || aligned16(res)) && (!add1 || aligned16(add1)) && (!add2 || aligned16(add2));
+                     (!res || aligned16(res)) && (!add1 || aligned16(add1)) && (!add2 || aligned16(add2)) &&
+                     ldx % 4 == 0 && ldy % 4 == 0 && ldr % 4 == 0 && lox % 4 == 0 && lor % 4 == 0 && loy % 4 == 0;
     if (vec) {
         if (D <= 256) return launch_ln_fwd<1, 4>(a, x_dt, y_dt, stream);
         static int npl3 = -1;
@@ -614,6 +668,14 @@ int svpc_ln_fwd_t(const void* x, int x_dt, const int* src_rows, const void* res,
     }
     svpc_set_error("ln_fwd: row width not supported");
     return -1;
+}
+int svpc_ln_fwd_t(const void* x, int x_dt, const int* src_rows, const void* res, const float* gamma, const float* beta, void* y,
+                  int y_dt, float* mean, float* rstd, int R, int D, float eps, float p_pre, unsigned site_pre, float p_post,
+                  unsigned site_post, const u64* seed, const float* add1, int mod1, const float* add2, const int* idx2,
+                  hipStream_t stream) {
+    SVPC_REQUIRE(x_dt != 2 && y_dt != 2, "ln_fwd_t: split tensors go through svpc_ln_fwd_s");
+    return svpc_ln_fwd_s(x, x_dt, D, 0, src_rows, res, D, 0, gamma, beta, y, y_dt, D, 0, mean, rstd, R, D, eps, p_pre, site_pre, p_post,
+                         site_post, seed, add1, mod1, add2, idx2, stream);
 }
 int svpc_ln_fwd(const float* x, const int* src_rows, const float* res, const float* gamma, const float* beta, float* y,
                 float* mean, float* rstd, int R, int D, float eps, float p_pre, unsigned site_pre, float p_post,
@@ -633,15 +695,28 @@ int svpc_ln_bwd_groups(int R) {
 }
 
 // rows part only: dh / dx and the per-workgroup [dgamma ; dbeta] partials (svpc_ln_bwd_groups(R) × 2D floats)
+// ldx / ldr: row strides (elements) of the saved x and residual (0 = dense): the hi planes of split rows are read in place
+int svpc_ln_bwd_rows_s(const void* dy, const void* x, int x_dt, int ldx, int y_dt, const int* src_rows, const void* res, int ldr,
+                       const float* gamma, const float* mean, const float* rstd, void* dh, void* dx, float* partial, int R, int D,
+                       float p_pre, unsigned site_pre, float p_post, unsigned site_post, const u64* seed, hipStream_t stream);
 int svpc_ln_bwd_rows_t(const void* dy, const void* x, int x_dt, int y_dt, const int* src_rows, const void* res, const float* gamma,
                        const float* mean, const float* rstd, void* dh, void* dx, float* partial, int R, int D, float p_pre,
                        unsigned site_pre, float p_post, unsigned site_post, const u64* seed, hipStream_t stream) {
+    return svpc_ln_bwd_rows_s(dy, x, x_dt, D, y_dt, src_rows, res, D, gamma, mean, rstd, dh, dx, partial, R, D, p_pre, site_pre, p_post,
+                              site_post, seed, stream);
+}
+int svpc_ln_bwd_rows_s(const void* dy, const void* x, int x_dt, int ldx, int y_dt, const int* src_rows, const void* res, int ldr,
+                       const float* gamma, const float* mean, const float* rstd, void* dh, void* dx, float* partial, int R, int D,
+                       float p_pre, unsigned site_pre, float p_post, unsigned site_post, const u64* seed, hipStream_t stream) {
     if (R == 0) return 0;
     SVPC_REQUIRE(!(x_dt == 1 && y_dt == 0), "ln_bwd: bf16 input with fp32 output is not instantiated");
+    SVPC_REQUIRE(x_dt != 2 && y_dt != 2, "ln_bwd: split tensors are read through their hi plane (dtype 1 with the row's leading dimension)");
+    if (ldx <= 0) ldx = D;
+    if (ldr <= 0) ldr = D;
     const int G = svpc_ln_bwd_groups(R);
-    LnBwdArgs a{dy, x, src_rows, res, gamma, mean, rstd, dh, dx, partial, R, D, p_pre, site_pre, p_post, site_post, seed};
+    LnBwdArgs a{dy, x, src_rows, res, gamma, mean, rstd, dh, dx, partial, R, D, p_pre, site_pre, p_post, site_post, seed, ldx, ldr};
     const bool vec = (D % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(gamma) && (!res || aligned16(res)) &&
-                     (!dh || aligned16(dh)) && (!dx || aligned16(dx));
+                     (!dh || aligned16(dh)) && (!dx || aligned16(dx)) && ldx % 4 == 0 && ldr % 4 == 0;
     int rc = -1;
     if (vec && !dh && !dx) {       // parameter gradients only: streaming two-output column sum
         const dim3 grid(ceil_div(D, 256), G);

@@ -5,8 +5,9 @@
 // HBM-bound: 4 reads + 3 writes of the parameter bytes (+2 with EMA, +½ for the bf16 weight shadow).
 #include "common.h"
 
-// shadow: optional bf16 copy of the parameter (operand of the direct-to-LDS GEMMs), rewritten by the Adam kernel
-struct TensorMeta { float* p; float* g; float* m; float* v; float* ema; long long n; float wd; int pad; __bf16* shadow; };
+// shadow: optional bf16 copy of the parameter (operand of the direct-to-LDS GEMMs), rewritten by the Adam kernel; shadow_lo: optional
+// second plane bf16(p - shadow) of the bf16x3 mode's split weights (gemm_p8x3.hip)
+struct TensorMeta { float* p; float* g; float* m; float* v; float* ema; long long n; float wd; int pad; __bf16* shadow; __bf16* shadow_lo; };
 
 constexpr int OPT_CHUNK = 16384;
 
@@ -72,7 +73,11 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(const TensorMeta* __restr
         if (t.wd > 0.f) upd += t.wd * p;
         p -= lr * upd;
         t.m[i] = m; t.v[i] = v; t.p[i] = p;
-        if (t.shadow) t.shadow[i] = (__bf16)p;
+        if (t.shadow) {
+            const __bf16 ph = (__bf16)p;
+            t.shadow[i] = ph;
+            if (t.shadow_lo) t.shadow_lo[i] = (__bf16)(p - (float)ph);
+        }
         if (t.ema && ema_decay >= 0.f) t.ema[i] = (1.f - ema_decay) * p + ema_decay * t.ema[i];
     }
 }

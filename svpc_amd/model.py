@@ -225,10 +225,12 @@ class BertLayerNoMemoryUntied(nn.Module):
         the selected rows are bit-for-bit what ``run`` produces for them (in eval mode)."""
         D = h.shape[1]
         att = self.attention.self
-        hq = ops.take_rows(h, sel_rows).float()      # the few selected rows leave the bf16 stream here (no-op in fp32 storage)
+        hq = ops.take_rows_f32(h, sel_rows)          # the few selected rows leave the bf16 / split stream here (no-op in fp32 storage)
         q = ops.linear(hq, att.query.weight, att.query.bias)
         wkv, bkv, wg, bg, w16 = att.packed("kv")
         kv = ops.linear(h, wkv, bkv, wgrad=wg, bgrad=bg, w16=w16)
+        if ops.lo_off(kv) is not None:               # bf16x3 mode: one query per clip against exact fp32 keys / values
+            kv = ops.to_f32(kv)
         ctx = ops.attention(q.to(kv.dtype), kv, (0, 0, D), D, cx.H, seq_sel, key_mask=key_mask, causal=False,
                             drop=cx.drop(cx.p_a)).float()
         so = self.attention.output
@@ -348,7 +350,8 @@ class BertDecoderNoMemoryUntied(nn.Module):
 
     def streams_bf16(self, rows, width):
         """whether ``run`` keeps the sentence activations of (rows, width) in bf16"""
-        return ops.bf16_stream_ok(rows, width, self.config.intermediate_size)
+        # (bf16x3 mode: the decoder keeps fp32 storage — three-term products built from fp32 operands, exact fp32 attention)
+        return (not ops.is_x3()) and ops.bf16_stream_ok(rows, width, self.config.intermediate_size)
 
     def run(self, x, text_mask, mem, seq_self, seq_cross, mem_mask, cx):
         # interior-only row counts in bf16 precision: the sentence activations (and their gradients) stream through HBM as bf16
@@ -775,14 +778,15 @@ class StateAwareRecursiveTransformer(nn.Module):
         Lv = self.config.max_v_len
         ve = self.video_embeddings
         # training forward at interior-only shapes: the clip-encoder activation stream lives in HBM as bf16
-        stream_bf16 = cls_only is not None and ops.bf16_stream_ok(video_rows.numel(), self.config.hidden_size,
-                                                                   self.config.video_feature_size, self.config.intermediate_size)
+        # (bf16x3 mode: the split stream also carries the reference-shaped forward_step — the greedy decoder's encoder side)
+        stream_bf16 = (cls_only is not None or ops.is_x3()) and ops.bf16_stream_ok(
+            video_rows.numel(), self.config.hidden_size, self.config.video_feature_size, self.config.intermediate_size)
         h = ve.video_embeddings.run(feats_flat, cx.eps, src_rows=video_rows, drop=cx.drop(cx.p_h),
                                     add1=ve.position_embeddings_video.pe[:Lv].contiguous(), add1_mod=Lv,
                                     add2=self.token_type_embeddings.weight, add2_idx=ids_v, out_bf16=stream_bf16)
         if cls_only is not None:      # (cls_rows, one-query segmentation): last layer only for the [CLS] rows
             return self.encoder.run(h, seq, key_mask_v, cx, last_rows=cls_only[0], last_seq=cls_only[1])
-        return self.encoder.run(h, seq, key_mask_v, cx)
+        return ops.to_f32(self.encoder.run(h, seq, key_mask_v, cx))
 
     def _lm_probs(self, dec, bank, plan_like, cx, labels=None, proj=None):
         """Head + pointer-generator (+ caption loss rows).  plan_like carries step_ne, row_vid, csr, row_c, c_max."""

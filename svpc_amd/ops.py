@@ -116,10 +116,10 @@ def _defer_wgrad16(dz, x, wgrad):
 
 def defer_wgrad(dz, x, wgrad, bgrad):
     """Queue dW += dzᵀ·x (and db += Σ dz) for the grouped launch; False if this problem must be launched on its own."""
-    if USE_GROUPED_WGRAD and GROUP_BF16 and _PRECISION == "bf16" and wgrad is not None and bgrad is None and not SIDE_WGRAD and \
+    if USE_GROUPED_WGRAD and GROUP_BF16 and _fast() and wgrad is not None and bgrad is None and not SIDE_WGRAD and \
             dz.dtype == torch.bfloat16 and x.dtype == torch.bfloat16:
         return _defer_wgrad16(dz, x, wgrad)
-    if not (USE_GROUPED_WGRAD and _PRECISION == "bf16" and wgrad is not None and dz.dtype == torch.float32 and x.dtype == torch.float32):
+    if not (USE_GROUPED_WGRAD and _fast() and wgrad is not None and dz.dtype == torch.float32 and x.dtype == torch.float32):
         return False
     rows, n_out = dz.shape
     n_in = x.shape[1]
@@ -397,7 +397,7 @@ class KernelTimer:
         ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in self.records)
         work = sum(w for w, _, _, _ in self.records)
         # algorithmic HBM bytes: every operand and the result once, in their storage types
-        el = lambda d: 2 if d else 4
+        el = lambda d: 2 if d == 1 else 4      # (split = two bf16 planes = 4 bytes per element)
         nbytes = sum(M * K * el(a) + N * K * el(b) + M * N * el(c) for _, _, _, (M, N, K, _, _, a, b, c) in self.records)
         # an event pair around NOTHING still measures a few µs (record-to-record latency on the stream): calibrate and remove it,
         # so the per-launch average is comparable with the profiler's kernel durations
@@ -412,19 +412,99 @@ class KernelTimer:
 
 GEMM_TIMER = None   # set by bench.py
 
-# Arithmetic type of the dense contractions: "fp32" (v_mfma_f32_32x32x2_f32, bit-level parity mode) or "bf16"
-# (v_mfma_f32_32x32x16_bf16 with fp32 accumulate — the throughput mode the baseline names).
+# Arithmetic type of the dense contractions:
+#   "fp32"   — v_mfma_f32_32x32x2_f32, fp32 storage: bit-level parity mode (1/16 of the bf16 matrix rate);
+#   "bf16"   — bf16 MFMA operands with fp32 accumulate, bf16 activation streams: the throughput mode the baseline names;
+#   "bf16x3" — the ≤1e-4-parity throughput mode: every FORWARD contraction is a three-term split-bf16 product
+#              (a_lo·b_hi + a_hi·b_lo + a_hi·b_hi on the bf16 matrix cores, fp32 accumulate: ≈2⁻¹⁷ per operand instead of 2⁻⁹), the
+#              clip-encoder stream is stored as two bf16 planes per row (hi = bf16(v), lo = bf16(v - hi): the bytes of fp32), all
+#              other activations as fp32; the BACKWARD runs the bf16 mode's kernels on the hi planes (gradients have bf16-mode
+#              accuracy, the loss / probabilities / token ids have ≈fp32 accuracy).
 _PRECISION = "fp32"
 
 
 def set_precision(p):
     global _PRECISION
-    assert p in ("fp32", "bf16")
+    assert p in ("fp32", "bf16", "bf16x3")
     _PRECISION = p
 
 
 def get_precision():
     return _PRECISION
+
+
+def _fast():
+    """the bf16 matrix cores carry the contractions (either throughput mode)"""
+    return _PRECISION != "fp32"
+
+
+def is_x3():
+    return _PRECISION == "bf16x3"
+
+
+# ---- split tensors (bf16x3 mode).  A split activation is handed around as its HI plane: a bf16 view (R, W) with row stride ≥ 2W of
+# a (R, 2W) buffer, tagged with ``_svpc_lo`` = the column offset of the lo plane.  To autograd it is an ordinary bf16 tensor (its
+# gradient is a dense (R, W) bf16 tensor); the x3 forward kernels read hi + lo, the bf16 backward kernels read the view in place.
+# The tag lives on the Python object: only tensors handed straight from one svpc op to the next carry it (every producer sets it);
+# anything else (a torch view / cast / cat) silently drops to the hi plane — use ``to_f32`` to leave the split domain.
+def lo_off(t):
+    return getattr(t, "_svpc_lo", None)
+
+
+def new_split(rows, width, device):
+    buf = torch.empty(rows, 2 * width, dtype=torch.bfloat16, device=device)
+    hi = buf[:, :width]
+    hi._svpc_lo = width
+    return hi
+
+
+def _lo_view(t):
+    return torch.as_strided(t.detach(), t.shape, t.stride(), t.storage_offset() + t._svpc_lo)
+
+
+class _ToF32(Function):
+    @staticmethod
+    def forward(ctx, t, lo):
+        out = t.float()
+        if lo is not None:
+            out += torch.as_strided(t, t.shape, t.stride(), t.storage_offset() + lo).float()
+        ctx.dt = t.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt), None
+
+
+def to_f32(t):
+    """fp32 copy of a bf16 / split tensor (hi + lo for a split one; data movement and one exact add)."""
+    if t.dtype == torch.float32:
+        return t
+    return _ToF32.apply(t, lo_off(t))
+
+
+def take_rows_f32(t, idx):
+    """fp32 rows ``idx`` of a (possibly split / bf16) 2-D tensor."""
+    lo = lo_off(t)
+    if lo is None:
+        return torch.index_select(t, 0, idx).float()
+    return _TakeSplit.apply(t, idx, lo)
+
+
+class _TakeSplit(Function):
+    @staticmethod
+    def forward(ctx, t, idx, lo):
+        ctx.save_for_backward(idx)
+        ctx.shape, ctx.dt = t.shape, t.dtype
+        low = torch.as_strided(t, t.shape, t.stride(), t.storage_offset() + lo)
+        return torch.index_select(t, 0, idx).float() + torch.index_select(low, 0, idx).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        out = torch.zeros(ctx.shape, dtype=ctx.dt, device=g.device)
+        out.index_add_(0, idx.long(), g.to(ctx.dt))
+        return out, None, None
 
 
 # bf16 activation stream: in "bf16" precision the clip encoder and the decoder keep their activations (and their gradients) in
@@ -441,30 +521,42 @@ def _dt(t):
 
 
 def bf16_stream_ok(rows, *dims):
-    if not (_PRECISION == "bf16" and BF16_STREAM and rows > 0):
+    if not (_fast() and BF16_STREAM and rows > 0):
         return False
+    if is_x3():          # the split stream's GEMM (gemm_p8x3.hip) walks 64-deep k-tiles
+        return USE_GLDS and all(d % 64 == 0 for d in dims)
     if USE_GLDS:
         return all(d % 32 == 0 for d in dims)
     return rows % 128 == 0 and all(d % 128 == 0 for d in dims)
 
 
-def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NONE, p=0.0, site=0, seed=None, accumulate=0, R=None, G=None):
+def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NONE, p=0.0, site=0, seed=None, accumulate=0, R=None, G=None,
+          x3=False):
     """C = epi(A·B) (+ R: an addend of C's type and layout, only on the bf16 direct-to-LDS path; other paths add it afterwards).
-    G = (aux, act): C = (A·B) ⊙ act'(aux) — absorbed only by the bf16 direct-to-LDS path; returns whether it was applied."""
+    G = (aux, act): C = (A·B) ⊙ act'(aux) — absorbed only by the bf16 direct-to-LDS path; returns whether it was applied.
+    x3 (fp32 operands, bf16x3 mode, forward products): three-term split-bf16 products (svpc_gemm_l32_x3); shapes that kernel does
+    not take (K not a multiple of 32: the 300-wide word vectors) run on the exact f32 MFMA instead — never on one-term bf16."""
     ws = _ws(C.device)
     g_done = False
     ev = (GEMM_TIMER.bracket(2.0 * M * N * K, (M, N, K, a_kc, b_kc, _dt(A), _dt(B), _dt(C)))
           if GEMM_TIMER is not None else None)
     if ev:
         ev[0].record()
-    if _PRECISION == "bf16" and USE_GLDS and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and \
+    if x3 and A.dtype == B.dtype == C.dtype == torch.float32:
+        if (A.data_ptr() | B.data_ptr()) % 16 == 0 and _lib.load().svpc_gemm_l32_supported(a_kc, b_kc, lda, ldb, M, N, K) == 1:
+            _lib.call("gemm_l32_x3", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), None, M, N, K, _p(bias), act, p, site,
+                      _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+        else:
+            _lib.call("gemm_f32", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
+                      _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+    elif _fast() and USE_GLDS and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and \
             (A.data_ptr() | B.data_ptr()) % 16 == 0 and _lib.load().svpc_gemm_glds_supported(a_kc, b_kc, lda, ldb, M, N, K) == 1:
         g_ok = G is not None and G[0].dtype == C.dtype and G[0].shape == C.shape and G[0].stride() == C.stride() and not accumulate
         _lib.call("gemm_glds_rg", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), _dt(C), C.stride(0), _p(Z), _p(R), _p(G[0]) if g_ok else None,
                   int(G[1]) if g_ok else 0, M, N, K, _p(bias), act, p, site, _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
         R = None
         g_done = g_ok
-    elif _PRECISION == "bf16" and USE_L32 and A.dtype == B.dtype == C.dtype == torch.float32 and \
+    elif _fast() and USE_L32 and A.dtype == B.dtype == C.dtype == torch.float32 and \
             (A.data_ptr() | B.data_ptr()) % 16 == 0 and _lib.load().svpc_gemm_l32_preferred(a_kc, b_kc, lda, ldb, M, N, K) == 1:
         if R is not None and not (R.dtype == torch.float32 and R.is_contiguous() and R.shape == C.shape and C.is_contiguous()):
             Rk = None
@@ -472,7 +564,7 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NON
             Rk, R = R, None       # absorbed by the epilogue
         _lib.call("gemm_l32_r", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), _p(Rk), M, N, K, _p(bias), act, p, site,
                   _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
-    elif _PRECISION == "bf16":
+    elif _fast():
         dt = lambda t: 1 if t.dtype == torch.bfloat16 else 0
         _lib.call("gemm_mx", _p(A), dt(A), lda, a_kc, _p(B), dt(B), ldb, b_kc, _p(C), dt(C), C.stride(0), _p(Z), M, N, K, _p(bias),
                   act, p, site, _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
@@ -520,15 +612,39 @@ def _ready(t, kind=None):
 
 
 def _shadow(w):
-    """bf16 shadow of parameter ``w`` (svpc_amd.optim.WeightStore), re-cast first if ``w`` changed behind the store's back."""
+    """bf16 shadow of parameter ``w`` (svpc_amd.optim.WeightStore), re-cast first if ``w`` changed behind the store's back.  A store
+    built with the lo plane (bf16x3 mode) keeps it ``_svpc_lo`` elements behind the shadow; it is re-cast together with it."""
     s = getattr(w, "_svpc_bf16", None)
     if s is None:
         return None
     if w._version != w._svpc_bf16_ver:
         with torch.no_grad():
             s.copy_(w.detach())
+            if lo_off(s) is not None:
+                split_planes(w.detach(), s, _lo_view_flat(s))
         w._svpc_bf16_ver = w._version
     return s
+
+
+def _lo_view_flat(s):
+    """the lo plane of a weight-shadow view (same shape and strides, ``_svpc_lo`` elements further on in the store's buffer)"""
+    return torch.as_strided(s, s.shape, s.stride(), s.storage_offset() + s._svpc_lo)
+
+
+def split_planes(src, hi, lo):
+    """hi ← bf16(src), lo ← bf16(src - hi) (weights leaving the fp32 master copy; data preparation, not on the step's hot path)"""
+    with torch.no_grad():
+        hi.copy_(src)
+        lo.copy_(src - hi.float())
+
+
+def _transient_split(w):
+    """(hi, lo offset) planes of a weight that has no store (first step, tests): one 2·numel bf16 buffer"""
+    buf = torch.empty(2, *w.shape, dtype=torch.bfloat16, device=w.device)
+    split_planes(w.detach(), buf[0], buf[1])
+    hi = buf[0]
+    hi._svpc_lo = w.numel()
+    return hi
 
 
 # Residual-gradient hand-over.  In `y = LayerNorm(sub(h) + h)` the gradient of h has two parts: the LayerNorm's dh (residual path)
@@ -546,14 +662,39 @@ class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, act, trans_w, drop, wgrad, bgrad, w16, tok_out=None, tok_in=None):
         _need_gpu(x)
+        x_lo = lo_off(x)
         x = _rows2d(x)
+        w_lo = lo_off(w16) if w16 is not None else None
         w = _c(w if w16 is None else w16)      # bf16 shadow: both GEMM operands stream straight into LDS
         M, K = x.shape
         N = w.shape[1] if trans_w else w.shape[0]
         p, site, seed = _drop_args(drop)
+        if x_lo is not None:
+            # bf16x3 stream: split activations × split weight shadow → split output (gemm_p8x3.hip); the pre-activation copy z is a
+            # plain bf16 matrix (all the bf16 backward needs, for ReLU too: z > 0 ⇔ y > 0)
+            if w_lo is None or trans_w or p > 0.0:
+                raise _lib.SvpcKernelError("linear: a split activation needs a split weight shadow, an (out, in) weight and no dropout")
+            y = new_split(M, N, x.device)
+            z = torch.empty(M, N, dtype=torch.bfloat16, device=x.device) if act != ACT_NONE else None
+            # (bench.py's roofline bracket: dtype code 2 = split operands; work = the product's 2·M·N·K, the kernel issues 3× that)
+            ev = GEMM_TIMER.bracket(2.0 * M * N * K, (M, N, K, 1, 1, 2, 2, 2)) if GEMM_TIMER is not None else None
+            if ev:
+                ev[0].record()
+            _lib.call("gemm_p8x3", _p(x), x.stride(0), x_lo, _p(w), w.stride(0), w_lo, _p(y), y.stride(0), y._svpc_lo, _p(z), N, M, N, K,
+                      _p(b), act, _stream())
+            if ev:
+                ev[1].record()
+            ctx.save_for_backward(x, w, z)
+            ctx.cfg = (act, trans_w, p, site, seed, b is not None)
+            ctx.direct = (wgrad, bgrad)
+            ctx.tok_out, ctx.tok_in = tok_out, tok_in
+            if tok_out is not None:
+                tok_out["aux"], tok_out["act"] = z, act
+            return y
         y = torch.empty(M, N, dtype=x.dtype, device=x.device)
         z = torch.empty_like(y) if act == ACT_GELU else None
-        _gemm(x, x.stride(0), 1, w, w.stride(0), 0 if trans_w else 1, y, M, N, K, Z=z, bias=b, act=act, p=p, site=site, seed=seed)
+        _gemm(x, x.stride(0), 1, w, w.stride(0), 0 if trans_w else 1, y, M, N, K, Z=z, bias=b, act=act, p=p, site=site, seed=seed,
+              x3=is_x3())
         ctx.save_for_backward(x, w, z if act == ACT_GELU else (y if act != ACT_NONE else None))
         ctx.cfg = (act, trans_w, p, site, seed, b is not None)
         ctx.direct = (wgrad, bgrad)
@@ -643,10 +784,16 @@ def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgr
     (C = dz·W ⊙ act'(z), svpc_gemm_glds_rg) and the separate activation-backward pass over the stream is skipped.  A second consumer
     is detected in backward and fails loudly."""
     tok_in = getattr(x, "_svpc_act_tok", None)
+    split = lo_off(x) is not None
     if x.dtype == torch.bfloat16:
         n_out = w.shape[1] if trans_w else w.shape[0]
-        if trans_w or drop is not None or not bf16_stream_ok(x.shape[0], x.shape[1], n_out):
-            x = x.float()          # shapes outside the bf16-stream GEMM variants fall back to fp32 storage
+        ok = bf16_stream_ok(x.shape[0], x.shape[1], n_out) and not trans_w and drop is None
+        if ok and split:
+            ok = act != ACT_SIGMOID and _lib.load().svpc_gemm_p8x3_supported(x.stride(0), x._svpc_lo, x.shape[1], 2 * n_out, n_out, n_out,
+                                                                             x.shape[0], n_out, x.shape[1]) == 1
+        if not ok:
+            x = to_f32(x)          # shapes outside the bf16-stream GEMM variants fall back to fp32 storage
+            split = False
     if wgrad is None:
         wgrad = _direct(w)
     if bgrad is None and b is not None:
@@ -654,6 +801,8 @@ def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgr
     if x.dtype == torch.bfloat16 and USE_GLDS:
         if w16 is None:
             w16 = _shadow(w)
+        if split and (w16 is None or lo_off(w16) is None):
+            w16 = _transient_split(w)          # no store with a lo plane (first step, a store built in another mode): split on the fly
         if w16 is None:            # no weight store yet (first step, inference without one): a transient bf16 copy
             w16 = w.detach().to(torch.bfloat16)
     else:
@@ -664,6 +813,8 @@ def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgr
     if tok_in is not None and (x.dtype != torch.bfloat16 or trans_w or not USE_GLDS):
         tok_in = None
     y = _Linear.apply(x, w, b, act, trans_w, drop, wgrad, bgrad, w16, tok_out, tok_in)
+    if split:
+        y._svpc_lo = y.shape[1]        # (a split activation yields a split output: see _Linear.forward)
     if tok_out is not None:
         y._svpc_act_tok = tok_out
     return y
@@ -673,25 +824,41 @@ def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgr
 class _LayerNorm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, add2, eps, src_rows, pad_row, pre_drop, post_drop, add1, add1_mod, add2_idx,
-                out_bf16=False, sink=False):
+                out_bf16=False, sink=False, out_split=False):
         _need_gpu(x)
         ctx.sink = bool(sink)
         ctx.direct = (_direct(gamma), _direct(beta), _direct(x) if src_rows is not None else None,
                       _direct(add2) if add2 is not None else None)
-        x = _c(x)
+        x_lo = lo_off(x)
+        r_lo = lo_off(residual) if residual is not None else None
+        split = out_split or x_lo is not None or r_lo is not None
+        if x_lo is None:
+            x = _c(x)
         D = x.shape[1]
         R = src_rows.numel() if src_rows is not None else x.shape[0]
         p_pre, s_pre, seed1 = _drop_args(pre_drop)
         p_post, s_post, seed2 = _drop_args(post_drop)
         seed = seed1 if seed1 is not None else seed2
+        mean = torch.empty(R, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(R, dtype=torch.float32, device=x.device)
+        add1 = _c(add1) if add1 is not None else None
+        if split:
+            # bf16x3 stream: x is fp32 (the gathered feature / embedding rows) or split, the residual is split, y is split
+            if (x_lo is None and x.dtype != torch.float32) or (residual is not None and r_lo is None):
+                raise _lib.SvpcKernelError("layernorm: a split output needs fp32 or split inputs and a split residual")
+            y = new_split(R, D, x.device)
+            _lib.call("ln_fwd_s", _p(x), 2 if x_lo is not None else 0, x.stride(0), x_lo or 0, _p(src_rows), _p(residual),
+                      residual.stride(0) if residual is not None else 0, r_lo or 0, _p(gamma), _p(beta), _p(y), 2, y.stride(0), y._svpc_lo,
+                      _p(mean), _p(rstd), R, D, float(eps), p_pre, s_pre, p_post, s_post, _p(seed), _p(add1), int(add1_mod), _p(add2),
+                      _p(add2_idx), _stream())
+            ctx.save_for_backward(x, gamma, residual, mean, rstd, src_rows, add2_idx, seed)      # (the hi planes: bf16 views)
+            ctx.cfg = (R, D, p_pre, s_pre, p_post, s_post, pad_row, add2.shape[0] if add2 is not None else 0)
+            return y
         residual = _c(residual) if residual is not None else None
         y_dtype = torch.bfloat16 if (out_bf16 or x.dtype == torch.bfloat16) else torch.float32
         if residual is not None and residual.dtype != y_dtype:
             residual = residual.to(y_dtype)
         y = torch.empty(R, D, dtype=y_dtype, device=x.device)
-        mean = torch.empty(R, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(R, dtype=torch.float32, device=x.device)
-        add1 = _c(add1) if add1 is not None else None
         _lib.call("ln_fwd_t", _p(x), _dt(x), _p(src_rows), _p(residual), _p(gamma), _p(beta), _p(y), _dt(y), _p(mean), _p(rstd), R, D,
                   float(eps), p_pre, s_pre, p_post, s_post, _p(seed), _p(add1), int(add1_mod), _p(add2), _p(add2_idx), _stream())
         ctx.save_for_backward(x, gamma, residual, mean, rstd, src_rows, add2_idx, seed)
@@ -717,8 +884,10 @@ class _LayerNorm(Function):
         dbeta = b_dir if direct_gb else torch.empty(D, dtype=torch.float32, device=dev)
         # rows part on this stream; the dgamma/dbeta tail only feeds the optimizer, so it is forked off (own partial buffer)
         partial = torch.empty(_lib.load().svpc_ln_bwd_groups(R) * 2 * D, dtype=torch.float32, device=dev)
-        _lib.call("ln_bwd_rows_t", _p(dy), _p(x), _dt(x), _dt(dy), _p(src_rows), _p(residual), _p(gamma), _p(mean), _p(rstd), _p(dh),
-                  _p(dx_rows), _p(partial), R, D, p_pre, s_pre, p_post, s_post, _p(seed), _stream())
+        # (strided form: in bf16x3 mode the saved x / residual are the hi planes of split rows, read in place)
+        _lib.call("ln_bwd_rows_s", _p(dy), _p(x), _dt(x), x.stride(0), _dt(dy), _p(src_rows), _p(residual),
+                  residual.stride(0) if residual is not None else 0, _p(gamma), _p(mean), _p(rstd), _p(dh), _p(dx_rows), _p(partial), R, D,
+                  p_pre, s_pre, p_post, s_post, _p(seed), _stream())
         if direct_gb and USE_MULTI_FINALIZE and not SIDE_WGRAD:
             defer_finalize(partial, _lib.load().svpc_ln_bwd_groups(R), 2 * D, dgamma, dbeta, D)
             dgamma = dbeta = None
@@ -746,20 +915,26 @@ class _LayerNorm(Function):
             else:
                 dadd2 = _colsum(dy, add2_idx, k_add2)
         dres = dh if need_res else None
-        if need_res and ctx.sink and USE_RES_SINK and (dh.dtype == torch.bfloat16 or (_PRECISION == "bf16" and USE_L32)):
+        if need_res and ctx.sink and USE_RES_SINK and (dh.dtype == torch.bfloat16 or (_fast() and USE_L32)):
             _RES_SINK[residual.data_ptr()] = dh       # joins the dgrad of the projection that consumes the residual tensor
             SINK_STATS[0] += 1
             _queue_end_of_backward_join()
             dres = None
-        return dx, dgamma, dbeta, dres, dadd2, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, dadd2, None, None, None, None, None, None, None, None, None, None, None
 
 
 def layernorm(x, gamma, beta, eps, residual=None, src_rows=None, pad_row=-1, pre_drop=None, post_drop=None,
               add1=None, add1_mod=0, add2=None, add2_idx=None, out_bf16=False, sink=False):
     """sink=True: the residual tensor's only other consumer is an ops.linear whose backward will absorb this LayerNorm's
-    residual-path gradient in its dgrad epilogue (see _RES_SINK)."""
-    return _LayerNorm.apply(x, gamma, beta, residual, add2, eps, src_rows, pad_row, pre_drop, post_drop, add1, add1_mod,
-                            add2_idx, out_bf16, sink)
+    residual-path gradient in its dgrad epilogue (see _RES_SINK).  out_bf16: the output joins an activation stream — bf16 in the
+    bf16 mode, split (two bf16 planes) in the bf16x3 mode; split inputs always give a split output."""
+    out_split = bool(out_bf16) and is_x3()
+    split = out_split or lo_off(x) is not None or (residual is not None and lo_off(residual) is not None)
+    y = _LayerNorm.apply(x, gamma, beta, residual, add2, eps, src_rows, pad_row, pre_drop, post_drop, add1, add1_mod,
+                         add2_idx, out_bf16, sink, out_split)
+    if split:
+        y._svpc_lo = y.shape[1]
+    return y
 
 
 # ------------------------------------------------------------------------------------------------ attention
@@ -767,6 +942,7 @@ class _Attention(Function):
     @staticmethod
     def forward(ctx, qt, kvt, cols, D, H, seq, key_mask, causal, drop):
         _need_gpu(qt)
+        q_lo, kv_lo = lo_off(qt), lo_off(kvt)
         qt, kvt_c = _rows2d(qt), None
         same = kvt is qt or (kvt.data_ptr() == qt.data_ptr() and kvt.shape == qt.shape)
         kvt_c = qt if same else _rows2d(kvt)
@@ -774,14 +950,35 @@ class _Attention(Function):
         p, site, seed = _drop_args(drop)
         if kvt_c.dtype != qt.dtype:
             raise _lib.SvpcKernelError("attention: query and key/value tensors must have the same dtype")
-        out = torch.empty(seq.n_q_rows, D, dtype=qt.dtype, device=qt.device)
+        split = q_lo is not None
+        if split != (kv_lo is not None):
+            raise _lib.SvpcKernelError("attention: query and key/value tensors must both be split or both be plain")
+        out = new_split(seq.n_q_rows, D, qt.device) if split else torch.empty(seq.n_q_rows, D, dtype=qt.dtype, device=qt.device)
         lse = torch.empty(seq.n, H, seq.max_q, dtype=torch.float32, device=qt.device)
         tbl = seq.table if seq.table.device == qt.device else seq.table.to(qt.device)
         es = qt.element_size()
         qp, kp, vp = qt.data_ptr() + cols[0] * es, kvt_c.data_ptr() + cols[1] * es, kvt_c.data_ptr() + cols[2] * es
-        mfma = (_PRECISION == "bf16" and ((qp | kp | vp) & 15) == 0 and
+        mfma = (_fast() and ((qp | kp | vp) & 15) == 0 and
                 _lib.load().svpc_attn_mfma_supported(dh, seq.max_q, seq.max_k, qt.stride(0), kvt_c.stride(0), kvt_c.stride(0)) == 1)
-        if (not torch.is_grad_enabled() and seq.max_q == 1 and p <= 0.0 and not causal and qt.dtype == torch.float32 and dh <= 64
+        fwd_done = False
+        if split:
+            # bf16x3 stream (the wrapper has checked the shape): three-term products over the hi / lo planes; the backward is the
+            # bf16 kernel on the hi planes
+            if causal or not mfma:
+                raise _lib.SvpcKernelError("attention: split tensors need the non-causal MFMA shape (head dim 32/64, ≤128 rows)")
+            _lib.call("attn_stream_x3_fwd", qp, qt.stride(0), q_lo, kp, kvt_c.stride(0), kv_lo, vp, kvt_c.stride(0), kv_lo, _p(out),
+                      out.stride(0), out._svpc_lo, _p(lse), _p(tbl), seq.n, H, dh, seq.max_q, seq.max_k, _p(key_mask), 1.0 / math.sqrt(dh),
+                      p, site, _p(seed), _stream())
+            fwd_done = True
+        elif is_x3() and qt.dtype == torch.float32 and not (not torch.is_grad_enabled() and seq.max_q == 1):
+            # bf16x3 mode, fp32 storage (step encoder, decoder, the [CLS]-only layer): exact fp32 forward; the backward still runs
+            # on the matrix cores when the shape allows (same LSE definition in both kernel families)
+            _lib.call("attn_fwd", qp, qt.stride(0), kp, kvt_c.stride(0), vp, kvt_c.stride(0), _p(out), D, _p(lse), _p(tbl), seq.n, H,
+                      dh, seq.max_q, seq.max_k, _p(key_mask), 1 if causal else 0, 1.0 / math.sqrt(dh), p, site, _p(seed), _stream())
+            fwd_done = True
+        if fwd_done:
+            pass
+        elif (not torch.is_grad_enabled() and seq.max_q == 1 and p <= 0.0 and not causal and qt.dtype == torch.float32 and dh <= 64
                 and not (qt.requires_grad or kvt_c.requires_grad)):
             # incremental decoding: one query per sequence — a wave per (sequence, head), no tiles, no LDS
             _lib.call("attn_q1_fwd", qp, qt.stride(0), kp, kvt_c.stride(0), vp, kvt_c.stride(0), _p(out), D, _p(lse), _p(tbl), seq.n, H,
@@ -828,7 +1025,7 @@ class _Attention(Function):
         es = qt.element_size()
         if ctx.mfma:
             _lib.call("attn_mfma_bwd_t", qt.data_ptr() + cols[0] * es, qt.stride(0), kvt.data_ptr() + cols[1] * es, kvt.stride(0),
-                      kvt.data_ptr() + cols[2] * es, kvt.stride(0), _p(out), D, _dt(qt), _p(lse), _p(dO), D,
+                      kvt.data_ptr() + cols[2] * es, kvt.stride(0), _p(out), out.stride(0), _dt(qt), _p(lse), _p(dO), D,
                       dq_t.data_ptr() + cols[0] * es, dq_t.stride(0), dkv_t.data_ptr() + cols[1] * es, dkv_t.stride(0),
                       dkv_t.data_ptr() + cols[2] * es, dkv_t.stride(0), _p(tbl), n, H, dh, max_q, max_k, _p(key_mask),
                       1 if causal else 0, 1.0 / math.sqrt(dh), p, site, _p(seed), _stream())
@@ -843,7 +1040,20 @@ class _Attention(Function):
 
 
 def attention(qt, kvt, cols, D, n_heads, seq, key_mask=None, causal=False, drop=None):
-    return _Attention.apply(qt, kvt, cols, D, n_heads, seq, key_mask, causal, drop)
+    split = lo_off(qt) is not None or lo_off(kvt) is not None
+    if split:
+        dh = D // n_heads
+        ok = (not causal and lo_off(qt) is not None and lo_off(kvt) is not None and
+              _lib.load().svpc_attn_mfma_supported(dh, seq.max_q, seq.max_k, 8, 8, 8) == 1 and qt.stride(0) % 8 == 0 and kvt.stride(0) % 8 == 0)
+        if not ok:          # leave the split domain: exact fp32 attention on fp32 copies
+            same = kvt is qt
+            qt = to_f32(qt)
+            kvt = qt if same else to_f32(kvt)
+            split = False
+    out = _Attention.apply(qt, kvt, cols, D, n_heads, seq, key_mask, causal, drop)
+    if split:
+        out._svpc_lo = out.shape[1]
+    return out
 
 
 class _SplitCols(Function):
@@ -1299,13 +1509,13 @@ class _GemmProblem(ctypes.Structure):
                 ("K", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int), ("ldc", ctypes.c_int)]
 
 
-def _gemm_pair(As, Bs, Cs, M, N, K, accumulate=0):
+def _gemm_pair(As, Bs, Cs, M, N, K, accumulate=0, x3=False):
     """C_z (+)= A_z · B_zᵀ for z = 0, 1 (all k-contiguous fp32) in one grouped launch"""
     probs = (_GemmProblem * 2)()
     for z in range(2):
         probs[z] = _GemmProblem(As[z].data_ptr(), Bs[z].data_ptr(), Cs[z].data_ptr(), M, N, K, As[z].stride(0), Bs[z].stride(0),
                                 Cs[z].stride(0))
-    _lib.call("gemm_group", ctypes.addressof(probs), 2, 1, 1, accumulate, _stream())
+    _lib.call("gemm_group_x3" if x3 else "gemm_group", ctypes.addressof(probs), 2, 1, 1, accumulate, _stream())
 
 
 def _ptr2(a, b):
@@ -1347,10 +1557,10 @@ class _BiLstmSeq(Function):
                     _ptr2(h_all[0][t], h_all[1][t]), None, _ptr2(h_all[0][t + 1], h_all[1][t + 1]),
                     _ptr2(c_all[0][t + 1], c_all[1][t + 1]), _ptr2(gates[0][t], gates[1][t])]
             if fused:       # recurrent projection + cell in one launch per time step
-                _lib.call("lstm_pair_step_fwd", args[4][0], args[3][0], pw[0], args[0][0], args[1][0], _p(active_t[t]), args[6][0],
-                          args[7][0], args[8][0], N, D, st)
+                _lib.call("lstm_pair_step_fwd_x3" if is_x3() else "lstm_pair_step_fwd", args[4][0], args[3][0], pw[0], args[0][0],
+                          args[1][0], _p(active_t[t]), args[6][0], args[7][0], args[8][0], N, D, st)
                 continue
-            _gemm_pair([h_all[0][t], h_all[1][t]], w, gh, N, 4 * D, D)
+            _gemm_pair([h_all[0][t], h_all[1][t]], w, gh, N, 4 * D, D, x3=is_x3())
             _lib.call("lstm_pair_fwd", args[0][0], args[1][0], args[2][0], args[3][0], args[4][0], _p(active_t[t]), args[6][0],
                       args[7][0], args[8][0], N, D, st)
         outs = [torch.index_select(h_all[z][1:].reshape(S * N, D), 0, pk) for z, pk in enumerate((pick_f, pick_b))]
@@ -1430,7 +1640,7 @@ class _BiLstmSeq(Function):
 
 def bilstm_sequences(gx_f, gx_b, w_f, w_b, rows_f, rows_b, active_t, pick_f, pick_b):
     """Both LSTM directions (see lstm_sequence for the arguments) → (out_f, out_b), each (T, D)."""
-    if _PRECISION == "bf16" and gx_f.is_cuda:
+    if _fast() and gx_f.is_cuda:
         return _BiLstmSeq.apply(gx_f, gx_b, w_f, w_b, rows_f, rows_b, active_t, pick_f, pick_b, _direct(w_f), _direct(w_b))
     return lstm_sequence(gx_f, w_f, rows_f, active_t, pick_f), lstm_sequence(gx_b, w_b, rows_b, active_t, pick_b)
 

@@ -31,7 +31,7 @@ def warmup_linear(progress, warmup):
 class _Meta(ctypes.Structure):
     _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
                 ("ema", ctypes.c_void_p), ("n", ctypes.c_longlong), ("wd", ctypes.c_float), ("pad", ctypes.c_int),
-                ("shadow", ctypes.c_void_p)]
+                ("shadow", ctypes.c_void_p), ("shadow_lo", ctypes.c_void_p)]
 
 
 _QKV = {"query.weight": 0, "key.weight": 1, "value.weight": 2, "query.bias": 3, "key.bias": 4, "value.bias": 5}
@@ -155,29 +155,40 @@ class WeightStore:
       tensor version counter (``ops._shadow``) or refreshed wholesale with ``refresh()``.
     """
 
-    def __init__(self, named_params, layout=None):
+    def __init__(self, named_params, layout=None, with_lo=None):
+        from . import ops
         self.names, self.params, self.offsets, self.numel = layout if layout is not None else _layout(named_params)
         dev = self.params[0].device
+        # bf16x3 mode: a second shadow plane lo = bf16(w - bf16(w)), same layout, ``numel`` elements behind the first in ONE buffer —
+        # every shadow view is tagged with that offset (``_svpc_lo``), which is how the x3 GEMM finds the lo plane of its B operand
+        self.with_lo = ops.is_x3() if with_lo is None else bool(with_lo)
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        self.shadow = torch.zeros(self.numel, dtype=torch.bfloat16, device=dev)
+        self.shadow2 = torch.zeros((2 if self.with_lo else 1) * self.numel, dtype=torch.bfloat16, device=dev)
+        self.shadow = self.shadow2[:self.numel]
+        self.shadow_lo = self.shadow2[self.numel:] if self.with_lo else None
+
+        def tag(t):
+            if self.with_lo:
+                t._svpc_lo = self.numel
+            return t
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 n = p.numel()
                 view = self.flat[o:o + n].view_as(p)
                 view.copy_(p.detach())
                 p.data = view
-                p._svpc_bf16 = self.shadow[o:o + n].view_as(p)
+                p._svpc_bf16 = tag(self.shadow[o:o + n].view_as(p))
         for q, ids, kinds in _packed_groups(self.names, self.params, self.offsets):
             D_out, D_in = q.shape
             fw = _packed_views(self.flat, self.offsets, ids, D_out, D_in, kinds)
             sw = _packed_views(self.shadow, self.offsets, ids, D_out, D_in, kinds)
-            q._svpc_packed_w = {k: (fw[k][0], fw[k][1], sw[k][0]) for k in fw}
+            q._svpc_packed_w = {k: (fw[k][0], fw[k][1], tag(sw[k][0])) for k in fw}
             q._svpc_packed_w_members = [self.params[i] for i in ids]
         for a, wi, bi in _stack_groups(self.names, self.params):
             D_out, D_in = a.shape
             fw = _stack_views(self.flat, self.offsets, wi, bi, D_out, D_in)
             sw = _stack_views(self.shadow, self.offsets, wi, bi, D_out, D_in)
-            a._svpc_stack_w = (fw[0], fw[1], sw[0])
+            a._svpc_stack_w = (fw[0], fw[1], tag(sw[0]))
             a._svpc_stack_w_members = [self.params[i] for i in wi]
         self.refresh()
 
@@ -194,6 +205,8 @@ class WeightStore:
         """shadow ← bf16(weights) for the whole store (after load_state_dict, EMA swap, manual edits …)."""
         with torch.no_grad():
             self.shadow.copy_(self.flat)
+            if self.with_lo:
+                self.shadow_lo.copy_(self.flat - self.shadow.float())
         for p in self.params:
             p._svpc_bf16_ver = p._version
 
@@ -276,7 +289,8 @@ class FusedBertAdam:
             es = 4
             metas[i] = _Meta(p.data_ptr(), self.arena.flat.data_ptr() + o * es, self.m.data_ptr() + o * es,
                              self.v.data_ptr() + o * es, (self.ema.data_ptr() + o * es) if self.ema is not None else None,
-                             n, wd, 0, self.weights.shadow.data_ptr() + o * 2)
+                             n, wd, 0, self.weights.shadow.data_ptr() + o * 2,
+                             (self.weights.shadow_lo.data_ptr() + o * 2) if self.weights.with_lo else None)
             for s in range(0, n, chunk):
                 chunk_tid.append(i)
                 chunk_start.append(s)

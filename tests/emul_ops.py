@@ -377,3 +377,20 @@ def greedy_pick(scores, row_c, row_x, lt, pos, unk):
 
 def bf16_stream_ok(rows, *dims):
     return False
+
+
+# bf16x3-mode surface of svpc_amd.ops (split tensors do not exist in the torch statement: everything is fp32)
+def is_x3():
+    return False
+
+
+def lo_off(t):
+    return None
+
+
+def to_f32(t):
+    return t.float()
+
+
+def take_rows_f32(t, idx):
+    return torch.index_select(t, 0, idx.long() if idx.dtype != torch.int64 else idx).float()

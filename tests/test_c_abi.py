@@ -12,8 +12,8 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in decls:
         assert hasattr(lib, name), name
-    assert lib.svpc_abi_version() == 1
-    assert lib.svpc_opt_chunk() > 0 and lib.svpc_opt_meta_bytes() == 64
+    assert lib.svpc_abi_version() == 2
+    assert lib.svpc_opt_chunk() > 0 and lib.svpc_opt_meta_bytes() == 72
     assert lib.svpc_ln_bwd_groups(19200) >= 1 and lib.svpc_colsum_chunks(19200) >= 1
 
 

@@ -1,10 +1,16 @@
 """Parity of THE THING THAT IS TIMED: the headline configuration of bench.py (MODEL_TYPE=vivt, N=16 videos × S=12 clips × Lv=100
 frames × F=3072, Lt=22, D=768, H=12, L=6, V=951, A=384, E=10 — BASELINE.json configs 2-4) against the CPU oracle
-(oracle/svpc_oracle.py, pinned to the reference by tests/golden), on the same seeded inputs, in BOTH arithmetic modes:
+(oracle/svpc_oracle.py, pinned to the reference by tests/golden), on the same seeded inputs, in ALL THREE arithmetic modes:
 
-* ``fp32`` (parity mode)      — north_star's bar: loss ≤ 1e-4 relative.
-* ``bf16`` (throughput mode, what bench.py's ``value`` is measured in) — bf16 GEMM/attention operands and bf16 activation
-  streams; the tolerance stated below is what that arithmetic delivers at this size and is explained in DESIGN.md §4.
+* ``fp32``   (f32-MFMA parity mode)  — north_star's bar: loss ≤ 1e-4 relative.
+* ``bf16x3`` (≤1e-4-parity THROUGHPUT mode, what bench.py's ``value`` is measured in) — every forward contraction a three-term
+  split-bf16 product, the clip-encoder stream stored as two bf16 planes; held to the SAME loss bar (≤ 1e-4) as fp32; its backward is
+  the bf16 mode's, so its gradients are held to the bf16 entry's bounds.
+* ``bf16``   (fastest mode, reported beside it with its measured loss error) — bf16 GEMM/attention operands and bf16 activation
+  streams; the tolerance stated below is ≤ 2× what that arithmetic measures at this size.
+The Gumbel hard arg-max of the re-simulation (model.py:1018) is a discontinuity of the loss: the test counts the positions where
+the GPU's probabilities and the oracle's pick a different word under the same injected noise and reports them (``gumbel_flips``):
+a flip moves one bag-of-words row, which is what the residual gradient differences of the re-simulator's tensors in fp32 mode are.
 
 Dropout is off (eval mode) and the Gumbel noise is injected, so both sides are deterministic functions of the same inputs; the
 gradients are taken twice on the GPU: through autograd's own accumulation (first backward) and through the optimizer's gradient
@@ -46,8 +52,12 @@ GRAD_NAMES = [
 # bf16: measured 3e-4 … 2.4e-3 (loss), 0.987 … 0.992 (argmax agreement), ≤ 5.2e-2 (gradient norms), ≥ 0.9925 (cosines) on the four
 # headline cases (profiles/r02_c_headline_parity.json); the single worst probability entry moves by up to 0.24 where the pointer's
 # softmax over ≤ 10 entities is nearly tied ("What the bf16 mode costs in accuracy"), hence a mean criterion beside the max.
+# round 3: the bf16 entry tightened to ≤ 2× the measured values of profiles/r02_f_headline_parity.json (loss 7.7e-4 worst case, worst
+# probability entry 0.19, mean 1.5e-5, gradient norms 5.8 %, cosine 0.9930); bf16x3: the fp32 entry's loss bar, measured probability
+# errors ≈1e-5, the bf16 entry's gradient bounds (its backward is the bf16 backward)
 TOL = {"fp32": dict(loss=1e-4, prob=5e-5, prob_mean=1e-6, gnorm=2e-3, cos=0.99999, argmax=0.9999),
-       "bf16": dict(loss=4e-3, prob=0.5, prob_mean=1e-4, gnorm=8e-2, cos=0.985, argmax=0.98)}
+       "bf16x3": dict(loss=1e-4, prob=2e-3, prob_mean=2e-6, gnorm=7e-2, cos=0.990, argmax=0.999),
+       "bf16": dict(loss=1.5e-3, prob=0.4, prob_mean=5e-5, gnorm=7e-2, cos=0.990, argmax=0.98)}
 
 _REPORT = {}
 
@@ -108,9 +118,23 @@ def _to_dev(batch):
     return out
 
 
-def _compare(tag, precision, loss, probs, grads, ref, names):
+def _gumbel_flips(probs, ref_probs, noise, tau):
+    """positions whose hard Gumbel pick (argmax of log(P + 1e-12) + G, model.py:1018) differs between the GPU's and the oracle's P"""
+    flips = total = 0
+    for p, r, g in zip(probs, ref_probs, noise):
+        p, g = p.detach().cpu().float(), g.cpu().float()
+        a = (torch.log(p + 1e-12) + g[..., :p.shape[-1]]).argmax(-1)
+        b = (torch.log(r + 1e-12) + g[..., :r.shape[-1]]).argmax(-1)
+        flips += int((a != b).sum())
+        total += a.numel()
+    return flips, total
+
+
+def _compare(tag, precision, loss, probs, grads, ref, names, noise=None):
     tol = TOL[precision]
     rep = {"loss": loss, "ref_loss": ref["loss"], "loss_rel": abs(loss - ref["loss"]) / abs(ref["loss"])}
+    if noise is not None:
+        rep["gumbel_flips"], rep["gumbel_positions"] = _gumbel_flips(probs, ref["probs"], noise, None)
     perr = max(float((p.detach().cpu() - r).abs().max()) for p, r in zip(probs, ref["probs"]))
     rep["prob_abs_max"] = perr
     rep["prob_abs_mean"] = float(np.mean([float((p.detach().cpu() - r).abs().mean()) for p, r in zip(probs, ref["probs"])]))
@@ -157,7 +181,8 @@ def _run_gpu(mt, init, precision):
         loss.backward()
         torch.cuda.synchronize()
         grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
-        _compare("%s/%s/%s/autograd" % (mt, init, precision), precision, float(loss), probs, grads, ref, names)
+        gn = noise if cfg.model_mode == "full" else None
+        _compare("%s/%s/%s/autograd" % (mt, init, precision), precision, float(loss), probs, grads, ref, names, noise=gn)
         # (2) the captured step's path: gradients written in place into the optimizer's arena
         opt = FusedBertAdam(list(model.named_parameters()), lr=0.0, grad_clip=-1.0, max_grad_norm=-1.0)
         opt.ensure_built()
@@ -167,14 +192,14 @@ def _run_gpu(mt, init, precision):
         ops.join_side()
         torch.cuda.synchronize()
         grads2 = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
-        _compare("%s/%s/%s/arena" % (mt, init, precision), precision, float(loss2), probs2, grads2, ref, names)
+        _compare("%s/%s/%s/arena" % (mt, init, precision), precision, float(loss2), probs2, grads2, ref, names, noise=gn)
     finally:
         ops.set_precision("fp32")
     return _REPORT
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 @pytest.mark.parametrize("init", ["bench", "drawn"])
 def test_headline_vivt_step_vs_oracle(init, precision):
     _run_gpu("vivt", init, precision)
@@ -183,6 +208,7 @@ def test_headline_vivt_step_vs_oracle(init, precision):
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("mt", ["vi", "viv"])
 def test_headline_vi_viv_bf16_vs_oracle(mt):
-    """BASELINE.json configs 2 and 3 in their stated dtype (plus the fp32 mode on the same oracle run)"""
+    """BASELINE.json configs 2 and 3 in their stated dtype, in the ≤1e-4 throughput mode and in the fp32 mode, on one oracle run"""
     _run_gpu(mt, "drawn", "bf16")
+    _run_gpu(mt, "drawn", "bf16x3")
     _run_gpu(mt, "drawn", "fp32")
