@@ -25,7 +25,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md dense peaks (f32-in MFMA; bf16 MFMA)
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}   # MI355X_MICROARCH.md dense peaks (f32-in MFMA; bf16 MFMA)
+MFMA_TERMS = {"fp32": 1, "bf16": 1, "bf16x3": 3}      # bf16 MFMA products issued per algorithmic product (three-term split-bf16)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "dominant_gemm_traffic.json")
 DOMINANT_SOURCES = ("svpc_amd/csrc/gemm_p8.hip", "svpc_amd/csrc/gemm_common.h", "svpc_amd/csrc/common.h")
 

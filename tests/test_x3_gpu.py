@@ -276,11 +276,16 @@ def test_c1_split_stream_vs_reference_golden_x3(golden_dir, mt):
         assert (p.argmax(-1) == z["probs_argmax/%d" % b]).mean() > 0.999
     loss.backward()
     O.join_side()
+    biggest = max(float(z[k]) for k in z.files if k.startswith("gradnorm/"))
     for k in z.files:
         if k.startswith("gradnorm/"):
             name = k[len("gradnorm/"):]
             g = dict(model.named_parameters())[name].grad
             refn = float(z[k])
+            if refn < 1e-5:      # analytically zero gradients (key biases: softmax shift invariance; the single-key cross-attention of
+                                 # MODEL_TYPE=v): what the bf16 backward leaves there is rounding noise — bounded against the real gradients
+                assert float(g.double().norm()) <= 2e-2 * biggest, (name, float(g.double().norm()), biggest)
+                continue
             assert abs(float(g.double().norm()) - refn) <= 6e-2 * refn + 2e-4, (name, float(g.double().norm()), refn)
 
 

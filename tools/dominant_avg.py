@@ -7,9 +7,9 @@ import csv
 import sys
 
 GRIDS = {"115200": "N=768", "230400": "N=1536", "345600": "N=2304"}
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "gemm_p8_kernel" in r["Kernel_Name"] and r["Grid_Size_X"] in GRIDS]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if ("gemm_p8_kernel" in r["Kernel_Name"] or "gemm_p8x3_kernel" in r["Kernel_Name"]) and r["Grid_Size_X"] in GRIDS]
 dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
-print("gemm_p8_kernel, M = 19,200 forward launches: %d calls, average %.2f us (min %.2f, max %.2f)"
+print("gemm_p8 / gemm_p8x3 kernel, M = 19,200 forward launches: %d calls, average %.2f us (min %.2f, max %.2f)"
       % (len(dur), sum(dur) / len(dur) / 1e3, min(dur) / 1e3, max(dur) / 1e3))
 for g, name in GRIDS.items():
     d = [x for x, r in zip(dur, rows) if r["Grid_Size_X"] == g]
