@@ -1,0 +1,212 @@
+"""BASELINE.json config 5 at its stated model size, and the reference caller's call surface, through the HIP kernels.
+
+(a) ``Translator.translate_batch`` (greedy, KV-cached, batched over videos, hipGraph replay as bench.py's ``secondary`` runs it) at
+    D=768, H=12, L=6, Lv=100, 8 videos × 12 clips against ``oracle.greedy_decode`` (the CPU restatement of src/translator.py:45-192,
+    pinned bit-exactly to the reference's own ids by tests/golden decode/*): token ids bit-exact in the fp32 parity mode; the
+    agreement rate of the bf16x3 and bf16 modes is measured, asserted against a stated floor and written to
+    gpurun_out/config5_parity.json (bench.py quotes it next to ``secondary``).
+(b) every sub-module call src/translator.py:57-104 makes (``ingredient_embeddings``, ``forward_step``, ``step_positional_encoding``,
+    ``step_wise_encoder(...)[-1]``, ``reasoner``, ``Went`` / ``Wac``, ``text_embeddings``, ``decoder(..., diagonal_mask=True)[-1]``,
+    ``pointer_generator_network``, ``decoder_classifier``) and ``model(..., predict=True)`` (dump_memories.py:60-65, model.py:1185)
+    on the GPU against the oracle / the reference's ``mid/*`` goldens — the twin of tests/test_model_host_logic.py:76-120, which runs
+    the same calls over emulated ops on the CPU."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from helpers import build_model  # noqa: E402
+from oracle import svpc_oracle as orc  # noqa: E402
+from svpc_amd import ops, synthetic as syn  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+_REPORT = {}
+_C5 = {}
+
+
+def _to_dev(batch):
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, list) and v and isinstance(v[0], torch.Tensor):
+            out[k] = [t.to(DEV) for t in v]
+        elif isinstance(v, torch.Tensor):
+            out[k] = v.to(DEV)
+        else:
+            out[k] = v
+    return out
+
+
+def _config5_case(init):
+    """the headline model (bench.py's own build) with bench / test-sensitive weights, 8 videos × 12 clips, and the oracle's ids"""
+    if init in _C5:
+        return _C5[init]
+    import bench
+    args = bench.parse_args([])
+    cfg, model = bench.build(args, "cpu", model_type="vivt")
+    if init == "drawn":
+        drawn = syn.draw_parameters(list(model.named_parameters()), seed=7)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                p.copy_(drawn[n])
+    model.eval()
+    batch = syn.make_batch(cfg, n_videos=8, max_steps=12, n_ingr=10, n_oov=0, seed=2021, full_clips=True)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = orc.greedy_decode(P, cfg, batch["input_ids_list"], batch["video_features_list"], batch["input_masks_list"],
+                            batch["ingr_input_ids"], batch["ingr_sep_masks"], batch["batch_step_num"], batch["ingr_id_dict"],
+                            batch["oov_word_dict"])
+    _C5[init] = (cfg, model, batch, ref)
+    return _C5[init]
+
+
+# floors of the token agreement with the oracle (fraction of the 8 × 12 × 22 emitted ids that are identical).  Greedy decoding
+# feeds every pick back, so ONE flipped arg-max changes the rest of that sentence: the rate measures sentences, not logits.
+FLOOR = {"fp32": 1.0, "bf16x3": 0.99, "bf16": 0.5}
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("init", ["drawn", "bench"])
+def test_config5_greedy_decode_at_headline_size(init, precision):
+    import copy
+    from svpc_amd.optim import WeightStore
+    from svpc_amd.translator import Translator
+    cfg, model_cpu, batch, ref = _config5_case(init)
+    ops.set_precision(precision)
+    try:
+        model = copy.deepcopy(model_cpu).to(DEV)
+        model.eval()
+        WeightStore.for_model(model)         # resident bf16 (and, in bf16x3 mode, lo-plane) weight shadow, as after a training step
+        tr = Translator(type("O", (), {"cuda": True})(), {"model_cfg": cfg, "model": model.state_dict()}, model=model, graph=True)
+        b = _to_dev(batch)
+        dec, _ = tr.translate_batch(syn.translate_inputs(b))
+        dec2, _ = tr.translate_batch(syn.translate_inputs(b))       # second call: the replayed hipGraph of this batch structure
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision("fp32")
+    same = total = sent_same = sent = 0
+    for d, d2, r in zip(dec, dec2, ref):
+        d = d.cpu()
+        assert torch.equal(d, d2.cpu()), "hipGraph replay differs from the eager decode"
+        same += int((d == r).sum()); total += r.numel()
+        sent_same += int((d == r).all(1).sum()); sent += r.shape[0]
+    rate = same / total
+    _REPORT["%s/%s" % (init, precision)] = dict(token_agreement=rate, identical_sentences=sent_same, sentences=sent, tokens=total,
+                                                bit_exact=bool(same == total))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "config5_parity.json"), "w") as f:
+        json.dump(_REPORT, f, indent=1)
+    print("config 5 (%s weights, %s): %d / %d ids identical (%.4f), %d / %d sentences" % (init, precision, same, total, rate, sent_same, sent))
+    if init == "drawn" or precision == "fp32":
+        assert rate >= FLOOR[precision], (init, precision, rate)
+
+
+# ------------------------------------------------------------------------------------------------ the reference caller's call surface
+# bf16x3: every stored value carries 2⁻¹⁷ ≈ 8e-6 relative to its row's magnitude (O(1) after a LayerNorm), a few stages deep
+TOLS = {"fp32": dict(rtol=1e-4, atol=2e-6), "bf16x3": dict(rtol=3e-4, atol=6e-5)}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("case,mt", [("tiny", "v"), ("tiny", "vivt"), ("c1", "vivt")])
+def test_reference_shaped_submodules_on_the_gpu(golden_dir, case, mt, precision):
+    """what translator.py:57-104 calls per video, through the HIP kernels (c1: D=128, F=3072 — in bf16x3 mode forward_step runs on
+    the split stream), against the oracle; for the tiny fixtures also against the reference's recorded intermediates"""
+    z, cfg, batch, model = build_model(case, mt, golden_dir, DEV)
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cb = {k: ([t.cpu() if isinstance(t, torch.Tensor) else t for t in v] if isinstance(v, list) else (v.cpu() if isinstance(v, torch.Tensor) else v))
+          for k, v in batch.items()}
+    tol = TOLS[precision]
+    D, Lv, Lt = cfg.hidden_size, cfg.max_v_len, cfg.max_t_len
+
+    def close(a, b, **kw):
+        t = dict(tol); t.update(kw)
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else b, **t)
+    ops.set_precision(precision)
+    try:
+        with torch.no_grad():
+            ids0, feat0, mask0 = batch["input_ids_list"][0], batch["video_features_list"][0], batch["input_masks_list"][0]
+            enc = model.forward_step(ids0, feat0, mask0)                                                  # translator.py:65
+            ref_enc = orc.forward_step(P, cb["input_ids_list"][0], cb["video_features_list"][0], cb["input_masks_list"][0], cfg)
+            close(enc, ref_enc)
+            ing = model.ingredient_embeddings(batch["ingr_input_ids"], batch["ingr_sep_masks"])           # :57
+            ref_ing = orc.ingredient_embed(P, cb["ingr_input_ids"], cb["ingr_sep_masks"], cfg)
+            n_ing = int(cb["ingr_sep_masks"][0].sum())
+            close(ing[0, :n_ing], ref_ing[0][:n_ing])
+            if case == "tiny":
+                close(enc, z["mid/encoder/0"])
+                close(ing, z["mid/ingredient_embeddings/0"])
+            N = enc.shape[0]
+            x = model.step_positional_encoding(enc[:, 0, :].unsqueeze(0))                                 # :66
+            g = model.step_wise_encoder(x, torch.ones(1, N, device=DEV))[-1]                              # :67
+            ref_g = orc.encoder(P, "step_wise_encoder", (ref_enc[:, 0] + orc.sinusoid_table(50, D)[:N]).unsqueeze(0), torch.ones(1, N), cfg)
+            close(g, ref_g)
+            t = model.text_embeddings(ids0[:, Lv:])                                                       # :98
+            ref_t = orc.text_embed(P, cb["input_ids_list"][0][:, Lv:], cfg)
+            close(t, ref_t)
+            if mt == "vivt":
+                outs = model.reasoner(g, ing[0, :n_ing])                                                  # :77
+                ref = orc.simulator(P, "reasoner", ref_g[0], ref_ing[0][:n_ing])
+                for a, b_ in zip(outs, ref):
+                    close(a, b_)
+                went, wac = model.Went(outs[2]), model.Wac(outs[4])                                       # :78-79
+                close(went, torch.relu(orc.linear(P, "Went.0", ref[2])))
+                close(wac, torch.relu(orc.linear(P, "Wac.0", ref[4])))
+                gen = torch.Generator().manual_seed(11)
+                mem = torch.randn(N, 3, D, generator=gen)
+                d = model.decoder(t, torch.ones(N, Lt, device=DEV), mem.to(DEV), torch.ones(N, 3, device=DEV), diagonal_mask=True)[-1]   # :99-100
+                ref_d = orc.decoder(P, ref_t, torch.ones(N, Lt), mem, torch.ones(N, 3), cfg)
+                close(d, ref_d)
+                bank = torch.randn(N, n_ing, D, generator=gen)
+                n_oov = len(cb["oov_word_dict"][0])
+                pg = model.pointer_generator_network(d, bank.to(DEV), batch["ingr_id_dict"][0], n_oov)    # :102-104
+                ref_pg = orc.pointer_generator(P, ref_d, bank, cb["ingr_id_dict"][0], n_oov, cfg)
+                close(pg, ref_pg, atol=1e-7 if precision == "fp32" else 2e-6)
+            ones = torch.ones(2, 3, D)
+            close(model.decoder_classifier(ones.to(DEV)), orc.lm_head(P, ones, cfg))                      # :159
+    finally:
+        ops.set_precision("fp32")
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_predict_contract_on_the_gpu(golden_dir, precision):
+    """model(..., predict=True) (dump_memories.py:60-65 → model.py:1185-1186): the memory dictionaries, entity / action probabilities
+    through the HIP kernels against the oracle's simulator on the same inputs"""
+    z, cfg, batch, model = build_model("tiny", "vivt", golden_dir, DEV)
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cb = {k: ([t.cpu() if isinstance(t, torch.Tensor) else t for t in v] if isinstance(v, list) else (v.cpu() if isinstance(v, torch.Tensor) else v))
+          for k, v in batch.items()}
+    ops.set_precision(precision)
+    try:
+        with torch.no_grad():
+            mem, ents, acts = model(*syn.forward_args(batch), predict=True)
+            _, _, ents_t, acts_t = model(*syn.forward_args(batch))
+    finally:
+        ops.set_precision("fp32")
+    steps = cb["batch_step_num"]
+    assert len(mem) == len(steps) and set(mem[0]) == {"entity_probs", "action_probs", "entity_vectors", "re_pred_entity_probs",
+                                                      "re_pred_action_probs", "re_entity_vectors"}
+    tol = TOLS[precision]
+    D, Lv = cfg.hidden_size, cfg.max_v_len
+    for b, S_b in enumerate(steps):
+        ids = torch.stack([cb["input_ids_list"][s][b] for s in range(S_b)])
+        masks = torch.stack([cb["input_masks_list"][s][b] for s in range(S_b)])
+        feats = torch.stack([cb["video_features_list"][s][b] for s in range(S_b)])
+        ingr = orc.ingredient_embed(P, cb["ingr_input_ids"][b:b + 1], cb["ingr_sep_masks"][b:b + 1], cfg)[0]
+        enc = orc.forward_step(P, ids, feats, masks, cfg)
+        g = orc.encoder(P, "step_wise_encoder", (enc[:, 0] + orc.sinusoid_table(50, D)[:S_b]).unsqueeze(0), torch.ones(1, S_b), cfg)[0]
+        e, a, bar_e, all_e, bar_f = orc.simulator(P, "reasoner", g, ingr)
+        md = mem[b]
+        np.testing.assert_allclose(md["entity_probs"].cpu().numpy(), e.numpy(), **tol)
+        np.testing.assert_allclose(md["action_probs"].cpu().numpy(), a.numpy(), **tol)
+        np.testing.assert_allclose(md["entity_vectors"][0].cpu().numpy(), ingr.numpy(), **tol)
+        np.testing.assert_allclose(md["entity_vectors"][1].cpu().numpy(), all_e.numpy(), **tol)
+        assert md["re_pred_entity_probs"].shape == e.shape and md["re_entity_vectors"].shape == all_e.shape
+        assert torch.equal(ents[b], ents_t[b]) and torch.equal(acts[b], acts_t[b])
