@@ -411,6 +411,18 @@ class KernelTimer:
 
 
 GEMM_TIMER = None   # set by bench.py
+ATTN_TIMER = None   # set by bench.py: {"select": predicate on (n_seq·H, max_q, max_k), "fwd": [(e0, e1, bytes)], "bwd": [...]} — HIP-event
+                    # brackets around the attention launches of the clip encoder (the roofline north_star names)
+
+
+def _attn_bracket(which, n_pairs, max_q, max_k, nbytes):
+    t = ATTN_TIMER
+    if t is None or not t["select"](n_pairs, max_q, max_k):
+        return None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t[which].append((e0, e1, nbytes))
+    e0.record()
+    return e1
 
 # Arithmetic type of the dense contractions:
 #   "fp32"   — v_mfma_f32_32x32x2_f32, fp32 storage: bit-level parity mode (1/16 of the bf16 matrix rate);
@@ -961,6 +973,9 @@ class _Attention(Function):
         mfma = (_fast() and ((qp | kp | vp) & 15) == 0 and
                 _lib.load().svpc_attn_mfma_supported(dh, seq.max_q, seq.max_k, qt.stride(0), kvt_c.stride(0), kvt_c.stride(0)) == 1)
         fwd_done = False
+        # algorithmic bytes of this launch: Q, O rows and K, V rows of every (sequence, head), in their storage types
+        ev1 = _attn_bracket("fwd", seq.n * H, seq.max_q, seq.max_k,
+                            (2 * seq.n_q_rows + 2 * seq.n_k_rows) * D * (4 if split else es)) if ATTN_TIMER is not None else None
         if split:
             # bf16x3 stream (the wrapper has checked the shape): three-term products over the hi / lo planes; the backward is the
             # bf16 kernel on the hi planes
@@ -993,6 +1008,8 @@ class _Attention(Function):
                 raise _lib.SvpcKernelError("attention: the bf16 stream needs the MFMA kernel (head dim 32/64, ≤128 rows)")
             _lib.call("attn_fwd", qp, qt.stride(0), kp, kvt_c.stride(0), vp, kvt_c.stride(0), _p(out), D, _p(lse), _p(tbl), seq.n, H,
                       dh, seq.max_q, seq.max_k, _p(key_mask), 1 if causal else 0, 1.0 / math.sqrt(dh), p, site, _p(seed), _stream())
+        if ev1 is not None:
+            ev1.record()
         ctx.save_for_backward(qt, kvt_c, out, lse, key_mask, seed, tbl)
         ctx.cfg = (cols, D, H, seq.n, seq.max_q, seq.max_k, causal, p, site, same)
         ctx.kv_into = None if same else getattr(kvt, "_svpc_grad_into", None)     # a column block of a shared gradient buffer
@@ -1023,12 +1040,17 @@ class _Attention(Function):
             else:
                 dkv_t = covered(kvt, 2 * D, n_k_rows)
         es = qt.element_size()
+        # backward: Q, K, V, O, dO read, dQ, dK, dV written (their storage types: the hi planes in bf16x3 mode)
+        ev1 = _attn_bracket("bwd", n * H, max_q, max_k, (3 * n_q_rows + 2 * n_k_rows + n_q_rows + 2 * n_k_rows) * D * es) \
+            if ATTN_TIMER is not None else None
         if ctx.mfma:
             _lib.call("attn_mfma_bwd_t", qt.data_ptr() + cols[0] * es, qt.stride(0), kvt.data_ptr() + cols[1] * es, kvt.stride(0),
                       kvt.data_ptr() + cols[2] * es, kvt.stride(0), _p(out), out.stride(0), _dt(qt), _p(lse), _p(dO), D,
                       dq_t.data_ptr() + cols[0] * es, dq_t.stride(0), dkv_t.data_ptr() + cols[1] * es, dkv_t.stride(0),
                       dkv_t.data_ptr() + cols[2] * es, dkv_t.stride(0), _p(tbl), n, H, dh, max_q, max_k, _p(key_mask),
                       1 if causal else 0, 1.0 / math.sqrt(dh), p, site, _p(seed), _stream())
+            if ev1 is not None:
+                ev1.record()
             return dq_t, (None if same else dkv_t), None, None, None, None, None, None, None
         delta = torch.empty(n, H, max_q, dtype=torch.float32, device=dev)
         _lib.call("attn_bwd", qt.data_ptr() + cols[0] * es, qt.stride(0), kvt.data_ptr() + cols[1] * es, kvt.stride(0),

@@ -27,6 +27,7 @@ class Translator(object):
         self.opt = opt
         self.incremental = incremental
         self.graph = graph          # replay the decode of a recurring batch structure as one hipGraph (see _decode_graphed)
+        self.phase_events = None    # bench.py: a list → _decode_core (eager) appends three HIP events: start, encoder side done, end
         self._preps = {}
         self.device = torch.device("cuda" if getattr(opt, "cuda", True) else "cpu")
         self.model_config = checkpoint["model_cfg"]
@@ -93,6 +94,14 @@ class Translator(object):
         dev = feats.device
         Lt, D = cfg.max_t_len, cfg.hidden_size
         cx = _Ctx(cfg, False, model.rng(dev))
+        stamps = self.phase_events if (self.phase_events is not None and not torch.cuda.is_current_stream_capturing()) else None
+
+        def stamp():
+            if stamps is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                stamps.append(e)
+        stamp()
         ents = model.ingredient_embeddings.run(ingr_ids_flat, prep["spans"], cx)
         cls = model._encode_clips(feats, plan.video_rows, ops.take_rows(ids_all, plan.video_rows),
                                   ops.take_rows(masks_all, plan.video_rows), plan.seq_enc, cx,
@@ -113,6 +122,7 @@ class Translator(object):
             mem = g
             bank = None
 
+        stamp()          # encoder side (clip encoder, step encoder, simulator, memory) done; the Lt decoding iterations follow
         text = torch.full((T, Lt), PAD, dtype=torch.int32, device=dev)
         ext = torch.full((T, Lt), PAD, dtype=torch.int32, device=dev)
         nxt = torch.full((T,), BOS, dtype=torch.int32, device=dev)
@@ -158,6 +168,7 @@ class Translator(object):
                 else:
                     scores, _ = model._lm_probs(dec, bank, pl, cx)
                 nxt_ext, nxt = ops.greedy_pick(scores, pl["row_c"], row_x, Lt, i, UNK)
+        stamp()
         return text if mode == "video" else ext
 
     @torch.no_grad()

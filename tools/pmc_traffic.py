@@ -21,15 +21,17 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 GRIDS = {"115200": "N=768 (attention-out / FFN / video embedding)", "230400": "N=1536 (K/V of the [CLS]-only layer)", "345600": "N=2304 (Q/K/V)"}
-SYMBOL = "gemm_p8_kernel"
-SYMBOL_DEMANGLED = "gemm_p8_kernel"
+# fourth argument (optional): the arithmetic mode the bench command ran in — "bf16" (gemm_p8_kernel, default) or "bf16x3" (gemm_p8x3_kernel)
+MODE = sys.argv[4] if len(sys.argv) > 4 else "bf16"
+SYMBOL = "gemm_p8x3_kernel" if MODE == "bf16x3" else "gemm_p8_kernel"
+SYMBOL_DEMANGLED = SYMBOL
 
 
 def read(path, counter):
     by_grid = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         name = r.get("Kernel_Name", "")
-        if SYMBOL not in name and SYMBOL_DEMANGLED not in name:
+        if SYMBOL not in name or (MODE != "bf16x3" and "gemm_p8x3" in name):
             continue
         if r.get("Counter_Name") != counter:
             continue
@@ -56,13 +58,13 @@ def main():
     with open(out_csv, "w") as f:
         f.write("counter,kernel,grid_threads,shape,launches,mean_KB_per_launch\n")
         for cname, g, what, n, m in rows:
-            f.write('%s,"gemm_p8_kernel",%s,"%s",%d,%.1f\n' % (cname, g, what, n, m))
+            f.write('%s,"%s",%s,"%s",%d,%.1f\n' % (cname, SYMBOL, g, what, n, m))
         f.write('FETCH_SIZE,"all M=19200 forward launches",,,%d,%.1f\n' % (n_f, mean_f))
         f.write('WRITE_SIZE,"all M=19200 forward launches",,,%d,%.1f\n' % (n_w, mean_w))
     rec = {"traffic_bytes_per_launch": traffic, "fetch_KB_mean": mean_f, "write_KB_mean": mean_w, "launches_fetch_pass": n_f,
            "launches_write_pass": n_w, "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: 128-B read requests are tallied at 64 B)",
-           "kernel_sources_sha16": bench.dominant_kernel_sha(), "source": "profiles/" + os.path.basename(out_csv)}
-    with open(bench.TRAFFIC_FILE, "w") as f:
+           "kernel_sources_sha16": bench.dominant_kernel_sha(MODE), "source": "profiles/" + os.path.basename(out_csv), "kernel": SYMBOL}
+    with open(bench.TRAFFIC_FILE_X3 if MODE == "bf16x3" else bench.TRAFFIC_FILE, "w") as f:
         json.dump(rec, f, indent=1)
         f.write("\n")
     print(json.dumps(rec))
