@@ -122,7 +122,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-warmup", type=int, default=3)     # >= 3 warm-up + >= 5 timed steps, median
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the CPUs this process may use (affinity / cgroup share), capped at the physical cores")
-    ap.add_argument("--no-cpu-alt", action="store_true", help="skip the second CPU figure (all physical cores when they exceed the share)")
+    ap.add_argument("--cpu-alt", action="store_true",
+                    help="also time the oracle with one thread per PHYSICAL core of the box when that exceeds this process's CPU share "
+                         "(measured on the round-3 box: 128 threads on a 16-CPU share = 59.9 s/step against 7.55 s/step with 16 — oversubscribed, so off by default)")
     ap.add_argument("--parity-steps", type=int, default=5)
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher/rendezvous check without a GPU: every rank joins the process group, SUM-all-reduces a small CPU "
@@ -678,9 +680,13 @@ def _train_main(args, device, world, rank, dist, joined):
                  "v_mfma_f32_16x16x32_bf16)")
     else:
         kname = "gemm_bf16_kernel<128,128,NT,interior,8 waves,%s>" % ("bf16·f32→bf16" if r["bf16_stream"] else "f32")
-    dtype = {"bf16": "bf16", "fp32": "f32",
-             "bf16x3": "bf16x3 (forward: three-term split-bf16 products on the bf16 MFMA, fp32 accumulate, activations stored as two bf16 "
-                       "planes or fp32; backward: bf16 operands; statistics, losses, master weights, optimizer fp32)"}[precision]
+    dtype = {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3"}[precision]
+    arithmetic = {"bf16": "bf16 MFMA operands (one-term products), fp32 accumulate, bf16 activation streams; statistics, losses, master "
+                          "weights, optimizer fp32",
+                  "fp32": "f32 MFMA, fp32 storage",
+                  "bf16x3": "forward: three-term split-bf16 products on the bf16 MFMA (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi), fp32 accumulate, "
+                            "activations stored as two bf16 planes (clip encoder) or fp32; backward: bf16 operands (the hi planes); "
+                            "statistics, losses, master weights, optimizer fp32"}[precision]
     out = {
         "metric": "train steps/sec (vivt, batch=16, clip_seq=12)", "value": joined * args.steps / elapsed,
         "unit": "steps/s (one step = 16 clip-sequences per GPU; whole-job aggregate)", "n_gpus": joined, "steps": args.steps,
@@ -690,7 +696,7 @@ def _train_main(args, device, world, rank, dist, joined):
                                "L=%d (enc+step-enc+dec), V=%d, A=%d, E=10; dropout .1/.1/.4; fwd+bwd+allreduce+clip+BertAdam"
                                % (args.model_type, args.batch, args.clips, cfg.max_v_len, cfg.video_feature_size, cfg.max_t_len,
                                   cfg.hidden_size, cfg.num_attention_heads, cfg.num_hidden_layers, cfg.vocab_size, cfg.action_vocab_size),
-                   "mode": precision, "parity": recorded_parity(precision),
+                   "mode": precision, "arithmetic": arithmetic, "parity": recorded_parity(precision),
                    "global_batch": args.batch * joined, "parallelism": "dp%d" % joined, "final_loss": r["final_loss"],
                    "host_enqueue_ms_per_step": r["host_enqueue_ms"], "launch": r["launch"], "degraded": r["degraded"],
                    "gpus_requested": args.gpus},
@@ -720,7 +726,7 @@ def _train_main(args, device, world, rank, dist, joined):
     if world == 1 and not args.no_cpu_baseline and not args.rehearse_dp:
         out["cpu_baseline"] = cpu_baseline(cfg, r["model"], args)
         physical, logical, usable = host_cpus()
-        if not args.no_cpu_alt and args.cpu_threads <= 0 and physical > out["cpu_baseline"]["cores"]:
+        if args.cpu_alt and args.cpu_threads <= 0 and physical > out["cpu_baseline"]["cores"]:
             # the box has more physical cores than this process's share: also time the oracle on all of them (1 + 3 steps)
             try:
                 alt = cpu_baseline(cfg, r["model"], args, threads=physical, warmup=1, steps=3)

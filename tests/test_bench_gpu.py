@@ -46,12 +46,14 @@ def test_gpus_flag_starts_two_ranks_on_the_card():
 
 
 @pytest.mark.timeout(290)
-def test_single_gpu_line_has_the_contract_fields():
-    rec, err = _bench()
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_single_gpu_line_has_the_contract_fields(precision):
+    rec, err = _bench("--precision", precision)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline"):
         assert k in rec, k
-    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["warmup"] == 2 and rec["dtype"] == "bf16" and rec["vs_baseline"] is None
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["warmup"] == 2 and rec["dtype"] == precision and rec["vs_baseline"] is None
     assert rec["config"]["launch"] == "hipGraph replay" and rec["config"]["degraded"] is None
-    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rec["roofline"])
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "attention")) <= set(rec["roofline"])
+    assert rec["config"]["mode"] == precision
     assert "AccumulateGrad node's stream does not match" not in err
