@@ -144,27 +144,63 @@ def _free_port():
 
 def launch_ranks(args, argv):
     """``--gpus N`` without a launcher: start N fresh rank processes (this process has made no GPU call and makes none), wait for
-    all of them, relay rank 0's JSON line.  Exit code = first non-zero rank exit code."""
+    all of them, relay rank 0's JSON line.  Exit code = first non-zero rank exit code.  The children never outlive this process:
+    each runs in its own session (process group), SIGTERM / SIGINT reaching the parent (the driver's ``timeout``, Ctrl-C) are
+    forwarded, and whatever ends the wait loop — a failed rank, a signal, an exception — terminates, then kills, every live child."""
+    import signal
     import tempfile
     port = _free_port()
     procs = []
     out0 = tempfile.TemporaryFile(mode="w+")
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None))
-    # wait for all; a rank that dies must not leave the others blocked in a collective for ever: after the first failure the
-    # remaining ranks get 20 s, then exactly these child PIDs are killed
-    failed_at = None
-    while any(p.poll() is None for p in procs):
-        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
-            failed_at = time.time()
-        if failed_at is not None and time.time() - failed_at > 20.0:
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()
-        time.sleep(0.2)
+
+    def stop_children(grace=5.0):
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            try:
+                os.killpg(p.pid, signal.SIGTERM)          # the rank and anything it started (start_new_session: pgid == pid)
+            except (ProcessLookupError, PermissionError):
+                pass
+        t_end = time.time() + grace
+        while time.time() < t_end and any(p.poll() is None for p in live):
+            time.sleep(0.1)
+        for p in live:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    class _Stop(Exception):
+        pass
+
+    def on_signal(signum, frame):
+        raise _Stop(signum)
+    old = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
+    interrupted = None
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None, start_new_session=True))
+        # wait for all; a rank that dies must not leave the others blocked in a collective for ever: after the first failure the
+        # remaining ranks get 20 s, then exactly these children are stopped
+        failed_at = None
+        while any(p.poll() is None for p in procs):
+            if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+                failed_at = time.time()
+            if failed_at is not None and time.time() - failed_at > 20.0:
+                stop_children()
+            time.sleep(0.2)
+    except _Stop as e:
+        interrupted = int(e.args[0])
+    finally:
+        stop_children()
+        for sig, h in old.items():
+            signal.signal(sig, h)
+    if interrupted is not None:
+        print("[bench] interrupted by signal %d: ranks stopped" % interrupted, file=sys.stderr)
+        sys.exit(128 + interrupted)
     codes = [p.returncode for p in procs]
     out0.seek(0)
     sys.stdout.write(out0.read())
@@ -587,6 +623,11 @@ def worker(args):
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         n_dev = torch.cuda.device_count()
+        if world > n_dev and args.backend == "nccl":
+            # RCCL needs one device per rank; sharing cards is a gloo-only rehearsal (tests) and is reported as such
+            print("[bench] %d ranks requested but %d device(s) visible: refusing to share devices over RCCL (use --backend gloo for a "
+                  "rehearsal on fewer cards)" % (world, n_dev), file=sys.stderr)
+            sys.exit(5)
         dev_index = local_rank % max(1, n_dev)
         torch.cuda.set_device(dev_index)
         if args.backend == "nccl":
@@ -718,6 +759,7 @@ def _train_main(args, device, world, rank, dist, joined):
     }
     if dist is not None:
         out["rccl_ranks"] = joined
+        out["distinct_devices"] = min(joined, torch.cuda.device_count())      # < n_gpus only in a gloo rehearsal that shares cards
         out["exchange"] = {"backend": args.backend, "allreduce_bytes_per_step": r["allreduce_bytes"], "buckets": r["n_buckets"],
                            "op": "SUM over the fp32 gradient arena, before the global clip (src/train.py:140-143)",
                            "ms_per_step_without_exchange": r["no_exchange_ms"],

@@ -3,12 +3,12 @@
 reference: src/train.py:401-405 writes ``{"model": state_dict, "model_cfg": EasyDict, "opt": EasyDict, "epoch": int}`` with
 ``torch.save``; src/translator.py:33-38 / src/translate.py read ``checkpoint["model_cfg"]`` and ``checkpoint["model"]``.
 
-``save_checkpoint`` writes the same four keys.  The two configs are pickled as ``easydict.EasyDict`` when that package is
-importable (what the reference's loaders expect: they use attribute access on ``checkpoint["model_cfg"]``), otherwise as plain
-``dict``s — never as a class of this package, so the file opens with a bare ``torch.load`` wherever it is read (a reference
-process without easydict-typed configs needs one line, ``EasyDict(ckpt["model_cfg"])``).  ``load_checkpoint``
-turns either form into ``ModelConfig`` and also opens files written by the reference on a box without easydict: that one class
-name is mapped onto ``ModelConfig`` while unpickling; nothing else is remapped.
+``save_checkpoint`` writes the same four keys, ALWAYS in one format: the two configs are pickled as ``easydict.EasyDict`` — by
+qualified name, without importing that package (it is not needed to write the file) — which is what the reference's loaders expect
+(attribute access on ``checkpoint["model_cfg"]``, src/translator.py:33-36) and what the reference itself writes; no class of this
+package is pickled, so a reference process (which always has easydict: src/rtransformer/model.py:8 imports it) reads the file with
+its bare ``torch.load``.  ``load_checkpoint`` maps that one class name onto ``ModelConfig`` while unpickling (so it opens files
+written by the reference, or by this function, on a box without easydict); nothing else is remapped.
 """
 from __future__ import annotations
 
@@ -33,17 +33,32 @@ _pickle_module.load = lambda f, **kw: _Unpickler(f, **kw).load()
 _pickle_module.__name__ = "pickle"
 
 
+class _AsEasyDict(dict):
+    """a config on its way into a checkpoint: pickled under the name ``easydict.EasyDict`` (see _Pickler.save_global)"""
+
+
+class _Pickler(pickle._Pickler):          # the pure-Python pickler: save_global can be overridden (tensors travel by persistent id)
+    def save_global(self, obj, name=None):
+        if obj is _AsEasyDict:
+            self.write(pickle.GLOBAL + b"easydict\nEasyDict\n")
+            self.memoize(obj)
+            return
+        super().save_global(obj, name)
+
+
+_save_module = types.ModuleType("svpc_amd._checkpoint_pickle_save")
+_save_module.Pickler = _Pickler
+_save_module.dump = lambda obj, f, protocol=None, **kw: _Pickler(f, protocol).dump(obj)
+_save_module.__name__ = "pickle"
+
+
 def save_checkpoint(path, model, opt=None, epoch=0, state_dict=None):
     """``state_dict`` overrides ``model.state_dict()`` (e.g. the EMA weights, as train.py:401 saves them)."""
     sd = state_dict if state_dict is not None else model.state_dict()
     sd = {k: v.detach().cpu().clone() for k, v in sd.items()}
-    try:
-        from easydict import EasyDict as _cfg_type       # the reference's own container, when the environment has it
-    except ImportError:
-        _cfg_type = dict
-    ckpt = {"model": sd, "model_cfg": _cfg_type(dict(model.config)), "opt": _cfg_type(dict(opt)) if opt is not None else None,
+    ckpt = {"model": sd, "model_cfg": _AsEasyDict(dict(model.config)), "opt": _AsEasyDict(dict(opt)) if opt is not None else None,
             "epoch": int(epoch)}
-    torch.save(ckpt, path)
+    torch.save(ckpt, path, pickle_module=_save_module)
     return ckpt
 
 

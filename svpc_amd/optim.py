@@ -440,6 +440,7 @@ class GradReducer:
         self.ready = [False] * len(self.buckets)
         self._next = 0
         self._releasing = False
+        self._finishing = False
 
     def mark_all_unlaunched(self):
         """first step after construction: the hooks were not installed during the backward that has just run"""
@@ -487,6 +488,13 @@ class GradReducer:
             left.discard(i)
             if not left and not self.launched[bi]:
                 self._release(bi)
+        elif self.launched[bi] and not self._finishing:
+            # a member of a bucket that is already being exchanged was written AGAIN in this step (a packed projection whose backward
+            # ran twice: module reuse, a forward_step-style loop): its first report released the bucket too early and the all-reduce
+            # raced the second accumulation.  Wrong gradients must not be silent.
+            raise RuntimeError("GradReducer: gradient %r was reported ready again after its bucket %d had been launched — a parameter "
+                               "view written by more than one backward kernel per step cannot be exchanged in overlap mode; use "
+                               "overlap=False (exchange after backward)" % (self.arena.names[i], bi))
 
     def _ready_ptr(self, ptr, numel=None, kind=None):
         """a kernel has just finished (enqueued) writing the arena gradient view at ``ptr`` — only packed views are tracked here"""
@@ -515,6 +523,7 @@ class GradReducer:
     def finish(self):
         """Launch whatever has not been launched (tensors without a gradient this step never fire a hook) and wait."""
         if self.active:
+            self._finishing = True       # (the queue flush of the launches below reports the remaining gradients: expected here)
             for bi in range(len(self.buckets)):
                 if not self.launched[bi]:
                     self._launch(bi)

@@ -143,3 +143,28 @@ def test_post_accumulate_hook_fires_without_a_gradient_tensor():
     w.register_post_accumulate_grad_hook(lambda p: fired.append(float(p.grad.abs().sum())))
     (F.apply(x, w).sum() + F.apply(2 * x, w).sum()).backward()
     assert len(fired) == 1 and fired[0] > 0          # once, after BOTH uses have written
+
+
+def test_reducer_refuses_a_view_written_again_after_launch():
+    from svpc_amd.optim import GradArena, GradReducer
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        params = [("w%d" % i, torch.nn.Parameter(torch.zeros(64, 64))) for i in range(4)]
+        for _, p in params:
+            p.grad = torch.zeros_like(p)
+        arena = GradArena(params)
+        red = GradReducer(arena, bucket_bytes=8 << 10, overlap=True, force=True)
+        bi_last = len(red.buckets) - 1
+        for bi, (_, _, members) in enumerate(red.buckets):
+            for i in members:
+                red._done(i, bi)
+        assert all(red.launched)
+        with pytest.raises(RuntimeError, match="reported ready again"):
+            red._done(red.buckets[bi_last][2][0], bi_last)
+        red.finish()
+        red.close()
+    finally:
+        dist.destroy_process_group()

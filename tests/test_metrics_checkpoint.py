@@ -67,7 +67,7 @@ def test_checkpoint_roundtrip_and_reference_layout(tmp_path):
     path = str(tmp_path / "model.chkpt")
     opt = syn.ModelConfig(lr=1e-4, max_v_len=8)
     CK.save_checkpoint(path, model, opt=opt, epoch=3)
-    raw = torch.load(path, weights_only=False)
+    raw = CK.load_checkpoint(path)       # (a bare torch.load needs the reference's easydict: test_saved_checkpoint_opens_without_this_package)
     assert set(raw) == {"model", "model_cfg", "opt", "epoch"} and raw["epoch"] == 3            # src/train.py:401-405
     cfg2, model2 = _tiny_model()
     with torch.no_grad():
@@ -109,18 +109,38 @@ def test_load_checkpoint_written_with_easydict(tmp_path):
 
 
 def test_saved_checkpoint_opens_without_this_package(tmp_path):
-    """The file must not pickle any class of svpc_amd: a fresh interpreter that cannot import the package reads it with a bare
-    ``torch.load`` (the reference's side of the interchange, src/translator.py:33-38)."""
+    """ONE deterministic format: the configs are pickled under the name ``easydict.EasyDict`` whether or not that package is installed
+    where the file is written, and no class of svpc_amd is pickled — a fresh interpreter that cannot import this package but has an
+    ``easydict`` module (the reference's own dependency, src/rtransformer/model.py:8; stubbed here as the oracle harness stubs it)
+    reads it with a bare ``torch.load`` and uses the reference Translator's access pattern (src/translator.py:33-38: attribute access
+    on ``checkpoint["model_cfg"]``, ``checkpoint["model"]`` a plain state_dict)."""
     import subprocess
     cfg, model = _tiny_model()
     path = str(tmp_path / "plain.chkpt")
     CK.save_checkpoint(path, model, opt=syn.ModelConfig(lr=1e-4), epoch=1)
-    code = ("import sys, torch\n"
+    raw = open(path, "rb").read()
+    assert b"easydict" in raw and b"svpc_amd" not in raw
+    code = ("import sys, types, torch\n"
             "sys.modules['svpc_amd'] = None\n"                       # any 'import svpc_amd…' inside the unpickler would raise
-            "ck = torch.load(%r, weights_only=False)\n"
-            "assert type(ck['model_cfg']) is dict and type(ck['opt']) is dict, (type(ck['model_cfg']), type(ck['opt']))\n"
-            "assert ck['model_cfg']['hidden_size'] == 32 and ck['epoch'] == 1\n"
-            "assert all(isinstance(v, torch.Tensor) for v in ck['model'].values())\n"
+            "m = types.ModuleType('easydict')\n"
+            "class EasyDict(dict):\n"
+            "    def __init__(self, d=None, **kw):\n"
+            "        super().__init__()\n"
+            "        for k, v in dict(d or {}, **kw).items(): self[k] = v\n"
+            "    def __setitem__(self, k, v):\n"
+            "        super().__setitem__(k, v); self.__dict__[k] = v\n"
+            "    __setattr__ = __setitem__\n"
+            "m.EasyDict = EasyDict; sys.modules['easydict'] = m\n"
+            "checkpoint = torch.load(%r, weights_only=False)\n"
+            "model_config = checkpoint['model_cfg']\n"
+            "assert type(model_config).__name__ == 'EasyDict' and type(checkpoint['opt']).__name__ == 'EasyDict'\n"
+            "assert model_config.hidden_size == 32 and model_config.max_t_len > 0 and model_config.max_v_len > 0\n"     # translator.py:34-36
+            "assert 'label_smoothing' in model_config and checkpoint['opt'].lr == 1e-4 and checkpoint['epoch'] == 1\n"
+            "assert all(isinstance(v, torch.Tensor) for v in checkpoint['model'].values())\n"
             "print('ok')\n" % path)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), timeout=240)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    # and this package's own loader reads the same file back (EasyDict → ModelConfig)
+    cfg2, model2 = _tiny_model()
+    ck = CK.load_checkpoint(path, model2)
+    assert isinstance(ck["model_cfg"], syn.ModelConfig) and ck["model_cfg"].hidden_size == 32 and ck["opt"].lr == 1e-4
