@@ -114,6 +114,9 @@ def parse_args(argv=None):
     ap.add_argument("--decode-eager", action="store_true", help="launch the decode kernels eagerly instead of replaying the batch structure's hipGraph")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU rehearsals)")
+    ap.add_argument("--exchange-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="wire format of the gradient buckets: fp32 (default: N ranks == one process with the N-fold batch, exactly) or "
+                         "bf16 (half the xGMI bytes for one 2^-9 rounding per rank; error bounded in tests/test_dp_gloo.py)")
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="run the data-parallel code path (process group, three graphs, bucketed all-reduce) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -444,6 +447,8 @@ def run_train(args, precision, device, world, rank, dist, steps, warmup, instrum
     state = {"reducer": None}
 
     def step():
+        if state["reducer"] is not None:
+            state["reducer"].mark_step_start()
         opt.zero_grad()
         loss = model(*fargs)[0]
         backward_all(model, loss)
@@ -451,7 +456,8 @@ def run_train(args, precision, device, world, rank, dist, steps, warmup, instrum
         if exchange_on:
             if state["reducer"] is None:
                 # graph mode: the exchange runs between captured graphs (no hooks); eager mode: overlapped with backward
-                state["reducer"] = GradReducer(arena, overlap=args.no_graph, force=args.rehearse_dp)
+                state["reducer"] = GradReducer(arena, overlap=args.no_graph, force=args.rehearse_dp, wire_dtype=args.exchange_dtype,
+                                               timeline=True)
                 state["reducer"].mark_all_unlaunched()   # first step: hooks were not installed during this backward
             state["reducer"].finish()
         opt.step()
@@ -573,6 +579,7 @@ def run_train(args, precision, device, world, rank, dist, steps, warmup, instrum
                degraded=degraded, gsum=gsum, asum=(asum if instrument else None), glds=glds, bf16_stream=bf16_stream, rows_enc=rows_enc,
                no_exchange_ms=no_exchange_ms,
                allreduce_bytes=(reducer.bytes_per_step() if reducer is not None else 0),
+               bucket_timeline=(reducer.timeline_ms() if reducer is not None else None),
                n_buckets=(len(reducer.buckets) if reducer is not None else 0))
     return res
 
@@ -761,7 +768,11 @@ def _train_main(args, device, world, rank, dist, joined):
         out["rccl_ranks"] = joined
         out["distinct_devices"] = min(joined, torch.cuda.device_count())      # < n_gpus only in a gloo rehearsal that shares cards
         out["exchange"] = {"backend": args.backend, "allreduce_bytes_per_step": r["allreduce_bytes"], "buckets": r["n_buckets"],
+                           "wire_dtype": args.exchange_dtype,
                            "op": "SUM over the fp32 gradient arena, before the global clip (src/train.py:140-143)",
+                           # last step of the run: when each bucket's all-reduce was issued and when the compute stream could pass
+                           # its wait, ms since the step's start on the compute stream's clock (diagnosis of an efficiency < 0.9)
+                           "bucket_timeline_ms": r["bucket_timeline"],
                            "ms_per_step_without_exchange": r["no_exchange_ms"],
                            "exposed_exchange_ms": (ms - r["no_exchange_ms"]) if r["no_exchange_ms"] is not None else None}
     out.update(extras)

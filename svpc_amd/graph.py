@@ -106,6 +106,8 @@ class GraphedTrainStep:
             self.opt.weights.refresh()
             self._versions = self.opt.weights.versions()
         self.opt.set_hyper()
+        if self.exchange is not None:
+            self.exchange.mark_step_start()
         self.graph.replay()
         if self.graph_opt is not None:
             self.exchange.start_early()          # text-side buckets travel while the clip encoder's backward runs

@@ -374,8 +374,17 @@ class GradReducer:
     backward; ``finish()`` waits before the clip/optimizer kernels read the arena.  SUM (not mean) keeps the reference's
     sum-over-videos loss semantics (model.py:1110-1115, :1188): N ranks × 16 videos ≡ one process with 16·N videos."""
 
-    def __init__(self, arena, process_group=None, bucket_bytes=64 << 20, overlap=True, force=False):
+    def __init__(self, arena, process_group=None, bucket_bytes=64 << 20, overlap=True, force=False, wire_dtype="fp32", timeline=False):
+        """wire_dtype="bf16": every bucket travels as bf16 (cast → all-reduce → the summed values written back into the fp32 arena):
+        half the bytes on the xGMI links for one 2⁻⁹ rounding of each rank's contribution and the collective's own bf16 adds — an
+        option for the day the fp32 exchange (340 MB per step) is what holds weak scaling under 0.9; the default stays fp32, which
+        keeps N ranks ≡ one process with the N-fold batch exactly (tests/test_dp_gloo.py bounds the bf16 error against it).
+        timeline=True: per-bucket issue / completion timestamps (HIP events on the compute stream, or host clocks on CPU) for
+        ``timeline_ms()`` — what bench.py prints in ``exchange.buckets`` so that an efficiency < 0.9 can be diagnosed from one line."""
         import torch.distributed as dist
+        assert wire_dtype in ("fp32", "bf16")
+        self.wire_dtype, self.timeline = wire_dtype, bool(timeline)
+        self._wire, self._stamps, self._t0 = {}, [], None
         self.dist, self.arena, self.pg = dist, arena, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # force: issue the collectives even with one rank (rehearsal of the data-parallel code path on a one-GPU box)
@@ -447,7 +456,35 @@ class GradReducer:
         self.reset()
 
     def bytes_per_step(self):
-        return sum((e - s) * 4 for s, e, _ in self.buckets)
+        return sum((e - s) * (2 if self.wire_dtype == "bf16" else 4) for s, e, _ in self.buckets)
+
+    # ---- per-bucket timeline (diagnostics)
+    def _now(self):
+        import time
+        if self.arena.flat.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        return time.perf_counter()
+
+    def mark_step_start(self):
+        """call at the start of a step (before zero_grad) when ``timeline`` is on"""
+        if self.timeline:
+            self._t0 = self._now()
+            self._stamps = []
+
+    def timeline_ms(self):
+        """→ [{bucket, bytes, issued_ms, complete_ms}] of the last finished step, times since ``mark_step_start`` (GPU: the compute
+        stream's clock — ``complete`` is when the compute stream could pass the bucket's wait, issue order)"""
+        if not self.timeline or self._t0 is None:
+            return None
+        if self.arena.flat.is_cuda:
+            torch.cuda.synchronize()
+            ms = lambda t: self._t0.elapsed_time(t)
+        else:
+            ms = lambda t: 1000.0 * (t - self._t0)
+        return [{"bucket": bi, "bytes": nb, "issued_ms": ms(t_i), "complete_ms": ms(t_c) if t_c is not None else None}
+                for bi, nb, t_i, t_c in self._stamps]
 
     def close(self):
         """remove the hooks (tests; a reducer normally lives as long as the model)"""
@@ -465,7 +502,17 @@ class GradReducer:
         s, e, _ = self.buckets[bi]
         if self.skip:
             return
-        self.works.append(self.dist.all_reduce(self.arena.flat[s:e], op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        if self.wire_dtype == "bf16":
+            buf = self._wire.get(bi)
+            if buf is None:
+                buf = self._wire[bi] = torch.empty(e - s, dtype=torch.bfloat16, device=self.arena.flat.device)
+            buf.copy_(self.arena.flat[s:e])
+            payload = buf
+        else:
+            payload = self.arena.flat[s:e]
+        if self.timeline:
+            self._stamps.append([bi, payload.numel() * payload.element_size(), self._now(), None])
+        self.works.append((bi, self.dist.all_reduce(payload, op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True)))
 
     def _release(self, bi):
         """Bucket ``bi`` is complete.  Collectives are issued strictly in bucket-index order (bucket i waits for 0..i-1): ranks
@@ -527,6 +574,14 @@ class GradReducer:
             for bi in range(len(self.buckets)):
                 if not self.launched[bi]:
                     self._launch(bi)
-            for w in self.works:
+            for k, (bi, w) in enumerate(self.works):
                 w.wait()
+                if self.wire_dtype == "bf16":
+                    s, e, _ = self.buckets[bi]
+                    self.arena.flat[s:e].copy_(self._wire[bi])      # the summed bucket back into the fp32 arena (before the global clip)
+                if self.timeline:
+                    for st in self._stamps:
+                        if st[0] == bi and st[3] is None:
+                            st[3] = self._now()
+                            break
         self.reset()
