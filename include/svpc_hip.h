@@ -212,6 +212,11 @@ int svpc_attn_mfma_fwd_t(const void* Q, int ldq, const void* K, int ldk, const v
 int svpc_attn_stream_x3_fwd(const void* Q, int ldq, int q_lo, const void* K, int ldk, int k_lo, const void* V, int ldv, int v_lo, void* O,
                             int ldo, int o_lo, float* LSE, const int* seq, int n_seq, int H, int dh, int max_q, int max_k,
                             const float* key_mask, float scale, float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
+/* general bf16x3 forward: sequences of <= 32 queries and keys (the decoder's causal self-attention and its memory cross-attention,
+ * model.py:620-663) run one wave per (sequence, head) and may be causal; longer ones take the stream kernel above (non-causal) */
+int svpc_attn_x3_fwd(const void* Q, int ldq, int q_lo, const void* K, int ldk, int k_lo, const void* V, int ldv, int v_lo, void* O, int ldo,
+                     int o_lo, float* LSE, const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,
+                     float scale, float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
 int svpc_attn_mfma_bwd_t(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O, int ldo, int dt,
                          const float* LSE, const void* dO, int lddo, void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv,
                          const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal, float scale,

@@ -791,6 +791,152 @@ __global__ __launch_bounds__(256, 2) void attn_stream_x3_fwd_kernel(X3AttnArgs x
             }
 }
 
+// ---- bf16x3 forward for SHORT split-stored sequences (≤ 32 queries × ≤ 32 keys per (sequence, head): the decoder's causal 22-token
+// self-attention and its 2-3-slot cross-attention, model.py:620-663): one WAVE per (sequence, head), four pairs per workgroup, no
+// workgroup barrier — the PERWAVE form of attn_mfma_fwd_kernel with the three-term products of attn_stream_x3_fwd_kernel.  K / V
+// planes in wave-private LDS images (4 × 32 rows), Q fragments straight into registers; causal ∧ key-pad mask as one −10000 term.
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_small_x3_fwd_kernel(X3AttnArgs xa) {
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const MAttnArgs& a = xa.m;
+    constexpr int AT = 32, RS = AImg<DH>::RS, IB = AT * RS, UPR = DH / 8, NIT = AT * UPR / 64;
+    constexpr int WAVE_BYTES = 4 * IB + AT * (int)sizeof(float);
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, lhi = lane >> 5;
+    char* smem = smem_all + wv * WAVE_BYTES;
+    char* Kh = smem; char* Kl = smem + IB; char* Vh = smem + 2 * IB; char* Vl = smem + 3 * IB;
+    float* mterm = reinterpret_cast<float*>(smem + 4 * IB);
+    const int sh = (int)blockIdx.x * 4 + wv;
+    if (sh >= a.n_seq * a.H) return;
+    const int s = sh / a.H, h = sh - s * a.H;
+    const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
+    const __bf16* Kp = (const __bf16*)a.K + (size_t)k_off * a.ldk + h * DH;
+    const __bf16* Vp = (const __bf16*)a.V + (size_t)k_off * a.ldv + h * DH;
+    bf16x8 qh[DH / 16], ql[DH / 16];
+    {
+        uint4 kh[NIT], kl[NIT], vh[NIT], vl[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int u = lane + 64 * it, row = u / UPR, c8 = u - row * UPR;
+            kh[it] = kl[it] = vh[it] = vl[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (row < k_len) {
+                const __bf16* kp = Kp + (size_t)row * a.ldk + 8 * c8;
+                const __bf16* vp = Vp + (size_t)row * a.ldv + 8 * c8;
+                kh[it] = *reinterpret_cast<const uint4*>(kp);
+                kl[it] = *reinterpret_cast<const uint4*>(kp + xa.k_lo);
+                vh[it] = *reinterpret_cast<const uint4*>(vp);
+                vl[it] = *reinterpret_cast<const uint4*>(vp + xa.v_lo);
+            }
+        }
+        const int qr = max(min(l31, q_len - 1), 0);       // rows past the sequence repeat its last query (never stored)
+        const __bf16* Qp = (const __bf16*)a.Q + (size_t)(q_off + qr) * a.ldq + h * DH + 8 * lhi;
+#pragma unroll
+        for (int ds = 0; ds < DH / 16; ++ds) {
+            qh[ds] = *reinterpret_cast<const bf16x8*>(Qp + 16 * ds);
+            ql[ds] = *reinterpret_cast<const bf16x8*>(Qp + xa.q_lo + 16 * ds);
+        }
+        if (lane < AT) mterm[lane] = lane < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + lane] : 1.0f)) * -10000.0f : -INFINITY;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int u = lane + 64 * it, row = u / UPR, c8 = u - row * UPR;
+            *reinterpret_cast<uint4*>(Kh + row * RS + c8 * 16) = kh[it];
+            *reinterpret_cast<uint4*>(Kl + row * RS + c8 * 16) = kl[it];
+            *reinterpret_cast<uint4*>(Vh + row * RS + c8 * 16) = vh[it];
+            *reinterpret_cast<uint4*>(Vl + row * RS + c8 * 16) = vl[it];
+        }
+    }
+    group_sync<true>();
+    floatx16 st;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+    for (int ds = 0; ds < DH / 16; ++ds) {
+        const bf16x8 kfh = frag_rows<DH>(Kh, 0, ds, lane), kfl = frag_rows<DH>(Kl, 0, ds, lane);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql[ds], st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qh[ds], st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, qh[ds], st, 0, 0, 0);
+    }
+    const int q = l31;                 // this lane's query
+    float mx = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 m4 = *reinterpret_cast<const float4*>(mterm + 8 * g + 4 * lhi);
+        const float mt4[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+        for (int e = 4 * g; e < 4 * g + 4; ++e) {
+            const int key = acc_row(e, lane);
+            float t = mt4[e & 3];
+            if (a.causal) t = (key > q && key < k_len) ? -10000.0f : t;
+            const float v = fmaf(st[e], a.scale, t);
+            st[e] = v;
+            mx = fmaxf(mx, v);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { const float p = expf(st[e] - mx); st[e] = p; sum += p; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (lane < 32 && q < q_len && a.LSE) a.LSE[((size_t)s * a.H + h) * a.max_q + q] = mx + logf(sum);
+    const DropCtx dctx(a.seed, a.site, a.p_drop, (u64)a.n_seq * a.H * a.max_q * a.max_k);
+    const u64 row_base = ((u64)(s * a.H + h) * a.max_q + q) * a.max_k;
+    float pv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) pv[e] = st[e] * inv;
+    if (a.p_drop > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pv[e] *= dctx.mul(row_base, acc_row(e, lane));
+    }
+    floatx16 acc[DH / 32];      // Oᵀ: rows = head columns 32·dt + acc_row(e), column = this lane's query
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[dt][e] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 ph, pl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const __bf16 hh = (__bf16)pv[8 * s2 + j];
+            ph[j] = hh; pl[j] = (__bf16)(pv[8 * s2 + j] - (float)hh);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt) {
+            const bf16x8 vfh = frag_tr<DH>(Vh, 16 * s2, 32 * dt, lane), vfl = frag_tr<DH>(Vl, 16 * s2, 32 * dt, lane);
+            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, pl, acc[dt], 0, 0, 0);
+            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl, ph, acc[dt], 0, 0, 0);
+            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, ph, acc[dt], 0, 0, 0);
+        }
+    }
+    __bf16* Op = (__bf16*)a.O + (size_t)(q_off + q) * a.ldo + h * DH;
+#pragma unroll
+    for (int plane = 0; plane < 2; ++plane)
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {
+                uint32_t y[4];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int e = 4 * (k + g);
+                    float v4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = acc[dt][e + j];
+                        v4[j] = plane ? v - (float)(__bf16)v : v;
+                    }
+                    union { __bf16 hh[2]; uint32_t u; } p0, p1;
+                    p0.hh[0] = (__bf16)v4[0]; p0.hh[1] = (__bf16)v4[1];
+                    p1.hh[0] = (__bf16)v4[2]; p1.hh[1] = (__bf16)v4[3];
+                    y[2 * g] = p0.u; y[2 * g + 1] = p1.u;
+                }
+                auto r0 = __builtin_amdgcn_permlane32_swap(y[0], y[2], false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(y[1], y[3], false, false);
+                if (q < q_len)
+                    *reinterpret_cast<uint4*>(Op + (plane ? xa.o_lo : 0) + 32 * dt + 8 * (k + lhi)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            }
+}
+
 static int mattn_set_lds(const void* fn, size_t bytes) { return svpc_raise_lds_once(fn, "attn_mfma"); }   // once per kernel symbol, process-wide table (api.cpp)
 static bool mattn_ok(int dh, int max_q, int max_k, int ldq, int ldk, int ldv, const void* Q, const void* K, const void* V, int dt) {
     const int al = 16, lm = dt ? 8 : 4;   // 16-byte staging units: 8 bf16 or 4 fp32 elements
@@ -877,10 +1023,23 @@ int svpc_attn_mfma_fwd(const float* Q, int ldq, const float* K, int ldk, const f
 // bf16x3 forward over split-stored Q / K / V / O (hi planes at the given pointers with the rows' leading dimensions, lo planes
 // q_lo / k_lo / v_lo / o_lo elements behind them); non-causal, ≤128 rows per sequence, head dim 32 / 64.  LSE as the other kernels.
 // reference: BertSelfAttention core, src/rtransformer/model.py:194-219 (clip encoder).
+int svpc_attn_x3_fwd(const void* Q, int ldq, int q_lo, const void* K, int ldk, int k_lo, const void* V, int ldv, int v_lo, void* O, int ldo,
+                     int o_lo, float* LSE, const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,
+                     float scale, float p_drop, unsigned site, const u64* seed, hipStream_t stream);
 int svpc_attn_stream_x3_fwd(const void* Q, int ldq, int q_lo, const void* K, int ldk, int k_lo, const void* V, int ldv, int v_lo, void* O,
                             int ldo, int o_lo, float* LSE, const int* seq, int n_seq, int H, int dh, int max_q, int max_k,
                             const float* key_mask, float scale, float p_drop, unsigned site, const u64* seed, hipStream_t stream) {
+    return svpc_attn_x3_fwd(Q, ldq, q_lo, K, ldk, k_lo, V, ldv, v_lo, O, ldo, o_lo, LSE, seq, n_seq, H, dh, max_q, max_k, key_mask, 0, scale,
+                            p_drop, site, seed, stream);
+}
+// general entry: sequences of ≤ 32 queries and keys take the one-wave-per-pair kernel (causal allowed: the decoder's self-attention),
+// longer ones the stream kernel (non-causal only)
+int svpc_attn_x3_fwd(const void* Q, int ldq, int q_lo, const void* K, int ldk, int k_lo, const void* V, int ldv, int v_lo, void* O, int ldo,
+                     int o_lo, float* LSE, const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,
+                     float scale, float p_drop, unsigned site, const u64* seed, hipStream_t stream) {
     if (n_seq == 0) return 0;
+    const bool small = max_q <= 32 && max_k <= 32;
+    SVPC_REQUIRE(small || !causal, "attn_x3: causal masks only on sequences of <= 32 rows");
     SVPC_REQUIRE(mattn_ok(dh, max_q, max_k, ldq, ldk, ldv, Q, K, V, 1) && ldo % 8 == 0 && ((((uintptr_t)O)) & 15) == 0 &&
                      q_lo % 8 == 0 && k_lo % 8 == 0 && v_lo % 8 == 0 && o_lo % 8 == 0,
                  "attn_stream_x3: unsupported shape/alignment (16-byte row pieces in every plane)");
@@ -888,9 +1047,22 @@ int svpc_attn_stream_x3_fwd(const void* Q, int ldq, int q_lo, const void* K, int
     X3AttnArgs xa{};
     MAttnArgs& a = xa.m;
     a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.LSE = LSE; a.seq = seq; a.n_seq = n_seq;
-    a.H = H; a.max_q = max_q; a.max_k = max_k; a.key_mask = key_mask; a.causal = 0; a.scale = scale; a.p_drop = p_drop;
+    a.H = H; a.max_q = max_q; a.max_k = max_k; a.key_mask = key_mask; a.causal = causal; a.scale = scale; a.p_drop = p_drop;
     a.site = site; a.seed = seed;
     xa.q_lo = q_lo; xa.k_lo = k_lo; xa.v_lo = v_lo; xa.o_lo = o_lo;
+    if (small) {
+        const int n_pairs = n_seq * H;
+        if (dh == 64) {
+            const size_t l = 4 * (4 * (size_t)32 * AImg<64>::RS + 32 * sizeof(float));
+            int rc = mattn_set_lds((const void*)attn_small_x3_fwd_kernel<64>, l);
+            if (rc) return rc;
+            hipLaunchKernelGGL((attn_small_x3_fwd_kernel<64>), dim3(ceil_div(n_pairs, 4)), dim3(256), l, stream, xa);
+        } else {
+            const size_t l = 4 * (4 * (size_t)32 * AImg<32>::RS + 32 * sizeof(float));
+            hipLaunchKernelGGL((attn_small_x3_fwd_kernel<32>), dim3(ceil_div(n_pairs, 4)), dim3(256), l, stream, xa);
+        }
+        return svpc_check_launch("attn_small_x3_fwd");
+    }
     const size_t lds = 4 * (size_t)128 * AImg<64>::RS + 128 * sizeof(float);
     if (dh == 64) {
         int rc = mattn_set_lds((const void*)attn_stream_x3_fwd_kernel<64>, lds);

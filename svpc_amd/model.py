@@ -350,19 +350,19 @@ class BertDecoderNoMemoryUntied(nn.Module):
 
     def streams_bf16(self, rows, width):
         """whether ``run`` keeps the sentence activations of (rows, width) in bf16"""
-        # (bf16x3 mode: the decoder keeps fp32 storage — three-term products built from fp32 operands, exact fp32 attention)
-        return (not ops.is_x3()) and ops.bf16_stream_ok(rows, width, self.config.intermediate_size)
+        return ops.bf16_stream_ok(rows, width, self.config.intermediate_size)
 
     def run(self, x, text_mask, mem, seq_self, seq_cross, mem_mask, cx):
         # interior-only row counts in bf16 precision: the sentence activations (and their gradients) stream through HBM as bf16
         stream_bf16 = self.streams_bf16(x.shape[0], x.shape[1])
+        x3 = ops.is_x3()
         if stream_bf16:
-            if x.dtype != torch.bfloat16:      # (the caller may have had the embedding LayerNorm write bf16 already)
-                x = x.to(torch.bfloat16)
+            if x.dtype != torch.bfloat16:      # (the caller may have had the embedding LayerNorm write bf16 / split rows already)
+                x = ops.to_split(x) if x3 else x.to(torch.bfloat16)
             # the memory rows join the stream once, not per layer: each layer's K|V projection then reads bf16 and writes bf16
             # (one cast instead of six casts forward and six backward; its weight gradients join the grouped bf16 launch)
             if mem.dtype == torch.float32 and ops.bf16_stream_ok(mem.shape[0], mem.shape[1], 2 * mem.shape[1]):
-                mem = mem.to(torch.bfloat16)
+                mem = ops.to_split(mem) if x3 else mem.to(torch.bfloat16)
         # Every layer projects the SAME memory rows to its keys and values (reference model.py:643-651): one (R, D) x (D, L·2D)
         # projection for the stack instead of L, each layer reads its 2D columns in place; backward likewise gathers the L
         # key / value gradients in one buffer and runs one dgrad (contraction L·2D) and one wgrad.
@@ -373,7 +373,7 @@ class BertDecoderNoMemoryUntied(nn.Module):
             kvs = ops.split_cols(ops.linear(mem, w, b, wgrad=wg, bgrad=bg, w16=w16), len(self.layer))
         for layer, kvc in zip(self.layer, kvs):
             x = layer.run(x, text_mask, mem, seq_self, seq_cross, mem_mask, cx, kvc=kvc)
-        return x.float() if stream_bf16 else x
+        return ops.to_f32(x) if stream_bf16 else x
 
     def forward(self, dec_hidden_states, dec_mask, enc_outputs, enc_mask, diagonal_mask=True,
                 output_all_encoded_layers=False):

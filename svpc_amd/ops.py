@@ -979,11 +979,11 @@ class _Attention(Function):
         if split:
             # bf16x3 stream (the wrapper has checked the shape): three-term products over the hi / lo planes; the backward is the
             # bf16 kernel on the hi planes
-            if causal or not mfma:
-                raise _lib.SvpcKernelError("attention: split tensors need the non-causal MFMA shape (head dim 32/64, ≤128 rows)")
-            _lib.call("attn_stream_x3_fwd", qp, qt.stride(0), q_lo, kp, kvt_c.stride(0), kv_lo, vp, kvt_c.stride(0), kv_lo, _p(out),
-                      out.stride(0), out._svpc_lo, _p(lse), _p(tbl), seq.n, H, dh, seq.max_q, seq.max_k, _p(key_mask), 1.0 / math.sqrt(dh),
-                      p, site, _p(seed), _stream())
+            if not mfma or (causal and (seq.max_q > 32 or seq.max_k > 32)):
+                raise _lib.SvpcKernelError("attention: split tensors need the MFMA shape (head dim 32/64, ≤128 rows; causal: ≤32 rows)")
+            _lib.call("attn_x3_fwd", qp, qt.stride(0), q_lo, kp, kvt_c.stride(0), kv_lo, vp, kvt_c.stride(0), kv_lo, _p(out),
+                      out.stride(0), out._svpc_lo, _p(lse), _p(tbl), seq.n, H, dh, seq.max_q, seq.max_k, _p(key_mask), 1 if causal else 0,
+                      1.0 / math.sqrt(dh), p, site, _p(seed), _stream())
             fwd_done = True
         elif is_x3() and qt.dtype == torch.float32 and not (not torch.is_grad_enabled() and seq.max_q == 1):
             # bf16x3 mode, fp32 storage (step encoder, decoder, the [CLS]-only layer): exact fp32 forward; the backward still runs
@@ -1065,7 +1065,7 @@ def attention(qt, kvt, cols, D, n_heads, seq, key_mask=None, causal=False, drop=
     split = lo_off(qt) is not None or lo_off(kvt) is not None
     if split:
         dh = D // n_heads
-        ok = (not causal and lo_off(qt) is not None and lo_off(kvt) is not None and
+        ok = ((not causal or (seq.max_q <= 32 and seq.max_k <= 32)) and lo_off(qt) is not None and lo_off(kvt) is not None and
               _lib.load().svpc_attn_mfma_supported(dh, seq.max_q, seq.max_k, 8, 8, 8) == 1 and qt.stride(0) % 8 == 0 and kvt.stride(0) % 8 == 0)
         if not ok:          # leave the split domain: exact fp32 attention on fp32 copies
             same = kvt is qt
@@ -1103,16 +1103,42 @@ class _SplitCols(Function):
 
 
 def split_cols(wide, n):
-    """→ n column blocks of ``wide`` (R, n·w) whose gradients are gathered in place (see _SplitCols)."""
-    if not (torch.is_grad_enabled() and wide.requires_grad):
-        w = wide.shape[1] // n
-        return tuple(wide[:, i * w:(i + 1) * w] for i in range(n))
-    gbuf = torch.empty_like(wide)
-    outs = _SplitCols.apply(wide, n, gbuf)
+    """→ n column blocks of ``wide`` (R, n·w) whose gradients are gathered in place (see _SplitCols).  A split ``wide`` gives split
+    blocks: the lo plane of a block lies the same number of columns behind it as the lo plane of the whole row."""
+    lo = lo_off(wide)
     w = wide.shape[1] // n
-    for i, o in enumerate(outs):
-        o._svpc_grad_into = gbuf[:, i * w:(i + 1) * w]
+    if not (torch.is_grad_enabled() and wide.requires_grad):
+        outs = tuple(wide[:, i * w:(i + 1) * w] for i in range(n))
+    else:
+        gbuf = torch.empty(wide.shape, dtype=wide.dtype, device=wide.device)
+        outs = _SplitCols.apply(wide, n, gbuf)
+        for i, o in enumerate(outs):
+            o._svpc_grad_into = gbuf[:, i * w:(i + 1) * w]
+    if lo is not None:
+        for o in outs:
+            o._svpc_lo = lo
     return outs
+
+
+def to_split(t):
+    """split copy (two bf16 planes) of an fp32 2-D tensor joining a bf16x3 stream (a handful of rows: the decoder's memory slots);
+    the gradient comes back as the dense bf16 tensor every split tensor has"""
+    y = _ToSplit.apply(t)
+    y._svpc_lo = t.shape[1]
+    return y
+
+
+class _ToSplit(Function):
+    @staticmethod
+    def forward(ctx, t):
+        out = new_split(t.shape[0], t.shape[1], t.device)
+        out.copy_(t)
+        torch.as_strided(out, out.shape, out.stride(), out.storage_offset() + out._svpc_lo).copy_(t - out.float())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.float()
 
 
 # ------------------------------------------------------------------------------------------------ spans / rows

@@ -394,3 +394,7 @@ def to_f32(t):
 
 def take_rows_f32(t, idx):
     return torch.index_select(t, 0, idx.long() if idx.dtype != torch.int64 else idx).float()
+
+
+def to_split(t):
+    return t.float()

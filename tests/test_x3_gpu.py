@@ -214,6 +214,56 @@ def test_attention_split_vs_torch(n, L, H, dh, drop):
     assert float((qkv.grad.float() - qr.grad).abs().max()) <= 3e-2 * float(qr.grad.abs().max())
 
 
+@pytest.mark.parametrize("n,Lq,Lk,H,dh,causal,drop", [(7, 22, 22, 12, 64, True, 0.0), (7, 22, 22, 12, 64, True, 0.1), (9, 22, 3, 12, 64, False, 0.0),
+                                                     (5, 32, 32, 4, 32, True, 0.0), (3, 6, 6, 4, 32, True, 0.0), (4, 22, 1, 12, 64, False, 0.0)])
+def test_attention_short_sequences_split_vs_torch(n, Lq, Lk, H, dh, causal, drop):
+    """the decoder's causal self-attention (packed Q/K/V) and its memory cross-attention (separate K|V rows) on split rows: one wave per
+    (sequence, head); backward = the bf16 PERWAVE kernel on the hi planes"""
+    D = H * dh
+    same = Lq == Lk and causal
+    if same:
+        qt, qv = _split(_rand(n * Lq, 3 * D, seed=40))
+        kt, kv, cols = qt, qv, (0, D, 2 * D)
+    else:
+        qt, qv = _split(_rand(n * Lq, D, seed=41))
+        kt, kv = _split(_rand(n * Lk, 2 * D, seed=42))
+        cols = (0, 0, D)
+    km = torch.ones(n * Lk, device=DEV)
+    if Lk > 3:
+        km.view(n, Lk)[:, -2:] = 0.0
+    seq = SeqInfo.uniform(n, Lq, Lk, DEV)
+    rng = O.make_rng(DEV, seed=11)
+    d = (drop, rng, 9) if drop > 0 else None
+    qt.requires_grad_(True)
+    if not same:
+        kt.requires_grad_(True)
+    out = O.attention(qt, kt, cols, D, H, seq, key_mask=km, causal=causal, drop=d)
+    assert O.lo_off(out) == D
+    qr = qv.clone().requires_grad_(True)
+    kr = qr if same else kv.clone().requires_grad_(True)
+    ref = E.attention(qr, kr, cols, D, H, seq, key_mask=km, causal=causal, drop=d)
+    err = float((_value(out) - ref).abs().max())
+    assert err <= 5e-5 * float(ref.abs().max()), err
+    g = _rand(n * Lq, D, seed=43).to(torch.bfloat16)
+    out.backward(g)
+    ref.backward(g.float())
+    if Lk > 1:       # (a single key: the softmax is the constant 1 and the query gradient is exactly zero — the bf16 backward leaves noise)
+        assert float((qt.grad.float() - qr.grad).abs().max()) <= 3e-2 * float(qr.grad.abs().max()) + 1e-6
+    if not same:
+        assert float((kt.grad.float() - kr.grad).abs().max()) <= 3e-2 * float(kr.grad.abs().max()) + 1e-6
+
+
+def test_split_cols_keeps_the_planes_and_gathers_gradients():
+    wide, wv = _split(_rand(40, 6 * 128, seed=44))
+    wide.requires_grad_(True)
+    blocks = O.split_cols(wide, 3)
+    assert all(O.lo_off(b) == 6 * 128 for b in blocks)
+    for i, b in enumerate(blocks):
+        assert torch.equal(O.to_f32(b), wv[:, i * 256:(i + 1) * 256])
+    t, tv = O.to_split(wv[:, :128].contiguous()), wv[:, :128]
+    assert O.lo_off(t) == 128 and float((O.to_f32(t) - tv).abs().max()) <= 1e-5 * float(tv.abs().max())
+
+
 def test_attention_fp32_storage_is_exact_forward_with_mfma_backward():
     n, L, H, dh = 6, 22, 12, 64
     D = H * dh

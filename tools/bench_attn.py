@@ -6,11 +6,19 @@ import torch
 from svpc_amd import ops
 
 dev = torch.device("cuda:0")
-ops.set_precision("bf16")
+MODE = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+ops.set_precision(MODE)
 B, L, H, dh = 192, 100, 12, 64
 D = H * dh
 torch.manual_seed(0)
-qkv = (0.5 * torch.randn(B * L, 3 * D, device=dev)).bfloat16().requires_grad_(True)
+if MODE == "bf16x3":
+    qkv = ops.new_split(B * L, 3 * D, dev)
+    src = 0.5 * torch.randn(B * L, 3 * D, device=dev)
+    qkv.copy_(src)
+    torch.as_strided(qkv, qkv.shape, qkv.stride(), qkv.storage_offset() + 3 * D).copy_(src - qkv.float())
+    qkv.requires_grad_(True)
+else:
+    qkv = (0.5 * torch.randn(B * L, 3 * D, device=dev)).bfloat16().requires_grad_(True)
 seq = ops.SeqInfo.uniform(B, L, L, dev)
 km = torch.ones(B * L, device=dev)
 rng = ops.default_rng(dev)
