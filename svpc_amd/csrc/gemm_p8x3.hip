@@ -1,7 +1,7 @@
 // Three-term split-bf16 GEMM ("bf16x3") for the forward projections of the activation streams in the ≤1e-4-parity throughput mode:
 //
 //   C = act( A·Bᵀ + bias ),  A = A_hi + A_lo,  B = B_hi + B_lo  (each an exact sum of two bf16 planes, 16-17 significant bits)
-//   A·Bᵀ ≈ A_lo·B_hiᵀ + A_hi·B_loᵀ + A_hi·B_hiᵀ          (the dropped A_lo·B_lo term is ≤ 2⁻¹⁶ relative)
+//   A·Bᵀ ≈ A_lo·B_hiᵀ + A_hi·B_hiᵀ + A_hi·B_loᵀ          (the dropped A_lo·B_lo term is ≤ 2⁻¹⁶ relative)
 //
 // i.e. ONE bf16 GEMM with a 3K-deep contraction whose k-tiles come from three (A plane, B plane) pairs — the structure, LDS images,
 // barriers and prefetch schedule are those of gemm_p8.hip (256×256×64 tiles, 8 phases per pair of k-tiles, both operands direct-to-LDS,
@@ -113,10 +113,12 @@ __global__ __launch_bounds__(512) void gemm_p8x3_kernel(const __bf16* __restrict
         gb[h] = B + (size_t)min(n0 + 128 * h + 16 * wave + sr, N - 1) * ldb + 8 * sc;
     }
     char* const my = smem + wave * 2048;
-    // k-tile t of the 3K-deep contraction: plane pair s = t / nk1 — s = 0: A_lo·B_hi, 1: A_hi·B_lo, 2: A_hi·B_hi (small terms first)
-    // — and k-tile t - s·nk1 inside the planes.  Element offsets from the hi-plane row pointers:
-#define X3_OFF_A(t) ((size_t)((t) - ((t) >= 2 * nk1 ? 2 * nk1 : ((t) >= nk1 ? nk1 : 0))) * X3_BK + ((t) < nk1 ? (size_t)a_lo : (size_t)0))
-#define X3_OFF_B(t) ((size_t)((t) - ((t) >= 2 * nk1 ? 2 * nk1 : ((t) >= nk1 ? nk1 : 0))) * X3_BK + (((t) >= nk1 && (t) < 2 * nk1) ? (size_t)b_lo : (size_t)0))
+    // k-tile t of the 3K-deep contraction: k-tile kt = t / 3 of the planes, plane pair s = t % 3 — s = 0: A_lo·B_hi, 1: A_hi·B_hi,
+    // 2: A_hi·B_lo.  The three uses of a 64-deep slice follow one another, so the A_hi slice (s = 1, 2) and the B_hi slice (s = 0, 1)
+    // are fetched twice BACK TO BACK — the second time from L2 — instead of once per sweep over K (measured with the sweep order
+    // lo·hi | hi·lo | hi·hi: 197 MB fetched per launch for 65 MB of operands).  Element offsets from the hi-plane row pointers:
+#define X3_OFF_A(t) ((size_t)((t) / 3) * X3_BK + (((t) % 3) == 0 ? (size_t)a_lo : (size_t)0))
+#define X3_OFF_B(t) ((size_t)((t) / 3) * X3_BK + (((t) % 3) == 2 ? (size_t)b_lo : (size_t)0))
     // the half-tile `which` (0 SA0, 1 SA1, 2 SB0, 3 SB1) of k-tile t: two 1-KiB pieces per wave
 #define X3_STAGE(t, which)                                                                                                 \
     do {                                                                                                                   \

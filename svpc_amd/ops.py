@@ -973,6 +973,10 @@ class _Attention(Function):
         mfma = (_fast() and ((qp | kp | vp) & 15) == 0 and
                 _lib.load().svpc_attn_mfma_supported(dh, seq.max_q, seq.max_k, qt.stride(0), kvt_c.stride(0), kvt_c.stride(0)) == 1)
         fwd_done = False
+        # incremental decoding (one query per sequence, nothing differentiates through it): a wave per (sequence, head), exact fp32.
+        # (grad mode is always off INSIDE a Function.forward: what tells inference from training here is requires_grad of the inputs)
+        use_q1 = (seq.max_q == 1 and p <= 0.0 and not causal and qt.dtype == torch.float32 and dh <= 64
+                  and not (qt.requires_grad or kvt_c.requires_grad))
         # algorithmic bytes of this launch: Q, O rows and K, V rows of every (sequence, head), in their storage types
         ev1 = _attn_bracket("fwd", seq.n * H, seq.max_q, seq.max_k,
                             (2 * seq.n_q_rows + 2 * seq.n_k_rows) * D * (4 if split else es)) if ATTN_TIMER is not None else None
@@ -985,7 +989,7 @@ class _Attention(Function):
                       out.stride(0), out._svpc_lo, _p(lse), _p(tbl), seq.n, H, dh, seq.max_q, seq.max_k, _p(key_mask), 1 if causal else 0,
                       1.0 / math.sqrt(dh), p, site, _p(seed), _stream())
             fwd_done = True
-        elif is_x3() and qt.dtype == torch.float32 and not (not torch.is_grad_enabled() and seq.max_q == 1):
+        elif is_x3() and qt.dtype == torch.float32 and not use_q1:
             # bf16x3 mode, fp32 storage (step encoder, decoder, the [CLS]-only layer): exact fp32 forward; the backward still runs
             # on the matrix cores when the shape allows (same LSE definition in both kernel families)
             _lib.call("attn_fwd", qp, qt.stride(0), kp, kvt_c.stride(0), vp, kvt_c.stride(0), _p(out), D, _p(lse), _p(tbl), seq.n, H,
@@ -993,8 +997,7 @@ class _Attention(Function):
             fwd_done = True
         if fwd_done:
             pass
-        elif (not torch.is_grad_enabled() and seq.max_q == 1 and p <= 0.0 and not causal and qt.dtype == torch.float32 and dh <= 64
-                and not (qt.requires_grad or kvt_c.requires_grad)):
+        elif use_q1:
             # incremental decoding: one query per sequence — a wave per (sequence, head), no tiles, no LDS
             _lib.call("attn_q1_fwd", qp, qt.stride(0), kp, kvt_c.stride(0), vp, kvt_c.stride(0), _p(out), D, _p(lse), _p(tbl), seq.n, H,
                       dh, seq.max_k, _p(key_mask), 1.0 / math.sqrt(dh), _stream())
