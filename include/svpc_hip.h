@@ -212,6 +212,16 @@ int svpc_attn_mfma_fwd_t(const void* Q, int ldq, const void* K, int ldk, const v
 int svpc_attn_stream_x3_fwd(const void* Q, int ldq, int q_lo, const void* K, int ldk, int k_lo, const void* V, int ldv, int v_lo, void* O,
                             int ldo, int o_lo, float* LSE, const int* seq, int n_seq, int H, int dh, int max_q, int max_k,
                             const float* key_mask, float scale, float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
+/* one fp32 query per sequence against bf16 (k_lo = v_lo = 0) or split keys / values, forward and backward — the [CLS]-only last
+ * clip-encoder layer of the training forward (model.py:1062-1064; core :194-219): a wave per (sequence, head), exact fp32 arithmetic on
+ * the values read, no LDS; <= 128 keys, head dim 32 / 64.  Backward: dQ fp32, dK / dV dense bf16 rows (every key row is written). */
+int svpc_attn_q1s_supported(int dh, int max_k, int ldq, int ldk, int ldv, int k_lo, int v_lo);
+int svpc_attn_q1s_fwd(const float* Q, int ldq, const void* K, int ldk, int k_lo, const void* V, int ldv, int v_lo, float* O, int ldo, float* LSE,
+                      const int* seq, int n_seq, int H, int dh, int max_k, const float* key_mask, float scale, float p_drop, unsigned site,
+                      const svpc_u64* seed, svpc_stream_t stream);
+int svpc_attn_q1s_bwd(const float* Q, int ldq, const void* K, int ldk, int k_lo, const void* V, int ldv, int v_lo, const float* dO, int lddo,
+                      float* dQ, int lddq, void* dK, int lddk, void* dV, int lddv, const int* seq, int n_seq, int H, int dh, int max_k,
+                      const float* key_mask, float scale, float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
 /* general bf16x3 forward: sequences of <= 32 queries and keys (the decoder's causal self-attention and its memory cross-attention,
  * model.py:620-663) run one wave per (sequence, head) and may be causal; longer ones take the stream kernel above (non-causal) */
 int svpc_attn_x3_fwd(const void* Q, int ldq, int q_lo, const void* K, int ldk, int k_lo, const void* V, int ldv, int v_lo, void* O, int ldo,

@@ -229,10 +229,8 @@ class BertLayerNoMemoryUntied(nn.Module):
         q = ops.linear(hq, att.query.weight, att.query.bias)
         wkv, bkv, wg, bg, w16 = att.packed("kv")
         kv = ops.linear(h, wkv, bkv, wgrad=wg, bgrad=bg, w16=w16)
-        if ops.lo_off(kv) is not None:               # bf16x3 mode: one query per clip against exact fp32 keys / values
-            kv = ops.to_f32(kv)
-        ctx = ops.attention(q.to(kv.dtype), kv, (0, 0, D), D, cx.H, seq_sel, key_mask=key_mask, causal=False,
-                            drop=cx.drop(cx.p_a)).float()
+        # (fp32 queries against the stream's keys / values in place: bf16 rows, or split rows in the bf16x3 mode — ops.attention)
+        ctx = ops.attention(q, kv, (0, 0, D), D, cx.H, seq_sel, key_mask=key_mask, causal=False, drop=cx.drop(cx.p_a)).float()
         so = self.attention.output
         ao = ops.linear(ctx, so.dense.weight, so.dense.bias)
         x1 = ops.layernorm(ao, so.LayerNorm.weight, so.LayerNorm.bias, cx.eps, residual=hq, pre_drop=cx.drop(cx.p_h))

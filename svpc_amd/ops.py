@@ -960,6 +960,26 @@ class _Attention(Function):
         kvt_c = qt if same else _rows2d(kvt)
         dh = D // H
         p, site, seed = _drop_args(drop)
+        if qt.dtype == torch.float32 and kvt_c.dtype == torch.bfloat16:
+            # ONE fp32 query per sequence against bf16 / split keys and values (the [CLS]-only clip-encoder layer): attention_q1s.hip
+            # (the wrapper has checked the shape)
+            es = 2
+            out = torch.empty(seq.n_q_rows, D, dtype=torch.float32, device=qt.device)
+            lse = torch.empty(seq.n, H, 1, dtype=torch.float32, device=qt.device)
+            tbl = seq.table if seq.table.device == qt.device else seq.table.to(qt.device)
+            ev1 = _attn_bracket("fwd", seq.n * H, seq.max_q, seq.max_k, 2 * seq.n_k_rows * D * (4 if kv_lo else 2)) if ATTN_TIMER is not None else None
+            _lib.call("attn_q1s_fwd", qt.data_ptr() + cols[0] * 4, qt.stride(0), kvt_c.data_ptr() + cols[1] * es, kvt_c.stride(0), kv_lo or 0,
+                      kvt_c.data_ptr() + cols[2] * es, kvt_c.stride(0), kv_lo or 0, _p(out), D, _p(lse), _p(tbl), seq.n, H, dh, seq.max_k,
+                      _p(key_mask), 1.0 / math.sqrt(dh), p, site, _p(seed), _stream())
+            if ev1 is not None:
+                ev1.record()
+            ctx.save_for_backward(qt, kvt_c, out, lse, key_mask, seed, tbl)
+            ctx.cfg = (cols, D, H, seq.n, seq.max_q, seq.max_k, causal, p, site, False)
+            ctx.kv_into = getattr(kvt, "_svpc_grad_into", None)
+            ctx.mfma, ctx.q1s = False, (kv_lo or 0, True)
+            ctx.n_k_rows = seq.n_k_rows
+            return out
+        ctx.q1s = None
         if kvt_c.dtype != qt.dtype:
             raise _lib.SvpcKernelError("attention: query and key/value tensors must have the same dtype")
         split = q_lo is not None
@@ -1032,6 +1052,19 @@ class _Attention(Function):
             mk = torch.empty_like if full else torch.zeros_like
             return mk(t, memory_format=torch.contiguous_format)
         n_q_rows, n_k_rows = out.shape[0], ctx.n_k_rows
+        if ctx.q1s is not None:
+            kv_lo = ctx.q1s[0]
+            dq_t = covered(qt, D, n_q_rows)
+            into = ctx.kv_into
+            if into is not None and into.shape == kvt.shape and into.dtype == kvt.dtype and kvt.shape == (n_k_rows, 2 * D):
+                dkv_t = into
+            else:
+                dkv_t = covered(kvt, 2 * D, n_k_rows)
+            _lib.call("attn_q1s_bwd", qt.data_ptr() + cols[0] * 4, qt.stride(0), kvt.data_ptr() + cols[1] * 2, kvt.stride(0), kv_lo,
+                      kvt.data_ptr() + cols[2] * 2, kvt.stride(0), kv_lo, _p(dO), D, dq_t.data_ptr() + cols[0] * 4, dq_t.stride(0),
+                      dkv_t.data_ptr() + cols[1] * 2, dkv_t.stride(0), dkv_t.data_ptr() + cols[2] * 2, dkv_t.stride(0), _p(tbl), n, H, dh,
+                      max_k, _p(key_mask), 1.0 / math.sqrt(dh), p, site, _p(seed), _stream())
+            return dq_t, dkv_t, None, None, None, None, None, None, None
         if same:
             dq_t = covered(qt, 3 * D, n_q_rows)
             dkv_t = dq_t
@@ -1064,7 +1097,23 @@ class _Attention(Function):
         return dq_t, (None if same else dkv_t), None, None, None, None, None, None, None
 
 
+USE_Q1S = os.environ.get("SVPC_NO_Q1S", "") == ""
+
+
 def attention(qt, kvt, cols, D, n_heads, seq, key_mask=None, causal=False, drop=None):
+    if qt.dtype == torch.float32 and kvt.dtype == torch.bfloat16 and kvt is not qt:
+        # fp32 queries against bf16 / split keys and values: one query per sequence (the [CLS]-only layer) has its own exact kernels;
+        # anything else joins one domain first
+        dh = D // n_heads
+        lo = lo_off(kvt) or 0
+        if (USE_Q1S and _fast() and seq.max_q == 1 and not causal and qt.is_cuda and qt.stride(1) == 1 and kvt.stride(1) == 1 and
+                (qt.data_ptr() | kvt.data_ptr()) % 16 == 0 and
+                _lib.load().svpc_attn_q1s_supported(dh, seq.max_k, qt.stride(0), kvt.stride(0), kvt.stride(0), lo, lo) == 1):
+            return _Attention.apply(qt, kvt, cols, D, n_heads, seq, key_mask, causal, drop)
+        if lo_off(kvt) is not None:
+            kvt = to_f32(kvt)
+        else:
+            qt = qt.to(torch.bfloat16)
     split = lo_off(qt) is not None or lo_off(kvt) is not None
     if split:
         dh = D // n_heads

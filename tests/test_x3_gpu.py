@@ -253,6 +253,40 @@ def test_attention_short_sequences_split_vs_torch(n, Lq, Lk, H, dh, causal, drop
         assert float((kt.grad.float() - kr.grad).abs().max()) <= 3e-2 * float(kr.grad.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("n,Lk,H,dh,drop,split", [(9, 100, 12, 64, 0.0, True), (9, 100, 12, 64, 0.1, True), (9, 100, 12, 64, 0.1, False),
+                                                   (5, 128, 4, 32, 0.0, True), (3, 37, 4, 32, 0.0, False), (4, 1, 12, 64, 0.0, True)])
+def test_one_query_attention_over_stream_rows(n, Lk, H, dh, drop, split):
+    """the [CLS]-only clip-encoder layer: ONE fp32 query per clip against the stream's K | V rows in place — split rows (bf16x3 mode) or
+    bf16 rows (bf16 mode); exact fp32 arithmetic on the stored values, forward and backward (attention_q1s.hip)"""
+    D = H * dh
+    O.set_precision("bf16x3" if split else "bf16")
+    src = _rand(n * Lk, 2 * D, seed=50)
+    if split:
+        kv, kvv = _split(src)
+    else:
+        kv = src.to(torch.bfloat16)
+        kvv = kv.float()
+    q = _rand(n, D, seed=51).requires_grad_(True)
+    kv.requires_grad_(True)
+    km = (torch.rand(n * Lk, generator=torch.Generator().manual_seed(3)) > 0.1).float().to(DEV)
+    km.view(n, Lk)[:, 0] = 1.0
+    seq = SeqInfo(list(range(n)), [1] * n, [i * Lk for i in range(n)], [Lk] * n, DEV)
+    rng = O.make_rng(DEV, seed=13)
+    d = (drop, rng, 4) if drop > 0 else None
+    out = O.attention(q, kv, (0, 0, D), D, H, seq, key_mask=km, causal=False, drop=d)
+    assert out.dtype == torch.float32 and out.shape == (n, D)
+    qr, kr = q.detach().clone().requires_grad_(True), kvv.clone().requires_grad_(True)
+    ref = E.attention(qr, kr, (0, 0, D), D, H, seq, key_mask=km, causal=False, drop=d)
+    assert float((out - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    g = _rand(n, D, seed=52)
+    out.backward(g)
+    ref.backward(g)
+    if Lk > 1:
+        assert float((q.grad - qr.grad).abs().max()) <= 1e-4 * float(qr.grad.abs().max()) + 1e-7
+    assert kv.grad.dtype == torch.bfloat16 and kv.grad.shape == (n * Lk, 2 * D)
+    assert float((kv.grad.float() - kr.grad).abs().max()) <= 6e-3 * float(kr.grad.abs().max()) + 1e-7
+
+
 def test_split_cols_keeps_the_planes_and_gathers_gradients():
     wide, wv = _split(_rand(40, 6 * 128, seed=44))
     wide.requires_grad_(True)
