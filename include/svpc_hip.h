@@ -132,6 +132,10 @@ int svpc_gemm_p8(const void* A, int lda, const void* B, int ldb, void* C, int ld
 int svpc_gemm_p8x3_supported(int lda, int a_lo, int ldb, int ldc, int c_lo, int ldz, int M, int N, int K);
 int svpc_gemm_p8x3(const void* A, int lda, int a_lo, const void* B, int ldb, long long b_lo, void* C, int ldc, int c_lo, void* Z, int ldz,
                    int M, int N, int K, const float* bias, int act, svpc_stream_t stream);
+/* the same contract on 128x128 tiles (4 waves, two workgroups per CU): the decoder's projections (4,224 sentence rows, 576 memory
+ * rows; model.py:620-663), where 256x256 tiles leave most of the 256 CUs idle */
+int svpc_gemm_s4x3(const void* A, int lda, int a_lo, const void* B, int ldb, long long b_lo, void* C, int ldc, int c_lo, void* Z, int ldz,
+                   int M, int N, int K, const float* bias, int act, svpc_stream_t stream);
 /* fp32-operand form with direct-to-LDS staging (deep LDS ring, operands rounded to bf16 when the MFMA fragments are built): the
  * latency-bound GEMMs of the decoder :620-694, step-wise encoder :594-617, simulators :742-823, BiLSTM :1017-1025, LM head
  * :697-739 and their dgrad/wgrad.  Any M, N (edges clamped); K % 32 == 0; k-strided operands need rows % 4 == 0. */

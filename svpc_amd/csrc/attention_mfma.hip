@@ -29,7 +29,8 @@ struct MAttnArgs {
     const void* dO; int lddo; void* dQ; int lddq; void* dK; int lddk; void* dV; int lddv;
 };
 
-constexpr int AT_MAX = 128;   // rows per image: 128 (clip encoder) or 32 (22-token decoder, ≤12-step sequences, ≤3-slot memory)
+constexpr int AT_MAX = 128;
+constexpr float LOG2E = 1.4426950408889634f;      // exp(x - m) = exp2(x·log2e - m·log2e): one v_fma + one v_exp per score   // rows per image: 128 (clip encoder) or 32 (22-token decoder, ≤12-step sequences, ≤3-slot memory)
 
 // Dropout multiplier for element index (row_base + key) of the (sequence, head, query, key) probability tensor.  The index
 // arithmetic stays 32-bit whenever the whole tensor has < 2^32 elements (checked once per kernel: `wide`), which is
@@ -47,6 +48,21 @@ struct DropCtx {
     __device__ __forceinline__ float mul(u64 row_base, int k) const {       // row_base = ((s·H + h)·max_q + q)·max_k
         if (wide) return drop_scale(seed, site, row_base + (u64)k, p, ik);
         return (svpc_mix32(((uint32_t)row_base + (uint32_t)k) ^ key) >> 16) >= thr ? ik : 0.0f;
+    }
+    // the 16 probabilities of one 32-key accumulator tile (element e ↔ key key0 + acc_row(e, lane)) times their dropout multipliers.
+    // ONE test of `wide` per tile instead of one uniform branch per element (64 per wave in the 128-key kernels: each ends a basic
+    // block, so nothing was scheduled across it)
+    __device__ __forceinline__ void mul16(u64 row_base, int key0, int lane, float* pv) const {
+        const int kb = key0 + 4 * (lane >> 5);
+        if (wide) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pv[e] *= drop_scale(seed, site, row_base + (u64)(kb + (e & 3) + 8 * (e >> 2)), p, ik);
+        } else {
+            const uint32_t b32 = (uint32_t)row_base + (uint32_t)kb;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                pv[e] = (svpc_mix32((b32 + (uint32_t)((e & 3) + 8 * (e >> 2))) ^ key) >> 16) >= thr ? pv[e] * ik : 0.0f;
+        }
     }
 };
 
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
 #pragma unroll
     for (int jt = 0; jt < NTL; ++jt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { const float p = __expf(st[jt][e] - mx); st[jt][e] = p; sum += p; }
+        for (int e = 0; e < 16; ++e) { const float p = __builtin_amdgcn_exp2f(fmaf(st[jt][e], LOG2E, -mx * LOG2E)); st[jt][e] = p; sum += p; }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (lane < 32 && q < q_len && a.LSE) a.LSE[((size_t)s * a.H + h) * a.max_q + q] = mx + logf(sum);
@@ -280,8 +296,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) pv[e] = st[jt][e] * inv;
             if (a.p_drop > 0.f) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) pv[e] *= dctx.mul(row_base, 32 * jt + acc_row(e, lane));
+                dctx.mul16(row_base, 32 * jt, lane, pv);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -382,7 +397,7 @@ __global__ __launch_bounds__(256, 4) void attn_stream_fwd_kernel(MAttnArgs a) {
 #pragma unroll
     for (int jt = 0; jt < NTL; ++jt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { const float p = __expf(st[jt][e] - mx); st[jt][e] = p; sum += p; }
+        for (int e = 0; e < 16; ++e) { const float p = __builtin_amdgcn_exp2f(fmaf(st[jt][e], LOG2E, -mx * LOG2E)); st[jt][e] = p; sum += p; }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (lane < 32 && q < q_len && a.LSE) a.LSE[((size_t)s * a.H + h) * a.max_q + q] = mx + logf(sum);
@@ -400,8 +415,7 @@ __global__ __launch_bounds__(256, 4) void attn_stream_fwd_kernel(MAttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) pv[e] = st[jt][e] * inv;
             if (a.p_drop > 0.f) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) pv[e] *= dctx.mul(row_base, 32 * jt + acc_row(e, lane));
+                dctx.mul16(row_base, 32 * jt, lane, pv);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -722,7 +736,7 @@ __global__ __launch_bounds__(256, 2) void attn_stream_x3_fwd_kernel(X3AttnArgs x
 #pragma unroll
     for (int jt = 0; jt < NTL; ++jt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { const float p = expf(st[jt][e] - mx); st[jt][e] = p; sum += p; }
+        for (int e = 0; e < 16; ++e) { const float p = __builtin_amdgcn_exp2f(fmaf(st[jt][e], LOG2E, -mx * LOG2E)); st[jt][e] = p; sum += p; }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (lane < 32 && q < q_len && a.LSE) a.LSE[((size_t)s * a.H + h) * a.max_q + q] = mx + logf(sum);
@@ -740,8 +754,7 @@ __global__ __launch_bounds__(256, 2) void attn_stream_x3_fwd_kernel(X3AttnArgs x
 #pragma unroll
             for (int e = 0; e < 16; ++e) pv[e] = st[jt][e] * inv;
             if (a.p_drop > 0.f) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) pv[e] *= dctx.mul(row_base, 32 * jt + acc_row(e, lane));
+                dctx.mul16(row_base, 32 * jt, lane, pv);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -874,7 +887,7 @@ __global__ __launch_bounds__(256, 2) void attn_small_x3_fwd_kernel(X3AttnArgs xa
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { const float p = expf(st[e] - mx); st[e] = p; sum += p; }
+    for (int e = 0; e < 16; ++e) { const float p = __builtin_amdgcn_exp2f(fmaf(st[e], LOG2E, -mx * LOG2E)); st[e] = p; sum += p; }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (lane < 32 && q < q_len && a.LSE) a.LSE[((size_t)s * a.H + h) * a.max_q + q] = mx + logf(sum);
@@ -884,8 +897,7 @@ __global__ __launch_bounds__(256, 2) void attn_small_x3_fwd_kernel(X3AttnArgs xa
 #pragma unroll
     for (int e = 0; e < 16; ++e) pv[e] = st[e] * inv;
     if (a.p_drop > 0.f) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) pv[e] *= dctx.mul(row_base, acc_row(e, lane));
+        dctx.mul16(row_base, 0, lane, pv);
     }
     floatx16 acc[DH / 32];      // Oᵀ: rows = head columns 32·dt + acc_row(e), column = this lane's query
 #pragma unroll

@@ -692,7 +692,9 @@ class _Linear(Function):
             ev = GEMM_TIMER.bracket(2.0 * M * N * K, (M, N, K, 1, 1, 2, 2, 2)) if GEMM_TIMER is not None else None
             if ev:
                 ev[0].record()
-            _lib.call("gemm_p8x3", _p(x), x.stride(0), x_lo, _p(w), w.stride(0), w_lo, _p(y), y.stride(0), y._svpc_lo, _p(z), N, M, N, K,
+            # 256×256 tiles when they fill the chip, else 128×128 (the decoder's 4,224 / 576 rows)
+            kern = "gemm_p8x3" if (-(-M // 256)) * (-(-N // 256)) >= X3_BIG_TILES else "gemm_s4x3"
+            _lib.call(kern, _p(x), x.stride(0), x_lo, _p(w), w.stride(0), w_lo, _p(y), y.stride(0), y._svpc_lo, _p(z), N, M, N, K,
                       _p(b), act, _stream())
             if ev:
                 ev[1].record()
@@ -1098,6 +1100,7 @@ class _Attention(Function):
 
 
 USE_Q1S = os.environ.get("SVPC_NO_Q1S", "") == ""
+X3_BIG_TILES = int(os.environ.get("SVPC_X3_BIG_TILES", "128"))      # fewer 256² tiles than this → the 128² split GEMM (gemm_s4x3.hip)
 
 
 def attention(qt, kvt, cols, D, n_heads, seq, key_mask=None, causal=False, drop=None):

@@ -59,7 +59,8 @@ def _act64(z, act):
 # ------------------------------------------------------------------------------------------------ split GEMM (gemm_p8x3.hip)
 @pytest.mark.parametrize("M,N,K,act", [(256, 256, 64, ACT_NONE), (300, 768, 768, ACT_NONE), (1000, 2304, 768, ACT_NONE),
                                        (517, 832, 128, ACT_RELU), (640, 768, 3072, ACT_RELU), (1111, 768, 768, ACT_GELU),
-                                       (19200, 768, 768, ACT_GELU), (3, 64, 64, ACT_NONE)])
+                                       (19200, 768, 768, ACT_GELU), (3, 64, 64, ACT_NONE), (4224, 768, 768, ACT_NONE),
+                                       (4224, 2304, 768, ACT_NONE), (576, 9216, 768, ACT_NONE), (4224, 768, 768, ACT_GELU)])
 def test_split_gemm_vs_fp64(M, N, K, act):
     x, xv = _split(_rand(M, K, seed=1))
     w = _rand(N, K, seed=2, scale=1.0 / math.sqrt(K))
@@ -78,9 +79,10 @@ def test_split_gemm_vs_fp64(M, N, K, act):
     assert float((one - ref).abs().max()) > 10 * err
 
 
-def test_split_gemm_c_abi_edges():
-    """svpc_gemm_p8x3 called directly: N % 8 == 0 (not a multiple of the tile), rows and columns past the edges are not written,
-    the pre-activation copy is plain bf16"""
+@pytest.mark.parametrize("kernel", ["gemm_p8x3", "gemm_s4x3"])
+def test_split_gemm_c_abi_edges(kernel):
+    """svpc_gemm_p8x3 / svpc_gemm_s4x3 called directly: N % 8 == 0 (not a multiple of the tile), rows and columns past the edges are
+    not written, the pre-activation copy is plain bf16"""
     M, N, K = 261, 776, 192
     x, xv = _split(_rand(M, K, seed=30))
     w = _rand(N, K, seed=31, scale=1.0 / math.sqrt(K))
@@ -89,7 +91,7 @@ def test_split_gemm_c_abi_edges():
     b = _rand(N, seed=32, scale=0.1)
     buf = torch.full((M + 3, 2 * N + 16), 7.0, dtype=torch.bfloat16, device=DEV)      # guard rows / columns around the output
     zbuf = torch.full((M + 3, N + 8), 7.0, dtype=torch.bfloat16, device=DEV)
-    _lib.call("gemm_p8x3", x.data_ptr(), x.stride(0), K, w16.data_ptr(), K, w16._svpc_lo, buf.data_ptr(), buf.stride(0), N + 8,
+    _lib.call(kernel, x.data_ptr(), x.stride(0), K, w16.data_ptr(), K, w16._svpc_lo, buf.data_ptr(), buf.stride(0), N + 8,
               zbuf.data_ptr(), zbuf.stride(0), M, N, K, b.data_ptr(), ACT_GELU, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     z64 = xv.double() @ wv.double().t() + b.double()
