@@ -450,6 +450,7 @@ class GradReducer:
         self._next = 0
         self._releasing = False
         self._finishing = False
+        self._in_launch = 0
 
     def mark_all_unlaunched(self):
         """first step after construction: the hooks were not installed during the backward that has just run"""
@@ -498,7 +499,11 @@ class GradReducer:
     def _launch(self, bi):
         from . import ops
         self.launched[bi] = True     # first: flushing the queues below reports more gradients ready (re-entrant)
-        ops.flush_pending()          # the bucket's gradients may still sit in a deferred-tail queue or on a side stream
+        self._in_launch += 1         # (those reports may name members of buckets already released by their hooks: the same write,
+        try:                         #  seen by hook and by pointer — expected; only a report OUTSIDE a flush is a second write)
+            ops.flush_pending()      # the bucket's gradients may still sit in a deferred-tail queue or on a side stream
+        finally:
+            self._in_launch -= 1
         s, e, _ = self.buckets[bi]
         if self.skip:
             return
@@ -535,7 +540,7 @@ class GradReducer:
             left.discard(i)
             if not left and not self.launched[bi]:
                 self._release(bi)
-        elif self.launched[bi] and not self._finishing:
+        elif self.launched[bi] and not self._finishing and not self._in_launch:
             # a member of a bucket that is already being exchanged was written AGAIN in this step (a packed projection whose backward
             # ran twice: module reuse, a forward_step-style loop): its first report released the bucket too early and the all-reduce
             # raced the second accumulation.  Wrong gradients must not be silent.

@@ -53,11 +53,12 @@ GRAD_NAMES = [
 # headline cases (profiles/r02_c_headline_parity.json); the single worst probability entry moves by up to 0.24 where the pointer's
 # softmax over ≤ 10 entities is nearly tied ("What the bf16 mode costs in accuracy"), hence a mean criterion beside the max.
 # round 3: the bf16 entry tightened to ≤ 2× the measured values of profiles/r02_f_headline_parity.json (loss 7.7e-4 worst case, worst
-# probability entry 0.19, mean 1.5e-5, gradient norms 5.8 %, cosine 0.9930); bf16x3: the fp32 entry's loss bar, measured probability
+# probability entry 0.19, mean 1.5e-5, gradient norms 5.8 % — 7.6 % on `Wing.weight` (viv) once the softmax used exp2: the pointer's
+# near-ties make that tensor the noisiest —, cosine 0.9930); bf16x3: the fp32 entry's loss bar, measured probability
 # errors ≈1e-5, the bf16 entry's gradient bounds (its backward is the bf16 backward)
 TOL = {"fp32": dict(loss=1e-4, prob=5e-5, prob_mean=1e-6, gnorm=2e-3, cos=0.99999, argmax=0.9999),
        "bf16x3": dict(loss=1e-4, prob=2e-3, prob_mean=2e-6, gnorm=7e-2, cos=0.990, argmax=0.999),
-       "bf16": dict(loss=1.5e-3, prob=0.4, prob_mean=5e-5, gnorm=7e-2, cos=0.990, argmax=0.98)}
+       "bf16": dict(loss=1.5e-3, prob=0.4, prob_mean=5e-5, gnorm=1e-1, cos=0.990, argmax=0.98)}
 
 _REPORT = {}
 
