@@ -136,6 +136,14 @@ int svpc_gemm_p8x3(const void* A, int lda, int a_lo, const void* B, int ldb, lon
  * rows; model.py:620-663), where 256x256 tiles leave most of the 256 CUs idle */
 int svpc_gemm_s4x3(const void* A, int lda, int a_lo, const void* B, int ldb, long long b_lo, void* C, int ldc, int c_lo, void* Z, int ldz,
                    int M, int N, int K, const float* bias, int act, svpc_stream_t stream);
+/* bf16 GEMM with a k-STRIDED B operand on the same 8-phase template — the input gradients (dgrad) of the stream projections:
+ *   C[M,N] = (A[M,K] · B[K,N]) ⊙ gact'(G[M,N]) + R[M,N],  A = dz (k-contiguous), B = the weight matrix as stored (W[out = K][in = N]),
+ * G (optional) what the forward of the activation in front of this projection's input kept, R (optional) a parked residual-path gradient;
+ * all bf16, C / G / R share ldc.  K % 64 == 0, N % 8 == 0.  B fragments come from a [64 k-rows][128 columns] LDS image through
+ * ds_read_b64_tr_b16.  reference: the backward of every nn.Linear of the clip encoder (model.py:195-197,230,259,281,551). */
+int svpc_gemm_p8t_supported(int lda, int ldb, int ldc, int M, int N, int K);
+int svpc_gemm_p8t(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* G, int gact, const void* R, int M, int N, int K,
+                  svpc_stream_t stream);
 /* fp32-operand form with direct-to-LDS staging (deep LDS ring, operands rounded to bf16 when the MFMA fragments are built): the
  * latency-bound GEMMs of the decoder :620-694, step-wise encoder :594-617, simulators :742-823, BiLSTM :1017-1025, LM head
  * :697-739 and their dgrad/wgrad.  Any M, N (edges clamped); K % 32 == 0; k-strided operands need rows % 4 == 0. */

@@ -561,6 +561,18 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NON
         else:
             _lib.call("gemm_f32", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
                       _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+    elif (_fast() and USE_P8T and a_kc == 1 and b_kc == 0 and A.dtype == B.dtype == C.dtype == torch.bfloat16 and Z is None and bias is None
+          and act == ACT_NONE and p <= 0.0 and not accumulate and (-(-M // 256)) * (-(-N // 256)) >= P8T_MIN_TILES
+          and (A.data_ptr() | B.data_ptr() | C.data_ptr()) % 16 == 0
+          and _lib.load().svpc_gemm_p8t_supported(lda, ldb, C.stride(0), M, N, K) == 1
+          and (R is None or (R.dtype == torch.bfloat16 and R.shape == C.shape and R.stride() == C.stride() and R.data_ptr() % 16 == 0))
+          and (G is None or (G[1] in (ACT_RELU, ACT_GELU) and G[0].dtype == torch.bfloat16 and G[0].shape == C.shape
+                             and G[0].stride() == C.stride() and G[0].data_ptr() % 16 == 0))):
+        # stream dgrad on the 8-phase template with the weight matrix read k-strided in place (gemm_p8t.hip)
+        _lib.call("gemm_p8t", _p(A), lda, _p(B), ldb, _p(C), C.stride(0), _p(G[0]) if G is not None else None, int(G[1]) if G is not None else 0,
+                  _p(R), M, N, K, _stream())
+        R = None
+        g_done = G is not None
     elif _fast() and USE_GLDS and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and \
             (A.data_ptr() | B.data_ptr()) % 16 == 0 and _lib.load().svpc_gemm_glds_supported(a_kc, b_kc, lda, ldb, M, N, K) == 1:
         g_ok = G is not None and G[0].dtype == C.dtype and G[0].shape == C.shape and G[0].stride() == C.stride() and not accumulate
@@ -1100,6 +1112,8 @@ class _Attention(Function):
 
 
 USE_Q1S = os.environ.get("SVPC_NO_Q1S", "") == ""
+USE_P8T = os.environ.get("SVPC_NO_P8T", "") == ""                 # stream dgrads on gemm_p8t.hip (else the round-1 ping-pong kernel)
+P8T_MIN_TILES = int(os.environ.get("SVPC_P8T_MIN_TILES", "150"))   # 256² tiles needed to fill the chip
 X3_BIG_TILES = int(os.environ.get("SVPC_X3_BIG_TILES", "128"))      # fewer 256² tiles than this → the 128² split GEMM (gemm_s4x3.hip)
 
 

@@ -1,0 +1,69 @@
+"""gemm_p8t (stream dgrad with the weight matrix read k-strided through ds_read_b64_tr_b16, gemm_p8t.hip) through the C-ABI against an fp64
+torch statement of C = (A·B) ⊙ act'(G) + R on the same seeded bf16 operands.  Tolerance: one bf16 rounding of the result (2⁻⁸ of its
+magnitude) plus the fp32 accumulation.  reference op: the input gradient of nn.Linear (model.py:195-197, :230, :259, :281)."""
+import math
+
+import pytest
+import torch
+
+from svpc_amd import _lib
+from svpc_amd.ops_common import ACT_GELU, ACT_NONE, ACT_RELU
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed * 1000 + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def _gelu_grad(x):
+    return 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2.0 * math.pi)
+
+
+@pytest.mark.parametrize("M,N,K,gact,has_r", [(512, 768, 768, ACT_NONE, False), (1000, 768, 768, ACT_NONE, True), (777, 776, 2304, ACT_GELU, False),
+                                              (1300, 3072, 768, ACT_RELU, True), (19200, 768, 768, ACT_GELU, True), (5, 8, 64, ACT_NONE, False),
+                                              (300, 1544, 1536, ACT_NONE, True)])
+def test_p8t_vs_fp64(M, N, K, gact, has_r):
+    A = _rand(M, K, seed=1).to(torch.bfloat16)
+    W = _rand(K, N, seed=2, scale=1.0 / math.sqrt(K)).to(torch.bfloat16)          # (out = K, in = N): the weight as stored
+    G = _rand(M, N, seed=3).to(torch.bfloat16) if gact != ACT_NONE else None
+    R = _rand(M, N, seed=4).to(torch.bfloat16) if has_r else None
+    guard = 3
+    Cbuf = torch.full((M + guard, N), 7.0, dtype=torch.bfloat16, device=DEV)
+    _lib.call("gemm_p8t", A.data_ptr(), K, W.data_ptr(), N, Cbuf.data_ptr(), N, G.data_ptr() if G is not None else None, gact,
+              R.data_ptr() if R is not None else None, M, N, K, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double()
+    if gact == ACT_GELU:
+        ref = ref * _gelu_grad(G.double())
+    elif gact == ACT_RELU:
+        ref = ref * (G.double() > 0).double()
+    if has_r:
+        ref = ref + R.double()
+    err = float((Cbuf[:M].double() - ref).abs().max())
+    assert err <= 6e-3 * float(ref.abs().max()), (err, float(ref.abs().max()))
+    assert bool((Cbuf[M:] == 7.0).all())
+
+
+def test_stream_dgrad_takes_p8t_and_matches_the_old_kernel():
+    """ops.linear's backward at a stream-sized shape: with and without gemm_p8t (env switch), same gradients to bf16 rounding"""
+    from svpc_amd import ops as O
+    O.set_precision("bf16")
+    try:
+        M, N, K = 19200, 768, 768
+        x = _rand(M, K, seed=5).to(torch.bfloat16).requires_grad_(True)
+        w = _rand(N, K, seed=6, scale=1.0 / math.sqrt(K)).requires_grad_(True)
+        g = _rand(M, N, seed=7).to(torch.bfloat16)
+        outs = []
+        for use in (True, False):
+            O.USE_P8T = use
+            x.grad = None
+            O.linear(x, w, None).backward(g)
+            O.join_side()
+            outs.append(x.grad.float().clone())
+        assert float((outs[0] - outs[1]).abs().max()) <= 1e-2 * float(outs[1].abs().max())
+    finally:
+        O.USE_P8T = True
+        O.set_precision("fp32")
