@@ -49,6 +49,18 @@ struct DropCtx {
         if (wide) return drop_scale(seed, site, row_base + (u64)k, p, ik);
         return (svpc_mix32(((uint32_t)row_base + (uint32_t)k) ^ key) >> 16) >= thr ? ik : 0.0f;
     }
+    // multipliers of four elements whose indices are base, base + stride, base + 2·stride, base + 3·stride (+ k): the backward's
+    // four consecutive queries of one key — one test of `wide` per group
+    __device__ __forceinline__ void mul4(u64 base, u64 stride, int k, float* dm) const {
+        if (wide) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dm[j] = drop_scale(seed, site, base + (u64)j * stride + (u64)k, p, ik);
+        } else {
+            const uint32_t b32 = (uint32_t)base + (uint32_t)k, s32 = (uint32_t)stride;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dm[j] = (svpc_mix32((b32 + (uint32_t)j * s32) ^ key) >> 16) >= thr ? ik : 0.0f;
+        }
+    }
     // the 16 probabilities of one 32-key accumulator tile (element e ↔ key key0 + acc_row(e, lane)) times their dropout multipliers.
     // ONE test of `wide` per tile instead of one uniform branch per element (64 per wave in the 128-key kernels: each ends a basic
     // block, so nothing was scheduled across it)
@@ -553,14 +565,15 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
                     // the four queries of the group are consecutive: their log-sum-exp and delta terms in one 16-byte LDS read each
                     const float4 l4 = *reinterpret_cast<const float4*>(lse + qb + 8 * g), d4 = *reinterpret_cast<const float4*>(delta + qb + 8 * g);
                     const float lq4[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+                    float dm4[4] = {1.0f, 1.0f, 1.0f, 1.0f};       // registers 4g..4g+3 ↔ queries qb + 8g + 0..3 of this lane's key
+                    if (a.p_drop > 0.f) dctx.mul4((dbase + qb + 8 * g) * a.max_k, (u64)a.max_k, key, dm4);
 #pragma unroll
                     for (int e = 4 * g; e < 4 * g + 4; ++e) {
                         const int q = qb + (e & 3) + 8 * (e >> 2);
                         float t = mt;
                         if (a.causal) t = (key > q && key < k_len) ? -10000.0f : t;
-                        const float p = __expf(sc[e] + t - lq4[e & 3]);
-                        float dm = 1.0f;
-                        if (a.p_drop > 0.f) dm = dctx.mul((dbase + qb) * a.max_k + (u64)(((e & 3) + 8 * (e >> 2)) * a.max_k), key);
+                        const float p = __builtin_amdgcn_exp2f(fmaf(sc[e], LOG2E, (t - lq4[e & 3]) * LOG2E));
+                        const float dm = dm4[e & 3];
                         pt[e] = p * dm;
                         dsv[e] = p * (dp[e] * dm - dq4[e & 3]);
                     }
