@@ -176,6 +176,11 @@ typedef struct svpc_wgrad_problem {
     int n_out, n_in, rows, ld_dz, ld_x, ld_dw;
 } svpc_wgrad_problem;
 int svpc_gemm_group_wgrad_max(void);
+/* the bf16-stream table (svpc_gemm_group_wgrad_bf16_ws below) on the 8-phase 256x256x64 template with BOTH operands read k-strided through
+ * ds_read_b64_tr_b16 (gemm_p8w.hip): problems at least 256 wide both ways; same balance (deep tiles of later rounds cut into k-parts →
+ * fp32 slabs in `workspace`, added in part order by a fix-up launch).  _ok: 1 if every problem of the table qualifies. */
+int svpc_gemm_group_wgrad_bf16_p8_ok(const void* problems, int n);
+int svpc_gemm_group_wgrad_bf16_p8(const void* problems, int n, float* workspace, size_t workspace_bytes, svpc_stream_t stream);
 /* the same for the bf16 activation streams (dz, x bf16; dw fp32; db must be NULL; n_out % 8 == 0, n_in % 8 == 0, any row count):
  * every 128² tile runs its whole k-loop — no split-K slabs, no reduce launches */
 int svpc_gemm_group_wgrad_bf16(const svpc_wgrad_problem* problems, int n, svpc_stream_t stream);

@@ -147,7 +147,10 @@ def flush_wgrads(bf16=True):
             probs[i] = _WgradProblem(dz.data_ptr(), x.data_ptr(), wg.data_ptr(), None, dz.shape[1], x.shape[1], dz.shape[0],
                                      dz.stride(0), x.stride(0), wg.stride(0))
         ws = _ws(_WQ16[0][0].device)
-        _lib.call("gemm_group_wgrad_bf16_ws", ctypes.addressof(probs), len(_WQ16), _p(ws), ws.numel() * 4, _stream())
+        # the 8-phase template with transposed fragment reads when every problem is at least 256 wide (gemm_p8w.hip), else the round-1 form
+        p8w = USE_P8W and _lib.load().svpc_gemm_group_wgrad_bf16_p8_ok(ctypes.addressof(probs), len(_WQ16)) == 1
+        _lib.call("gemm_group_wgrad_bf16_p8" if p8w else "gemm_group_wgrad_bf16_ws", ctypes.addressof(probs), len(_WQ16), _p(ws),
+                  ws.numel() * 4, _stream())
         done = list(_WQ16)
         del _WQ16[:]
         for _, _, wg, _ in done:
@@ -1112,6 +1115,7 @@ class _Attention(Function):
 
 
 USE_Q1S = os.environ.get("SVPC_NO_Q1S", "") == ""
+USE_P8W = os.environ.get("SVPC_NO_P8W", "") == ""                 # grouped stream wgrads on gemm_p8w.hip (else the round-1 ping-pong kernel)
 USE_P8T = os.environ.get("SVPC_NO_P8T", "") == ""                 # stream dgrads on gemm_p8t.hip (else the round-1 ping-pong kernel)
 P8T_MIN_TILES = int(os.environ.get("SVPC_P8T_MIN_TILES", "150"))   # 256² tiles needed to fill the chip
 X3_BIG_TILES = int(os.environ.get("SVPC_X3_BIG_TILES", "128"))      # fewer 256² tiles than this → the 128² split GEMM (gemm_s4x3.hip)
