@@ -37,7 +37,7 @@ __device__ __forceinline__ bf16x8 p8w_frag_tr(const char* __restrict__ a) {
 // C[256 × 256 block at (0,0) of C] (+)= Σ_{k < K} A[k][m] · B[k][n];  A: [K][lda] (columns m < Mv valid), B: [K][ldb] (n < Nv valid)
 template <bool ACCUM>
 __device__ __forceinline__ void p8w_tile(char* __restrict__ smem, const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B, int ldb,
-                                         float* __restrict__ C, int ldc, int Mv, int Nv, int K) {
+                                         float* __restrict__ C, int ldc, int Mv, int Nv, int K, int pf) {
     const int nk = (K + P8W_BK - 1) / P8W_BK;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;             // wr = the wave's group = its 128-row half of C; wc = its 64-column strip
@@ -61,6 +61,14 @@ __device__ __forceinline__ void p8w_tile(char* __restrict__ smem, const __bf16* 
     }
     const size_t stepA = (size_t)P8W_BK * lda, stepB = (size_t)P8W_BK * ldb;
     const __bf16* const zsrc = reinterpret_cast<const __bf16*>(p8w_zeros);
+    // L2 prefetch: one dword of each 128-byte line of a later k-tile (64 rows × 4 lines of A, × 4 of B = 512 lanes), fetched by LDS-DMA
+    // into a 256-byte scratch strip per wave — the OLDEST loads in flight when the end-of-k-tile wait comes, a full k-tile after their issue
+    const int pf_row = 8 * wave + (lane >> 3), pf_j = lane & 7;
+    const __bf16* const pf_ptr = pf_j < 4 ? A + (size_t)pf_row * lda + min(64 * pf_j, max(Mv - 1, 0))
+                                          : B + (size_t)pf_row * ldb + min(64 * (pf_j - 4), max(Nv - 1, 0));
+    const size_t pf_step = pf_j < 4 ? stepA : stepB;
+    const int pf_ahead = pf_j < 4 ? 2 : 3;
+    char* const pf_sink = smem + 2 * P8W_BUF + wave * 256;
     char* const my = smem + wave * 2048;
     // the half-tile `which` (0 A0, 1 A1, 2 B0, 3 B1) of k-tile t: two 1-KiB pieces per wave; k-rows ≥ K are zero-sourced
 #define P8W_STAGE(t, which)                                                                                                \
@@ -111,6 +119,10 @@ __device__ __forceinline__ void p8w_tile(char* __restrict__ smem, const __bf16* 
         const char* sa = smem + (t & 1) * P8W_BUF + wr * P8W_HALF;
         const char* sb = smem + (t & 1) * P8W_BUF + (2 + (wc >> 1)) * P8W_HALF;
         bf16x8 afr[2][4], b0[2][2], b1[2][2];
+        if (pf) {
+            const int tt = t + pf_ahead;
+            if (tt * P8W_BK + pf_row < K) __builtin_amdgcn_global_load_lds((p8w_gptr)(pf_ptr + (size_t)tt * pf_step), (p8w_lptr)(pf_sink), 4, 0, 0);
+        }
         // ---- phase 0: rows 0-63 × columns 0-31 of the wave tile
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -208,11 +220,15 @@ struct W8Prob {
     int whole, split, slab0, stile0;      // leading tiles run whole (accumulating into dw), the others in `split` k-parts → slabs
 };
 constexpr int W8_MAX = 48;
-struct W8Args { int n; int total; W8Prob p[W8_MAX]; };
+struct W8Args { int n; int total; int chunk; int pf; W8Prob p[W8_MAX]; };
 
 __global__ __launch_bounds__(512) void gemm_group_wgrad16_p8_kernel(W8Args g, float* __restrict__ slabs) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * P8W_BUF];
-    const int wg = blockIdx.x;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * P8W_BUF + 8 * 256];
+    int wg = blockIdx.x;
+    if (g.chunk > 0) {                                    // experiment knob SVPC_P8W_CHUNK: XCD x takes `chunk` consecutive items of each run
+        const int run = 8 * g.chunk, base = (wg / run) * run;
+        if (base + run <= g.total) { const int j = wg - base; wg = base + (j & 7) * g.chunk + (j >> 3); }
+    }
     int pi = 0;
     while (pi + 1 < g.n && wg >= g.p[pi + 1].tile0) ++pi;
     const W8Prob& q = g.p[pi];
@@ -221,7 +237,7 @@ __global__ __launch_bounds__(512) void gemm_group_wgrad16_p8_kernel(W8Args g, fl
         const int tm = item / q.tiles_n, tn = item - tm * q.tiles_n;
         const int m0 = tm * 256, n0 = tn * 256;
         p8w_tile<true>(smem, q.dz + m0, q.ld_dz, q.x + n0, q.ld_x, q.dw + (size_t)m0 * q.ld_dw + n0, q.ld_dw, min(256, q.n_out - m0),
-                       min(256, q.n_in - n0), q.rows);
+                       min(256, q.n_in - n0), q.rows, g.pf);
         return;
     }
     const int st = (item - q.whole) / q.split, part = (item - q.whole) - st * q.split;
@@ -232,7 +248,7 @@ __global__ __launch_bounds__(512) void gemm_group_wgrad16_p8_kernel(W8Args g, fl
     const int m0 = tm * 256, n0 = tn * 256;
     float* slab = slabs + (size_t)(q.slab0 + st * q.split + part) * 65536;
     p8w_tile<false>(smem, q.dz + (size_t)k0 * q.ld_dz + m0, q.ld_dz, q.x + (size_t)k0 * q.ld_x + n0, q.ld_x, slab, 256,
-                    min(256, q.n_out - m0), min(256, q.n_in - n0), k1 - k0);
+                    min(256, q.n_out - m0), min(256, q.n_in - n0), k1 - k0, g.pf);
 }
 // dW += Σ_parts slab (part order): 16 workgroups per cut tile, 16 rows each.  Slab elements outside the valid block are never read.
 __global__ __launch_bounds__(256) void wgrad16_p8_fixup_kernel(W8Args g, const float* __restrict__ slabs) {
@@ -322,6 +338,12 @@ int svpc_gemm_group_wgrad_bf16_p8(const void* problems, int n, float* workspace,
         seen += tp;
     }
     g.total = items;
+    static int chunk_env = -1;
+    if (chunk_env < 0) { const char* e = getenv("SVPC_P8W_CHUNK"); chunk_env = e ? atoi(e) : 0; }
+    g.chunk = chunk_env;
+    static int pf_env = -1;
+    if (pf_env < 0) { const char* e = getenv("SVPC_P8W_PF"); pf_env = e ? atoi(e) : 0; }
+    g.pf = pf_env;
     hipLaunchKernelGGL(gemm_group_wgrad16_p8_kernel, dim3(items), dim3(512), 0, stream, g, workspace);
     int rc = svpc_check_launch("gemm_group_wgrad_bf16_p8");
     if (rc || stiles == 0) return rc;
