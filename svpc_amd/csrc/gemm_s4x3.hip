@@ -50,11 +50,11 @@ __device__ __forceinline__ float s4_act(float z) {
 // one epilogue pass over the wave's 64×64 block: MODE 0 bf16(z) | 1 hi plane of act(z) | 2 lo plane → wave-private LDS image
 // [64 rows][128 B] (16-byte chunk c of row r kept at c ^ (r & 7)) → whole 128-byte lines
 template <int ACT, int MODE>
-__device__ __forceinline__ void s4_store_pass(const floatx4 (&acc)[4][4], __bf16* __restrict__ C, int ldc, const float4 (&bb)[4], int row0,
+__device__ __forceinline__ void s4_store_pass(const floatx4 (&acc)[2][4], __bf16* __restrict__ C, int ldc, const float4 (&bb)[4], int row0,
                                               int col0, int M, int N, int lane, char* __restrict__ wl) {
     const int l15 = lane & 15, q = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
         const int r = i * 16 + l15;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -72,7 +72,7 @@ __device__ __forceinline__ void s4_store_pass(const floatx4 (&acc)[4][4], __bf16
     const uint32_t step = 16u * (uint32_t)ldc;                         // 8 rows
     const bool col_ok = cc + 8 <= N;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < 4; ++it) {
         const int r = it * 8 + r0;
         const uint4 v = *reinterpret_cast<const uint4*>(wl + r * 128 + ((chunk ^ (r & 7)) << 4));
         if (col_ok && row0 + r < M) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(C) + off) = v;
@@ -80,72 +80,70 @@ __device__ __forceinline__ void s4_store_pass(const floatx4 (&acc)[4][4], __bf16
     }
 }
 
-template <int ACT, bool HASZ>
-__global__ __launch_bounds__(256, 2) void gemm_s4x3_kernel(const __bf16* __restrict__ A, int lda, int a_lo, const __bf16* __restrict__ B, int ldb,
+template <int ACT, bool HASZ, int NS>
+__global__ __launch_bounds__(512, NS == 2 ? 2 : 1) void gemm_s4x3_kernel(const __bf16* __restrict__ A, int lda, int a_lo, const __bf16* __restrict__ B, int ldb,
                                                            long long b_lo, __bf16* __restrict__ C, int ldc, int c_lo, __bf16* __restrict__ Z,
                                                            int ldz, const float* __restrict__ bias, int M, int N, int K, int tiles_m,
                                                            int tiles_n, int remap) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * S4_STAGE];
+    __shared__ __attribute__((aligned(1024))) char smem[NS * S4_STAGE];
     const int wg = remap ? xcd_remap(blockIdx.x, tiles_m * tiles_n) : (int)blockIdx.x;
     const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
     const int m0 = tm * 128, n0 = tn * 128;
     const int nk = 3 * (K / S4_BK);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 1, wc = wave & 1;             // the wave's 64-row / 64-column quadrant
+    const int wr = wave >> 1, wc = wave & 1;             // the wave's 32-row strip (of four) / 64-column half
 
     // ---- staging: a tile image = 8 row blocks (16 rows) × 2 k blocks (32 k) of 1-KiB subtiles, subtile (rb, kb) at ((rb·2 + kb) << 10);
     // this wave fills row blocks wave and wave + 4 (both k blocks) of the A and of the B image: 8 DMA instructions per k-tile.
     // LDS slot (row r = lane>>2, chunk slot lane&3) of a subtile holds logical 16-byte chunk (lane&3) ^ 2·(r >= 8)  (st_16x32)
     const int sr = lane >> 2, sc = (lane & 3) ^ (((lane >> 5) & 1) << 1);
-    const __bf16* ga[2];
-    const __bf16* gb[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        ga[h] = A + (size_t)min(m0 + 16 * (wave + 4 * h) + sr, M - 1) * lda + 8 * sc;
-        gb[h] = B + (size_t)min(n0 + 16 * (wave + 4 * h) + sr, N - 1) * ldb + 8 * sc;
-    }
+    const __bf16* const ga = A + (size_t)min(m0 + 16 * wave + sr, M - 1) * lda + 8 * sc;
+    const __bf16* const gb = B + (size_t)min(n0 + 16 * wave + sr, N - 1) * ldb + 8 * sc;
     // k-tile t: slice t / 3 of plane pair t % 3 — 0: A_lo·B_hi, 1: A_hi·B_hi, 2: A_hi·B_lo
 #define S4_OFF_A(t) ((size_t)((t) / 3) * S4_BK + (((t) % 3) == 0 ? (size_t)a_lo : (size_t)0))
 #define S4_OFF_B(t) ((size_t)((t) / 3) * S4_BK + (((t) % 3) == 2 ? (size_t)b_lo : (size_t)0))
 #define S4_ISSUE(t)                                                                                                               \
     do {                                                                                                                          \
-        char* st_ = smem + ((t) & 1) * S4_STAGE;                                                                                  \
+        char* da_ = smem + ((t) % NS) * S4_STAGE + ((wave * 2) << 10);                                                            \
         const size_t oa_ = S4_OFF_A(t), ob_ = S4_OFF_B(t);                                                                        \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                                           \
-            char* da_ = st_ + (((wave + 4 * h) * 2) << 10);                                                                       \
-            __builtin_amdgcn_global_load_lds((s4_gptr)(ga[h] + oa_), (s4_lptr)(da_), 16, 0, 0);                                   \
-            __builtin_amdgcn_global_load_lds((s4_gptr)(ga[h] + oa_ + 32), (s4_lptr)(da_ + 1024), 16, 0, 0);                       \
-            __builtin_amdgcn_global_load_lds((s4_gptr)(gb[h] + ob_), (s4_lptr)(da_ + S4_HALF), 16, 0, 0);                         \
-            __builtin_amdgcn_global_load_lds((s4_gptr)(gb[h] + ob_ + 32), (s4_lptr)(da_ + S4_HALF + 1024), 16, 0, 0);             \
-        }                                                                                                                         \
+        __builtin_amdgcn_global_load_lds((s4_gptr)(ga + oa_), (s4_lptr)(da_), 16, 0, 0);                                          \
+        __builtin_amdgcn_global_load_lds((s4_gptr)(ga + oa_ + 32), (s4_lptr)(da_ + 1024), 16, 0, 0);                              \
+        __builtin_amdgcn_global_load_lds((s4_gptr)(gb + ob_), (s4_lptr)(da_ + S4_HALF), 16, 0, 0);                                \
+        __builtin_amdgcn_global_load_lds((s4_gptr)(gb + ob_ + 32), (s4_lptr)(da_ + S4_HALF + 1024), 16, 0, 0);                    \
     } while (0)
     // fragment: block `blk` (16 rows) and k block kb of an image; lane: row lane&15, logical chunk lane>>4
     const int fr_off = (lane & 15) * 64 + ((((lane >> 4) ^ (((lane >> 3) & 1) << 1))) << 4);
 #define S4_FRAG(img, blk, kb) (*reinterpret_cast<const bf16x8*>((img) + (((blk) * 2 + (kb)) << 10) + fr_off))
 
-    floatx4 acc[4][4];
+    floatx4 acc[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    S4_ISSUE(0);
+    // NS stages: k-tiles t+1 … t+NS-2 are in flight while k-tile t is awaited (4 DMA instructions per wave and k-tile: the counted
+    // wait lets the later ones stay outstanding); NS = 2 is the plain double buffer
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) S4_ISSUE(t);
     for (int t = 0; t < nk; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of k-tile t have landed
+        if (NS == 4 && t + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (NS >= 3 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of k-tile t have landed
         __builtin_amdgcn_s_barrier();                            // … everyone's have; everyone is done reading k-tile t-1
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < nk) S4_ISSUE(t + 1);                         // into the stage k-tile t-1 used; lands under the MFMAs below
-        const char* sa = smem + (t & 1) * S4_STAGE;
+        if (t + NS - 1 < nk) S4_ISSUE(t + NS - 1);               // into the stage k-tile t-1 used; lands under the MFMAs of the next k-tiles
+        const char* sa = smem + (t % NS) * S4_STAGE;
         const char* sb = sa + S4_HALF;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            bf16x8 bfr[4], afr[4];
+            bf16x8 bfr[4], afr[2];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bfr[j] = S4_FRAG(sb, wc * 4 + j, kb);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) afr[i] = S4_FRAG(sa, wr * 4 + i, kb);
+            for (int i = 0; i < 2; ++i) afr[i] = S4_FRAG(sa, wr * 2 + i, kb);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], afr[i], acc[i][j], 0, 0, 0);
         }
@@ -155,8 +153,8 @@ __global__ __launch_bounds__(256, 2) void gemm_s4x3_kernel(const __bf16* __restr
 #undef S4_OFF_A
 #undef S4_OFF_B
     __syncthreads();                                             // every wave is past its last LDS read: the stages are free
-    char* wl = smem + wave * 8192;                               // 8 KiB per wave
-    const int row0 = m0 + wr * 64, col0 = n0 + wc * 64;
+    char* wl = smem + wave * 4096;                               // 4 KiB per wave: [32 rows][128 B]
+    const int row0 = m0 + wr * 32, col0 = n0 + wc * 64;
     float4 bb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -184,9 +182,17 @@ int svpc_gemm_s4x3(const void* A, int lda, int a_lo, const void* B, int ldb, lon
     static int remap = -1;
     if (remap < 0) { const char* e = getenv("SVPC_GEMM_REMAP"); remap = e ? atoi(e) : 1; }
     const int tiles_m = ceil_div(M, 128), tiles_n = ceil_div(N, 128);
+    // at most one workgroup per CU anyway (the decoder's N = 768 projections: 198): four stages, three k-tiles in flight
+    static int deep_max = -1;
+    if (deep_max < 0) { const char* e = getenv("SVPC_S4X3_DEEP_MAX"); deep_max = e ? atoi(e) : 256; }
+    const bool deep = tiles_m * tiles_n <= deep_max;
 #define S4_GO(ACTV, ZV)                                                                                                           \
-    hipLaunchKernelGGL((gemm_s4x3_kernel<ACTV, ZV>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, (const __bf16*)A, lda, a_lo,   \
-                       (const __bf16*)B, ldb, b_lo, (__bf16*)C, ldc, c_lo, (__bf16*)Z, ldz, bias, M, N, K, tiles_m, tiles_n, remap)
+    do {                                                                                                                          \
+        if (deep) hipLaunchKernelGGL((gemm_s4x3_kernel<ACTV, ZV, 4>), dim3(tiles_m * tiles_n), dim3(512), 0, stream, (const __bf16*)A, lda, a_lo, \
+                       (const __bf16*)B, ldb, b_lo, (__bf16*)C, ldc, c_lo, (__bf16*)Z, ldz, bias, M, N, K, tiles_m, tiles_n, remap); \
+        else hipLaunchKernelGGL((gemm_s4x3_kernel<ACTV, ZV, 2>), dim3(tiles_m * tiles_n), dim3(512), 0, stream, (const __bf16*)A, lda, a_lo, \
+                       (const __bf16*)B, ldb, b_lo, (__bf16*)C, ldc, c_lo, (__bf16*)Z, ldz, bias, M, N, K, tiles_m, tiles_n, remap); \
+    } while (0)
     const bool z = Z != nullptr;
     if (act == ACT_GELU) { if (z) S4_GO(ACT_GELU, true); else S4_GO(ACT_GELU, false); }
     else if (act == ACT_RELU) { if (z) S4_GO(ACT_RELU, true); else S4_GO(ACT_RELU, false); }

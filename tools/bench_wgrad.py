@@ -1,13 +1,16 @@
 """Microbenchmark of the grouped bf16 weight-gradient kernels on uniform tables (one chip-wide round of whole tiles):
 python tools/bench_wgrad.py    → µs per launch, TFLOP/s, µs per 64-row k-tile of a 256×256 tile."""
 import ctypes, sys, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from svpc_amd import ops as O, _lib
 
 DEV = "cuda:0"
 CASES = [("28x 768x768 K19200 ld=n", 28, 19200, 768, 768, 1), ("28x 768x768 K19200 ld=2n", 28, 19200, 768, 768, 2),
          ("9x 2304x768 K19200", 9, 19200, 2304, 768, 1), ("7x 768x3072 K19200", 7, 19200, 768, 3072, 1),
          ("28x 768x768 K4224", 28, 4224, 768, 768, 1), ("4x 768x768 K19200 (36 tiles)", 4, 19200, 768, 768, 1)]
+if len(sys.argv) > 1:
+    CASES = [CASES[int(i)] for i in sys.argv[1].split(",")]
 ws = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
 for label, n, rows, n_out, n_in, mul in CASES:
     dz = [torch.randn(rows, n_out, device=DEV).to(torch.bfloat16) for _ in range(min(n, 6))]

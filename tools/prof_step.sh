@@ -13,6 +13,7 @@ trace=$(find "$out" -name "p_kernel_trace.csv" | head -1)
 stats=$(find "$out" -name "p_kernel_stats.csv" | head -1)
 if [ -n "$trace" ]; then
     python3 tools/step_profile.py "$trace" 70 > "$out/step_profile.txt" 2>&1
+    python3 tools/step_profile.py "$trace" 0 --seq > "$out/seq.txt" 2>&1
     python3 tools/dominant_avg.py "$trace" > "$out/dominant_avg.txt" 2>&1
     cp "$stats" "$out/kernel_stats.csv" 2>/dev/null
     find "$out" -name "p_*" -delete          # the raw trace is tens of MB: keep the summaries only
