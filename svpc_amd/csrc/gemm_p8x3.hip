@@ -3,11 +3,16 @@
 //   C = act( A·Bᵀ + bias ),  A = A_hi + A_lo,  B = B_hi + B_lo  (each an exact sum of two bf16 planes, 16-17 significant bits)
 //   A·Bᵀ ≈ A_lo·B_hiᵀ + A_hi·B_hiᵀ + A_hi·B_loᵀ          (the dropped A_lo·B_lo term is ≤ 2⁻¹⁶ relative)
 //
-// i.e. ONE bf16 GEMM with a 3K-deep contraction whose k-tiles come from three (A plane, B plane) pairs — the structure, LDS images,
-// barriers and prefetch schedule are those of gemm_p8.hip (256×256×64 tiles, 8 phases per pair of k-tiles, both operands direct-to-LDS,
-// v_mfma_f32_16x16x32_bf16; see the comment there); only the per-k-tile SOURCE offset differs.  fp32 accumulation of bf16 products is
-// exact per product, so the result carries ≈ fp32 accuracy at 3× the bf16 MFMA work — against 16× for the f32 MFMA
-// (MI355X_MICROARCH.md: f32-input MFMA runs at 1/16 of the bf16 rate).
+// The structure, LDS images, barriers and prefetch schedule are those of gemm_p8.hip (256×256 tiles, 8 phases per pair of staged buffers,
+// both operands direct-to-LDS, v_mfma_f32_16x16x32_bf16; see the comment there) with ONE difference in what a staged buffer holds: the
+// two 32-wide "k blocks" of a half-tile image are the HI and the LO plane of the same 32-deep k-slice (not two consecutive k blocks of
+// one plane).  A buffer then carries everything the three products of its slice need — A_hi, A_lo, B_hi, B_lo fetched ONCE, their
+// fragments read from LDS ONCE — and every phase issues 24 MFMAs (lo·hi, hi·hi, hi·lo per output block) on the 12 fragments that fed 16:
+// the kernel is bound by the LDS fill rate of a CU (≈40–50 GB/s direct-to-LDS from L2 / Infinity Cache: MI355X_MICROARCH.md "gather
+// into LDS"), so 1.5× the matrix work per staged byte is what pays (round 3, first form: a 3K-deep contraction of three plane pairs,
+// every hi tile staged twice — 6 tiles per 64-deep slice instead of 4).  fp32 accumulation of bf16 products is exact per product, so the
+// result carries ≈ fp32 accuracy at 3× the bf16 MFMA work — against 16× for the f32 MFMA (MI355X_MICROARCH.md: f32-input MFMA runs at
+// 1/16 of the bf16 rate).
 //
 // Storage ("split16", see layernorm.hip): a row of A holds its hi plane at columns [0, K) and its lo plane at [a_lo, a_lo + K); the
 // weight shadow keeps two planes of identical layout b_lo elements apart; C is written the same way (hi at column c, lo at c_lo + c).
@@ -23,7 +28,8 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef const void __attribute__((address_space(1))) * x3_gptr;
 typedef void __attribute__((address_space(3))) * x3_lptr;
 
-constexpr int X3_BK = 64;
+constexpr int X3_BK = 64;            // width of a staged half-tile image: 2 planes × 32 k
+constexpr int X3_KS = 32;            // k-slice per staged buffer
 constexpr int X3_HALF = 128 * X3_BK * 2;      // 16 KiB: one staged half-tile
 constexpr int X3_BUF = 4 * X3_HALF;           // 64 KiB: SA0 SA1 SB0 SB1 of one k-tile
 
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(512) void gemm_p8x3_kernel(const __bf16* __restrict
     const int wg = remap ? xcd_remap(blockIdx.x, tiles_m * tiles_n) : (int)blockIdx.x;
     const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
     const int m0 = tm * 256, n0 = tn * 256;
-    const int nk1 = K / X3_BK, nk = 3 * nk1;             // k-tiles of one plane pair / of the whole 3K-deep contraction
+    const int nk = K / X3_KS;                            // staged buffers = 32-deep k-slices (hi and lo plane of both operands)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;             // wr = the wave's group = its 128-row half; wc = its 64-column strip
 
@@ -113,19 +119,14 @@ __global__ __launch_bounds__(512) void gemm_p8x3_kernel(const __bf16* __restrict
         gb[h] = B + (size_t)min(n0 + 128 * h + 16 * wave + sr, N - 1) * ldb + 8 * sc;
     }
     char* const my = smem + wave * 2048;
-    // k-tile t of the 3K-deep contraction: k-tile kt = t / 3 of the planes, plane pair s = t % 3 — s = 0: A_lo·B_hi, 1: A_hi·B_hi,
-    // 2: A_hi·B_lo.  The three uses of a 64-deep slice follow one another, so the A_hi slice (s = 1, 2) and the B_hi slice (s = 0, 1)
-    // are fetched twice BACK TO BACK — the second time from L2 — instead of once per sweep over K (measured with the sweep order
-    // lo·hi | hi·lo | hi·hi: 197 MB fetched per launch for 65 MB of operands).  Element offsets from the hi-plane row pointers:
-#define X3_OFF_A(t) ((size_t)((t) / 3) * X3_BK + (((t) % 3) == 0 ? (size_t)a_lo : (size_t)0))
-#define X3_OFF_B(t) ((size_t)((t) / 3) * X3_BK + (((t) % 3) == 2 ? (size_t)b_lo : (size_t)0))
-    // the half-tile `which` (0 SA0, 1 SA1, 2 SB0, 3 SB1) of k-tile t: two 1-KiB pieces per wave
+    // buffer t = k-slice t (32 deep): "k block" 0 of every half-tile image is the slice of the hi plane, "k block" 1 the slice of the
+    // lo plane (element offsets from the hi-plane row pointers).  The half-tile `which` (0 SA0, 1 SA1, 2 SB0, 3 SB1): two 1-KiB pieces per wave
 #define X3_STAGE(t, which)                                                                                                 \
     do {                                                                                                                   \
         char* dst_ = my + ((t) & 1) * X3_BUF + (which) * X3_HALF;                                                          \
-        const __bf16* src_ = ((which) < 2 ? ga[(which) & 1] + X3_OFF_A(t) : gb[(which) & 1] + X3_OFF_B(t));                \
+        const __bf16* src_ = ((which) < 2 ? ga[(which) & 1] : gb[(which) & 1]) + (size_t)(t) * X3_KS;                      \
         __builtin_amdgcn_global_load_lds((x3_gptr)(src_), (x3_lptr)(dst_), 16, 0, 0);                                      \
-        __builtin_amdgcn_global_load_lds((x3_gptr)(src_ + 32), (x3_lptr)(dst_ + 1024), 16, 0, 0);                          \
+        __builtin_amdgcn_global_load_lds((x3_gptr)(src_ + ((which) < 2 ? (size_t)a_lo : (size_t)b_lo)), (x3_lptr)(dst_ + 1024), 16, 0, 0); \
     } while (0)
     // every DMA of k-tile t+1 issued by this wave has landed (the two B halves of tile t+2, issued after them, may stay in flight)
 #define X3_WAIT(t)                                                                                                         \
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(512) void gemm_p8x3_kernel(const __bf16* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: k-tile 0 whole, the B halves of k-tile 1 (nk = 3·nk1 ≥ 3: there always is a k-tile 1)
+    // ---- prologue: buffer 0 whole, the B halves of buffer 1 (K ≥ 64: there always is a slice 1)
 #pragma unroll
     for (int w = 0; w < 4; ++w) X3_STAGE(0, w);
     X3_STAGE(1, 2); X3_STAGE(1, 3);
@@ -176,11 +177,12 @@ __global__ __launch_bounds__(512) void gemm_p8x3_kernel(const __bf16* __restrict
         X3_SYNC();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int term = 0; term < 3; ++term)            // lo·hi, hi·hi, hi·lo: plane 1 = lo
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[kb][j], afr[kb][i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[term == 2 ? 1 : 0][j], afr[term == 0 ? 1 : 0][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         X3_SYNC();
         // ---- phase 1: rows 0-63 × columns 32-63
@@ -193,11 +195,12 @@ __global__ __launch_bounds__(512) void gemm_p8x3_kernel(const __bf16* __restrict
         X3_SYNC();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int term = 0; term < 3; ++term)            // lo·hi, hi·hi, hi·lo: plane 1 = lo
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[kb][j], afr[kb][i], acc[i][2 + j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j)
+                    acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[term == 2 ? 1 : 0][j], afr[term == 0 ? 1 : 0][i], acc[i][2 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         X3_SYNC();
         // ---- phase 2: rows 64-127 × columns 32-63
@@ -210,11 +213,12 @@ __global__ __launch_bounds__(512) void gemm_p8x3_kernel(const __bf16* __restrict
         X3_SYNC();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int term = 0; term < 3; ++term)            // lo·hi, hi·hi, hi·lo: plane 1 = lo
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[kb][j], afr[kb][i], acc[4 + i][2 + j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j)
+                    acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[term == 2 ? 1 : 0][j], afr[term == 0 ? 1 : 0][i], acc[4 + i][2 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         X3_SYNC();
         // ---- phase 3: rows 64-127 × columns 0-31 (fragments already in registers)
@@ -223,11 +227,12 @@ __global__ __launch_bounds__(512) void gemm_p8x3_kernel(const __bf16* __restrict
         X3_SYNC();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int term = 0; term < 3; ++term)            // lo·hi, hi·hi, hi·lo: plane 1 = lo
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[kb][j], afr[kb][i], acc[4 + i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j)
+                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[term == 2 ? 1 : 0][j], afr[term == 0 ? 1 : 0][i], acc[4 + i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         if (wr == 0 && t + 1 < nk) X3_WAIT(t);
         X3_SYNC();
@@ -237,8 +242,6 @@ __global__ __launch_bounds__(512) void gemm_p8x3_kernel(const __bf16* __restrict
 #undef X3_WAIT
 #undef X3_SYNC
 #undef X3_FRAG
-#undef X3_OFF_A
-#undef X3_OFF_B
 
     // every wave is past its last LDS read and every LDS-DMA has landed: the ring is free, 16 KiB per wave
     char* wl = smem + wave * 16384;
@@ -258,7 +261,7 @@ extern "C" {
 
 // 1 if (shape, layout) runs on this kernel
 int svpc_gemm_p8x3_supported(int lda, int a_lo, int ldb, int ldc, int c_lo, int ldz, int M, int N, int K) {
-    if (M <= 0 || N <= 0 || K < X3_BK || K % X3_BK != 0 || (N & 7) != 0) return 0;
+    if (M <= 0 || N <= 0 || K < 2 * X3_KS || K % X3_KS != 0 || (N & 7) != 0) return 0;
     if ((lda & 7) || (a_lo & 7) || (ldb & 7) || (ldc & 7) || (c_lo & 7) || (ldz & 7)) return 0;
     if (a_lo < K || lda < a_lo + K || c_lo < N || ldc < c_lo + N || ldb < K) return 0;
     if ((unsigned long long)M * (unsigned long long)ldc * 2ull >= (1ull << 32)) return 0;
@@ -276,7 +279,7 @@ int svpc_gemm_p8x3(const void* A, int lda, int a_lo, const void* B, int ldb, lon
     SVPC_REQUIRE(svpc_gemm_p8x3_supported(lda, a_lo, ldb, ldc, c_lo, ldz, M, N, K) == 1 && (b_lo & 7) == 0 &&
                      ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)Z) | ((uintptr_t)bias)) & 15) == 0 &&
                      (act == ACT_RELU || act == ACT_GELU || (act == ACT_NONE && Z == nullptr)) && (Z == nullptr || ldz >= N),
-                 "gemm_p8x3: needs K % 64 == 0, N % 8 == 0, 16-byte aligned split rows (lo plane behind the hi plane), act in {none, relu, gelu}");
+                 "gemm_p8x3: needs K % 32 == 0, K >= 64, N % 8 == 0, 16-byte aligned split rows (lo plane behind the hi plane), act in {none, relu, gelu}");
     static int remap = -1;
     if (remap < 0) { const char* e = getenv("SVPC_GEMM_REMAP"); remap = e ? atoi(e) : 1; }
     const int tiles_m = ceil_div(M, 256), tiles_n = ceil_div(N, 256);

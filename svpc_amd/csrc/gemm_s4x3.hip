@@ -1,17 +1,17 @@
 // Three-term split-bf16 GEMM on 128×128 tiles ("s4x3") — the small-M sibling of gemm_p8x3.hip for the decoder's projections in the
 // bf16x3 mode (4,224 sentence rows, 576 memory rows: reference src/rtransformer/model.py:620-663, the Linear layers of
 // BertDecoderLayerNoMemoryUntied).  At M = 4,224 a 256×256 tiling yields 51 (N = 768) … 153 (N = 2304) workgroups for 256 CUs and a
-// launch lasts as long as ONE tile's 3K-deep k-loop (57–62 µs measured); 128×128 tiles give 198 … 594 workgroups of a quarter of the
-// work, two resident per CU.
+// launch lasts as long as ONE tile's k-loop (57–62 µs measured); 128×128 tiles give 198 … 594 workgroups of a quarter of the work.
 //
-//   C (split) = act( A (split) · B (split)ᵀ + bias ),  A·Bᵀ ≈ A_lo·B_hiᵀ + A_hi·B_hiᵀ + A_hi·B_loᵀ  (k-slices of the three plane pairs adjacent)
+//   C (split) = act( A (split) · B (split)ᵀ + bias ),  A·Bᵀ ≈ A_lo·B_hiᵀ + A_hi·B_hiᵀ + A_hi·B_loᵀ
 //
-// 4 waves, wave tile 64×64 = 4×4 v_mfma_f32_16x16x32_bf16 tiles, weights in the MFMA's A slot (a lane holds 4 consecutive columns of
-// one output row, as gemm_p8x3.hip); 64-deep k-tiles, both operands direct-to-LDS in the st_16x32 subtile layout of gemm_p8.hip
-// (one 1-KiB wave-instruction per [16 rows][32 k] subtile, swizzle on the DMA source address and on the read address); two 32-KiB
-// stages: the DMA of k-tile t+1 is issued right after the barrier that retires k-tile t-1 and lands under the 32 MFMAs of k-tile t —
-// with two workgroups per CU one computes while the other waits.  Epilogue as gemm_p8x3.hip (bias, ReLU / GELU, hi / lo planes through
-// a wave-private LDS image, whole-line stores; optional plain-bf16 pre-activation copy Z).
+// 8 waves, wave tile 32×64 = 2×4 v_mfma_f32_16x16x32_bf16 tiles (two waves per SIMD cover each other's LDS-read latency: 31 → 28 µs at
+// M = 4,224, N = 768), weights in the MFMA's A slot (a lane holds 4 consecutive columns of one output row, as gemm_p8x3.hip); both
+// operands direct-to-LDS in the st_16x32 subtile layout of gemm_p8.hip (one 1-KiB wave-instruction per [16 rows][32 k] subtile, swizzle
+// on the DMA source address and on the read address).  A staged 32-KiB buffer holds the hi AND the lo plane of one 32-deep k-slice of
+// both operands (as gemm_p8x3.hip): 12 fragment reads feed 24 MFMAs.  NS = 2 stages with two workgroups per CU, or NS = 4 when the grid
+// leaves at most one workgroup per CU anyway (three slices in flight).  Epilogue as gemm_p8x3.hip (bias, ReLU / GELU, hi / lo planes
+// through a wave-private LDS image, whole-line stores; optional plain-bf16 pre-activation copy Z).
 #include "gemm_common.h"
 #include <stdlib.h>
 
@@ -20,7 +20,8 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef const void __attribute__((address_space(1))) * s4_gptr;
 typedef void __attribute__((address_space(3))) * s4_lptr;
 
-constexpr int S4_BK = 64;
+constexpr int S4_BK = 64;            // width of a staged tile image: 2 planes × 32 k
+constexpr int S4_KS = 32;            // k-slice per staged buffer
 constexpr int S4_HALF = 128 * S4_BK * 2;      // 16 KiB: 128 rows × 64 k
 constexpr int S4_STAGE = 2 * S4_HALF;         // A tile + B tile
 
@@ -47,8 +48,8 @@ __device__ __forceinline__ float s4_act(float z) {
     return z;
 }
 
-// one epilogue pass over the wave's 64×64 block: MODE 0 bf16(z) | 1 hi plane of act(z) | 2 lo plane → wave-private LDS image
-// [64 rows][128 B] (16-byte chunk c of row r kept at c ^ (r & 7)) → whole 128-byte lines
+// one epilogue pass over the wave's 32×64 block: MODE 0 bf16(z) | 1 hi plane of act(z) | 2 lo plane → wave-private LDS image
+// [32 rows][128 B] (16-byte chunk c of row r kept at c ^ (r & 7)) → whole 128-byte lines
 template <int ACT, int MODE>
 __device__ __forceinline__ void s4_store_pass(const floatx4 (&acc)[2][4], __bf16* __restrict__ C, int ldc, const float4 (&bb)[4], int row0,
                                               int col0, int M, int N, int lane, char* __restrict__ wl) {
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 2 : 1) void gemm_s4x3_kernel(const _
     const int wg = remap ? xcd_remap(blockIdx.x, tiles_m * tiles_n) : (int)blockIdx.x;
     const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
     const int m0 = tm * 128, n0 = tn * 128;
-    const int nk = 3 * (K / S4_BK);
+    const int nk = K / S4_KS;                            // staged buffers = 32-deep k-slices, hi and lo plane of both operands (gemm_p8x3.hip)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 1, wc = wave & 1;             // the wave's 32-row strip (of four) / 64-column half
 
@@ -99,17 +100,15 @@ __global__ __launch_bounds__(512, NS == 2 ? 2 : 1) void gemm_s4x3_kernel(const _
     const int sr = lane >> 2, sc = (lane & 3) ^ (((lane >> 5) & 1) << 1);
     const __bf16* const ga = A + (size_t)min(m0 + 16 * wave + sr, M - 1) * lda + 8 * sc;
     const __bf16* const gb = B + (size_t)min(n0 + 16 * wave + sr, N - 1) * ldb + 8 * sc;
-    // k-tile t: slice t / 3 of plane pair t % 3 — 0: A_lo·B_hi, 1: A_hi·B_hi, 2: A_hi·B_lo
-#define S4_OFF_A(t) ((size_t)((t) / 3) * S4_BK + (((t) % 3) == 0 ? (size_t)a_lo : (size_t)0))
-#define S4_OFF_B(t) ((size_t)((t) / 3) * S4_BK + (((t) % 3) == 2 ? (size_t)b_lo : (size_t)0))
+    // buffer t = k-slice t: "k block" 0 of a tile image is the slice of the hi plane, "k block" 1 the slice of the lo plane
 #define S4_ISSUE(t)                                                                                                               \
     do {                                                                                                                          \
         char* da_ = smem + ((t) % NS) * S4_STAGE + ((wave * 2) << 10);                                                            \
-        const size_t oa_ = S4_OFF_A(t), ob_ = S4_OFF_B(t);                                                                        \
-        __builtin_amdgcn_global_load_lds((s4_gptr)(ga + oa_), (s4_lptr)(da_), 16, 0, 0);                                          \
-        __builtin_amdgcn_global_load_lds((s4_gptr)(ga + oa_ + 32), (s4_lptr)(da_ + 1024), 16, 0, 0);                              \
-        __builtin_amdgcn_global_load_lds((s4_gptr)(gb + ob_), (s4_lptr)(da_ + S4_HALF), 16, 0, 0);                                \
-        __builtin_amdgcn_global_load_lds((s4_gptr)(gb + ob_ + 32), (s4_lptr)(da_ + S4_HALF + 1024), 16, 0, 0);                    \
+        const size_t o_ = (size_t)(t) * S4_KS;                                                                                    \
+        __builtin_amdgcn_global_load_lds((s4_gptr)(ga + o_), (s4_lptr)(da_), 16, 0, 0);                                           \
+        __builtin_amdgcn_global_load_lds((s4_gptr)(ga + o_ + a_lo), (s4_lptr)(da_ + 1024), 16, 0, 0);                             \
+        __builtin_amdgcn_global_load_lds((s4_gptr)(gb + o_), (s4_lptr)(da_ + S4_HALF), 16, 0, 0);                                 \
+        __builtin_amdgcn_global_load_lds((s4_gptr)(gb + o_ + b_lo), (s4_lptr)(da_ + S4_HALF + 1024), 16, 0, 0);                   \
     } while (0)
     // fragment: block `blk` (16 rows) and k block kb of an image; lane: row lane&15, logical chunk lane>>4
     const int fr_off = (lane & 15) * 64 + ((((lane >> 4) ^ (((lane >> 3) & 1) << 1))) << 4);
@@ -135,23 +134,24 @@ __global__ __launch_bounds__(512, NS == 2 ? 2 : 1) void gemm_s4x3_kernel(const _
         if (t + NS - 1 < nk) S4_ISSUE(t + NS - 1);               // into the stage k-tile t-1 used; lands under the MFMAs of the next k-tiles
         const char* sa = smem + (t % NS) * S4_STAGE;
         const char* sb = sa + S4_HALF;
+        bf16x8 bfr[2][4], afr[2][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            bf16x8 bfr[4], afr[2];
+        for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = S4_FRAG(sb, wc * 4 + j, kb);
+            for (int j = 0; j < 4; ++j) bfr[pl][j] = S4_FRAG(sb, wc * 4 + j, pl);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) afr[i] = S4_FRAG(sa, wr * 2 + i, kb);
+            for (int i = 0; i < 2; ++i) afr[pl][i] = S4_FRAG(sa, wr * 2 + i, pl);
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term)            // lo·hi, hi·hi, hi·lo: plane 1 = lo
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], afr[i], acc[i][j], 0, 0, 0);
-        }
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[term == 2 ? 1 : 0][j], afr[term == 0 ? 1 : 0][i], acc[i][j], 0, 0, 0);
     }
 #undef S4_ISSUE
 #undef S4_FRAG
-#undef S4_OFF_A
-#undef S4_OFF_B
     __syncthreads();                                             // every wave is past its last LDS read: the stages are free
     char* wl = smem + wave * 4096;                               // 4 KiB per wave: [32 rows][128 B]
     const int row0 = m0 + wr * 32, col0 = n0 + wc * 64;
@@ -173,12 +173,12 @@ int svpc_gemm_s4x3(const void* A, int lda, int a_lo, const void* B, int ldb, lon
                    int M, int N, int K, const float* bias, int act, hipStream_t stream) {
     if (M <= 0 || N <= 0) return 0;
     if (Z == nullptr) ldz = 0;
-    SVPC_REQUIRE(K >= S4_BK && K % S4_BK == 0 && (N & 7) == 0 && !((lda | a_lo | ldb | ldc | c_lo | ldz) & 7) && a_lo >= K && lda >= a_lo + K &&
+    SVPC_REQUIRE(K >= 2 * S4_KS && K % S4_KS == 0 && (N & 7) == 0 && !((lda | a_lo | ldb | ldc | c_lo | ldz) & 7) && a_lo >= K && lda >= a_lo + K &&
                      c_lo >= N && ldc >= c_lo + N && ldb >= K && (b_lo & 7) == 0 &&
                      (unsigned long long)M * (unsigned long long)ldc * 2ull < (1ull << 32) &&
                      ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)Z) | ((uintptr_t)bias)) & 15) == 0 &&
                      (act == ACT_RELU || act == ACT_GELU || (act == ACT_NONE && Z == nullptr)) && (Z == nullptr || ldz >= N),
-                 "gemm_s4x3: needs K % 64 == 0, N % 8 == 0, 16-byte aligned split rows (lo plane behind the hi plane), act in {none, relu, gelu}");
+                 "gemm_s4x3: needs K % 32 == 0, K >= 64, N % 8 == 0, 16-byte aligned split rows (lo plane behind the hi plane), act in {none, relu, gelu}");
     static int remap = -1;
     if (remap < 0) { const char* e = getenv("SVPC_GEMM_REMAP"); remap = e ? atoi(e) : 1; }
     const int tiles_m = ceil_div(M, 128), tiles_n = ceil_div(N, 128);

@@ -4,7 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from svpc_amd import ops as O
 O.set_precision("bf16x3")
 DEV = "cuda:0"
-for M, N, K in [(4224, 768, 768), (4224, 2304, 768), (576, 9216, 768), (19200, 768, 768), (19200, 2304, 768)]:
+SHAPES = [(4224, 768, 768), (4224, 2304, 768), (576, 9216, 768), (19200, 768, 768), (19200, 2304, 768)]
+if len(sys.argv) > 1:
+    SHAPES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+for M, N, K in SHAPES:
     x = O.to_split(torch.randn(M, K, device=DEV))
     w = torch.randn(N, K, device=DEV) / math.sqrt(K)
     b = torch.randn(N, device=DEV) * 0.1
