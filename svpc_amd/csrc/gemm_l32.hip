@@ -94,6 +94,7 @@ __device__ __forceinline__ void l32_fragment2(const char* __restrict__ img, int 
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);     \
     } while (0)
 
+
 template <int BM, int BN, bool A_KC, bool B_KC, int NS, bool X3 = false>
 __global__ __launch_bounds__(256) void gemm_l32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                        float* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_m,
@@ -110,7 +111,10 @@ __global__ __launch_bounds__(256) void gemm_l32_kernel(const float* __restrict__
     const int m0 = tm * BM, n0 = tn * BN;
     const int k_begin = ks_id * k_chunk;
     const int k_end = min(K, k_begin + k_chunk);
-    const int nk = (k_end - k_begin) / L32_BK;
+    const int nk = (k_end - k_begin + L32_BK - 1) / L32_BK;
+    // K % 32 != 0 (the 300-wide word vectors; both operands k-contiguous, K % 4 == 0 — checked on the host): the 16-byte chunks of
+    // the last k-tile that lie past K are sourced from a block of zeros
+    const int k_tail = (k_end - k_begin) - (nk - 1) * L32_BK;      // valid k of the last tile (32 when there is no tail)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -132,15 +136,20 @@ __global__ __launch_bounds__(256) void gemm_l32_kernel(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // (k-contiguous images) the k offset of this lane's chunk inside a k-tile: 4·(slot ^ swizzle(row)), piece j ↔ rows 8j … 8j+7
+#define L32_KOFS(j) (4 * ((lane & 7) ^ (((8 * (j) + (lane >> 3)) >> 1) & 7)))
 #define L32_ISSUE(t)                                                                                                              \
     do {                                                                                                                          \
         char* st = l32_smem + ((t) % NS) * STAGE;                                                                                 \
+        const bool tail_ = A_KC && B_KC && k_tail < L32_BK && (t) == nk - 1;                                                      \
         _Pragma("unroll") for (int i = 0; i < A_PER_WAVE; ++i) {                                                                  \
-            __builtin_amdgcn_global_load_lds((l32_gptr)ga[i], (l32_lptr)(st + (wave * A_PER_WAVE + i) * 1024), 16, 0, 0);        \
+            const float* s_ = (tail_ && L32_KOFS(wave * A_PER_WAVE + i) >= k_tail) ? l32_zeros : ga[i];                          \
+            __builtin_amdgcn_global_load_lds((l32_gptr)s_, (l32_lptr)(st + (wave * A_PER_WAVE + i) * 1024), 16, 0, 0);           \
             ga[i] += stepA;                                                                                                       \
         }                                                                                                                         \
         _Pragma("unroll") for (int i = 0; i < B_PER_WAVE; ++i) {                                                                  \
-            __builtin_amdgcn_global_load_lds((l32_gptr)gb[i], (l32_lptr)(st + A_BYTES + (wave * B_PER_WAVE + i) * 1024), 16, 0, 0); \
+            const float* s_ = (tail_ && L32_KOFS(wave * B_PER_WAVE + i) >= k_tail) ? l32_zeros : gb[i];                          \
+            __builtin_amdgcn_global_load_lds((l32_gptr)s_, (l32_lptr)(st + A_BYTES + (wave * B_PER_WAVE + i) * 1024), 16, 0, 0);  \
             gb[i] += stepB;                                                                                                       \
         }                                                                                                                         \
     } while (0)
@@ -191,6 +200,7 @@ __global__ __launch_bounds__(256) void gemm_l32_kernel(const float* __restrict__
         }
     }
 #undef L32_ISSUE
+#undef L32_KOFS
 
     const u64 seed = (epi.p_drop > 0.f && splitk == 1) ? epi.seed[0] : 0ull;
     const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
@@ -639,7 +649,9 @@ int svpc_lstm_pair_step_fwd_x3(const float* const* h_prev, const float* const* c
 // 1 if the fp32 direct-to-LDS kernel can run this (shape, layout): whole k-tiles, 16-byte aligned chunks, and for a k-strided
 // operand a row count that is a multiple of 4 (its 16-byte chunks run along the rows)
 int svpc_gemm_l32_supported(int a_kc, int b_kc, int lda, int ldb, int M, int N, int K) {
-    if (M <= 0 || N <= 0 || K <= 0 || K % L32_BK != 0 || lda % 4 != 0 || ldb % 4 != 0) return 0;
+    if (M <= 0 || N <= 0 || K <= 0 || lda % 4 != 0 || ldb % 4 != 0) return 0;
+    // a k tail (K % 32 != 0) only on the single-problem tiled form, both operands k-contiguous, whole 16-byte chunks
+    if (K % L32_BK != 0 && !(a_kc && b_kc && K % 4 == 0 && K > L32_BK)) return 0;
     if (!a_kc && (M % 4 != 0)) return 0;
     if (!b_kc && (N % 4 != 0)) return 0;
     return 1;
@@ -653,6 +665,7 @@ int svpc_gemm_l32_preferred(int a_kc, int b_kc, int lda, int ldb, int M, int N, 
     const int t128 = ceil_div(M, 128) * ceil_div(N, 128), t64 = ceil_div(M, 64) * ceil_div(N, 64);
     static int env_w = -1;
     if (env_w < 0) { const char* e = getenv("SVPC_L32_WAVESPLIT"); env_w = e ? atoi(e) : 1; }
+    if (K % L32_BK != 0) return (t128 <= 300) ? 1 : 0;                         // k tail: the tiled form only
     if (env_w && t64 <= 256 && K >= 4 * L32_BK && t64 * 4 >= 32) return 1;      // wave-split-K form, any K
     return (t128 <= 300 && K < 2048) ? 1 : 0;
 }
@@ -681,7 +694,7 @@ static int gemm_group_x(const void* problems, int n, int a_kc, int b_kc, int acc
     const int T = skinny ? 32 : 64;
     for (int i = 0; i < n; ++i) {
         const HostGemmProblem& h = hp[i];
-        SVPC_REQUIRE(svpc_gemm_l32_supported(a_kc, b_kc, h.lda, h.ldb, h.M, h.N, h.K) && ((((uintptr_t)h.A) | ((uintptr_t)h.B)) & 15) == 0,
+        SVPC_REQUIRE(svpc_gemm_l32_supported(a_kc, b_kc, h.lda, h.ldb, h.M, h.N, h.K) && h.K % L32_BK == 0 && ((((uintptr_t)h.A) | ((uintptr_t)h.B)) & 15) == 0,
                      "gemm_group: needs K % 32 == 0 and 16-byte aligned fp32 rows");
         GemmProb& q = g.p[i];
         q.A = h.A; q.B = h.B; q.C = h.C; q.M = h.M; q.N = h.N; q.K = h.K; q.lda = h.lda; q.ldb = h.ldb; q.ldc = h.ldc;
@@ -785,7 +798,7 @@ static int gemm_l32_x(const float* A, int lda, int a_kc, const float* B, int ldb
                       float* workspace, size_t workspace_bytes, int x3, hipStream_t stream) {
     if (M == 0 || N == 0) return 0;
     SVPC_REQUIRE(svpc_gemm_l32_supported(a_kc, b_kc, lda, ldb, M, N, K) && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0,
-                 "gemm_l32: needs K % 32 == 0 and 16-byte aligned fp32 rows");
+                 "gemm_l32: needs K % 32 == 0 (or both operands k-contiguous and K % 4 == 0) and 16-byte aligned fp32 rows");
     SVPC_REQUIRE(p_drop <= 0.f || seed != nullptr, "gemm: dropout needs a seed pointer");
     Epi epi{bias, act, p_drop, site, seed, accumulate, Z, R};
     static int env_tile = -1, env_split = -1, remap = -1;
@@ -813,6 +826,8 @@ static int gemm_l32_x(const float* A, int lda, int a_kc, const float* B, int ldb
     if (env_w < 0) { const char* e = getenv("SVPC_L32_WAVESPLIT"); env_w = e ? atoi(e) : 1; }
     if (env_w && t64 <= 256 && K >= 4 * L32_BK) mode = 66;
     if (env_tile == 128 || env_tile == 64 || env_tile == 65 || env_tile == 66) mode = env_tile;
+    const bool k_tail = K % L32_BK != 0;           // the tiled form below takes it (one k-range per tile: no split-K, no wave split)
+    if (k_tail && (mode == 66 || mode == 64)) mode = 65;
     if (mode == 66) {
         const int tm_ = ceil_div(M, 64), tn_ = ceil_div(N, 64);
         dim3 gridw(tm_ * tn_);
@@ -841,6 +856,7 @@ static int gemm_l32_x(const float* A, int lda, int a_kc, const float* B, int ldb
         if (splitk > 32) splitk = 32;
     }
     if (env_split > 0) splitk = env_split;
+    if (k_tail) splitk = 1;
     while (splitk > 1 && (size_t)splitk * M * N * sizeof(float) > workspace_bytes) --splitk;
     if (splitk < 1) splitk = 1;
     int k_chunk = ceil_div(ceil_div(K, splitk), L32_BK) * L32_BK;

@@ -550,7 +550,7 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NON
     """C = epi(A·B) (+ R: an addend of C's type and layout, only on the bf16 direct-to-LDS path; other paths add it afterwards).
     G = (aux, act): C = (A·B) ⊙ act'(aux) — absorbed only by the bf16 direct-to-LDS path; returns whether it was applied.
     x3 (fp32 operands, bf16x3 mode, forward products): three-term split-bf16 products (svpc_gemm_l32_x3); shapes that kernel does
-    not take (K not a multiple of 32: the 300-wide word vectors) run on the exact f32 MFMA instead — never on one-term bf16."""
+    not take (a k-strided operand with K % 32 != 0, K % 4 != 0) run on the exact f32 MFMA instead — never on one-term bf16."""
     ws = _ws(C.device)
     g_done = False
     ev = (GEMM_TIMER.bracket(2.0 * M * N * K, (M, N, K, a_kc, b_kc, _dt(A), _dt(B), _dt(C)))

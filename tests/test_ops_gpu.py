@@ -418,7 +418,9 @@ def test_gemm_glds_direct_to_lds(bf16_mode, M, N, K, a_kc, b_kc, c_bf16):
     (2304, 768, 4224, 0, 0, 0, False), (132, 136, 2048, 0, 0, 0, False),
     # wave-split-K form (≤ 256 tiles of 64², ≥ 4 k-tiles): uneven k-tile counts per wave, edges, every layout, long K
     (192, 768, 160, 1, 1, 0, True), (16, 768, 3072, 1, 0, 0, False), (576, 1536, 768, 1, 1, 0, True), (700, 60, 224, 0, 1, 1, False),
-    (64, 64, 128, 0, 0, 0, False), (192, 2304, 768, 1, 1, 1, True)])
+    (64, 64, 128, 0, 0, 0, False), (192, 2304, 768, 1, 1, 1, True),
+    # k tail (K % 32 != 0, both operands k-contiguous: the 300-wide word vectors): chunks past K are zero-sourced
+    (4224, 768, 300, 1, 1, 0, True), (70, 50, 300, 1, 1, 1, False), (192, 768, 44, 1, 1, 0, True), (2112, 300, 36, 1, 1, 0, False)])
 def test_gemm_l32_fp32_direct_to_lds(bf16_mode, M, N, K, a_kc, b_kc, acc, bias_act):
     """fp32-operand direct-to-LDS GEMM (deep ring, bf16 rounding at fragment build): all four layouts, clamped M/N edges,
     128² / 64² tiles, split-K, accumulate and bias+activation epilogues — against fp64 on the bf16-rounded operands."""
@@ -445,10 +447,13 @@ def test_gemm_l32_fp32_direct_to_lds(bf16_mode, M, N, K, a_kc, b_kc, acc, bias_a
 
 
 def test_gemm_l32_unsupported_shapes_fall_back(bf16_mode):
-    """K % 32 != 0 (word vectors W=300, vocabulary as K) or a k-strided operand whose row count is not a multiple of 4 stay
-    on the register-staged kernel."""
+    """a k tail with a k-strided operand, K < 32, K % 4 != 0, or a k-strided operand whose row count is not a multiple of 4 stay on
+    the register-staged kernel; a k tail with both operands k-contiguous runs on the direct-to-LDS kernel."""
     lib = O._lib.load()
-    assert lib.svpc_gemm_l32_supported(1, 1, 300, 300, 64, 64, 300) == 0
+    assert lib.svpc_gemm_l32_supported(1, 1, 300, 300, 64, 64, 300) == 1
+    assert lib.svpc_gemm_l32_supported(1, 0, 300, 64, 64, 64, 300) == 0
+    assert lib.svpc_gemm_l32_supported(1, 1, 28, 28, 64, 64, 28) == 0
+    assert lib.svpc_gemm_l32_supported(1, 1, 304, 304, 64, 64, 302) == 0
     assert lib.svpc_gemm_l32_supported(0, 1, 951, 768, 951, 768, 4224) == 0
     assert lib.svpc_gemm_l32_supported(1, 0, 960, 768, 64, 768, 951) == 0
     g = torch.Generator().manual_seed(0)

@@ -124,7 +124,8 @@ def test_split_gemm_backward_is_the_bf16_backward():
 
 # ------------------------------------------------------------------------------------------------ fp32-storage GEMMs with x3 products
 @pytest.mark.parametrize("M,N,K,trans", [(192, 768, 768, False), (192, 2304, 768, False), (4224, 768, 768, False), (4224, 951, 768, False),
-                                         (192, 300, 384, True), (16, 3072, 768, False), (4224, 768, 300, False), (100, 33, 64, False)])
+                                         (192, 300, 384, True), (16, 3072, 768, False), (4224, 768, 300, False), (100, 33, 64, False),
+                                         (192, 768, 300, False), (2112, 300, 44, False)])
 def test_fp32_storage_gemm_x3_vs_fp64(M, N, K, trans):
     x = _rand(M, K, seed=8)
     w = _rand(K, N, seed=9, scale=1.0 / math.sqrt(K)) if trans else _rand(N, K, seed=9, scale=1.0 / math.sqrt(K))
