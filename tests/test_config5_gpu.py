@@ -168,7 +168,8 @@ def test_reference_shaped_submodules_on_the_gpu(golden_dir, case, mt, precision)
                 n_oov = len(cb["oov_word_dict"][0])
                 pg = model.pointer_generator_network(d, bank.to(DEV), batch["ingr_id_dict"][0], n_oov)    # :102-104
                 ref_pg = orc.pointer_generator(P, ref_d, bank, cb["ingr_id_dict"][0], n_oov, cfg)
-                close(pg, ref_pg, atol=1e-7 if precision == "fp32" else 2e-6)
+                # bf16x3: a probability's relative error is the absolute error of its logit (≈ 10 · 2⁻¹⁷ · a few stages)
+                close(pg, ref_pg, **(dict(atol=1e-7) if precision == "fp32" else dict(atol=2e-6, rtol=6e-4)))
             ones = torch.ones(2, 3, D)
             close(model.decoder_classifier(ones.to(DEV)), orc.lm_head(P, ones, cfg))                      # :159
     finally:
