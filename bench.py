@@ -720,9 +720,9 @@ def _train_main(args, device, world, rank, dist, joined):
     default_cfg = (args.batch, args.clips, L_, D_, F_, args.model_type) == (16, 12, 6, 768, 3072, "vivt") and r["bf16_stream"]
     traffic, traffic_src = measured_traffic(precision) if (default_cfg and r["glds"]) else (None, None)
     if precision == "bf16x3" and r["bf16_stream"]:
-        kname = ("gemm_p8x3_kernel (split-bf16 three-term product: ONE bf16 GEMM over a 3K-deep contraction of (A_lo,B_hi), (A_hi,B_lo), "
-                 "(A_hi,B_hi) k-tiles; operands and output stored as two bf16 planes; 256x256x64 tiles, 8 phases per pair of k-tiles, both "
-                 "operands direct-to-LDS, v_mfma_f32_16x16x32_bf16)")
+        kname = ("gemm_p8x3_kernel (split-bf16 three-term product A_lo·B_hi + A_hi·B_hi + A_hi·B_lo on the bf16 matrix cores; operands and "
+                 "output stored as two bf16 planes; 256x256 tiles, a staged buffer = hi and lo plane of one 32-deep k-slice of both operands "
+                 "(24 MFMAs per 12 fragment reads), 8 phases per pair of buffers, both operands direct-to-LDS, v_mfma_f32_16x16x32_bf16)")
     elif r["glds"]:
         kname = ("gemm_p8_kernel (bf16·bf16→bf16, both operands direct-to-LDS, 256x256x64 tiles, 8 phases per pair of k-tiles, "
                  "v_mfma_f32_16x16x32_bf16)")
