@@ -141,6 +141,11 @@ int svpc_gemm_s4x3(const void* A, int lda, int a_lo, const void* B, int ldb, lon
  * G (optional) what the forward of the activation in front of this projection's input kept, R (optional) a parked residual-path gradient;
  * all bf16, C / G / R share ldc.  K % 64 == 0, N % 8 == 0.  B fragments come from a [64 k-rows][128 columns] LDS image through
  * ds_read_b64_tr_b16.  reference: the backward of every nn.Linear of the clip encoder (model.py:195-197,230,259,281,551). */
+/* the same dgrad on 128x128 tiles, 8 waves, up to four 32-KiB stages: the decoder's projections with M = 4,224 or 576 rows, where a
+   256x256 tiling leaves most CUs idle. gemm_s4t.hip; replaces the backward of the nn.Linear layers of BertDecoderLayerNoMemoryUntied,
+   src/rtransformer/model.py:620-663.  C = A·B + R with R optional; no activation factor. */
+int svpc_gemm_s4t_supported(int lda, int ldb, int ldc, int M, int N, int K);
+int svpc_gemm_s4t(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* R, int M, int N, int K, svpc_stream_t stream);
 int svpc_gemm_p8t_supported(int lda, int ldb, int ldc, int M, int N, int K);
 int svpc_gemm_p8t(const void* A, int lda, const void* B, int ldb, void* C, int ldc, const void* G, int gact, const void* R, int M, int N, int K,
                   svpc_stream_t stream);

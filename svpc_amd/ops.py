@@ -576,6 +576,14 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NON
                   _p(R), M, N, K, _stream())
         R = None
         g_done = G is not None
+    elif (_fast() and USE_S4T and a_kc == 1 and b_kc == 0 and A.dtype == B.dtype == C.dtype == torch.bfloat16 and Z is None and bias is None
+          and act == ACT_NONE and p <= 0.0 and not accumulate and G is None and S4T_MIN_TILES <= (-(-M // 128)) * (-(-N // 128)) <= S4T_MAX_TILES
+          and (A.data_ptr() | B.data_ptr() | C.data_ptr()) % 16 == 0
+          and _lib.load().svpc_gemm_s4t_supported(lda, ldb, C.stride(0), M, N, K) == 1
+          and (R is None or (R.dtype == torch.bfloat16 and R.shape == C.shape and R.stride() == C.stride() and R.data_ptr() % 16 == 0))):
+        # small-M stream dgrad (the decoder's 4,224 / 576 rows) on 128² tiles with the weight matrix read k-strided in place (gemm_s4t.hip)
+        _lib.call("gemm_s4t", _p(A), lda, _p(B), ldb, _p(C), C.stride(0), _p(R), M, N, K, _stream())
+        R = None
     elif _fast() and USE_GLDS and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and \
             (A.data_ptr() | B.data_ptr()) % 16 == 0 and _lib.load().svpc_gemm_glds_supported(a_kc, b_kc, lda, ldb, M, N, K) == 1:
         g_ok = G is not None and G[0].dtype == C.dtype and G[0].shape == C.shape and G[0].stride() == C.stride() and not accumulate
@@ -1118,6 +1126,9 @@ USE_Q1S = os.environ.get("SVPC_NO_Q1S", "") == ""
 USE_P8W = os.environ.get("SVPC_NO_P8W", "") == ""                 # grouped stream wgrads on gemm_p8w.hip (else the round-1 ping-pong kernel)
 USE_P8T = os.environ.get("SVPC_NO_P8T", "") == ""                 # stream dgrads on gemm_p8t.hip (else the round-1 ping-pong kernel)
 P8T_MIN_TILES = int(os.environ.get("SVPC_P8T_MIN_TILES", "150"))   # 256² tiles needed to fill the chip
+USE_S4T = os.environ.get("SVPC_NO_S4T", "") == ""                 # small-M stream dgrads (the decoder) on gemm_s4t.hip (128² tiles)
+S4T_MIN_TILES = int(os.environ.get("SVPC_S4T_MIN_TILES", "64"))    # fewer 128² tiles: a long k-loop on a few CUs wants split-K (gemm_glds)
+S4T_MAX_TILES = int(os.environ.get("SVPC_S4T_MAX_TILES", "640"))
 X3_BIG_TILES = int(os.environ.get("SVPC_X3_BIG_TILES", "128"))      # fewer 256² tiles than this → the 128² split GEMM (gemm_s4x3.hip)
 
 

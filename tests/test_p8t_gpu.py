@@ -47,6 +47,49 @@ def test_p8t_vs_fp64(M, N, K, gact, has_r):
     assert bool((Cbuf[M:] == 7.0).all())
 
 
+@pytest.mark.parametrize("M,N,K,has_r", [(4224, 768, 768, False), (4224, 768, 2304, True), (576, 768, 9216, True), (300, 776, 192, True),
+                                          (5, 8, 64, False), (1000, 2304, 768, True), (129, 136, 128, False)])
+def test_s4t_vs_fp64(M, N, K, has_r):
+    """gemm_s4t (the decoder's dgrads: 128² tiles, 8 waves, k-strided weights through ds_read_b64_tr_b16, 2 or 4 stages) through the C-ABI:
+    C = A·B + R against fp64 on the same bf16 operands; rows past M are not written"""
+    A = _rand(M, K, seed=11).to(torch.bfloat16)
+    W = _rand(K, N, seed=12, scale=1.0 / math.sqrt(K)).to(torch.bfloat16)
+    R = _rand(M, N, seed=14).to(torch.bfloat16) if has_r else None
+    assert _lib.load().svpc_gemm_s4t_supported(K, N, N, M, N, K) == 1
+    Cbuf = torch.full((M + 3, N), 7.0, dtype=torch.bfloat16, device=DEV)
+    _lib.call("gemm_s4t", A.data_ptr(), K, W.data_ptr(), N, Cbuf.data_ptr(), N, R.data_ptr() if R is not None else None, M, N, K,
+              torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double()
+    if has_r:
+        ref = ref + R.double()
+    err = float((Cbuf[:M].double() - ref).abs().max())
+    assert err <= 6e-3 * float(ref.abs().max()), (err, float(ref.abs().max()))
+    assert bool((Cbuf[M:] == 7.0).all())
+
+
+def test_decoder_dgrad_takes_s4t_and_matches_the_old_kernel():
+    """ops.linear's backward at the decoder's shape (4,224 sentence rows): with and without gemm_s4t, same gradients to bf16 rounding"""
+    from svpc_amd import ops as O
+    O.set_precision("bf16")
+    try:
+        M, N, K = 4224, 768, 768
+        x = _rand(M, K, seed=15).to(torch.bfloat16).requires_grad_(True)
+        w = _rand(N, K, seed=16, scale=1.0 / math.sqrt(K)).requires_grad_(True)
+        g = _rand(M, N, seed=17).to(torch.bfloat16)
+        outs = []
+        for use in (True, False):
+            O.USE_S4T = use
+            x.grad = None
+            O.linear(x, w, None).backward(g)
+            O.join_side()
+            outs.append(x.grad.float().clone())
+        assert float((outs[0] - outs[1]).abs().max()) <= 1e-2 * float(outs[1].abs().max())
+    finally:
+        O.USE_S4T = True
+        O.set_precision("fp32")
+
+
 def test_stream_dgrad_takes_p8t_and_matches_the_old_kernel():
     """ops.linear's backward at a stream-sized shape: with and without gemm_p8t (env switch), same gradients to bf16 rounding"""
     from svpc_amd import ops as O
