@@ -469,89 +469,57 @@ static int gemm_group_go(const GemmGroupArgs& g, int tiles, hipStream_t stream) 
 // A k-contiguous [M][lda]; B k-contiguous [N][ldb] (B_KC) or k-strided [K][ldb]; K % 16 == 0; rows past an edge are clamped.
 // the k-loop of one 32×32 tile: this wave's share of the 16-deep k-steps, partial tile → part[wave] (the caller syncs and sums).
 // arow / brow: this lane's operand rows (A row lane&31, B column lane&31) already advanced by 8·(lane>>5) k-elements.
-template <bool X3>
-__device__ __forceinline__ void skinny_mfma(const float* a8, const float* b8, floatx16& acc) {
-    if constexpr (X3) {
-        bf16x8 ah, al, bh, bl;
-        l32_split8(a8, ah, al);
-        l32_split8(b8, bh, bl);
-        L32_MFMA3(ah, al, bh, bl, acc);
-    } else {
-        bf16x8 af, bf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { af[j] = (__bf16)a8[j]; bf[j] = (__bf16)b8[j]; }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
-    }
-}
-// k order inside a 32-deep PAIR of k-steps: the MFMA's k-slot (half h = lane>>5, element j) of the first step takes k = 32p + 16h + j,
-// of the second step k = 32p + 16h + 8 + j — for both operands alike, so the contraction is unchanged, and a lane's 16 values are 64
-// CONTIGUOUS bytes of its row (the two halves of a row: one 128-byte line) instead of two 32-byte pieces 64 bytes apart: half the
-// distinct lines per load instruction for the address unit to look up (the limiter of these launches once the loads are batched).
 template <bool B_KC, int NW, bool X3 = false>
 __device__ __forceinline__ void skinny_partials(float (*part)[16][64], const float* __restrict__ arow, const float* __restrict__ brow,
                                                 int ldb, int K) {
-    constexpr int BATCH = NW == 8 ? 5 : 6;                      // pairs in flight: 6 × 32 fp32 operand registers (5: the 512-thread form spills at 6)
+    constexpr int BATCH = 12;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = lane >> 5;
-    const int nsteps = K >> 4, npairs = nsteps >> 1;            // 16-deep k-steps; this wave takes the pairs wave, wave+NW, …
-    // (arow / brow arrive advanced by 8·h k-elements: the pair form wants 16·h)
-    const float* const ap0 = arow + 8 * h;
-    const float* const bp0 = B_KC ? brow + 8 * h : brow + (size_t)(8 * h) * ldb;
+    const int nsteps = K >> 4;                                  // 16-deep k-steps; this wave takes wave, wave+NW, …
     floatx16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (int s0 = wave; s0 < npairs; s0 += NW * BATCH) {
-        float av[BATCH][16];
-        float bv[BATCH][16];
+    for (int s0 = wave; s0 < nsteps; s0 += NW * BATCH) {
+        float4 av[BATCH][2];
+        float bv[BATCH][8];
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
             const int s = s0 + NW * u;
-            if (s < npairs) {
-                const float* ap = ap0 + 32 * s;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 t = *reinterpret_cast<const float4*>(ap + 4 * q);
-                    av[u][4 * q] = t.x; av[u][4 * q + 1] = t.y; av[u][4 * q + 2] = t.z; av[u][4 * q + 3] = t.w;
-                }
+            if (s < nsteps) {
+                const float* ap = arow + 16 * s;
+                av[u][0] = *reinterpret_cast<const float4*>(ap);
+                av[u][1] = *reinterpret_cast<const float4*>(ap + 4);
                 if (B_KC) {
-                    const float* bp = bp0 + 32 * s;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 t = *reinterpret_cast<const float4*>(bp + 4 * q);
-                        bv[u][4 * q] = t.x; bv[u][4 * q + 1] = t.y; bv[u][4 * q + 2] = t.z; bv[u][4 * q + 3] = t.w;
-                    }
+                    const float* bp = brow + 16 * s;
+                    const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+                    bv[u][0] = b0.x; bv[u][1] = b0.y; bv[u][2] = b0.z; bv[u][3] = b0.w;
+                    bv[u][4] = b1.x; bv[u][5] = b1.y; bv[u][6] = b1.z; bv[u][7] = b1.w;
                 } else {
-                    const float* bp = bp0 + (size_t)(32 * s) * ldb;
+                    const float* bp = brow + (size_t)(16 * s) * ldb;
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) bv[u][j] = bp[(size_t)j * ldb];
+                    for (int j = 0; j < 8; ++j) bv[u][j] = bp[(size_t)j * ldb];
                 }
             }
         }
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
             const int s = s0 + NW * u;
-            if (s < npairs) {
-                skinny_mfma<X3>(&av[u][0], &bv[u][0], acc);
-                skinny_mfma<X3>(&av[u][8], &bv[u][8], acc);
+            if (s < nsteps) {
+                if constexpr (X3) {
+                    const float a8[8] = {av[u][0].x, av[u][0].y, av[u][0].z, av[u][0].w, av[u][1].x, av[u][1].y, av[u][1].z, av[u][1].w};
+                    bf16x8 ah, al, bh, bl;
+                    l32_split8(a8, ah, al);
+                    l32_split8(bv[u], bh, bl);
+                    L32_MFMA3(ah, al, bh, bl, acc);
+                } else {
+                    bf16x8 af, bf;
+                    af[0] = (__bf16)av[u][0].x; af[1] = (__bf16)av[u][0].y; af[2] = (__bf16)av[u][0].z; af[3] = (__bf16)av[u][0].w;
+                    af[4] = (__bf16)av[u][1].x; af[5] = (__bf16)av[u][1].y; af[6] = (__bf16)av[u][1].z; af[7] = (__bf16)av[u][1].w;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bf[j] = (__bf16)bv[u][j];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+                }
             }
         }
-    }
-    if ((nsteps & 1) && wave == npairs % NW) {                 // K % 32 == 16: the last single k-step, in the plain order
-        const int s = nsteps - 1;
-        float a8[8], b8[8];
-        const float* ap = arow + 16 * s;
-        const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
-        a8[0] = a0.x; a8[1] = a0.y; a8[2] = a0.z; a8[3] = a0.w; a8[4] = a1.x; a8[5] = a1.y; a8[6] = a1.z; a8[7] = a1.w;
-        if (B_KC) {
-            const float* bp = brow + 16 * s;
-            const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
-            b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w;
-        } else {
-            const float* bp = brow + (size_t)(16 * s) * ldb;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) b8[j] = bp[(size_t)j * ldb];
-        }
-        skinny_mfma<X3>(a8, b8, acc);
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) part[wave][e][lane] = acc[e];

@@ -37,7 +37,7 @@ __device__ __forceinline__ bf16x8 p8w_frag_tr(const char* __restrict__ a) {
 // C[256 × 256 block at (0,0) of C] (+)= Σ_{k < K} A[k][m] · B[k][n];  A: [K][lda] (columns m < Mv valid), B: [K][ldb] (n < Nv valid)
 template <bool ACCUM>
 __device__ __forceinline__ void p8w_tile(char* __restrict__ smem, const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B, int ldb,
-                                         float* __restrict__ C, int ldc, int Mv, int Nv, int K, int pf) {
+                                         float* __restrict__ C, int ldc, int Mv, int Nv, int K, float* __restrict__ bdst, int bmask, bool bstore) {
     const int nk = (K + P8W_BK - 1) / P8W_BK;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;             // wr = the wave's group = its 128-row half of C; wc = its 64-column strip
@@ -61,14 +61,6 @@ __device__ __forceinline__ void p8w_tile(char* __restrict__ smem, const __bf16* 
     }
     const size_t stepA = (size_t)P8W_BK * lda, stepB = (size_t)P8W_BK * ldb;
     const __bf16* const zsrc = reinterpret_cast<const __bf16*>(p8w_zeros);
-    // L2 prefetch: one dword of each 128-byte line of a later k-tile (64 rows × 4 lines of A, × 4 of B = 512 lanes), fetched by LDS-DMA
-    // into a 256-byte scratch strip per wave — the OLDEST loads in flight when the end-of-k-tile wait comes, a full k-tile after their issue
-    const int pf_row = 8 * wave + (lane >> 3), pf_j = lane & 7;
-    const __bf16* const pf_ptr = pf_j < 4 ? A + (size_t)pf_row * lda + min(64 * pf_j, max(Mv - 1, 0))
-                                          : B + (size_t)pf_row * ldb + min(64 * (pf_j - 4), max(Nv - 1, 0));
-    const size_t pf_step = pf_j < 4 ? stepA : stepB;
-    const int pf_ahead = pf_j < 4 ? 2 : 3;
-    char* const pf_sink = smem + 2 * P8W_BUF + wave * 256;
     char* const my = smem + wave * 2048;
     // the half-tile `which` (0 A0, 1 A1, 2 B0, 3 B1) of k-tile t: two 1-KiB pieces per wave; k-rows ≥ K are zero-sourced
 #define P8W_STAGE(t, which)                                                                                                \
@@ -104,6 +96,28 @@ __device__ __forceinline__ void p8w_tile(char* __restrict__ smem, const __bf16* 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+    // Bias gradient (bmask != 0: a problem with a bias): db[m] = Σ_k dz[k][m] is one more MFMA per dz fragment with an all-ones operand in
+    // the x slot — every output column then holds the column sum of the fragment.  The wave with strip index wc takes the 16-column block
+    // wc (bit 0 of bmask: during phase 0) and / or 4 + wc (bit 1: phase 2) of its half; the tile columns 0 and 1 of a problem share the
+    // work (bit 0 / bit 1), so a tile pays 2 extra MFMAs per wave and k-tile, 8 accumulator registers.
+    floatx4 bacc0 = floatx4{0.f, 0.f, 0.f, 0.f}, bacc1 = floatx4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#define P8W_BIAS(bacc, bit)                                                                                                   \
+    do {                                                                                                                   \
+        if (bmask & (bit)) {                                                                                               \
+            _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                             \
+                switch (wc) {                                                                                              \
+                    case 0: bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, afr[kb][0], bacc, 0, 0, 0); break;       \
+                    case 1: bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, afr[kb][1], bacc, 0, 0, 0); break;       \
+                    case 2: bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, afr[kb][2], bacc, 0, 0, 0); break;       \
+                    default: bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, afr[kb][3], bacc, 0, 0, 0); break;      \
+                }                                                                                                          \
+            }                                                                                                              \
+        }                                                                                                                  \
+    } while (0)
+
     if (nk > 0) {
         // ---- prologue: k-tile 0 whole, the B halves of k-tile 1
 #pragma unroll
@@ -119,10 +133,6 @@ __device__ __forceinline__ void p8w_tile(char* __restrict__ smem, const __bf16* 
         const char* sa = smem + (t & 1) * P8W_BUF + wr * P8W_HALF;
         const char* sb = smem + (t & 1) * P8W_BUF + (2 + (wc >> 1)) * P8W_HALF;
         bf16x8 afr[2][4], b0[2][2], b1[2][2];
-        if (pf) {
-            const int tt = t + pf_ahead;
-            if (tt * P8W_BK + pf_row < K) __builtin_amdgcn_global_load_lds((p8w_gptr)(pf_ptr + (size_t)tt * pf_step), (p8w_lptr)(pf_sink), 4, 0, 0);
-        }
         // ---- phase 0: rows 0-63 × columns 0-31 of the wave tile
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -141,6 +151,7 @@ __device__ __forceinline__ void p8w_tile(char* __restrict__ smem, const __bf16* 
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[kb][j], afr[kb][i], acc[i][j], 0, 0, 0);
+        P8W_BIAS(bacc0, 1);
         __builtin_amdgcn_s_setprio(0);
         P8W_SYNC();
         // ---- phase 1: rows 0-63 × columns 32-63
@@ -175,6 +186,7 @@ __device__ __forceinline__ void p8w_tile(char* __restrict__ smem, const __bf16* 
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[kb][j], afr[kb][i], acc[4 + i][2 + j], 0, 0, 0);
+        P8W_BIAS(bacc1, 2);
         __builtin_amdgcn_s_setprio(0);
         P8W_SYNC();
         // ---- phase 3: rows 64-127 × columns 0-31 (fragments already in registers)
@@ -197,6 +209,7 @@ __device__ __forceinline__ void p8w_tile(char* __restrict__ smem, const __bf16* 
 #undef P8W_WAIT
 #undef P8W_SYNC
 #undef P8W_FRAG
+#undef P8W_BIAS
 
     // ---- epilogue: a lane holds columns 4q … 4q+3 of row l15 of every 16×16 block: one 16-byte read-modify-write each
     const int l15 = lane & 15, q = lane >> 4;
@@ -213,22 +226,35 @@ __device__ __forceinline__ void p8w_tile(char* __restrict__ smem, const __bf16* 
             else *d = acc[i][j];
         }
     }
+    if (bmask && q == 0) {                                // lanes 0-15: column l15 of the wave's two blocks (every output column holds the sum)
+        const int c0 = wr * 128 + wc * 16 + l15, c1 = c0 + 64;
+        if (!bstore) {                                    // whole tile: the only writer of these bias-gradient entries
+            if ((bmask & 1) && c0 < Mv) bdst[c0] += bacc0[0];
+            if ((bmask & 2) && c1 < Mv) bdst[c1] += bacc1[0];
+        } else {                                          // k-part: a 256-float strip behind the slabs, summed in part order by the fix-up
+            if (bmask & 1) bdst[c0] = bacc0[0];
+            if (bmask & 2) bdst[c1] = bacc1[0];
+        }
+    }
 }
 
 struct W8Prob {
-    const __bf16* dz; const __bf16* x; float* dw; int n_out, n_in, rows, ld_dz, ld_x, ld_dw, tile0, tiles_n;
+    const __bf16* dz; const __bf16* x; float* dw; float* db; int n_out, n_in, rows, ld_dz, ld_x, ld_dw, tile0, tiles_n;
     int whole, split, slab0, stile0;      // leading tiles run whole (accumulating into dw), the others in `split` k-parts → slabs
 };
 constexpr int W8_MAX = 48;
-struct W8Args { int n; int total; int chunk; int pf; W8Prob p[W8_MAX]; };
+struct W8Args { int n; int total; int nslabs; W8Prob p[W8_MAX]; };      // nslabs: the bias strips of the k-parts start behind that many slabs
+
+// which of a tile's bias columns tile column tn computes: the blocks of phase 0 (columns c with (c & 64) == 0: bit 0) or of phase 2 (bit 1)
+__device__ __forceinline__ int p8w_bias_mask(const W8Prob& q, int tn) {
+    if (!q.db) return 0;
+    if (q.tiles_n == 1) return 3;
+    return tn == 0 ? 1 : (tn == 1 ? 2 : 0);
+}
 
 __global__ __launch_bounds__(512) void gemm_group_wgrad16_p8_kernel(W8Args g, float* __restrict__ slabs) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * P8W_BUF + 8 * 256];
-    int wg = blockIdx.x;
-    if (g.chunk > 0) {                                    // experiment knob SVPC_P8W_CHUNK: XCD x takes `chunk` consecutive items of each run
-        const int run = 8 * g.chunk, base = (wg / run) * run;
-        if (base + run <= g.total) { const int j = wg - base; wg = base + (j & 7) * g.chunk + (j >> 3); }
-    }
+    __shared__ __attribute__((aligned(1024))) char smem[2 * P8W_BUF];
+    const int wg = blockIdx.x;
     int pi = 0;
     while (pi + 1 < g.n && wg >= g.p[pi + 1].tile0) ++pi;
     const W8Prob& q = g.p[pi];
@@ -237,7 +263,7 @@ __global__ __launch_bounds__(512) void gemm_group_wgrad16_p8_kernel(W8Args g, fl
         const int tm = item / q.tiles_n, tn = item - tm * q.tiles_n;
         const int m0 = tm * 256, n0 = tn * 256;
         p8w_tile<true>(smem, q.dz + m0, q.ld_dz, q.x + n0, q.ld_x, q.dw + (size_t)m0 * q.ld_dw + n0, q.ld_dw, min(256, q.n_out - m0),
-                       min(256, q.n_in - n0), q.rows, g.pf);
+                       min(256, q.n_in - n0), q.rows, q.db ? q.db + m0 : nullptr, p8w_bias_mask(q, tn), false);
         return;
     }
     const int st = (item - q.whole) / q.split, part = (item - q.whole) - st * q.split;
@@ -246,9 +272,11 @@ __global__ __launch_bounds__(512) void gemm_group_wgrad16_p8_kernel(W8Args g, fl
     const int units = (q.rows + P8W_BK - 1) / P8W_BK, upp = (units + q.split - 1) / q.split;
     const int k0 = min(q.rows, part * upp * P8W_BK), k1 = min(q.rows, k0 + upp * P8W_BK);
     const int m0 = tm * 256, n0 = tn * 256;
-    float* slab = slabs + (size_t)(q.slab0 + st * q.split + part) * 65536;
+    const int sidx = q.slab0 + st * q.split + part;
+    float* slab = slabs + (size_t)sidx * 65536;
     p8w_tile<false>(smem, q.dz + (size_t)k0 * q.ld_dz + m0, q.ld_dz, q.x + (size_t)k0 * q.ld_x + n0, q.ld_x, slab, 256,
-                    min(256, q.n_out - m0), min(256, q.n_in - n0), k1 - k0, g.pf);
+                    min(256, q.n_out - m0), min(256, q.n_in - n0), k1 - k0, slabs + (size_t)g.nslabs * 65536 + (size_t)sidx * 256,
+                    p8w_bias_mask(q, tn), true);
 }
 // dW += Σ_parts slab (part order): 16 workgroups per cut tile, 16 rows each.  Slab elements outside the valid block are never read.
 __global__ __launch_bounds__(256) void wgrad16_p8_fixup_kernel(W8Args g, const float* __restrict__ slabs) {
@@ -259,6 +287,16 @@ __global__ __launch_bounds__(256) void wgrad16_p8_fixup_kernel(W8Args g, const f
     const int st = bt - q.stile0, tile = q.whole + st;
     const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
     const float4* sl = reinterpret_cast<const float4*>(slabs + (size_t)(q.slab0 + st * q.split) * 65536);
+    const int bm = p8w_bias_mask(q, tn);
+    if (chunk == 0 && bm) {                               // bias gradient of a cut tile: the parts' strips, in part order
+        const float* bs = slabs + (size_t)g.nslabs * 65536 + (size_t)(q.slab0 + st * q.split) * 256;
+        const int c = tm * 256 + threadIdx.x;
+        if (c < q.n_out && (bm & ((threadIdx.x & 64) ? 2 : 1))) {
+            float v = bs[threadIdx.x];
+            for (int p = 1; p < q.split; ++p) v += bs[(size_t)p * 256 + threadIdx.x];
+            q.db[c] += v;
+        }
+    }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int i = chunk * 1024 + it * 256 + threadIdx.x;
@@ -281,25 +319,26 @@ struct HostWgrad16ProblemP8 { const void* dz; const void* x; float* dw; float* d
 
 extern "C" {
 
-// 1 if every problem of the table can run on this kernel: both widths ≥ 256 and multiples of 8, 16-byte aligned rows, no bias output
+// 1 if every problem of the table can run on this kernel: both widths ≥ 256 and multiples of 8, 16-byte aligned rows
 int svpc_gemm_group_wgrad_bf16_p8_ok(const void* problems, int n) {
     if (n <= 0 || n > W8_MAX) return 0;
     const HostWgrad16ProblemP8* hp = reinterpret_cast<const HostWgrad16ProblemP8*>(problems);
     for (int i = 0; i < n; ++i) {
         const HostWgrad16ProblemP8& h = hp[i];
         if (h.n_out < 256 || h.n_in < 256 || (h.n_out & 7) || (h.n_in & 7) || (h.ld_dz & 7) || (h.ld_x & 7) || (h.ld_dw & 3) || h.rows <= 0 ||
-            h.db != nullptr || ((((uintptr_t)h.dz) | ((uintptr_t)h.x) | ((uintptr_t)h.dw)) & 15) != 0)
+            ((((uintptr_t)h.dz) | ((uintptr_t)h.x) | ((uintptr_t)h.dw)) & 15) != 0 || (((uintptr_t)h.db) & 3) != 0)
             return 0;
     }
     return 1;
 }
 
-// same problem table as svpc_gemm_group_wgrad_bf16_ws (svpc_wgrad_problem with bf16 dz / x, fp32 dw, db = NULL); `workspace`: room for
-// the k-part slabs of the balanced form (65,536 floats per part; without it every tile runs whole)
+// same problem table as svpc_gemm_group_wgrad_bf16_ws (svpc_wgrad_problem with bf16 dz / x, fp32 dw); db (optional, fp32 [n_out]): the bias
+// gradient db += Σ_rows dz, taken from the dz tiles this launch holds in LDS anyway (one all-ones MFMA per fragment in the tile column 0).
+// `workspace`: room for the k-part slabs of the balanced form (65,536 + 256 floats per part; without it every tile runs whole)
 int svpc_gemm_group_wgrad_bf16_p8(const void* problems, int n, float* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (n == 0) return 0;
     SVPC_REQUIRE(svpc_gemm_group_wgrad_bf16_p8_ok(problems, n) == 1,
-                 "gemm_group_wgrad_bf16_p8: 1..48 problems, widths >= 256 and multiples of 8, 16-byte aligned rows, no bias output");
+                 "gemm_group_wgrad_bf16_p8: 1..48 problems, widths >= 256 and multiples of 8, 16-byte aligned rows");
     const HostWgrad16ProblemP8* hp = reinterpret_cast<const HostWgrad16ProblemP8*>(problems);
     W8Args g{};
     g.n = n;
@@ -321,7 +360,7 @@ int svpc_gemm_group_wgrad_bf16_p8(const void* problems, int n, float* workspace,
     for (int i = 0; i < n; ++i) {
         const HostWgrad16ProblemP8& h = hp[order[i]];
         W8Prob& q = g.p[i];
-        q.dz = (const __bf16*)h.dz; q.x = (const __bf16*)h.x; q.dw = h.dw; q.n_out = h.n_out; q.n_in = h.n_in; q.rows = h.rows;
+        q.dz = (const __bf16*)h.dz; q.x = (const __bf16*)h.x; q.dw = h.dw; q.db = h.db; q.n_out = h.n_out; q.n_in = h.n_in; q.rows = h.rows;
         q.ld_dz = h.ld_dz; q.ld_x = h.ld_x; q.ld_dw = h.ld_dw; q.tiles_n = ceil_div(h.n_in, 256);
         const int tp = ceil_div(h.n_out, 256) * q.tiles_n;
         const int units = ceil_div(h.rows, P8W_BK);
@@ -330,7 +369,7 @@ int svpc_gemm_group_wgrad_bf16_p8(const void* problems, int n, float* workspace,
         if (split < 2) split = 1;
         int whole = tp;
         if (split > 1) whole = seen >= cus ? 0 : (cus - seen < tp ? cus - seen : tp);
-        if (split > 1 && (size_t)(slabs + (tp - whole) * split) * 65536 * sizeof(float) > workspace_bytes) { split = 1; whole = tp; }
+        if (split > 1 && (size_t)(slabs + (tp - whole) * split) * (65536 + 256) * sizeof(float) > workspace_bytes) { split = 1; whole = tp; }
         if (whole == tp) split = 1;
         q.whole = whole; q.split = split; q.slab0 = slabs; q.stile0 = stiles; q.tile0 = items;
         items += whole + (tp - whole) * split;
@@ -338,12 +377,7 @@ int svpc_gemm_group_wgrad_bf16_p8(const void* problems, int n, float* workspace,
         seen += tp;
     }
     g.total = items;
-    static int chunk_env = -1;
-    if (chunk_env < 0) { const char* e = getenv("SVPC_P8W_CHUNK"); chunk_env = e ? atoi(e) : 0; }
-    g.chunk = chunk_env;
-    static int pf_env = -1;
-    if (pf_env < 0) { const char* e = getenv("SVPC_P8W_PF"); pf_env = e ? atoi(e) : 0; }
-    g.pf = pf_env;
+    g.nslabs = slabs;
     hipLaunchKernelGGL(gemm_group_wgrad16_p8_kernel, dim3(items), dim3(512), 0, stream, g, workspace);
     int rc = svpc_check_launch("gemm_group_wgrad_bf16_p8");
     if (rc || stiles == 0) return rc;

@@ -99,7 +99,10 @@ def _queue_end_of_backward_join():
 _WQ16 = []          # bf16-stream problems (dz, x, wgrad, None): one launch at the join points, whole k-loop per tile
 
 
-def _defer_wgrad16(dz, x, wgrad):
+P8W_BIAS = os.environ.get("SVPC_NO_P8W_BIAS", "") == ""      # bias gradients of the bf16-stream linears inside the grouped wgrad launch
+
+
+def _defer_wgrad16(dz, x, wgrad, bgrad=None):
     rows, n_out = dz.shape
     n_in = x.shape[1]
     if n_out % 8 or n_in % 8 or dz.stride(0) % 8 or x.stride(0) % 8 or wgrad.stride(0) % 4 or rows < 1:
@@ -107,18 +110,20 @@ def _defer_wgrad16(dz, x, wgrad):
     if (dz.data_ptr() | x.data_ptr()) % 16 or dz.stride(1) != 1 or x.stride(1) != 1 or not wgrad.is_contiguous():
         return False
     wp = wgrad.data_ptr()
-    if any(q[2].data_ptr() == wp for q in _WQ16) or len(_WQ16) >= _lib.load().svpc_gemm_group_wgrad_max():
+    bp = bgrad.data_ptr() if bgrad is not None else -1
+    if any(q[2].data_ptr() == wp or (q[3] is not None and q[3].data_ptr() == bp) for q in _WQ16) or \
+            len(_WQ16) >= _lib.load().svpc_gemm_group_wgrad_max():
         flush_wgrads()
-    _WQ16.append((dz, x, wgrad, None))
+    _WQ16.append((dz, x, wgrad, bgrad))
     _queue_end_of_backward_join()
     return True
 
 
 def defer_wgrad(dz, x, wgrad, bgrad):
     """Queue dW += dzᵀ·x (and db += Σ dz) for the grouped launch; False if this problem must be launched on its own."""
-    if USE_GROUPED_WGRAD and GROUP_BF16 and _fast() and wgrad is not None and bgrad is None and not SIDE_WGRAD and \
+    if USE_GROUPED_WGRAD and GROUP_BF16 and _fast() and wgrad is not None and not SIDE_WGRAD and \
             dz.dtype == torch.bfloat16 and x.dtype == torch.bfloat16:
-        return _defer_wgrad16(dz, x, wgrad)
+        return _defer_wgrad16(dz, x, wgrad, bgrad)
     if not (USE_GROUPED_WGRAD and _fast() and wgrad is not None and dz.dtype == torch.float32 and x.dtype == torch.float32):
         return False
     rows, n_out = dz.shape
@@ -143,18 +148,26 @@ def defer_wgrad(dz, x, wgrad, bgrad):
 def flush_wgrads(bf16=True):
     if _WQ16 and bf16:
         probs = (_WgradProblem * len(_WQ16))()
-        for i, (dz, x, wg, _) in enumerate(_WQ16):
-            probs[i] = _WgradProblem(dz.data_ptr(), x.data_ptr(), wg.data_ptr(), None, dz.shape[1], x.shape[1], dz.shape[0],
-                                     dz.stride(0), x.stride(0), wg.stride(0))
+        for i, (dz, x, wg, bg) in enumerate(_WQ16):
+            probs[i] = _WgradProblem(dz.data_ptr(), x.data_ptr(), wg.data_ptr(), bg.data_ptr() if bg is not None else None, dz.shape[1],
+                                     x.shape[1], dz.shape[0], dz.stride(0), x.stride(0), wg.stride(0))
         ws = _ws(_WQ16[0][0].device)
-        # the 8-phase template with transposed fragment reads when every problem is at least 256 wide (gemm_p8w.hip), else the round-1 form
+        # the 8-phase template with transposed fragment reads when every problem is at least 256 wide (gemm_p8w.hip: it also takes the
+        # bias gradients from the dz tiles it stages), else the round-1 form with the column sums as a pass of their own
         p8w = USE_P8W and _lib.load().svpc_gemm_group_wgrad_bf16_p8_ok(ctypes.addressof(probs), len(_WQ16)) == 1
-        _lib.call("gemm_group_wgrad_bf16_p8" if p8w else "gemm_group_wgrad_bf16_ws", ctypes.addressof(probs), len(_WQ16), _p(ws),
-                  ws.numel() * 4, _stream())
         done = list(_WQ16)
         del _WQ16[:]
-        for _, _, wg, _ in done:
+        if not p8w:
+            for i, (dz, x, wg, bg) in enumerate(done):
+                if bg is not None:
+                    probs[i].db = None
+                    defer_colsum(dz, bg)
+        _lib.call("gemm_group_wgrad_bf16_p8" if p8w else "gemm_group_wgrad_bf16_ws", ctypes.addressof(probs), len(done), _p(ws),
+                  ws.numel() * 4, _stream())
+        for _, _, wg, bg in done:
             _ready(wg, "w")
+            if bg is not None and p8w:
+                _ready(bg, "b")
     if not _WQ:
         return
     dev = _WQ[0][0].device
@@ -780,8 +793,14 @@ class _Linear(Function):
         w_done = False
         if wgrad is not None and not trans_w and (not has_b or bgrad is not None):
             if dz.dtype == torch.bfloat16:
-                if defer_wgrad(dz, x, wgrad, None):           # bf16 stream: grouped wgrad; the bias gradient goes its usual way below
+                # bf16 stream: grouped wgrad; the bias gradient rides along (taken from the dz tiles the launch stages) when it is a
+                # plain fp32 arena vector, else it goes its usual way below
+                ride = (P8W_BIAS and USE_P8W and has_b and bgrad is not None and bgrad.dtype == torch.float32 and bgrad.is_contiguous()
+                        and bgrad.numel() == N and min(N, K) >= 256)
+                if defer_wgrad(dz, x, wgrad, bgrad if ride else None):
                     w_done = True
+                    if ride:
+                        return dx, None, None, None, None, None, None, None, None, None, None
             elif defer_wgrad(dz, x, wgrad, bgrad if has_b else None):
                 return dx, None, None, None, None, None, None, None, None, None, None
         if not w_done and (wgrad is not None or ctx.needs_input_grad[1]):

@@ -115,34 +115,42 @@ def test_stream_dgrad_takes_p8t_and_matches_the_old_kernel():
 def test_grouped_wgrad_p8_vs_fp64_and_the_old_kernel():
     """svpc_gemm_group_wgrad_bf16_p8 (gemm_p8w.hip: both operands k-strided through ds_read_b64_tr_b16) on a table like a step's —
     deep and shallow problems, a ragged row count, widths that are not multiples of the tile, strided operands (the hi planes of split
-    rows), accumulation into non-zero gradients, enough deep tiles that some are cut into k-parts — against fp64, and against the
-    round-1 kernel on the same table"""
+    rows), accumulation into non-zero gradients, enough deep tiles that some are cut into k-parts, bias gradients (db += Σ_rows dz) on
+    whole and on cut tiles — against fp64, and against the round-1 kernel on the same table"""
     import ctypes
     from svpc_amd import ops as O
     specs = [(19200, 768, 768), (19200, 2304, 768), (19200, 768, 3072), (4224, 768, 768), (4224, 2304, 768), (1300, 776, 264), (576, 9216, 768),
              (19200, 768, 768), (19200, 768, 768), (19200, 2304, 768), (19200, 768, 768), (19200, 768, 768)]
+    with_bias = [True, True, False, True, True, True, True, False, True, True, True, True]
     tens, probs = [], (O._WgradProblem * len(specs))()
     for i, (rows, n_out, n_in) in enumerate(specs):
         dz = _rand(rows, n_out, seed=20 + i).to(torch.bfloat16)
         xb = _rand(rows, 2 * n_in, seed=40 + i).to(torch.bfloat16)
         x = xb[:, :n_in]                                     # a strided view: row stride 2·n_in (as the hi plane of a split tensor)
         dw0 = _rand(n_out, n_in, seed=60 + i, scale=0.5)
-        tens.append((dz, x, dw0))
+        db0 = _rand(n_out, seed=80 + i, scale=2.0)
+        tens.append((dz, x, dw0, db0))
     ws = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
     outs = {}
     for name in ("gemm_group_wgrad_bf16_p8", "gemm_group_wgrad_bf16_ws"):
         dws = [t[2].clone() for t in tens]
-        for i, ((dz, x, _), dw) in enumerate(zip(tens, dws)):
-            probs[i] = O._WgradProblem(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), None, dz.shape[1], x.shape[1], dz.shape[0], dz.stride(0),
+        dbs = [t[3].clone() for t in tens]
+        for i, ((dz, x, _, _), dw) in enumerate(zip(tens, dws)):
+            db = dbs[i].data_ptr() if (with_bias[i] and name.endswith("_p8")) else None
+            probs[i] = O._WgradProblem(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), db, dz.shape[1], x.shape[1], dz.shape[0], dz.stride(0),
                                        x.stride(0), dw.stride(0))
         if name.endswith("_p8"):
             assert _lib.load().svpc_gemm_group_wgrad_bf16_p8_ok(ctypes.addressof(probs), len(specs)) == 1
         _lib.call(name, ctypes.addressof(probs), len(specs), ws.data_ptr(), ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        outs[name] = dws
-    for i, (dz, x, dw0) in enumerate(tens):
+        outs[name] = (dws, dbs)
+    for i, (dz, x, dw0, db0) in enumerate(tens):
         ref = dw0.double() + dz.double().t() @ x.double()
         scale = float(ref.abs().max())
-        for name, dws in outs.items():
+        for name, (dws, dbs) in outs.items():
             err = float((dws[i].double() - ref).abs().max())
             assert err <= 2e-5 * scale * math.sqrt(dz.shape[0] / 1000.0) + 1e-4, (name, i, specs[i], err, scale)
+        got = outs["gemm_group_wgrad_bf16_p8"][1][i].double()
+        refb = db0.double() + (dz.double().sum(0) if with_bias[i] else 0.0)
+        errb = float((got - refb).abs().max())
+        assert errb <= 2e-5 * float(refb.abs().max()) * math.sqrt(dz.shape[0] / 1000.0) + 1e-4, ("db", i, specs[i], errb)
