@@ -162,6 +162,11 @@ int svpc_gemm_l32(const float* A, int lda, int a_kc, const float* B, int ldb, in
 int svpc_gemm_l32_r(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,
                     int N, int K, const float* bias, int act, float p_drop, unsigned site, const svpc_u64* seed, int accumulate,
                     float* workspace, size_t workspace_bytes, svpc_stream_t stream);
+/* ... and with the activation-backward factor, C = (A·B) * gact'(G) + R: G in fp32 and C's layout is what the forward of activation gact
+ * kept, z for GELU, y for ReLU or sigmoid. The dgrad of the projection that consumes an activated tensor writes the gradient of the
+ * pre-activation directly: the FFN of the step-wise encoder, model.py:565-591. No bias, activation or dropout in this form. */
+int svpc_gemm_l32_rg(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, const float* R, const float* G,
+                     int gact, int M, int N, int K, int accumulate, float* workspace, size_t workspace_bytes, svpc_stream_t stream);
 /* the same contract with bf16x3 products: every fp32 operand value enters as hi + lo bf16 terms when the MFMA fragments are built,
  * three MFMAs per product — the forward arithmetic of the ≤1e-4-parity throughput mode for every projection in fp32 storage */
 int svpc_gemm_l32_x3(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,

@@ -12,7 +12,8 @@ struct Epi {
                      // fp32: the element-wise epilogues below (svpc_gemm_l32_r)
     const void* G; int gact;   // optional: C = (A·B) ⊙ gact'(G) (+ R) — G of C's type and layout is what the forward of activation `gact` kept
                                // (z for GELU, y for ReLU / sigmoid): a dgrad whose output feeds an activation's backward applies it.
-                               // Like a bf16 R only in the 16-byte row-store epilogues of gemm_glds.hip (the launcher refuses it elsewhere)
+                               // bf16: like a bf16 R only in the 16-byte row-store epilogues of gemm_glds.hip (the launcher refuses it
+                               // elsewhere); fp32: the element-wise epilogue below (svpc_gemm_l32_rg)
 };
 
 __device__ __forceinline__ void epilogue_store(float v, int row, int col, float* __restrict__ C, int ldc, const Epi& e,
@@ -22,6 +23,7 @@ __device__ __forceinline__ void epilogue_store(float v, int row, int col, float*
     if (e.Z) e.Z[o] = v;
     v = apply_act(v, e.act);
     if (e.p_drop > 0.f) v *= drop_scale(seed, e.site, o, e.p_drop, inv_keep);
+    if (e.G) v *= act_grad_from_aux(reinterpret_cast<const float*>(e.G)[o], e.gact, false);      // (fp32 G: svpc_gemm_l32_rg)
     if (e.accumulate) v += C[o];
     if (e.R) v += reinterpret_cast<const float*>(e.R)[o];
     C[o] = v;

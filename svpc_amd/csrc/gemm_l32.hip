@@ -767,21 +767,29 @@ int svpc_gemm_group_wgrad(const void* problems, int n, hipStream_t stream) {
 
 // Same contract as svpc_gemm_mx with fp32 A, B, C (reference: every nn.Linear / matmul of model.py that is not on the
 // clip-encoder bf16 stream — e.g. :620-663 decoder, :594-617 step-wise encoder, :742-823 simulator, :1017-1025 BiLSTM).
-static int gemm_l32_x(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,
-                      int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
-                      float* workspace, size_t workspace_bytes, int x3, hipStream_t stream);
+static int gemm_l32_x(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R,
+                      const float* G, int gact, int M, int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed,
+                      int accumulate, float* workspace, size_t workspace_bytes, int x3, hipStream_t stream);
 int svpc_gemm_l32_r(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,
                     int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
                     float* workspace, size_t workspace_bytes, hipStream_t stream) {
-    return gemm_l32_x(A, lda, a_kc, B, ldb, b_kc, C, ldc, Z, R, M, N, K, bias, act, p_drop, site, seed, accumulate, workspace,
+    return gemm_l32_x(A, lda, a_kc, B, ldb, b_kc, C, ldc, Z, R, nullptr, ACT_NONE, M, N, K, bias, act, p_drop, site, seed, accumulate, workspace,
                       workspace_bytes, 0, stream);
+}
+// … and with the activation-backward factor: C = (A·B) ⊙ gact'(G) + R, G (fp32, C's layout) = what the forward of activation `gact`
+// kept (z for GELU, y for ReLU / sigmoid) — the fp32 twin of svpc_gemm_glds_rg: the dgrad of the projection that consumes an activated
+// tensor writes the gradient of the pre-activation directly (step-wise encoder FFN, model.py:565-591); no bias / activation / dropout
+int svpc_gemm_l32_rg(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, const float* R, const float* G,
+                     int gact, int M, int N, int K, int accumulate, float* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return gemm_l32_x(A, lda, a_kc, B, ldb, b_kc, C, ldc, nullptr, R, G, gact, M, N, K, nullptr, ACT_NONE, 0.f, 0u, nullptr, accumulate,
+                      workspace, workspace_bytes, 0, stream);
 }
 // the same contract with bf16x3 products: every fp32 operand value enters as hi + lo bf16 terms, three MFMAs per product — the
 // arithmetic of the ≤1e-4-parity throughput mode for every projection kept in fp32 storage (text side, step level, simulators, LSTM)
 int svpc_gemm_l32_x3(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,
                      int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
                      float* workspace, size_t workspace_bytes, hipStream_t stream) {
-    return gemm_l32_x(A, lda, a_kc, B, ldb, b_kc, C, ldc, Z, R, M, N, K, bias, act, p_drop, site, seed, accumulate, workspace,
+    return gemm_l32_x(A, lda, a_kc, B, ldb, b_kc, C, ldc, Z, R, nullptr, ACT_NONE, M, N, K, bias, act, p_drop, site, seed, accumulate, workspace,
                       workspace_bytes, 1, stream);
 }
 int svpc_gemm_l32(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, int M, int N, int K,
@@ -793,14 +801,14 @@ int svpc_gemm_l32(const float* A, int lda, int a_kc, const float* B, int ldb, in
 }  // extern "C"
 // R (optional): fp32 addend with C's leading dimension, C = epi(A·B) + R — the residual-path gradient joining the dgrad of the
 // projection that consumes the residual tensor (fp32 twin of svpc_gemm_glds_r)
-static int gemm_l32_x(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R, int M,
-                      int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed, int accumulate,
-                      float* workspace, size_t workspace_bytes, int x3, hipStream_t stream) {
+static int gemm_l32_x(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, float* Z, const float* R,
+                      const float* G, int gact, int M, int N, int K, const float* bias, int act, float p_drop, unsigned site, const u64* seed,
+                      int accumulate, float* workspace, size_t workspace_bytes, int x3, hipStream_t stream) {
     if (M == 0 || N == 0) return 0;
     SVPC_REQUIRE(svpc_gemm_l32_supported(a_kc, b_kc, lda, ldb, M, N, K) && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0,
                  "gemm_l32: needs K % 32 == 0 (or both operands k-contiguous and K % 4 == 0) and 16-byte aligned fp32 rows");
     SVPC_REQUIRE(p_drop <= 0.f || seed != nullptr, "gemm: dropout needs a seed pointer");
-    Epi epi{bias, act, p_drop, site, seed, accumulate, Z, R};
+    Epi epi{bias, act, p_drop, site, seed, accumulate, Z, R, G, gact};
     static int env_tile = -1, env_split = -1, remap = -1;
     if (env_tile < 0) { const char* e = getenv("SVPC_L32_TILE"); env_tile = e ? atoi(e) : 0; }      // 128 | 64 (deep ring) | 65 (64, 4 stages)
     if (env_split < 0) { const char* e = getenv("SVPC_L32_SPLITK"); env_split = e ? atoi(e) : 0; }

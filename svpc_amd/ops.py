@@ -610,8 +610,15 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NON
             Rk = None
         else:
             Rk, R = R, None       # absorbed by the epilogue
-        _lib.call("gemm_l32_r", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), _p(Rk), M, N, K, _p(bias), act, p, site,
-                  _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+        g_ok = (G is not None and G[0].dtype == torch.float32 and G[0].shape == C.shape and G[0].is_contiguous() and C.is_contiguous()
+                and Z is None and bias is None and act == ACT_NONE and p <= 0.0)
+        if g_ok:                  # C = (A·B) ⊙ act'(aux) + R: the activation backward of the tensor this dgrad differentiates
+            _lib.call("gemm_l32_rg", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Rk), _p(G[0]), int(G[1]), M, N, K,
+                      accumulate, _p(ws), ws.numel() * 4, _stream())
+            g_done = True
+        else:
+            _lib.call("gemm_l32_r", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), _p(Rk), M, N, K, _p(bias), act, p, site,
+                      _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
     elif _fast():
         dt = lambda t: 1 if t.dtype == torch.bfloat16 else 0
         _lib.call("gemm_mx", _p(A), dt(A), lda, a_kc, _p(B), dt(B), ldb, b_kc, _p(C), dt(C), C.stride(0), _p(Z), M, N, K, _p(bias),
@@ -702,6 +709,7 @@ def _transient_split(w):
 # that exactly one ops.linear consumes h and needs its input gradient; join_side() fails loudly if a parked gradient is left over.
 USE_RES_SINK = os.environ.get("SVPC_RES_SINK", "1") != "0"
 FUSE_ACT_BWD = os.environ.get("SVPC_FUSE_ACT_BWD", "1") != "0"      # activation backward inside the following projection's dgrad
+FUSE_ACT_BWD_F32 = os.environ.get("SVPC_FUSE_ACT_BWD_F32", "1") != "0"      # … also for fp32-storage projections (step-wise encoder)
 _RES_SINK = {}
 SINK_STATS = [0, 0]        # parked by LayerNorm backwards / absorbed by dgrad epilogues (since import)
 
@@ -863,10 +871,11 @@ def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgr
             w16 = w.detach().to(torch.bfloat16)
     else:
         w16 = None
-    fuse = (fuse_act_bwd and FUSE_ACT_BWD and act != ACT_NONE and drop is None and x.dtype == torch.bfloat16 and USE_GLDS and
-            torch.is_grad_enabled())
+    # (bf16 streams: the direct-to-LDS dgrads; fp32 storage in the fast modes: svpc_gemm_l32_rg)
+    can_g = (x.dtype == torch.bfloat16 and USE_GLDS) or (x.dtype == torch.float32 and USE_L32 and FUSE_ACT_BWD_F32 and _fast())
+    fuse = fuse_act_bwd and FUSE_ACT_BWD and act != ACT_NONE and drop is None and can_g and torch.is_grad_enabled()
     tok_out = {} if fuse else None
-    if tok_in is not None and (x.dtype != torch.bfloat16 or trans_w or not USE_GLDS):
+    if tok_in is not None and (trans_w or not can_g):
         tok_in = None
     y = _Linear.apply(x, w, b, act, trans_w, drop, wgrad, bgrad, w16, tok_out, tok_in)
     if split:

@@ -446,6 +446,36 @@ def test_gemm_l32_fp32_direct_to_lds(bf16_mode, M, N, K, a_kc, b_kc, acc, bias_a
     assert (C.double() - ref).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize("M,N,K,b_kc,gact,has_r", [(192, 768, 768, 0, O.ACT_GELU, False), (192, 768, 768, 0, O.ACT_RELU, True),
+                                                    (4224, 768, 768, 0, O.ACT_GELU, True), (200, 96, 64, 1, O.ACT_SIGMOID, False)])
+def test_gemm_l32_rg_activation_backward_in_the_dgrad_epilogue(bf16_mode, M, N, K, b_kc, gact, has_r):
+    """svpc_gemm_l32_rg: C = (A·B) ⊙ act'(G) + R in fp32 storage (the dgrad of the projection that consumes an activated tensor of the
+    step-wise encoder) against fp64 on the bf16-rounded operands"""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    B = (torch.randn(K, N, generator=g) / math.sqrt(K)).to(DEV)
+    G = torch.randn(M, N, generator=g).to(DEV)
+    if gact == O.ACT_SIGMOID:
+        G = torch.sigmoid(G)
+    R = torch.randn(M, N, generator=g).to(DEV) if has_r else None
+    Bm = B.t().contiguous() if b_kc else B
+    C = torch.empty(M, N, device=DEV)
+    ws = O._ws(C.device)
+    O._lib.call("gemm_l32_rg", A.data_ptr(), K, 1, Bm.data_ptr(), Bm.stride(0), b_kc, C.data_ptr(), N, R.data_ptr() if has_r else None,
+                G.data_ptr(), gact, M, N, K, 0, ws.data_ptr(), ws.numel() * 4, O._stream())
+    ref = A.bfloat16().double() @ B.bfloat16().double()
+    gd = G.double()
+    if gact == O.ACT_GELU:
+        ref = ref * (0.5 * (1.0 + torch.erf(gd / math.sqrt(2.0))) + gd * torch.exp(-0.5 * gd * gd) / math.sqrt(2.0 * math.pi))
+    elif gact == O.ACT_RELU:
+        ref = ref * (gd > 0).double()
+    else:
+        ref = ref * gd * (1.0 - gd)
+    if has_r:
+        ref = ref + R.double()
+    assert (C.double() - ref).abs().max().item() <= 2e-6 * math.sqrt(K) * max(1.0, ref.abs().max().item())
+
+
 def test_gemm_l32_unsupported_shapes_fall_back(bf16_mode):
     """a k tail with a k-strided operand, K < 32, K % 4 != 0, or a k-strided operand whose row count is not a multiple of 4 stay on
     the register-staged kernel; a k tail with both operands k-contiguous runs on the direct-to-LDS kernel."""
