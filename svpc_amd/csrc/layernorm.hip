@@ -688,7 +688,7 @@ int svpc_ln_fwd(const float* x, const int* src_rows, const float* res, const flo
 // workspace: at least svpc_ln_bwd_groups(R) * 2 * D floats
 int svpc_ln_bwd_groups(int R) {
     static int cap = -1, rpw = -1;
-    if (cap < 0) { const char* e = getenv("SVPC_LN_GROUPS"); cap = e ? atoi(e) : 768; /* three 4-wave workgroups per CU at 12 values per lane (best of 512 / 768 / 1024) */ }
+    if (cap < 0) { const char* e = getenv("SVPC_LN_GROUPS"); cap = e ? atoi(e) : 1024; /* four 4-wave workgroups per CU at 12 values per lane: 512 / 768 / 1024 / 1536 groups = 31.9 / 25.7 / 23.6 / worse µs per launch averaged over a step's 29 (same box, round 3) */ }
     if (rpw < 0) { const char* e = getenv("SVPC_LN_ROWS_PER_WAVE"); rpw = e ? atoi(e) : 1; }
     int g = ceil_div(R, 4 * rpw);
     return g < 1 ? 1 : (g > cap ? cap : g);
