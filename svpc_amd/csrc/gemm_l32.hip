@@ -228,12 +228,23 @@ __global__ __launch_bounds__(256) void gemm_l32_kernel(const float* __restrict__
 // bytes in flight per CU — these launches are bound by the memory round trip per k-tile, nothing else.
 // `asum` (optional): += Σ_k A(m, k) for the tile's 64 rows m — the bias gradient of a wgrad (A = dz, k-strided) — taken from the
 // fp32 LDS image (not the bf16-rounded fragments) by the workgroups of the first tile column.
-template <bool A_KC, bool B_KC, int NS = 2, bool X3 = false>
+// PRE (the grouped weight gradients: a plain accumulate epilogue): the 16 values of C a thread will add to are requested BEFORE the
+// operand tiles, so the read half of the read-modify-write travels with the operands instead of after the reduction.
+template <bool A_KC, bool B_KC, int NS = 2, bool X3 = false, bool PRE = false>
 __device__ __forceinline__ void l32w_tile(char* l32_smem, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                           float* __restrict__ C, int ldc, int M, int N, int K, const Epi& epi, int tm, int tn,
                                           float* __restrict__ asum) {
     constexpr int T = 64, OP = T * L32_BK * 4, STAGE = 2 * OP, PIECES = OP / 1024;      // 8 pieces of 1 KiB per operand tile; NS stages per wave
     const int m0 = tm * T, n0 = tn * T;
+    float cpre[PRE ? T * T / 256 : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int u = 0; u < T * T / 256; ++u) {
+            const int idx = threadIdx.x + 256 * u;
+            const int row = m0 + (idx >> 6), col = n0 + (idx & 63);
+            cpre[u] = (row < M && col < N) ? C[(size_t)row * ldc + col] : 0.f;
+        }
+    }
     const bool want_asum = !A_KC && asum != nullptr && tn == 0;
     float bsum = 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -348,7 +359,8 @@ __device__ __forceinline__ void l32w_tile(char* l32_smem, const float* __restric
         const int r = idx >> 6, c = idx & 63;
         const float v = ((p0[idx] + p0[T * T + idx]) + p0[2 * T * T + idx]) + p0[3 * T * T + idx];
         const int row = m0 + r, col = n0 + c;
-        if (row < M && col < N) epilogue_store(v, row, col, C, ldc, epi, seed, inv_keep);
+        if constexpr (PRE) { if (row < M && col < N) C[(size_t)row * ldc + col] = v + cpre[u]; }
+        else if (row < M && col < N) epilogue_store(v, row, col, C, ldc, epi, seed, inv_keep);
     }
     if (want_asum && threadIdx.x < T && m0 + (int)threadIdx.x < M) {
         const int i = threadIdx.x;
@@ -382,7 +394,7 @@ __global__ __launch_bounds__(256) void gemm_group_wgrad_kernel(GArgs g) {
     const int tile = blockIdx.x - q.tile0;
     const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
     Epi epi{nullptr, ACT_NONE, 0.f, 0u, nullptr, 1, nullptr};
-    l32w_tile<false, false, NS>(l32_smem, q.dz, q.ld_dz, q.x, q.ld_x, q.dw, q.ld_dw, q.n_out, q.n_in, q.rows, epi, tm, tn, q.db);
+    l32w_tile<false, false, NS, false, true>(l32_smem, q.dz, q.ld_dz, q.x, q.ld_x, q.dw, q.ld_dw, q.n_out, q.n_in, q.rows, epi, tm, tn, q.db);
 }
 
 
