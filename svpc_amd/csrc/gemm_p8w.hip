@@ -211,19 +211,38 @@ __device__ __forceinline__ void p8w_tile(char* __restrict__ smem, const __bf16* 
 #undef P8W_FRAG
 #undef P8W_BIAS
 
-    // ---- epilogue: a lane holds columns 4q … 4q+3 of row l15 of every 16×16 block: one 16-byte read-modify-write each
+    // ---- epilogue: a lane holds columns 4q … 4q+3 of row l15 of every 16×16 block: one 16-byte read-modify-write each.  The reads of
+    // TWO row blocks (8 × 16 bytes per lane) are issued together, then their sums are stored: written as one load → add → store per block
+    // the compiler must keep every load behind the previous store (the addresses may alias for all it knows) — 32 dependent memory round
+    // trips per tile instead of 4.
     const int l15 = lane & 15, q = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = wr * 128 + i * 16 + l15;
-        if (row >= Mv) continue;
+    for (int i0 = 0; i0 < 8; i0 += 2) {
+        floatx4 old[2][4];
+        if (ACCUM) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = wc * 64 + j * 16 + 4 * q;
-            if (col + 4 > Nv) continue;                   // Nv % 8 == 0: a group of four is inside or outside as a whole
-            floatx4* d = reinterpret_cast<floatx4*>(C + (size_t)row * ldc + col);
-            if (ACCUM) { floatx4 o = *d; o += acc[i][j]; *d = o; }
-            else *d = acc[i][j];
+            for (int u = 0; u < 2; ++u) {
+                const int row = wr * 128 + (i0 + u) * 16 + l15;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = wc * 64 + j * 16 + 4 * q;
+                    old[u][j] = (row < Mv && col + 4 <= Nv) ? *reinterpret_cast<const floatx4*>(C + (size_t)row * ldc + col)
+                                                            : floatx4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = wr * 128 + (i0 + u) * 16 + l15;
+            if (row >= Mv) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = wc * 64 + j * 16 + 4 * q;
+                if (col + 4 > Nv) continue;               // Nv % 8 == 0: a group of four is inside or outside as a whole
+                floatx4* d = reinterpret_cast<floatx4*>(C + (size_t)row * ldc + col);
+                if (ACCUM) *d = old[u][j] + acc[i0 + u][j];
+                else *d = acc[i0 + u][j];
+            }
         }
     }
     if (bmask && q == 0) {                                // lanes 0-15: column l15 of the wave's two blocks (every output column holds the sum)
