@@ -46,6 +46,43 @@ __device__ __forceinline__ void p8t_store_half(const floatx4 (&acc)[8][4], int j
                                                const __bf16* __restrict__ R, int ldc, int row0, int col0, int M, int N, int lane,
                                                char* __restrict__ wl) {
     const int l15 = lane & 15, q = lane >> 4;
+    const int c8 = lane & 3, cc = col0 + 32 * jh + 8 * c8, r0 = lane >> 2;      // 8 columns = chunks 2·c8, 2·c8 + 1
+    const bool col_ok = cc + 8 <= N;
+    // the G / R pieces of all 8 row groups are requested FIRST and land under the LDS staging: written as load → use → store per row
+    // group the compiler has to keep every load behind the previous store (16 dependent round trips per tile: + 10 µs for R, + 18 for G)
+    bf16x8 gv[GACT != ACT_NONE ? 8 : 1], rv[HASR ? 8 : 1];
+    // an interior block (the common case) runs without per-row predicates: with them every store sits in its own exec-masked region
+    // and the compiler drains the memory counter in front of each (8 store round trips per pass instead of 1)
+    const bool interior = row0 + 128 <= M && col0 + 32 * jh + 32 <= N;      // wave-uniform
+#define P8T_EPI_LOADS(GUARD)                                                                                               \
+    _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                                     \
+        const int r = it * 16 + r0;                                                                                        \
+        if (!(GUARD) || (col_ok && row0 + r < M)) {                                                                        \
+            const size_t o = (size_t)(row0 + r) * ldc + cc;                                                                \
+            if (GACT != ACT_NONE) gv[it] = *reinterpret_cast<const bf16x8*>(G + o);                                        \
+            if (HASR) rv[it] = *reinterpret_cast<const bf16x8*>(R + o);                                                    \
+        }                                                                                                                  \
+    }
+#define P8T_EPI_STORES(GUARD)                                                                                              \
+    _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                                     \
+        const int r = it * 16 + r0;                                                                                        \
+        const floatx4 v0 = *reinterpret_cast<const floatx4*>(wl + r * 128 + (((2 * c8) ^ (r & 7)) << 4));                  \
+        const floatx4 v1 = *reinterpret_cast<const floatx4*>(wl + r * 128 + (((2 * c8 + 1) ^ (r & 7)) << 4));              \
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};                                             \
+        if (!(GUARD) || (col_ok && row0 + r < M)) {                                                                        \
+            const size_t o = (size_t)(row0 + r) * ldc + cc;                                                                \
+            if (GACT != ACT_NONE) {                                                                                        \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] *= act_grad_from_aux((float)gv[it][j], GACT, true);     \
+            }                                                                                                              \
+            if (HASR) {                                                                                                    \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] += (float)rv[it][j];                                    \
+            }                                                                                                              \
+            bf16x8 ov;                                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) ov[j] = (__bf16)v[j];                                            \
+            *reinterpret_cast<bf16x8*>(C + o) = ov;                                                                        \
+        }                                                                                                                  \
+    }
+    if (interior) { P8T_EPI_LOADS(false) } else { P8T_EPI_LOADS(true) }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = i * 16 + l15;
@@ -55,32 +92,9 @@ __device__ __forceinline__ void p8t_store_half(const floatx4 (&acc)[8][4], int j
             *reinterpret_cast<floatx4*>(wl + r * 128 + ((c16 ^ (r & 7)) << 4)) = acc[i][2 * jh + jj];
         }
     }
-    const int c8 = lane & 3, cc = col0 + 32 * jh + 8 * c8, r0 = lane >> 2;      // 8 columns = chunks 2·c8, 2·c8 + 1
-    const bool col_ok = cc + 8 <= N;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int r = it * 16 + r0;
-        const floatx4 v0 = *reinterpret_cast<const floatx4*>(wl + r * 128 + (((2 * c8) ^ (r & 7)) << 4));
-        const floatx4 v1 = *reinterpret_cast<const floatx4*>(wl + r * 128 + (((2 * c8 + 1) ^ (r & 7)) << 4));
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        if (col_ok && row0 + r < M) {
-            const size_t o = (size_t)(row0 + r) * ldc + cc;
-            if (GACT != ACT_NONE) {
-                const bf16x8 g = *reinterpret_cast<const bf16x8*>(G + o);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= act_grad_from_aux((float)g[j], GACT, true);
-            }
-            if (HASR) {
-                const bf16x8 rr = *reinterpret_cast<const bf16x8*>(R + o);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
-            }
-            bf16x8 ov;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ov[j] = (__bf16)v[j];
-            *reinterpret_cast<bf16x8*>(C + o) = ov;
-        }
-    }
+    if (interior) { P8T_EPI_STORES(false) } else { P8T_EPI_STORES(true) }
+#undef P8T_EPI_LOADS
+#undef P8T_EPI_STORES
 }
 
 template <int GACT, bool HASR>

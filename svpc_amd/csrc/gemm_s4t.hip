@@ -120,6 +120,14 @@ __global__ __launch_bounds__(512, NS == 2 ? 2 : 1) void gemm_s4t_kernel(const __
     char* wl = smem + wave * 8192;
     const int row0 = m0 + wr * 32, col0 = n0 + wc * 64;
     const int l15 = lane & 15, q = lane >> 4;
+    const int c8 = lane & 7, cc = col0 + 8 * c8, r0 = lane >> 3;
+    const bool col_ok = cc + 8 <= N;
+    bf16x8 rv[HASR ? 4 : 1];                                     // the R pieces of all four row groups are requested first (see gemm_p8t.hip)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + r0;
+        if (HASR && col_ok && row0 + r < M) rv[it] = *reinterpret_cast<const bf16x8*>(R + (size_t)(row0 + r) * ldc + cc);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = i * 16 + l15;
@@ -129,8 +137,6 @@ __global__ __launch_bounds__(512, NS == 2 ? 2 : 1) void gemm_s4t_kernel(const __
             *reinterpret_cast<floatx4*>(wl + r * 256 + ((c16 ^ (r & 7)) << 4)) = acc[i][j];
         }
     }
-    const int c8 = lane & 7, cc = col0 + 8 * c8, r0 = lane >> 3;
-    const bool col_ok = cc + 8 <= N;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int r = it * 8 + r0;
@@ -140,9 +146,8 @@ __global__ __launch_bounds__(512, NS == 2 ? 2 : 1) void gemm_s4t_kernel(const __
         if (col_ok && row0 + r < M) {
             const size_t o = (size_t)(row0 + r) * ldc + cc;
             if (HASR) {
-                const bf16x8 rr = *reinterpret_cast<const bf16x8*>(R + o);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
+                for (int j = 0; j < 8; ++j) v[j] += (float)rv[it][j];
             }
             bf16x8 ov;
 #pragma unroll
