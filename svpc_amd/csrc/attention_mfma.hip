@@ -90,27 +90,37 @@ struct RowStage {
     float4 raw[NIT];     // 16 bytes: 4 fp32 values or 8 bf16 values
     int tid;
     __device__ __forceinline__ RowStage(int t) : tid(t) {}
+    // rows past the sequence are read from its last row and zeroed when the image is written (store): a per-lane predicate around the
+    // load puts every load in an exec-masked region of its own, and the compiler then waits for each before it issues the next (seen in
+    // the fp32 instances: 32 memory round trips in a row instead of one); a select right behind the load draws the wait up as well
+    int len_;
     __device__ __forceinline__ void load(const T* __restrict__ src, int ld, int len) {
+        len_ = len;
+        if (len <= 0) {                                   // (wave-uniform)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) raw[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int u = tid + NT * it, row = u / UPR, c = u - row * UPR;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < len) t = *reinterpret_cast<const float4*>(src + (size_t)row * ld + EPU * c);
-            raw[it] = t;
+            raw[it] = *reinterpret_cast<const float4*>(src + (size_t)min(row, len - 1) * ld + EPU * c);
         }
     }
     __device__ __forceinline__ void store(char* __restrict__ img, float scale) const {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int u = tid + NT * it, row = u / UPR, c = u - row * UPR;
+            const bool ok = row < len_;
+            const float4 rw = make_float4(ok ? raw[it].x : 0.f, ok ? raw[it].y : 0.f, ok ? raw[it].z : 0.f, ok ? raw[it].w : 0.f);
             if (sizeof(T) == 4) {
                 bf16x4 b;
-                b[0] = (__bf16)(raw[it].x * scale); b[1] = (__bf16)(raw[it].y * scale);
-                b[2] = (__bf16)(raw[it].z * scale); b[3] = (__bf16)(raw[it].w * scale);
+                b[0] = (__bf16)(rw.x * scale); b[1] = (__bf16)(rw.y * scale);
+                b[2] = (__bf16)(rw.z * scale); b[3] = (__bf16)(rw.w * scale);
                 *reinterpret_cast<bf16x4*>(img + row * AImg<DH>::RS + c * 8) = b;
             } else {
                 union { float4 f; bf16x8 h; } cv;
-                cv.f = raw[it];
+                cv.f = rw;
                 if (scale != 1.0f) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) cv.h[j] = (__bf16)((float)cv.h[j] * scale);
@@ -484,6 +494,13 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
     // Every global load of the prologue (K, V, Q, dO images and the dO/O row segments of delta) is issued before the first
     // conversion or LDS store: one memory round trip instead of one per image / per delta row.
     {
+        // (the two per-row scalars first, with clamped indices and no per-lane branch: written inside the store loop below they end up
+        // behind the wait for the row images, each with a memory round trip of its own)
+        float kmv = 1.0f, lsv = 0.f;
+        if (tid < AT) {
+            if (a.key_mask) kmv = a.key_mask[k_off + min(tid, max(k_len - 1, 0))];
+            lsv = a.LSE[((size_t)s * a.H + h) * a.max_q + min(tid, max(q_len - 1, 0))];
+        }
         RowStage<DH, T, AT, NT> sk(tid), sv(tid), sq(tid), sd(tid);
         sk.load((const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len);
         sv.load((const T*)a.V + (size_t)k_off * a.ldv + h * DH, a.ldv, k_len);
@@ -503,9 +520,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
                 y[c] = reinterpret_cast<const dvec*>(oo)[c];
             }
         }
-        for (int j = tid; j < AT; j += NT) {
-            mterm[j] = j < k_len ? (1.0f - (a.key_mask ? a.key_mask[k_off + j] : 1.0f)) * -10000.0f : -INFINITY;
-            lse[j] = j < q_len ? a.LSE[((size_t)s * a.H + h) * a.max_q + j] : 0.f;
+        static_assert(AT <= NT, "one thread per image row");
+        if (tid < AT) {
+            mterm[tid] = tid < k_len ? (1.0f - kmv) * -10000.0f : -INFINITY;
+            lse[tid] = tid < q_len ? lsv : 0.f;
         }
         sk.store(Ks, 1.0f); sv.store(Vs, 1.0f); sq.store(Qs, a.scale); sd.store(Ds, 1.0f);
         float d = 0.f;
