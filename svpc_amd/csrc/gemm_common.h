@@ -30,6 +30,61 @@ __device__ __forceinline__ void epilogue_store(float v, int row, int col, float*
 }
 
 
+// The same epilogue for NE elements of one thread at once: every load it needs (bias, the old C of an accumulate, R, G) is issued before
+// the first is consumed.  Called element by element (epilogue_store in a loop) each conditional load sits in a region of its own and the
+// compiler drains the memory counter behind every one of them — NE × (features) dependent round trips per thread.  `row` / `col` must be
+// valid (clamped) coordinates for every element; `ok[k]` says whether element k is stored.  Same arithmetic, same order.
+template <int NE>
+__device__ __forceinline__ void epilogue_store_n(const float (&vin)[NE], const int (&row)[NE], const int (&col)[NE], const bool (&ok)[NE],
+                                                 float* __restrict__ C, int ldc, const Epi& e, u64 seed, float inv_keep) {
+    size_t o[NE];
+    float b[NE], old[NE], r[NE], g[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) { o[k] = (size_t)row[k] * ldc + col[k]; b[k] = 0.f; old[k] = 0.f; r[k] = 0.f; g[k] = 0.f; }
+    if (e.bias) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) b[k] = e.bias[col[k]];
+    }
+    if (e.accumulate) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) old[k] = C[o[k]];
+    }
+    if (e.R) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) r[k] = reinterpret_cast<const float*>(e.R)[o[k]];
+    }
+    if (e.G) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) g[k] = reinterpret_cast<const float*>(e.G)[o[k]];
+    }
+    float v[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) v[k] = vin[k] + b[k];
+    if (e.Z) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+            if (ok[k]) e.Z[o[k]] = v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        float t = apply_act(v[k], e.act);
+        if (e.p_drop > 0.f) t *= drop_scale(seed, e.site, o[k], e.p_drop, inv_keep);
+        if (e.G) t *= act_grad_from_aux(g[k], e.gact, false);
+        v[k] = (t + old[k]) + r[k];
+    }
+    bool all_ok = true;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) all_ok = all_ok && ok[k];
+    if (__all(all_ok)) {                                  // interior (wave-uniform): stores back to back, no exec-masked regions
+#pragma unroll
+        for (int k = 0; k < NE; ++k) C[o[k]] = v[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+            if (ok[k]) C[o[k]] = v[k];
+    }
+}
+
 // typed variant: C and the optional pre-activation copy Z are stored as TC (float or __bf16)
 template <typename TC>
 __device__ __forceinline__ void epilogue_store_t(float v, int row, int col, TC* __restrict__ C, int ldc, const Epi& e, u64 seed,

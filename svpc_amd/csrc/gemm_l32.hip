@@ -210,13 +210,22 @@ __global__ __launch_bounds__(256) void gemm_l32_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wc * (BN / 2) + j * 32 + l31;
+            if (splitk == 1) {                            // (wave-uniform) the 16 elements of a lane with every epilogue load in flight at once
+                float vs[16]; int rs[16], cs[16]; bool oks[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                    vs[e] = acc[i][j][e]; oks[e] = row < M && col < N; rs[e] = min(row, M - 1); cs[e] = min(col, N - 1);
+                }
+                epilogue_store_n<16>(vs, rs, cs, oks, C, ldc, epi, seed, inv_keep);
+                continue;
+            }
             if (col >= N) continue;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
                 if (row >= M) continue;
-                if (splitk == 1) epilogue_store(acc[i][j][e], row, col, C, ldc, epi, seed, inv_keep);
-                else slabs[((size_t)ks_id * M + row) * N + col] = acc[i][j][e];
+                slabs[((size_t)ks_id * M + row) * N + col] = acc[i][j][e];
             }
         }
 }
@@ -353,15 +362,18 @@ __device__ __forceinline__ void l32w_tile(char* l32_smem, const float* __restric
     const float* p0 = reinterpret_cast<const float*>(l32_smem);
     const u64 seed = epi.p_drop > 0.f ? epi.seed[0] : 0ull;
     const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
+    constexpr int NE = T * T / 256;
+    float vs[NE]; int rs[NE], cs[NE]; bool oks[NE];
 #pragma unroll
-    for (int u = 0; u < T * T / 256; ++u) {
+    for (int u = 0; u < NE; ++u) {
         const int idx = threadIdx.x + 256 * u;
         const int r = idx >> 6, c = idx & 63;
         const float v = ((p0[idx] + p0[T * T + idx]) + p0[2 * T * T + idx]) + p0[3 * T * T + idx];
         const int row = m0 + r, col = n0 + c;
         if constexpr (PRE) { if (row < M && col < N) C[(size_t)row * ldc + col] = v + cpre[u]; }
-        else if (row < M && col < N) epilogue_store(v, row, col, C, ldc, epi, seed, inv_keep);
+        else { vs[u] = v; oks[u] = row < M && col < N; rs[u] = min(row, M - 1); cs[u] = min(col, N - 1); }
     }
+    if constexpr (!PRE) epilogue_store_n<NE>(vs, rs, cs, oks, C, ldc, epi, seed, inv_keep);      // every load of the epilogue in flight at once
     if (want_asum && threadIdx.x < T && m0 + (int)threadIdx.x < M) {
         const int i = threadIdx.x;
         asum[m0 + i] += ((bpart[i] + bpart[T + i]) + bpart[2 * T + i]) + bpart[3 * T + i];
@@ -484,7 +496,7 @@ static int gemm_group_go(const GemmGroupArgs& g, int tiles, hipStream_t stream) 
 template <bool B_KC, int NW, bool X3 = false>
 __device__ __forceinline__ void skinny_partials(float (*part)[16][64], const float* __restrict__ arow, const float* __restrict__ brow,
                                                 int ldb, int K) {
-    constexpr int BATCH = 12;
+    constexpr int BATCH = NW == 8 ? 10 : 12;          // (12 spills 21 registers in the 512-thread form)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nsteps = K >> 4;                                  // 16-deep k-steps; this wave takes wave, wave+NW, …
     floatx16 acc;
@@ -550,15 +562,20 @@ __device__ __forceinline__ void skinny_tile(float (*part)[16][64], const float* 
     const u64 seed = epi.p_drop > 0.f ? epi.seed[0] : 0ull;
     const float inv_keep = epi.p_drop > 0.f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
     const int col = threadIdx.x & 31;
+    constexpr int NE = 16 / NW;
+    float vs[NE]; int rs[NE], cs[NE]; bool oks[NE];
 #pragma unroll
-    for (int i = 0; i < 16 / NW; ++i) {
+    for (int i = 0; i < NE; ++i) {
         const int row = (threadIdx.x >> 5) + 2 * NW * i;        // accumulator element e of lane l holds row (e&3) + 8(e>>2) + 4(l>>5), column l&31
         const int e = (row & 3) + 4 * (row >> 3), l = col + 32 * ((row >> 2) & 1);
         float v = part[0][e][l];
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += part[w][e][l];        // wave order: deterministic
-        if (m0 + row < M && n0 + col < N) epilogue_store(v, m0 + row, n0 + col, C, ldc, epi, seed, inv_keep);
+        vs[i] = v;
+        oks[i] = m0 + row < M && n0 + col < N;
+        rs[i] = min(m0 + row, M - 1); cs[i] = min(n0 + col, N - 1);
     }
+    epilogue_store_n<NE>(vs, rs, cs, oks, C, ldc, epi, seed, inv_keep);      // every load of the epilogue in flight at once
 }
 template <bool B_KC, bool X3 = false>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
