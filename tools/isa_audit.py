@@ -29,6 +29,6 @@ for src in sys.argv[1:]:
             continue
         lone = len(re.findall(r"(?<![L])LW", "W" + s))          # a single load directly followed by a full wait
         rmw = len(re.findall(r"LWS", s))
-        if lone >= 4 or rmw >= 4:
+        if lone >= int(__import__("os").environ.get("AUDIT_MIN", "4")) or rmw >= int(__import__("os").environ.get("AUDIT_MIN", "4")):
             dem = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip()[:110]
             print(f"{src.split('/')[-1]:22s} loads {loads:3d}  lone load+wait {lone:3d}  load-wait-store {rmw:3d}  {dem}")
