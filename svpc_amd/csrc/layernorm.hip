@@ -247,7 +247,11 @@ __global__ __launch_bounds__(256, (W == 4 && NPL * W <= 12 && RU == 2) ? 4 : 1) 
     for (int r0 = blockIdx.x * 4 + wave; r0 < a.R; r0 += stride * RU) {
         float h[RU][NPL * W], d[RU][NPL * W];
         float mean[RU], rstd[RU];
-        // ---- load phase: every row's bytes are requested before anything is consumed
+        // ---- load phase.  `full` (wave-uniform: the row fills the lanes exactly, D = 64·NPL·W) takes the loads of a row out of every
+        // per-lane predicate and feature test: left inside `if (col < D)` / `if (a.res)` each load sits in an exec-masked region of its
+        // own and the compiler drains the memory counter behind it — 9 dependent round trips per row pair instead of 2
+        // (tools/isa_audit.py; both rows' loads before any arithmetic would be 1, but spills at the 128 registers of four waves per SIMD)
+        const bool full = D == NPL * W * 64;
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             const int r = r0 + u * stride;
@@ -255,6 +259,29 @@ __global__ __launch_bounds__(256, (W == 4 && NPL * W <= 12 && RU == 2) ? 4 : 1) 
                 const size_t xrow = (size_t)(a.src_rows ? a.src_rows[r] : r) * a.ldx;
                 const size_t orow = (size_t)r * D, rrow = (size_t)r * a.ldr;
                 mean[u] = a.mean[r]; rstd[u] = a.rstd[r];
+                if (full) {
+                    float t[NPL * W];
+#pragma unroll
+                    for (int i = 0; i < NPL; ++i) VecIO<W, TX>::load(xp + xrow + (lane + 64 * i) * W, &h[u][i * W]);
+#pragma unroll
+                    for (int i = 0; i < NPL; ++i) VecIO<W, TY>::load(dyp + orow + (lane + 64 * i) * W, &d[u][i * W]);
+                    if (a.res) {
+#pragma unroll
+                        for (int i = 0; i < NPL; ++i) VecIO<W, TY>::load(rp + rrow + (lane + 64 * i) * W, &t[i * W]);
+                    }
+                    if (a.p_pre > 0.f) {
+#pragma unroll
+                        for (int i = 0; i < NPL; ++i)
+#pragma unroll
+                            for (int j = 0; j < W; ++j)
+                                h[u][i * W + j] *= drop_scale(seed, a.site_pre, orow + (lane + 64 * i) * W + j, a.p_pre, ik_pre);
+                    }
+                    if (a.res) {
+#pragma unroll
+                        for (int k = 0; k < NPL * W; ++k) h[u][k] += t[k];
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < NPL; ++i) {
                     const int col = (lane + 64 * i) * W;
