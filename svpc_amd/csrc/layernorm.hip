@@ -113,8 +113,51 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
 
     float v[NPL * W];
     float sum = 0.f;
+    // `full` (wave-uniform: the row fills the lanes exactly, D = 64·NPL·W): the loads of the row without per-lane predicates and feature
+    // tests around them — inside `if (col < D)` / `if (a.res)` each load sits in an exec-masked region of its own with a drain of the
+    // memory counter behind it (NPL dependent round trips per row for x, NPL more for the residual, NPL more for gamma / beta:
+    // tools/isa_audit.py)
+    const bool full = D == NPL * W * 64;
+    if (full) {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) ln_load<W, TX>(xp + xrow + (lane + 64 * i) * W, a.lox, &v[i * W]);
+        if constexpr (NPL * W <= 16) {
+            float t[NPL * W];
+            if (a.res) {
+#pragma unroll
+                for (int i = 0; i < NPL; ++i) ln_load<W, TY>(rp + rrow + (lane + 64 * i) * W, a.lor, &t[i * W]);
+            }
+            if (a.p_pre > 0.f) {
+#pragma unroll
+                for (int k = 0; k < NPL * W; ++k)
+                    v[k] *= drop_scale(seed, a.site_pre, orow + (lane + 64 * (k / W)) * W + (k % W), a.p_pre, ik_pre);
+            }
+            if (a.res) {
+#pragma unroll
+                for (int k = 0; k < NPL * W; ++k) v[k] += t[k];
+            }
+        } else {
+            if (a.p_pre > 0.f) {
+#pragma unroll
+                for (int k = 0; k < NPL * W; ++k)
+                    v[k] *= drop_scale(seed, a.site_pre, orow + (lane + 64 * (k / W)) * W + (k % W), a.p_pre, ik_pre);
+            }
+            if (a.res) {
+#pragma unroll
+                for (int i = 0; i < NPL; ++i) {
+                    float t[W];
+                    ln_load<W, TY>(rp + rrow + (lane + 64 * i) * W, a.lor, t);
+#pragma unroll
+                    for (int j = 0; j < W; ++j) v[i * W + j] += t[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NPL * W; ++k) sum += v[k];
+    }
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
+        if (full) break;
         const int col = (lane + 64 * i) * W;
         if (col < D) {
             ln_load<W, TX>(xp + xrow + col, a.lox, &v[i * W]);
@@ -153,6 +196,48 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
     }
     const size_t a1row = a.add1 ? (size_t)(r % a.mod1) * D : 0;
     const size_t a2row = a.add2 ? (size_t)a.idx2[r] * D : 0;
+    if (full) {                                           // gamma / beta / table rows of up to four column groups in flight at once
+        constexpr int CH = NPL < 4 ? NPL : 4;
+#pragma unroll
+        for (int i0 = 0; i0 < NPL; i0 += CH) {
+            float g[CH][W], b[CH][W], t1[CH][W], t2[CH][W];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (i0 + c < NPL) {
+                    const int col = (lane + 64 * (i0 + c)) * W;
+                    VecIO<W, float>::load(a.gamma + col, g[c]);
+                    VecIO<W, float>::load(a.beta + col, b[c]);
+                }
+            }
+            if (a.add1) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    if (i0 + c < NPL) VecIO<W, float>::load(a.add1 + a1row + (lane + 64 * (i0 + c)) * W, t1[c]);
+            }
+            if (a.add2) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    if (i0 + c < NPL) VecIO<W, float>::load(a.add2 + a2row + (lane + 64 * (i0 + c)) * W, t2[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (i0 + c < NPL) {
+                    const int i = i0 + c, col = (lane + 64 * i) * W;
+                    float o[W];
+#pragma unroll
+                    for (int j = 0; j < W; ++j) {
+                        float t = (v[i * W + j] - mean) * rstd * g[c][j] + b[c][j];
+                        if (a.p_post > 0.f) t *= drop_scale(seed, a.site_post, orow + col + j, a.p_post, ik_post);
+                        if (a.add1) t += t1[c][j];
+                        if (a.add2) t += t2[c][j];
+                        o[j] = t;
+                    }
+                    ln_store<W, TY>(yp + yrow + col, a.loy, o);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int col = (lane + 64 * i) * W;
