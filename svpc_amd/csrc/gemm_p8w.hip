@@ -316,21 +316,35 @@ __global__ __launch_bounds__(256) void wgrad16_p8_fixup_kernel(W8Args g, const f
             q.db[c] += v;
         }
     }
+    // the old dW values of all four pieces are requested first, then each piece's parts together (written as load → add → load … → store
+    // per piece every load waited for the one before it: tools/isa_audit.py)
+    float4 oldv[4];
+    bool okv[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int i = chunk * 1024 + it * 256 + threadIdx.x;
         const int row = i >> 6, c4 = i & 63;
         const int gr = tm * 256 + row, gc = tn * 256 + 4 * c4;
-        if (gr >= q.n_out || gc >= q.n_in) continue;
-        float4 v = sl[i];
-        for (int p = 1; p < q.split; ++p) {
-            const float4 t = sl[(size_t)p * 16384 + i];
-            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-        }
-        float4* d = reinterpret_cast<float4*>(q.dw + (size_t)gr * q.ld_dw + gc);
-        float4 o = *d;
+        okv[it] = gr < q.n_out && gc < q.n_in;
+        oldv[it] = okv[it] ? *reinterpret_cast<const float4*>(q.dw + (size_t)gr * q.ld_dw + gc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = chunk * 1024 + it * 256 + threadIdx.x;
+        const int row = i >> 6, c4 = i & 63;
+        const int gr = tm * 256 + row, gc = tn * 256 + 4 * c4;
+        if (!okv[it]) continue;
+        float4 pv[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            if (p < q.split) pv[p] = sl[(size_t)p * 16384 + i];      // (split ≤ 8: wave-uniform)
+        float4 v = pv[0];
+#pragma unroll
+        for (int p = 1; p < 8; ++p)
+            if (p < q.split) { v.x += pv[p].x; v.y += pv[p].y; v.z += pv[p].z; v.w += pv[p].w; }
+        float4 o = oldv[it];
         o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-        *d = o;
+        *reinterpret_cast<float4*>(q.dw + (size_t)gr * q.ld_dw + gc) = o;
     }
 }
 

@@ -27,7 +27,7 @@ for src in sys.argv[1:]:
         loads = s.count("L")
         if loads < 4:
             continue
-        lone = len(re.findall(r"(?<![L])LW", "W" + s))          # a single load directly followed by a full wait
+        lone = len(re.findall(r"(?<![L])L{1,2}W", "W" + s))     # one or two loads directly followed by a full wait
         rmw = len(re.findall(r"LWS", s))
         if lone >= int(__import__("os").environ.get("AUDIT_MIN", "4")) or rmw >= int(__import__("os").environ.get("AUDIT_MIN", "4")):
             dem = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip()[:110]
