@@ -432,6 +432,25 @@ __global__ __launch_bounds__(256, (W == 4 && NPL * W <= 12 && RU == 2) ? 4 : 1) 
             if (a.dh || a.dx) {
                 s1 = wave_sum(s1) * invD;
                 s2 = wave_sum(s2) * invD;
+                if (full) {                               // stores back to back: no per-lane predicate, the feature tests outside the loops
+                    float o[NPL * W];
+#pragma unroll
+                    for (int k = 0; k < NPL * W; ++k) o[k] = rstd[u] * (d[u][k] - s1 - h[u][k] * s2);
+                    if (a.dh) {
+#pragma unroll
+                        for (int i = 0; i < NPL; ++i) VecIO<W, TY>::store(dhp + orow + (lane + 64 * i) * W, &o[i * W]);
+                    }
+                    if (a.dx && a.dx != a.dh) {
+                        if (a.p_pre > 0.f) {
+#pragma unroll
+                            for (int k = 0; k < NPL * W; ++k)
+                                o[k] *= drop_scale(seed, a.site_pre, orow + (lane + 64 * (k / W)) * W + (k % W), a.p_pre, ik_pre);
+                        }
+#pragma unroll
+                        for (int i = 0; i < NPL; ++i) VecIO<W, TX>::store(dxp + orow + (lane + 64 * i) * W, &o[i * W]);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < NPL; ++i) {
                     const int col = (lane + 64 * i) * W;

@@ -25,10 +25,11 @@ for src in sys.argv[1:]:
     for k, seq in kernels.items():
         s = "".join(seq)
         loads = s.count("L")
-        if loads < 4:
+        if loads < 4 and s.count("S") < 4:
             continue
         lone = len(re.findall(r"(?<![L])L{1,2}W", "W" + s))     # one or two loads directly followed by a full wait
         rmw = len(re.findall(r"LWS", s))
-        if lone >= int(__import__("os").environ.get("AUDIT_MIN", "4")) or rmw >= int(__import__("os").environ.get("AUDIT_MIN", "4")):
+        sws = len(re.findall(r"SW(?=S)", s))                    # a store, a full drain, the next store
+        if lone >= int(__import__("os").environ.get("AUDIT_MIN", "4")) or rmw >= int(__import__("os").environ.get("AUDIT_MIN", "4")) or sws >= int(__import__("os").environ.get("AUDIT_MIN", "4")):
             dem = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip()[:110]
-            print(f"{src.split('/')[-1]:22s} loads {loads:3d}  lone load+wait {lone:3d}  load-wait-store {rmw:3d}  {dem}")
+            print(f"{src.split('/')[-1]:22s} loads {loads:3d}  lone load+wait {lone:3d}  load-wait-store {rmw:3d}  store-wait-store {sws:3d}  {dem}")
