@@ -64,6 +64,66 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(const TensorMeta* __restr
     }
     const long long s = chunk_start[c];
     const long long e = s + OPT_CHUNK < t.n ? s + OPT_CHUNK : t.n;
+    // a whole chunk of 16-byte aligned state: 16-byte accesses, the loads of four groups (16–20 per thread) requested before the first
+    // is consumed.  (Element by element every iteration is a memory round trip of its own: the compiler cannot move the next
+    // iteration's loads above this one's stores — the state arrays may alias for all it knows — and a lane moves 4 bytes per access.)
+    const bool use_ema = t.ema && ema_decay >= 0.f;
+    const unsigned long long al = (unsigned long long)(t.g + s) | (unsigned long long)(t.m + s) | (unsigned long long)(t.v + s) |
+                                  (unsigned long long)(t.p + s) | (use_ema ? (unsigned long long)(t.ema + s) : 0ull) |
+                                  ((t.shadow ? (unsigned long long)(t.shadow + s) : 0ull) << 1) |
+                                  ((t.shadow && t.shadow_lo ? (unsigned long long)(t.shadow_lo + s) : 0ull) << 1);
+    if ((e - s) == OPT_CHUNK && (al & 15ull) == 0) {
+        constexpr int NB = 4, PER = OPT_CHUNK / 4 / 256 / NB;      // 4 batches of 4 float4 per thread
+        float4* __restrict__ g4 = reinterpret_cast<float4*>(t.g + s);
+        float4* __restrict__ m4 = reinterpret_cast<float4*>(t.m + s);
+        float4* __restrict__ v4 = reinterpret_cast<float4*>(t.v + s);
+        float4* __restrict__ p4 = reinterpret_cast<float4*>(t.p + s);
+        float4* __restrict__ e4 = reinterpret_cast<float4*>(t.ema + s);
+        uint2* __restrict__ sh = reinterpret_cast<uint2*>(t.shadow + s);
+        uint2* __restrict__ sl = reinterpret_cast<uint2*>(t.shadow_lo + s);
+        for (int b = 0; b < NB; ++b) {
+            float4 g[PER], m[PER], v[PER], p[PER], em[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i = threadIdx.x + 256 * (b * PER + k);
+                g[k] = g4[i]; m[k] = m4[i]; v[k] = v4[i]; p[k] = p4[i];
+                if (use_ema) em[k] = e4[i];
+            }
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i = threadIdx.x + 256 * (b * PER + k);
+                float gg[4] = {g[k].x, g[k].y, g[k].z, g[k].w}, mm[4] = {m[k].x, m[k].y, m[k].z, m[k].w};
+                float vv[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, pp[4] = {p[k].x, p[k].y, p[k].z, p[k].w};
+                float ee[4] = {0.f, 0.f, 0.f, 0.f};
+                if (use_ema) { ee[0] = em[k].x; ee[1] = em[k].y; ee[2] = em[k].z; ee[3] = em[k].w; }
+                __bf16 hi[4], lo[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                 // the same operations in the same order as the scalar form below
+                    const float gj = gg[j] * coef;
+                    mm[j] = b1 * mm[j] + (1.f - b1) * gj;
+                    vv[j] = b2 * vv[j] + (1.f - b2) * gj * gj;
+                    float upd = mm[j] / (sqrtf(vv[j]) + eps);
+                    if (t.wd > 0.f) upd += t.wd * pp[j];
+                    pp[j] -= lr * upd;
+                    hi[j] = (__bf16)pp[j];
+                    lo[j] = (__bf16)(pp[j] - (float)hi[j]);
+                    if (use_ema) ee[j] = (1.f - ema_decay) * pp[j] + ema_decay * ee[j];
+                }
+                m4[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+                v4[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                p4[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+                if (t.shadow) {
+                    union { __bf16 h[4]; uint2 u; } ph, pl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { ph.h[j] = hi[j]; pl.h[j] = lo[j]; }
+                    sh[i] = ph.u;
+                    if (t.shadow_lo) sl[i] = pl.u;
+                }
+                if (use_ema) e4[i] = make_float4(ee[0], ee[1], ee[2], ee[3]);
+            }
+        }
+        return;
+    }
     for (long long i = s + threadIdx.x; i < e; i += 256) {
         const float g = t.g[i] * coef;
         const float m = b1 * t.m[i] + (1.f - b1) * g;
