@@ -569,13 +569,20 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(LnBwdArgs a, int row
 }
 
 // Column sums of the per-workgroup partials: 32 columns × 32 row-groups per workgroup (1,024 threads), every thread's loads
-// issued four at a time, then a fixed-order LDS tree over the 32 row-groups — deterministic.  These launches are pure latency
+// issued eight (then four) at a time, then a fixed-order LDS tree over the 32 row-groups — deterministic.  These launches are pure latency
 // (≤3 MB read), so memory-level parallelism is what matters.
 __device__ __forceinline__ float finalize_column(const float* __restrict__ partial, int G, int ncols, int c, int rg, float (*red)[33]) {
     const int cl = threadIdx.x & 31;
     float s = 0.f;
     if (c < ncols) {
         int g = rg;
+        for (; g + 224 < G; g += 256) {                   // eight rows in flight per thread (1,024 groups = 4 round trips)
+            float a[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = partial[(size_t)(g + 32 * k) * ncols + c];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += a[k];
+        }
         for (; g + 96 < G; g += 128) {
             const float a0 = partial[(size_t)g * ncols + c], a1 = partial[(size_t)(g + 32) * ncols + c];
             const float a2 = partial[(size_t)(g + 64) * ncols + c], a3 = partial[(size_t)(g + 96) * ncols + c];
