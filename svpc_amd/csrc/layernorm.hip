@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
     const size_t a1row = a.add1 ? (size_t)(r % a.mod1) * D : 0;
     const size_t a2row = a.add2 ? (size_t)a.idx2[r] * D : 0;
     if (full) {                                           // gamma / beta / table rows of up to four column groups in flight at once
-        constexpr int CH = NPL < 4 ? NPL : 4;
+        constexpr int CH = NPL < 4 ? NPL : (NPL > 8 ? 2 : 4);
 #pragma unroll
         for (int i0 = 0; i0 < NPL; i0 += CH) {
             float g[CH][W], b[CH][W], t1[CH][W], t2[CH][W];
