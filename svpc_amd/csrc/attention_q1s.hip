@@ -78,6 +78,36 @@ __device__ __forceinline__ float q1s_probs(const Q1sArgs& a, const float* __rest
     return mx + logf(sum);
 }
 
+// acc[c] += Σ_k w[k]·X[k][c0 + c] with a column pair (DH = 64) / one column (DH = 32) per lane, lanes 0-31 the even keys, 32-63 the odd
+// keys; w[k] lives in lane k & 63, slot k >> 6 of `w`.  The row pieces of EIGHT key pairs are requested before the first is consumed:
+// walking the keys with the load inside the loop body made every pair a memory round trip of its own (50 in a row for 100 keys).
+template <int DH, bool SPLIT>
+__device__ __forceinline__ void q1s_weighted_sum(const __bf16* __restrict__ X, int ldx, int x_lo, int k_len, const float (&w)[2], int lane,
+                                                 float* acc) {
+    constexpr int CPL = DH / 32, UN = 8;
+    const int half = lane >> 5, c0 = (lane & 31) * CPL;
+    for (int k2 = 0; k2 < k_len; k2 += 2 * UN) {
+        float2 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int kc = min(k2 + 2 * u + half, k_len - 1);          // (clamped: the weight of a key past the end is zeroed below)
+            const __bf16* row = X + (size_t)kc * ldx + c0;
+            if (CPL == 2) v[u] = q1s_pair<SPLIT>(row, x_lo);
+            else { float t = (float)row[0]; if (SPLIT) t += (float)row[x_lo]; v[u] = make_float2(t, 0.f); }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int ke = k2 + 2 * u, k = ke + half;
+            const float pe0 = __shfl(w[0], ke & 63, 64), po0 = __shfl(w[0], (ke + 1) & 63, 64);
+            const float pe1 = __shfl(w[1], ke & 63, 64), po1 = __shfl(w[1], (ke + 1) & 63, 64);
+            float wk = half ? ((ke + 1) >> 6 ? po1 : po0) : (ke >> 6 ? pe1 : pe0);
+            if (k >= k_len) wk = 0.f;
+            acc[0] = fmaf(wk, v[u].x, acc[0]);
+            if (CPL == 2) acc[CPL - 1] = fmaf(wk, v[u].y, acc[CPL - 1]);
+        }
+    }
+}
+
 template <int DH, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_q1s_fwd_kernel(Q1sArgs a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -107,24 +137,7 @@ __global__ __launch_bounds__(256) void attn_q1s_fwd_kernel(Q1sArgs a) {
     float acc[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
-    for (int k2 = 0; k2 < k_len; k2 += 2) {
-        const int k = k2 + half;                  // wave-uniform per half
-        const int kc = min(k, k_len - 1);
-        // p̃ of key k lives in lane k & 63, slot k >> 6: fetch it for both halves (two readlanes per slot, selected per half)
-        const float pe0 = __shfl(p[0], k2 & 63, 64), po0 = __shfl(p[0], (k2 + 1) & 63, 64);
-        const float pe1 = __shfl(p[1], k2 & 63, 64), po1 = __shfl(p[1], (k2 + 1) & 63, 64);
-        float pk = half ? ((k2 + 1) >> 6 ? po1 : po0) : (k2 >> 6 ? pe1 : pe0);
-        if (k >= k_len) pk = 0.f;
-        const __bf16* row = Vp + (size_t)kc * a.ldv + c0;
-        if (CPL == 2) {
-            const float2 v = q1s_pair<SPLIT>(row, a.v_lo);
-            acc[0] = fmaf(pk, v.x, acc[0]); acc[CPL - 1] = fmaf(pk, v.y, acc[CPL - 1]);
-        } else {
-            float v = (float)row[0];
-            if (SPLIT) v += (float)row[a.v_lo];
-            acc[0] = fmaf(pk, v, acc[0]);
-        }
-    }
+    q1s_weighted_sum<DH, SPLIT>(Vp, a.ldv, a.v_lo, k_len, p, lane, acc);
 #pragma unroll
     for (int j = 0; j < CPL; ++j) acc[j] += __shfl_xor(acc[j], 32, 64);
     if (half == 0) {
@@ -209,23 +222,7 @@ __global__ __launch_bounds__(256) void attn_q1s_bwd_kernel(Q1sArgs a) {
     float acc[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
-    for (int k2 = 0; k2 < k_len; k2 += 2) {
-        const int k = k2 + half;
-        const int kc = min(k, k_len - 1);
-        const float se0 = __shfl(ds[0], k2 & 63, 64), so0 = __shfl(ds[0], (k2 + 1) & 63, 64);
-        const float se1 = __shfl(ds[1], k2 & 63, 64), so1 = __shfl(ds[1], (k2 + 1) & 63, 64);
-        float sk = half ? ((k2 + 1) >> 6 ? so1 : so0) : (k2 >> 6 ? se1 : se0);
-        if (k >= k_len) sk = 0.f;
-        const __bf16* row = Kp + (size_t)kc * a.ldk + c0;
-        if (CPL == 2) {
-            const float2 v = q1s_pair<SPLIT>(row, a.k_lo);
-            acc[0] = fmaf(sk, v.x, acc[0]); acc[CPL - 1] = fmaf(sk, v.y, acc[CPL - 1]);
-        } else {
-            float v = (float)row[0];
-            if (SPLIT) v += (float)row[a.k_lo];
-            acc[0] = fmaf(sk, v, acc[0]);
-        }
-    }
+    q1s_weighted_sum<DH, SPLIT>(Kp, a.ldk, a.k_lo, k_len, ds, lane, acc);
 #pragma unroll
     for (int j = 0; j < CPL; ++j) acc[j] += __shfl_xor(acc[j], 32, 64);
     if (half == 0) {
