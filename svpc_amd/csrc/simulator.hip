@@ -29,7 +29,18 @@ __global__ __launch_bounds__(1024) void sim_recur_fwd_kernel(SimArgs a) {
     float* prev = ev + SIM_EMAX;      // 32
     float* al = prev + SIM_EMAX;      // 32
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NT = blockDim.x, NW = blockDim.x >> 6;
-    for (int i = threadIdx.x; i < E * D; i += NT) Es[i] = a.E0[(size_t)e0 * D + i];
+    // (eight pieces of the initial entity matrix in flight per thread: with the load inside a one-piece loop body every piece was a
+    // memory round trip of its own — E of them in a row before the recurrence starts)
+    for (int i0 = 0; i0 < E * D; i0 += 8 * NT) {
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = a.E0[(size_t)e0 * D + min(i0 + u * NT + (int)threadIdx.x, E * D - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * NT + (int)threadIdx.x;
+            if (i < E * D) Es[i] = v8[u];
+        }
+    }
     float my_prev = 0.f;              // thread e < 32: e_{t-1}[e] (read and replaced by the same thread: no LDS, no barrier)
     (void)prev;
     // The recurrence is a chain of dependent steps on ONE workgroup per video: what a step costs is its exposed latency.  The step
