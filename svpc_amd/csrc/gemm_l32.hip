@@ -505,23 +505,24 @@ __device__ __forceinline__ void skinny_partials(float (*part)[16][64], const flo
     for (int s0 = wave; s0 < nsteps; s0 += NW * BATCH) {
         float4 av[BATCH][2];
         float bv[BATCH][8];
+        // (no predicate around the loads: a k-step past the end re-reads the last one and is not multiplied.  Inside `if (s < nsteps)` the
+        // loads of every k-step sat in a region of their own with a drain of the memory counter behind it — the "up to 12 k-steps
+        // requested before the first is consumed" of the comment above were 12 memory round trips in a row: tools/isa_audit.py)
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int s = s0 + NW * u;
-            if (s < nsteps) {
-                const float* ap = arow + 16 * s;
-                av[u][0] = *reinterpret_cast<const float4*>(ap);
-                av[u][1] = *reinterpret_cast<const float4*>(ap + 4);
-                if (B_KC) {
-                    const float* bp = brow + 16 * s;
-                    const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
-                    bv[u][0] = b0.x; bv[u][1] = b0.y; bv[u][2] = b0.z; bv[u][3] = b0.w;
-                    bv[u][4] = b1.x; bv[u][5] = b1.y; bv[u][6] = b1.z; bv[u][7] = b1.w;
-                } else {
-                    const float* bp = brow + (size_t)(16 * s) * ldb;
+            const int s = min(s0 + NW * u, nsteps - 1);
+            const float* ap = arow + 16 * s;
+            av[u][0] = *reinterpret_cast<const float4*>(ap);
+            av[u][1] = *reinterpret_cast<const float4*>(ap + 4);
+            if (B_KC) {
+                const float* bp = brow + 16 * s;
+                const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+                bv[u][0] = b0.x; bv[u][1] = b0.y; bv[u][2] = b0.z; bv[u][3] = b0.w;
+                bv[u][4] = b1.x; bv[u][5] = b1.y; bv[u][6] = b1.z; bv[u][7] = b1.w;
+            } else {
+                const float* bp = brow + (size_t)(16 * s) * ldb;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) bv[u][j] = bp[(size_t)j * ldb];
-                }
+                for (int j = 0; j < 8; ++j) bv[u][j] = bp[(size_t)j * ldb];
             }
         }
 #pragma unroll
