@@ -616,8 +616,14 @@ __global__ __launch_bounds__(256) void lstm_pair_step_fwd_kernel(LstmStep a) {
     const int N = a.N, D = a.D;
     const float* arow = a.h_prev[z] + (size_t)min(m0 + r, N - 1) * D + 8 * hh;
     const float* brow = a.w_hh[z] + (size_t)((r >> 3) * D + u0 + (r & 7)) * D + 8 * hh;      // tile column r ↔ gate r>>3 of unit u0 + (r&7)
-    skinny_partials<true, 4, X3>(part, arow, brow, D, D);
+    // what the cell needs besides the gate sums — the input projections of its (video, unit), the old cell / hidden state, the activity
+    // flag — is requested BEFORE the recurrent projection's k-loop and lands under it (two dependent round trips after it otherwise)
     const int row = threadIdx.x >> 3, j = threadIdx.x & 7, n = m0 + row;
+    const int nc = min(n, N - 1), dpre = u0 + j;
+    const float* gxp = a.gx[z] + (size_t)a.rows[z][nc] * 4 * D + dpre;
+    const float gx0 = gxp[0], gx1 = gxp[D], gx2 = gxp[2 * D], gx3 = gxp[3 * D];
+    const float cp_pre = a.c_prev[z][(size_t)nc * D + dpre], hp_pre = a.h_prev[z][(size_t)nc * D + dpre], act_pre = a.active[nc];
+    skinny_partials<true, 4, X3>(part, arow, brow, D, D);
     if (n >= N) return;
     float gsum[4];
     const int e = (row & 3) + 4 * (row >> 3), lb = 32 * ((row >> 2) & 1);      // accumulator element / lane half that hold this row
@@ -631,19 +637,18 @@ __global__ __launch_bounds__(256) void lstm_pair_step_fwd_kernel(LstmStep a) {
     }
     const int d = u0 + j;
     const size_t i = (size_t)n * D + d, g0 = (size_t)n * 4 * D + d;
-    const float* gx = a.gx[z] + (size_t)a.rows[z][n] * 4 * D + d;
-    const float gi = sigmoidf_(gx[0] + gsum[0]);
-    const float gf = sigmoidf_(gx[D] + gsum[1]);
-    const float gg = tanhf(gx[2 * D] + gsum[2]);
-    const float go = sigmoidf_(gx[3 * D] + gsum[3]);
+    const float gi = sigmoidf_(gx0 + gsum[0]);
+    const float gf = sigmoidf_(gx1 + gsum[1]);
+    const float gg = tanhf(gx2 + gsum[2]);
+    const float go = sigmoidf_(gx3 + gsum[3]);
     float* ga = a.gates[z];
     ga[g0] = gi; ga[g0 + D] = gf; ga[g0 + 2 * D] = gg; ga[g0 + 3 * D] = go;
-    const float cp = a.c_prev[z][i];
+    const float cp = cp_pre;
     const float cn = gf * cp + gi * gg;
     const float hn = go * tanhf(cn);
-    const float act = a.active[n];
+    const float act = act_pre;
     a.c[z][i] = act * cn + (1.f - act) * cp;
-    a.h[z][i] = act * hn + (1.f - act) * a.h_prev[z][i];
+    a.h[z][i] = act * hn + (1.f - act) * hp_pre;
 }
 
 extern "C" {

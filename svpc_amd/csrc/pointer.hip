@@ -369,10 +369,16 @@ __global__ __launch_bounds__(256) void gumbel_fwd_row_kernel(const float* __rest
     const float* Nr = noise + (size_t)r * c_max;
     float l[NPL];
     float best = -INFINITY; int bi = 0x7fffffff;
+    // (all loads of the row first, with clamped indices: inside `v < C ? … : …` every load sat in a predicated region of its own with a
+    // drain behind it — 2·NPL memory round trips per row: tools/isa_audit.py)
+    float pr[NPL], nr[NPL];
+    const int cl = max(C - 1, 0);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { const int vc = min(lane + 64 * i, cl); pr[i] = Pr[vc]; nr[i] = Nr[vc]; }
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int v = lane + 64 * i;
-        l[i] = v < C ? (logf(Pr[v] + 1e-12f) + Nr[v]) * inv_tau : -INFINITY;
+        l[i] = v < C ? (logf(pr[i] + 1e-12f) + nr[i]) * inv_tau : -INFINITY;
         if (l[i] > best) { best = l[i]; bi = v; }           // ascending v: the first index wins a tie
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -404,15 +410,22 @@ __global__ __launch_bounds__(256) void gumbel_bwd_row_kernel(const float* __rest
     const float* Nr = noise + (size_t)r * c_max;
     float y[NPL], pe[NPL], d[NPL];
     float dot = 0.f;
+    float pr[NPL], nr[NPL], dr[NPL];              // all loads of the row first, clamped indices (see gumbel_fwd_row_kernel)
+    const int cl = max(C - 1, 0);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int vc = min(lane + 64 * i, cl);
+        pr[i] = Pr[vc]; nr[i] = Nr[vc]; dr[i] = dy[(size_t)r * V + min(vc, V - 1)];
+    }
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int v = lane + 64 * i;
         y[i] = 0.f; pe[i] = 1.f; d[i] = 0.f;
         if (v < C) {
-            const float p = Pr[v];
+            const float p = pr[i];
             pe[i] = p + 1e-12f;
-            y[i] = expf((logf(pe[i]) + Nr[v]) * inv_tau - mx) * inv;
-            d[i] = v < V ? dy[(size_t)r * V + v] : 0.f;
+            y[i] = expf((logf(pe[i]) + nr[i]) * inv_tau - mx) * inv;
+            d[i] = v < V ? dr[i] : 0.f;
             if (v < V) dot += y[i] * d[i];
         }
     }

@@ -30,6 +30,7 @@ for src in sys.argv[1:]:
         lone = len(re.findall(r"(?<![L])L{1,2}W", "W" + s))     # one or two loads directly followed by a full wait
         rmw = len(re.findall(r"LWS", s))
         sws = len(re.findall(r"SW(?=S)", s))                    # a store, a full drain, the next store
-        if lone >= int(__import__("os").environ.get("AUDIT_MIN", "4")) or rmw >= int(__import__("os").environ.get("AUDIT_MIN", "4")) or sws >= int(__import__("os").environ.get("AUDIT_MIN", "4")):
+        trips = len(re.findall(r"L+[SL]*W", s))                 # runs of loads each closed by a full drain = memory round trips in the text
+        if lone >= int(__import__("os").environ.get("AUDIT_MIN", "4")) or rmw >= int(__import__("os").environ.get("AUDIT_MIN", "4")) or sws >= int(__import__("os").environ.get("AUDIT_MIN", "4")) or trips >= int(__import__("os").environ.get("AUDIT_TRIPS", "6")):
             dem = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip()[:110]
-            print(f"{src.split('/')[-1]:22s} loads {loads:3d}  lone load+wait {lone:3d}  load-wait-store {rmw:3d}  store-wait-store {sws:3d}  {dem}")
+            print(f"{src.split('/')[-1]:22s} loads {loads:3d}  lone load+wait {lone:3d}  load-wait-store {rmw:3d}  store-wait-store {sws:3d}  load-runs {trips:3d}  {dem}")
