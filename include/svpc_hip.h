@@ -254,6 +254,14 @@ int svpc_attn_q1s_bwd(const float* Q, int ldq, const void* K, int ldk, int k_lo,
 int svpc_attn_x3_fwd(const void* Q, int ldq, int q_lo, const void* K, int ldk, int k_lo, const void* V, int ldv, int v_lo, void* O, int ldo,
                      int o_lo, float* LSE, const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,
                      float scale, float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
+/* Sequences of 33-104 rows (the clip encoder's 100 x 100 x 64) of the bf16 / split streams take a PERSISTENT forward inside
+ * svpc_attn_mfma_fwd_t / svpc_attn_x3_fwd (attention_pipe.hip: a loader wave keeps the K / V planes of the next two (sequence, head)
+ * pairs in flight by LDS-DMA while four waves compute the current one; same arithmetic, dropout draws and LSE).  This switch selects
+ * it (1, default), the one-workgroup-per-pair kernels (0), or just reports (negative); returns the previous setting.  A/B use only. */
+int svpc_attn_pipe_enable(int on);
+/* timing experiments on that kernel (tools/dbg/pipe_phases.py, pipe_stamps.py): bits 1 no LDS-DMA, 2 no arithmetic, 4 no O stores,
+ * 8 no Q loads, 16 s_memtime stamps of workgroups 0-15 into buf (16 x 128 u64 of device memory).  0 / NULL = production. */
+int svpc_attn_pipe_debug(int bits, void* buf);
 int svpc_attn_mfma_bwd_t(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O, int ldo, int dt,
                          const float* LSE, const void* dO, int lddo, void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv,
                          const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal, float scale,
@@ -380,6 +388,10 @@ int svpc_add(const float* a, const float* b, float* c, size_t n, svpc_stream_t s
 int svpc_sum_all(const float* x, size_t n, float* out, float scale, svpc_stream_t stream);
 int svpc_fill_from(float* x, size_t n, const float* v, svpc_stream_t stream);
 int svpc_dropout_mask(float* out, size_t n, float p, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
+/* keep mask (1 / 0) of the dropout on the attention probabilities (model.py:213), (n_rows, max_k) with rows (sequence·H + head)·max_q +
+ * query: the draw every attention kernel of the library makes for that element — one full hash per ROW, one add + xor-shift + 24-bit
+ * multiply per element (the kernels are bound by vector-instruction issue).  For tests: the fp32 reference applies the kernels' own mask. */
+int svpc_attn_dropout_mask(float* out, size_t n_rows, int max_k, float p, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
 int svpc_bump_seed(svpc_u64* seed, svpc_stream_t stream);
 
 /* ---- fused training-step tail: clip_grad_norm_ train.py:141-142, BertAdam optimization.py:284-331, EMA :196-203.

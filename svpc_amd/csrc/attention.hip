@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             if (valid && j < k_len) {
                 float p = sc[u] * inv;
                 if (a.p_drop > 0.f)
-                    p *= drop_scale(seed, a.site, ((u64)(s * a.H + h) * a.max_q + i) * a.max_k + j, a.p_drop, ik);
+                    p *= attn_drop_scale(seed, a.site, (u64)(s * a.H + h) * a.max_q + i, (uint32_t)j, a.p_drop, ik);
                 pb[wave * a.max_k + j] = p;
             }
         }
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
                 sacc += mask_term(a, k_off, i, j);
                 const float p = expf(sacc - lse);
                 if (a.p_drop > 0.f)
-                    dp *= drop_scale(seed, a.site, ((u64)(s * a.H + h) * a.max_q + i) * a.max_k + j, a.p_drop, ik);
+                    dp *= attn_drop_scale(seed, a.site, (u64)(s * a.H + h) * a.max_q + i, (uint32_t)j, a.p_drop, ik);
                 pb[wave * a.max_k + j] = p * (dp - dlt);
             }
         }
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
                 sacc += mask_term(a, k_off, i, j);
                 const float p = expf(sacc - a.LSE[stat0 + i]);
                 float dm = 1.0f;
-                if (a.p_drop > 0.f) dm = drop_scale(seed, a.site, ((u64)(s * a.H + h) * a.max_q + i) * a.max_k + j, a.p_drop, ik);
+                if (a.p_drop > 0.f) dm = attn_drop_scale(seed, a.site, (u64)(s * a.H + h) * a.max_q + i, (uint32_t)j, a.p_drop, ik);
                 pb[wave * a.max_q + i] = p * dm;
                 sb[wave * a.max_q + i] = p * (dp * dm - a.delta[stat0 + i]);
             }

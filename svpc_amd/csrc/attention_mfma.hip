@@ -16,67 +16,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef short short4v __attribute__((ext_vector_type(4)));
-
-struct MAttnArgs {
-    const void* Q; int ldq; const void* K; int ldk; const void* V; int ldv;
-    void* O; int ldo; float* LSE;
-    const int* seq; int n_seq, H, max_q, max_k;
-    const float* key_mask; int causal; float scale; float p_drop; uint32_t site; const u64* seed;
-    const void* dO; int lddo; void* dQ; int lddq; void* dK; int lddk; void* dV; int lddv;
-};
-
-constexpr int AT_MAX = 128;
-constexpr float LOG2E = 1.4426950408889634f;      // exp(x - m) = exp2(x·log2e - m·log2e): one v_fma + one v_exp per score   // rows per image: 128 (clip encoder) or 32 (22-token decoder, ≤12-step sequences, ≤3-slot memory)
-
-// Dropout multiplier for element index (row_base + key) of the (sequence, head, query, key) probability tensor.  The index
-// arithmetic stays 32-bit whenever the whole tensor has < 2^32 elements (checked once per kernel: `wide`), which is
-// bit-identical to drop_scale(): svpc_hash32 mixes ((uint32)idx ^ key) when the upper index word is 0.
-struct DropCtx {
-    uint32_t key, thr, site; float ik, p; u64 seed; bool wide;
-    __device__ __forceinline__ DropCtx(const u64* seed_ptr, uint32_t site_, float p_, u64 total_elems) {
-        p = p_; site = site_;
-        seed = p_ > 0.f ? seed_ptr[0] : 0ull;
-        ik = p_ > 0.f ? 1.0f / (1.0f - p_) : 1.0f;
-        key = (uint32_t)(seed ^ (seed >> 32)) + (site_ + 1u) * 0x9E3779B9u;
-        thr = (uint32_t)(p_ * 65536.0f);
-        wide = total_elems >= (1ull << 32);
-    }
-    __device__ __forceinline__ float mul(u64 row_base, int k) const {       // row_base = ((s·H + h)·max_q + q)·max_k
-        if (wide) return drop_scale(seed, site, row_base + (u64)k, p, ik);
-        return (svpc_mix32(((uint32_t)row_base + (uint32_t)k) ^ key) >> 16) >= thr ? ik : 0.0f;
-    }
-    // multipliers of four elements whose indices are base, base + stride, base + 2·stride, base + 3·stride (+ k): the backward's
-    // four consecutive queries of one key — one test of `wide` per group
-    __device__ __forceinline__ void mul4(u64 base, u64 stride, int k, float* dm) const {
-        if (wide) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dm[j] = drop_scale(seed, site, base + (u64)j * stride + (u64)k, p, ik);
-        } else {
-            const uint32_t b32 = (uint32_t)base + (uint32_t)k, s32 = (uint32_t)stride;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dm[j] = (svpc_mix32((b32 + (uint32_t)j * s32) ^ key) >> 16) >= thr ? ik : 0.0f;
-        }
-    }
-    // the 16 probabilities of one 32-key accumulator tile (element e ↔ key key0 + acc_row(e, lane)) times their dropout multipliers.
-    // ONE test of `wide` per tile instead of one uniform branch per element (64 per wave in the 128-key kernels: each ends a basic
-    // block, so nothing was scheduled across it)
-    __device__ __forceinline__ void mul16(u64 row_base, int key0, int lane, float* pv) const {
-        const int kb = key0 + 4 * (lane >> 5);
-        if (wide) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) pv[e] *= drop_scale(seed, site, row_base + (u64)(kb + (e & 3) + 8 * (e >> 2)), p, ik);
-        } else {
-            const uint32_t b32 = (uint32_t)row_base + (uint32_t)kb;
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                pv[e] = (svpc_mix32((b32 + (uint32_t)((e & 3) + 8 * (e >> 2))) ^ key) >> 16) >= thr ? pv[e] * ik : 0.0f;
-        }
-    }
-};
+#include "attn_common.h"
 
 template <int DH> struct AImg { static constexpr int RS = DH * 2 + 16; };
 
@@ -218,7 +158,6 @@ template <int DH>
 __device__ __forceinline__ bf16x8 frag_tr(const char* __restrict__ img, int r0, int c0, int lane) {
     return frag_tr_rs<AImg<DH>::RS>(img, r0, c0, lane);
 }
-__device__ __forceinline__ int acc_row(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
 __device__ __forceinline__ bf16x8 pack8(const float* v) {
     bf16x8 r;
 #pragma unroll
@@ -250,6 +189,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
     if (PERWAVE && sh >= a.n_seq * a.H) return;
     const int s = sh / a.H, h = sh - s * a.H;
     const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
+    const DropCtx dctx(a.seed, a.site, a.p_drop);      // (the seed word is requested with the segment table, ahead of the row images: read where
+                                                       // the draws are made it costs a memory round trip of its own in the middle of the kernel)
     {   // all three images in flight at once: one memory round trip for the prologue
         RowStage<DH, T, AT, NT> sk(tid), sv(tid), sq(tid);
         sk.load((const T*)a.K + (size_t)k_off * a.ldk + h * DH, a.ldk, k_len);
@@ -304,8 +245,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (lane < 32 && q < q_len && a.LSE) a.LSE[((size_t)s * a.H + h) * a.max_q + q] = mx + logf(sum);
-    const DropCtx dctx(a.seed, a.site, a.p_drop, (u64)a.n_seq * a.H * a.max_q * a.max_k);
-    const u64 row_base = ((u64)(s * a.H + h) * a.max_q + q) * a.max_k;
+    const uint32_t arow = dctx.row((u64)(s * a.H + h) * a.max_q + q);       // this lane's probability row
     floatx16 acc[DH / 32];
 #pragma unroll
     for (int dt = 0; dt < DH / 32; ++dt)
@@ -318,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(MAttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) pv[e] = st[jt][e] * inv;
             if (a.p_drop > 0.f) {
-                dctx.mul16(row_base, 32 * jt, lane, pv);
+                dctx.mul16(arow, 32 * jt, lane, pv);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -355,6 +295,8 @@ __global__ __launch_bounds__(256, 4) void attn_stream_fwd_kernel(MAttnArgs a) {
     const int sh = blockIdx.x;
     const int s = sh / a.H, h = sh - s * a.H;
     const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
+    const DropCtx dctx(a.seed, a.site, a.p_drop);      // (the seed word is requested with the segment table, ahead of the row images: read where
+                                                       // the draws are made it costs a memory round trip of its own in the middle of the kernel)
     const int q0 = 32 * wave;
     const __bf16* Kp = (const __bf16*)a.K + (size_t)k_off * a.ldk + h * DH;
     const __bf16* Vp = (const __bf16*)a.V + (size_t)k_off * a.ldv + h * DH;
@@ -423,8 +365,7 @@ __global__ __launch_bounds__(256, 4) void attn_stream_fwd_kernel(MAttnArgs a) {
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (lane < 32 && q < q_len && a.LSE) a.LSE[((size_t)s * a.H + h) * a.max_q + q] = mx + logf(sum);
-    const DropCtx dctx(a.seed, a.site, a.p_drop, (u64)a.n_seq * a.H * a.max_q * a.max_k);
-    const u64 row_base = ((u64)(s * a.H + h) * a.max_q + q) * a.max_k;
+    const uint32_t arow = dctx.row((u64)(s * a.H + h) * a.max_q + q);       // this lane's probability row
     floatx16 acc[DH / 32];      // Oᵀ: rows = head columns 32·dt + acc_row(e), column = this lane's query
 #pragma unroll
     for (int dt = 0; dt < DH / 32; ++dt)
@@ -437,7 +378,7 @@ __global__ __launch_bounds__(256, 4) void attn_stream_fwd_kernel(MAttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) pv[e] = st[jt][e] * inv;
             if (a.p_drop > 0.f) {
-                dctx.mul16(row_base, 32 * jt, lane, pv);
+                dctx.mul16(arow, 32 * jt, lane, pv);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -478,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
     // does not read (head dim 32 with 128-row images: those two are too small, the image gets LDS of its own)
     constexpr int TRS_ = AT * 2 + 16, T_BYTES = AT * TRS_, NQT = AT / 32;
     constexpr bool T_OVER = 2 * IB >= T_BYTES;
-    constexpr int GROUP_BYTES = 4 * IB + 3 * AT * (int)sizeof(float) + (T_OVER ? 0 : T_BYTES), NT = PERWAVE ? 64 : 256;
+    constexpr int GROUP_BYTES = 4 * IB + 4 * AT * (int)sizeof(float) + (T_OVER ? 0 : T_BYTES), NT = PERWAVE ? 64 : 256;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31;
     const int wave = PERWAVE ? 0 : wv, tid = PERWAVE ? lane : (int)threadIdx.x;
     char* smem = smem_all + (PERWAVE ? wv * GROUP_BYTES : 0);
@@ -486,11 +427,14 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
     float* mterm = reinterpret_cast<float*>(smem + 4 * IB);
     float* lse = mterm + AT;
     float* delta = lse + AT;
-    char* Ts = T_OVER ? Vs : reinterpret_cast<char*>(delta + AT);
+    uint32_t* arow_tab = reinterpret_cast<uint32_t*>(delta + AT);          // dropout row hash of every query of the pair (attn_common.h)
+    char* Ts = T_OVER ? Vs : reinterpret_cast<char*>(arow_tab + AT);
     const int sh = PERWAVE ? (int)blockIdx.x * 4 + wv : (int)blockIdx.x;
     if (PERWAVE && sh >= a.n_seq * a.H) return;
     const int s = sh / a.H, h = sh - s * a.H;
     const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
+    const DropCtx dctx(a.seed, a.site, a.p_drop);      // (the seed word is requested with the segment table, ahead of the row images: read where
+                                                       // the draws are made it costs a memory round trip of its own in the middle of the kernel)
     // Every global load of the prologue (K, V, Q, dO images and the dO/O row segments of delta) is issued before the first
     // conversion or LDS store: one memory round trip instead of one per image / per delta row.
     {
@@ -524,6 +468,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
         if (tid < AT) {
             mterm[tid] = tid < k_len ? (1.0f - kmv) * -10000.0f : -INFINITY;
             lse[tid] = tid < q_len ? lsv : 0.f;
+            arow_tab[tid] = dctx.row((u64)(s * a.H + h) * a.max_q + tid);
         }
         sk.store(Ks, 1.0f); sv.store(Vs, 1.0f); sq.store(Qs, a.scale); sd.store(Ds, 1.0f);
         float d = 0.f;
@@ -545,8 +490,6 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
         if ((tid & 1) == 0 && r < AT) delta[r] = d;
     }
     group_sync<PERWAVE>();
-    const DropCtx dctx(a.seed, a.site, a.p_drop, (u64)a.n_seq * a.H * a.max_q * a.max_k);
-    const u64 dbase = (u64)(s * a.H + h) * a.max_q;
     const int nqt = (q_len + 31) >> 5, nkt = (k_len + 31) >> 5;
 
     bf16x8 keep[NQT][2];                          // this wave's key tile: dS against every query tile, as packed for the dK product
@@ -584,7 +527,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
                     const float4 l4 = *reinterpret_cast<const float4*>(lse + qb + 8 * g), d4 = *reinterpret_cast<const float4*>(delta + qb + 8 * g);
                     const float lq4[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
                     float dm4[4] = {1.0f, 1.0f, 1.0f, 1.0f};       // registers 4g..4g+3 ↔ queries qb + 8g + 0..3 of this lane's key
-                    if (a.p_drop > 0.f) dctx.mul4((dbase + qb + 8 * g) * a.max_k, (u64)a.max_k, key, dm4);
+                    if (a.p_drop > 0.f) {
+                        const uint4 a4 = *reinterpret_cast<const uint4*>(arow_tab + qb + 8 * g);
+                        const uint32_t ar4[4] = {a4.x, a4.y, a4.z, a4.w};
+                        dctx.mul4(ar4, (uint32_t)key * SVPC_ATTN_PHI, dm4);
+                    }
 #pragma unroll
                     for (int e = 4 * g; e < 4 * g + 4; ++e) {
                         const int q = qb + (e & 3) + 8 * (e >> 2);
@@ -678,10 +625,6 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_bwd_kernel(MAttnArgs a) {   
 // attn_mfma_bwd_kernel on the hi planes — recomputes them).  Structure of attn_stream_fwd_kernel: Q fragments straight into
 // registers, K / V planes staged with 16-byte units (four images: 74 KB → two workgroups per CU), O accumulated transposed and
 // written as two planes of 16-byte pieces.  The 1/√dh scale is applied to the fp32 scores (exact for any dh).
-struct X3AttnArgs {
-    MAttnArgs m;
-    int q_lo, k_lo, v_lo, o_lo;      // element offsets of the lo planes from the hi-plane pointers
-};
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_stream_x3_fwd_kernel(X3AttnArgs xa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -693,6 +636,8 @@ __global__ __launch_bounds__(256, 2) void attn_stream_x3_fwd_kernel(X3AttnArgs x
     const int sh = blockIdx.x;
     const int s = sh / a.H, h = sh - s * a.H;
     const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
+    const DropCtx dctx(a.seed, a.site, a.p_drop);      // (the seed word is requested with the segment table, ahead of the row images: read where
+                                                       // the draws are made it costs a memory round trip of its own in the middle of the kernel)
     const int q0 = 32 * wave;
     const __bf16* Kp = (const __bf16*)a.K + (size_t)k_off * a.ldk + h * DH;
     const __bf16* Vp = (const __bf16*)a.V + (size_t)k_off * a.ldv + h * DH;
@@ -771,8 +716,7 @@ __global__ __launch_bounds__(256, 2) void attn_stream_x3_fwd_kernel(X3AttnArgs x
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (lane < 32 && q < q_len && a.LSE) a.LSE[((size_t)s * a.H + h) * a.max_q + q] = mx + logf(sum);
-    const DropCtx dctx(a.seed, a.site, a.p_drop, (u64)a.n_seq * a.H * a.max_q * a.max_k);
-    const u64 row_base = ((u64)(s * a.H + h) * a.max_q + q) * a.max_k;
+    const uint32_t arow = dctx.row((u64)(s * a.H + h) * a.max_q + q);       // this lane's probability row
     floatx16 acc[DH / 32];      // Oᵀ: rows = head columns 32·dt + acc_row(e), column = this lane's query
 #pragma unroll
     for (int dt = 0; dt < DH / 32; ++dt)
@@ -785,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void attn_stream_x3_fwd_kernel(X3AttnArgs x
 #pragma unroll
             for (int e = 0; e < 16; ++e) pv[e] = st[jt][e] * inv;
             if (a.p_drop > 0.f) {
-                dctx.mul16(row_base, 32 * jt, lane, pv);
+                dctx.mul16(arow, 32 * jt, lane, pv);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -853,6 +797,8 @@ __global__ __launch_bounds__(256, 2) void attn_small_x3_fwd_kernel(X3AttnArgs xa
     if (sh >= a.n_seq * a.H) return;
     const int s = sh / a.H, h = sh - s * a.H;
     const int q_off = a.seq[s], q_len = a.seq[a.n_seq + s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
+    const DropCtx dctx(a.seed, a.site, a.p_drop);      // (the seed word is requested with the segment table, ahead of the row images: read where
+                                                       // the draws are made it costs a memory round trip of its own in the middle of the kernel)
     const __bf16* Kp = (const __bf16*)a.K + (size_t)k_off * a.ldk + h * DH;
     const __bf16* Vp = (const __bf16*)a.V + (size_t)k_off * a.ldv + h * DH;
     bf16x8 qh[DH / 16], ql[DH / 16];
@@ -922,13 +868,12 @@ __global__ __launch_bounds__(256, 2) void attn_small_x3_fwd_kernel(X3AttnArgs xa
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (lane < 32 && q < q_len && a.LSE) a.LSE[((size_t)s * a.H + h) * a.max_q + q] = mx + logf(sum);
-    const DropCtx dctx(a.seed, a.site, a.p_drop, (u64)a.n_seq * a.H * a.max_q * a.max_k);
-    const u64 row_base = ((u64)(s * a.H + h) * a.max_q + q) * a.max_k;
+    const uint32_t arow = dctx.row((u64)(s * a.H + h) * a.max_q + q);       // this lane's probability row
     float pv[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) pv[e] = st[e] * inv;
     if (a.p_drop > 0.f) {
-        dctx.mul16(row_base, 0, lane, pv);
+        dctx.mul16(arow, 0, lane, pv);
     }
     floatx16 acc[DH / 32];      // Oᵀ: rows = head columns 32·dt + acc_row(e), column = this lane's query
 #pragma unroll
@@ -980,6 +925,10 @@ __global__ __launch_bounds__(256, 2) void attn_small_x3_fwd_kernel(X3AttnArgs xa
             }
 }
 
+// attention_pipe.hip: the persistent, LDS-DMA-pipelined forward for ≤ 104-row sequences of the bf16 / split streams
+bool attn_pipe_supported(const X3AttnArgs& xa, int dh, bool x3);
+int attn_pipe_fwd_launch(const X3AttnArgs& xa, bool x3, hipStream_t stream);
+
 static int mattn_set_lds(const void* fn, size_t bytes) { return svpc_raise_lds_once(fn, "attn_mfma"); }   // once per kernel symbol, process-wide table (api.cpp)
 static bool mattn_ok(int dh, int max_q, int max_k, int ldq, int ldk, int ldv, const void* Q, const void* K, const void* V, int dt) {
     const int al = 16, lm = dt ? 8 : 4;   // 16-byte staging units: 8 bf16 or 4 fp32 elements
@@ -1000,7 +949,7 @@ template <typename T, int DH, int AT>
 static int mattn_bwd_go(const MAttnArgs& a, int n_pairs, hipStream_t stream) {
     constexpr bool PW = (AT == 32);
     constexpr size_t t_bytes = (size_t)AT * (AT * 2 + 16);         // dSᵀ image: lies over the V / dO images when they are large enough
-    const size_t lds = (4 * (size_t)AT * AImg<DH>::RS + 3 * AT * sizeof(float) + (2 * (size_t)AT * AImg<DH>::RS >= t_bytes ? 0 : t_bytes)) *
+    const size_t lds = (4 * (size_t)AT * AImg<DH>::RS + 4 * AT * sizeof(float) + (2 * (size_t)AT * AImg<DH>::RS >= t_bytes ? 0 : t_bytes)) *
                        (PW ? 4 : 1);
     int rc = mattn_set_lds((const void*)attn_mfma_bwd_kernel<DH, T, AT, PW>, lds);
     if (rc) return rc;
@@ -1023,8 +972,12 @@ static bool mattn_stream_ok(const MAttnArgs& a) {       // 16-byte row pieces ev
 template <typename T>
 static int mattn_fwd_launch(const MAttnArgs& a, int dh, int n_blocks, hipStream_t stream) {
     const bool small = a.max_q <= 32 && a.max_k <= 32;
-    if (sizeof(T) == 2 && !small && !a.causal && mattn_stream_ok(a))      // (the causal decoder sequences take the 32-row form)
+    if (sizeof(T) == 2 && !small && !a.causal && mattn_stream_ok(a)) {    // (the causal decoder sequences take the 32-row form)
+        X3AttnArgs xa{};
+        xa.m = a;
+        if (attn_pipe_supported(xa, dh, false)) return attn_pipe_fwd_launch(xa, false, stream);
         return dh == 64 ? mattn_stream_fwd_go<64>(a, n_blocks, stream) : mattn_stream_fwd_go<32>(a, n_blocks, stream);
+    }
     if (dh == 64) return small ? mattn_fwd_go<T, 64, 32>(a, n_blocks, stream) : mattn_fwd_go<T, 64, 128>(a, n_blocks, stream);
     return small ? mattn_fwd_go<T, 32, 32>(a, n_blocks, stream) : mattn_fwd_go<T, 32, 128>(a, n_blocks, stream);
 }
@@ -1106,6 +1059,7 @@ int svpc_attn_x3_fwd(const void* Q, int ldq, int q_lo, const void* K, int ldk, i
         }
         return svpc_check_launch("attn_small_x3_fwd");
     }
+    if (attn_pipe_supported(xa, dh, true)) return attn_pipe_fwd_launch(xa, true, stream);
     const size_t lds = 4 * (size_t)128 * AImg<64>::RS + 128 * sizeof(float);
     if (dh == 64) {
         int rc = mattn_set_lds((const void*)attn_stream_x3_fwd_kernel<64>, lds);

@@ -1,0 +1,409 @@
+// Persistent, software-pipelined attention forward for the clip encoder's bf16 / split (bf16x3) activation streams: sequences of
+// ≤ 104 queries × ≤ 104 keys per (sequence, head), head dim 64, non-causal (reference semantics: src/rtransformer/model.py:194-219;
+// the arithmetic — three-term split-bf16 products, fp32 softmax, the library's dropout draws, LSE — is that of
+// attn_stream_fwd_kernel / attn_stream_x3_fwd_kernel in attention_mfma.hip, which remain the forms for longer sequences).
+//
+// Why a second structure.  The one-workgroup-per-(sequence, head) kernels live load → barrier → compute → store with nothing in
+// flight while they compute, and the co-resident workgroups of a CU run in lockstep: HBM idles while the chip computes and the
+// matrix pipes idle while it loads (0.45 of the HBM roofline in round 3).  Here a workgroup is PERSISTENT and walks the pairs
+// blockIdx.x, blockIdx.x + gridDim.x, …:
+//   * wave 7 is a LOADER: it brings the K / V planes of the pair TWO ahead of the one being computed into a three-stage LDS ring by
+//     LDS-DMA (global_load_lds_dwordx4: no staging registers), so a CU always has one to two pairs (53–106 KB in bf16x3) in flight;
+//     its only waits are counted (`vmcnt` = the instructions of the newest pair), the compute waves never wait for memory it moves;
+//   * waves 0–6 COMPUTE, two per SIMD: wave w = the 16 queries 16·w … of the current pair on v_mfma_f32_16x16x32_bf16 (7 × 16 = 112 ≥
+//     104 rows: 89 % of the issued tiles are live, 78 % with four 32-query waves): Sᵀ = K·Qᵀ (a query on a lane column, its keys
+//     over the four 16-lane groups and the accumulator registers: softmax = in-lane work + two cross-group shuffles), the P̃
+//     registers are directly the B operand of Oᵀ = Vᵀ·P̃ᵀ (key order of a k-step permuted the same way in the V fragments, which come
+//     through ds_read_b64_tr_b16).  Q fragments come straight from global memory into registers one pair ahead; O leaves by 16-byte
+//     stores (v_permlane16_swap pairs the 4-column runs of two accumulator tiles) that nobody waits for;
+//   * ONE workgroup barrier per pair (ring hand-over both ways: "pair c has landed" / "the stage of pair c − 1 is free").
+// LDS images are [104 rows][128 B] with no padding (an LDS-DMA instruction writes 1 KiB = 8 rows lane-linearly); bank conflicts of
+// the ds_read_b128 row fragments AND the ds_read_b64_tr_b16 transposed fragments are removed by one XOR swizzle of the 16-byte
+// chunk index, chunk' = chunk ^ f(row), f = (row bit 1) << 2 | (row bit 2 ^ row bit 3) << 1 | (row bit 2), applied on the DMA's per-lane
+// SOURCE address and on every read address (never on the LDS destination) — checked exhaustively by tools/lds_bank_check.py.  Rows
+// past a sequence's end are filled from its last row (finite values; their scores carry −inf, their probabilities are exactly 0).
+// Bound: HBM — algorithmic bytes per pair (2·Lq + 2·Lk)·64·e, e = 2 (bf16) or 4 (split).
+#include "attn_common.h"
+#include <stdlib.h>
+
+typedef const void __attribute__((address_space(1))) * pp_gptr;
+typedef void __attribute__((address_space(3))) * pp_lptr;
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int PP_ROWS = 104;                  // image rows: 13 DMA blocks of 8
+constexpr int PP_RB = 128;                    // bytes per image row (64 bf16 head columns)
+constexpr int PP_IMG = PP_ROWS * PP_RB;       // 13,312 B per plane image
+constexpr int PP_NBLK = PP_ROWS / 8;
+constexpr int PP_NSTAGE = 3;
+constexpr int PP_NT = 7;                      // 16-row tiles per image (the last one has 8 rows)
+constexpr int PP_MT = 128 * (int)sizeof(float);   // mask terms of one stage (keys 0 … 127)
+
+__device__ __forceinline__ int pp_swz(int r) { return (((r >> 1) & 1) << 2) | ((((r >> 2) ^ (r >> 3)) & 1) << 1) | ((r >> 2) & 1); }
+
+typedef short4v __attribute__((address_space(3))) * pp_tr_ptr;
+__device__ __forceinline__ bf16x8 pp_join(short4v lo, short4v hi) {        // two 8-byte halves, no element shuffles
+    union { short4v h[2]; bf16x8 v; } u;
+    u.h[0] = lo; u.h[1] = hi;
+    return u.v;
+}
+typedef float pp_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pp_h2 __attribute__((ext_vector_type(2)));
+// two floats → one dword of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pp_cvt2(float lo, float hi) {
+    const pp_f2 v = {lo, hi};
+    union { pp_h2 h; uint32_t u; } pk;
+    pk.h = __builtin_convertvector(v, pp_h2);
+    return pk.u;
+}
+__device__ __forceinline__ bf16x8 pp_frag(const uint32_t (&w)[4]) {
+    union { uint32_t u[4]; bf16x8 v; } x;
+    x.u[0] = w[0]; x.u[1] = w[1]; x.u[2] = w[2]; x.u[3] = w[3];
+    return x.v;
+}
+__device__ __forceinline__ uint32_t pp_pack2(float lo, float hi) {
+    union { __bf16 h[2]; uint32_t u; } pk;
+    pk.h[0] = (__bf16)lo; pk.h[1] = (__bf16)hi;
+    return pk.u;
+}
+
+template <bool X3>
+__global__ __launch_bounds__(512) void attn_pipe_fwd_kernel(X3AttnArgs xa, int n_pairs) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const MAttnArgs& a = xa.m;
+    constexpr int NPL = X3 ? 4 : 2, STAGE = NPL * PP_IMG, VPL = X3 ? 2 : 1;       // planes per stage; index of the first V plane
+    constexpr int NI = NPL * PP_NBLK + 2;                                         // DMA instructions per pair (+ 2: the key mask)
+    static_assert(NI <= 63, "vmcnt is a 6-bit counter");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bid = blockIdx.x, G = gridDim.x;
+    const int n_my = bid < n_pairs ? (n_pairs - bid + G - 1) / G : 0;
+    float* const mterm_all = reinterpret_cast<float*>(smem + PP_NSTAGE * STAGE);
+    // timing experiments only (dbg & 16): s_memtime stamps kept in LDS (an LDS write does not touch the loader's vmcnt bookkeeping) and
+    // dumped by wave 0 at the end: slot [iteration][8] — 0-2 loader (after barrier, after issue, after the landing wait), 3-7 compute wave 0
+    // (at barrier, after barrier, end of compute, after the Q wait, after the stores)
+    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(smem + PP_NSTAGE * (STAGE + PP_MT));
+    const bool do_stamp = (xa.dbg & 16) && bid < 16;
+#define PP_STAMP(it, slot) do { if (do_stamp && lane == 0 && (it) < 16) stamps[(it) * 8 + (slot)] = clock64(); } while (0)
+    // Per-pair metadata: lane j keeps the segment-table entries of this workgroup's j-th pair (host check: ≤ 64 pairs per workgroup)
+    // and every iteration broadcasts its own with v_readlane.  Loaded inside the loops they are VECTOR loads (the table is not provably
+    // invariant), and the wait for one of them is a vmcnt(0) that drains the prefetches in flight.
+    int m_qoff = 0, m_qlen = 0, m_koff = 0, m_klen = 0;
+    if (lane < n_my) {
+        const int s = (bid + lane * G) / a.H;
+        m_qoff = a.seq[s]; m_qlen = a.seq[a.n_seq + s]; m_koff = a.seq[2 * a.n_seq + s]; m_klen = a.seq[3 * a.n_seq + s];
+    }
+    asm volatile("" : "+v"(m_qoff), "+v"(m_qlen), "+v"(m_koff), "+v"(m_klen));      // landed before either loop starts
+
+    if (wave == 7) {
+        // ------------------------------------------------------------------------------------------------ loader
+        __builtin_amdgcn_s_setprio(2);
+        const int lrow = lane >> 3, ch0 = (lane & 7) ^ pp_swz(lrow);      // chunk this lane sources for even 8-row blocks (odd: ^ 2)
+        auto issue = [&](int j) {
+            const int pair = bid + j * G, s = pair / a.H, h = pair - s * a.H;
+            const int k_off = __builtin_amdgcn_readlane(m_koff, j), k_len = __builtin_amdgcn_readlane(m_klen, j);
+            char* const st = smem + (j % PP_NSTAGE) * STAGE;
+            const char* const Kp = reinterpret_cast<const char*>((const __bf16*)a.K + (size_t)k_off * a.ldk + h * 64);
+            const char* const Vp = reinterpret_cast<const char*>((const __bf16*)a.V + (size_t)k_off * a.ldv + h * 64);
+#pragma unroll 1
+            for (int b = 0; b < PP_NBLK; ++b) {
+                const int re = max(min(8 * b + lrow, k_len - 1), 0), ch = ch0 ^ ((b & 1) << 1);
+                const unsigned ko = ((unsigned)re * (unsigned)a.ldk + 8u * ch) * 2u, vo = ((unsigned)re * (unsigned)a.ldv + 8u * ch) * 2u;
+                char* const d = st + b * 1024;
+                __builtin_amdgcn_global_load_lds((pp_gptr)(Kp + ko), (pp_lptr)d, 16, 0, 0);
+                if (X3) __builtin_amdgcn_global_load_lds((pp_gptr)(Kp + ko + 2 * (size_t)xa.k_lo), (pp_lptr)(d + PP_IMG), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((pp_gptr)(Vp + vo), (pp_lptr)(d + VPL * PP_IMG), 16, 0, 0);
+                if (X3) __builtin_amdgcn_global_load_lds((pp_gptr)(Vp + vo + 2 * (size_t)xa.v_lo), (pp_lptr)(d + 3 * PP_IMG), 16, 0, 0);
+            }
+            // the raw key-pad mask of the pair's keys (converted to additive terms once it has landed); without a mask any readable word
+            char* const mt = reinterpret_cast<char*>(mterm_all) + (j % PP_NSTAGE) * PP_MT;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* src = a.key_mask ? a.key_mask + k_off + max(min(lane + 64 * i, k_len - 1), 0) : reinterpret_cast<const float*>(a.seq);
+                __builtin_amdgcn_global_load_lds((pp_gptr)src, (pp_lptr)(mt + 256 * i), 4, 0, 0);
+            }
+        };
+        const bool no_dma = xa.dbg & 1;
+        if (n_my > 0 && !no_dma) issue(0);
+        if (n_my > 1 && !no_dma) issue(1);
+        for (int c = 0; c < n_my; ++c) {
+            // everything but the newest pair's instructions has landed → pair c is in LDS
+            if (c + 1 < n_my && !no_dma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            {
+                const int k_len = __builtin_amdgcn_readlane(m_klen, c);
+                const unsigned mt = (unsigned)(size_t)((pp_lptr)(reinterpret_cast<char*>(mterm_all) + (c % PP_NSTAGE) * PP_MT)) + 4u * lane;
+                // (inline asm: a compiler-visible LDS read here would be preceded by vmcnt(0) — the DMA writes LDS — and drain the ring)
+                float v0, v1;
+                asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(mt) : "memory");
+                if (!a.key_mask) { v0 = 1.0f; v1 = 1.0f; }
+                v0 = lane < k_len ? (1.0f - v0) * (-10000.0f * LOG2E) : -INFINITY;        // (exp2 domain: the compute waves' scores carry log2 e)
+                v1 = lane + 64 < k_len ? (1.0f - v1) * (-10000.0f * LOG2E) : -INFINITY;
+                asm volatile("ds_write_b32 %2, %0\n\tds_write_b32 %2, %1 offset:256\n\ts_waitcnt lgkmcnt(0)" ::"v"(v0), "v"(v1), "v"(mt) : "memory");
+            }
+            PP_STAMP(c, 2);
+            __builtin_amdgcn_s_barrier();                    // A_c: pair c landed; the stage of pair c − 1 is free
+            PP_STAMP(c, 0);
+            if (c + 2 < n_my && !no_dma) issue(c + 2);
+            PP_STAMP(c, 1);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------------- compute waves
+    const int g = lane >> 4, l15 = lane & 15, q0 = 16 * wave;
+    const DropCtx dctx(a.seed, a.site, a.p_drop);
+    // Lane parts of the fragment addresses (image-relative bytes).  K row fragment (key tile t, k-step ks = head columns 32·ks …):
+    // row 16·t + l15, chunk 4·ks + g → (kb ^ ks << 6) + 2048·t; the last tile's rows stop at the image's last row (kb6).  V transposed
+    // fragment (k-step u = keys 32·u …, half ab, column tile dt): row 32·u + 16·ab + 4·g + q, chunk 2·dt + (p >> 1) → (vb ^ dt << 5) +
+    // 128·(32·u + 16·ab): a row's swizzle depends on its bits 1-3 only; keys 96-111 stop at the image's last row (vb3).
+    const int kb = l15 * PP_RB + ((g ^ pp_swz(l15)) << 4);
+    const int kr6 = min(96 + l15, PP_ROWS - 1), kb6 = kr6 * PP_RB + ((g ^ pp_swz(kr6)) << 4);
+    const int vq = l15 >> 2, vp = l15 & 3, vr = 4 * g + vq;
+    const int vb = vr * PP_RB + (((vp >> 1) ^ pp_swz(vr)) << 4) + 8 * (vp & 1);
+    const int vr3 = min(96 + vr, PP_ROWS - 1), vb3 = vr3 * PP_RB + (((vp >> 1) ^ pp_swz(vr3)) << 4) + 8 * (vp & 1);
+    // Q fragments: the next pair's are requested into a second register set before the barrier and land under this pair's arithmetic
+    // (requested into the live set right after the score products, the compiler waits for them at once to copy them: measured)
+    bf16x8 nqh[2], nql[2];
+    auto load_q = [&](int j) {
+        const int pair = bid + j * G, s = pair / a.H, h = pair - s * a.H;
+        const int q_off = __builtin_amdgcn_readlane(m_qoff, j), q_len = __builtin_amdgcn_readlane(m_qlen, j);
+        const int qr = max(min(q0 + l15, q_len - 1), 0);          // rows past the sequence repeat its last query (never stored)
+        const __bf16* Qp = (const __bf16*)a.Q + (size_t)(q_off + qr) * a.ldq + h * 64 + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            nqh[ks] = *reinterpret_cast<const bf16x8*>(Qp + 32 * ks);
+            if (X3) nql[ks] = *reinterpret_cast<const bf16x8*>(Qp + xa.q_lo + 32 * ks);
+        }
+    };
+    auto land_q = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            asm volatile("" : "+v"(nqh[ks]));
+            if (X3) asm volatile("" : "+v"(nql[ks]));
+        }
+    };
+    if (n_my > 0) {
+        load_q(0);
+        land_q();                                 // the loop is entered with no load pending on either edge
+    }
+    for (int c = 0; c < n_my; ++c) {
+        const int pair = bid + c * G, s = pair / a.H, h = pair - s * a.H;
+        const int q_off = __builtin_amdgcn_readlane(m_qoff, c), q_len = __builtin_amdgcn_readlane(m_qlen, c), k_len = __builtin_amdgcn_readlane(m_klen, c);
+        bf16x8 qh[2], ql[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qh[ks] = nqh[ks];
+            if (X3) ql[ks] = nql[ks];
+            else {                                // the bf16 form carries 1/sqrt(dh) on Q (exact: a power of two)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qh[ks][j] = (__bf16)((float)qh[ks][j] * a.scale);
+            }
+        }
+        load_q(min(c + 1, n_my - 1));             // (unconditional — the last iteration re-requests its own: a conditional request makes the
+                                                  // compiler merge register sets behind it, i.e. wait for the loads on the spot)
+        if (wave == 0) PP_STAMP(c, 3);
+        __builtin_amdgcn_s_barrier();                        // A_c
+        if (wave == 0) PP_STAMP(c, 4);
+        // LDS byte addresses of this iteration's fragments: stage base + lane part, everything else an instruction immediate
+        // This iteration's fragment addresses = LDS base + (stage offset + lane part) + an instruction immediate.  The integer parts are
+        // pinned in registers (empty asm): the compiler otherwise re-derives stage base + lane part in front of every single read.
+        const int soff = (c % PP_NSTAGE) * STAGE;
+        int ki0 = soff + kb, ki1 = soff + (kb ^ 64), ki60 = soff + kb6, ki61 = soff + (kb6 ^ 64);      // K row fragments, k-step 0 / 1
+        int mi = PP_NSTAGE * STAGE + (c % PP_NSTAGE) * PP_MT + 16 * g;
+        asm volatile("" : "+v"(ki0), "+v"(ki1), "+v"(ki60), "+v"(ki61), "+v"(mi));
+        const char* const ka0 = smem + ki0; const char* const ka1 = smem + ki1;
+        const char* const ka60 = smem + ki60; const char* const ka61 = smem + ki61;
+        const float* const mta = reinterpret_cast<const float*>(smem + mi);
+        if (q0 < q_len && !(xa.dbg & 2)) {
+            // ---- Sᵀ = K·Qᵀ: tile t = keys 16·t …; register r of lane (g, l15) ↔ key 16·t + 4·g + r, query q0 + l15.  Every tile of the
+            // image is computed: keys past the sequence read finite rows and carry −inf mask terms.
+            floatx4 sc[PP_NT];
+            const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                // the K fragments of all seven tiles first, then the products TERM-major: consecutive MFMAs write different accumulators
+                bf16x8 kfh[PP_NT], kfl[PP_NT];
+#pragma unroll
+                for (int t = 0; t < PP_NT; ++t) {
+                    const char* const o = t < 6 ? (ks ? ka1 : ka0) + 2048 * t : (ks ? ka61 : ka60);
+                    kfh[t] = *reinterpret_cast<const bf16x8*>(o);
+                    if (X3) kfl[t] = *reinterpret_cast<const bf16x8*>(o + PP_IMG);
+                }
+                // (the very first product of an accumulator takes a literal zero: no register initialisation)
+                if (X3) {
+#pragma unroll
+                    for (int t = 0; t < PP_NT; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfh[t], ql[ks], ks ? sc[t] : zero4, 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < PP_NT; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl[t], qh[ks], sc[t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < PP_NT; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfh[t], qh[ks], (X3 || ks) ? sc[t] : zero4, 0, 0, 0);
+            }
+            const int q = q0 + l15;                 // this lane's query
+            // softmax in the exp2 domain: t = s·(scale·log2 e) + m·log2 e (the loader stores the mask terms already multiplied)
+            const float cs = X3 ? a.scale * LOG2E : LOG2E;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < PP_NT; ++t) {       // registers 0..3 ↔ four consecutive keys: their mask terms in one 16-byte LDS read
+                const float4 m4 = *reinterpret_cast<const float4*>(mta + 16 * t);
+                sc[t][0] = fmaf(sc[t][0], cs, m4.x); sc[t][1] = fmaf(sc[t][1], cs, m4.y);
+                sc[t][2] = fmaf(sc[t][2], cs, m4.z); sc[t][3] = fmaf(sc[t][3], cs, m4.w);
+                mx = fmaxf(fmaxf(mx, sc[t][0]), fmaxf(sc[t][1], fmaxf(sc[t][2], sc[t][3])));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < PP_NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(sc[t][r] - mx); sc[t][r] = p; sum += p; }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            // (v_log_f32 / v_rcp_f32: 1 ulp, where logf and the IEEE division cost a dozen instructions each)
+            if (g == 0 && q < q_len && a.LSE) a.LSE[((size_t)s * a.H + h) * a.max_q + q] = (mx + __builtin_amdgcn_logf(sum)) * (1.0f / LOG2E);
+            // P stays unnormalised (and un-rescaled by the dropout's 1/(1-p)): O is multiplied once at the end
+            const float oscale = dctx.ik * __builtin_amdgcn_rcpf(sum);
+            // dropout draws of this lane's query row (common.h: svpc_attn_draw16): A + (4·g)·φ once, a literal added per element
+            const uint32_t arow = dctx.row((u64)(s * a.H + h) * a.max_q + q) + (uint32_t)(4 * g) * SVPC_ATTN_PHI;
+            // ---- Oᵀ = Vᵀ·P̃ᵀ: k-step u = keys 32·u …, element j of a lane's B fragment ↔ key 32·u + 16·(j >> 2) + 4·g + (j & 3)
+            // = registers of the score tiles 2·u (j < 4) and 2·u + 1; the V fragments read the same keys in the same order
+            floatx4 acc[4];      // tile dt: register r ↔ head column 16·dt + 4·g + r of this lane's query
+            // V fragments: lane part ^ (dt << 5), one base per column tile; keys 96-111 from the row-clamped lane part
+            const char* va[4]; const char* va3[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                int i0 = soff + VPL * PP_IMG + (vb ^ (dt << 5)), i3 = soff + VPL * PP_IMG + (vb3 ^ (dt << 5));
+                asm volatile("" : "+v"(i0), "+v"(i3));
+                va[dt] = smem + i0; va3[dt] = smem + i3;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = 2 * u + (j >> 2);
+                    pv[j] = t < PP_NT ? sc[t < PP_NT ? t : 0][j & 3] : 0.f;
+                }
+                if (a.p_drop > 0.f) {
+#pragma unroll
+                    for (int j = 0; j < (u < 3 ? 8 : 4); ++j)
+                        pv[j] = svpc_attn_draw16(arow + (uint32_t)(32 * u + 16 * (j >> 2) + (j & 3)) * SVPC_ATTN_PHI) >= dctx.thr ? pv[j] : 0.0f;
+                }
+                // hi = bf16(p) and lo = bf16(p − hi), two values per v_cvt_pk_bf16_f32
+                uint32_t ph[4], pl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ph[j] = pp_cvt2(pv[2 * j], pv[2 * j + 1]);
+                    if (X3) pl[j] = pp_cvt2(pv[2 * j] - __uint_as_float(ph[j] << 16), pv[2 * j + 1] - __uint_as_float(ph[j] & 0xffff0000u));
+                }
+                const bf16x8 phv = pp_frag(ph), plv = X3 ? pp_frag(pl) : phv;
+                // keys 32·u … +15 and … +16 … +31 (the second half of the last k-step, keys 112-127, is never live: zeros); all eight
+                // fragments first, then the products term-major over the four column tiles
+                bf16x8 vfh[4], vfl[4];
+                const short4v z4 = {0, 0, 0, 0};
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const char* const oa = u < 3 ? va[dt] + 4096 * u : va3[dt]; const char* const ob = va[dt] + 4096 * u + 2048;
+                    vfh[dt] = pp_join(__builtin_amdgcn_ds_read_tr16_b64_v4i16((pp_tr_ptr)oa),
+                                      u < 3 ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((pp_tr_ptr)ob) : z4);
+                    if (X3) vfl[dt] = pp_join(__builtin_amdgcn_ds_read_tr16_b64_v4i16((pp_tr_ptr)(oa + PP_IMG)),
+                                              u < 3 ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((pp_tr_ptr)(ob + PP_IMG)) : z4);
+                }
+                if (X3) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfh[dt], plv, u ? acc[dt] : zero4, 0, 0, 0);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl[dt], phv, acc[dt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfh[dt], phv, (X3 || u) ? acc[dt] : zero4, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);      // one k-step at a time: the dropout draws of later ones must not be hoisted (registers)
+            }
+            // the next pair's Q fragments are waited for HERE, before this pair's stores enter the memory queue: they were requested
+            // a whole compute phase ago, whereas a wait at their first use (next iteration) would also drain the stores just issued
+            if (wave == 0) PP_STAMP(c, 5);
+            land_q();
+            if (wave == 0) PP_STAMP(c, 6);
+            // tiles 2e and 2e+1 of a plane: v_permlane16_swap hands the odd lane groups' tile-2e runs to the even groups and the even
+            // groups' tile-(2e+1) runs to the odd ones → every lane holds 8 consecutive head columns: 16·(2e + (g & 1)) + 8·(g >> 1)
+            __bf16* Op = (__bf16*)a.O + (size_t)(q_off + q) * a.ldo + h * 64 + 16 * (g & 1) + 8 * (g >> 1);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                uint32_t xh[2], yh[2], xl[2], yl[2];
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) {
+                        const float v0 = acc[2 * e + d][2 * r2] * oscale, v1 = acc[2 * e + d][2 * r2 + 1] * oscale;
+                        const uint32_t hh = pp_cvt2(v0, v1);
+                        (d ? yh : xh)[r2] = hh;
+                        if (X3) (d ? yl : xl)[r2] = pp_cvt2(v0 - __uint_as_float(hh << 16), v1 - __uint_as_float(hh & 0xffff0000u));
+                    }
+#pragma unroll
+                for (int plane = 0; plane < (X3 ? 2 : 1); ++plane) {
+                    auto s0 = __builtin_amdgcn_permlane16_swap(plane ? xl[0] : xh[0], plane ? yl[0] : yh[0], false, false);
+                    auto s1 = __builtin_amdgcn_permlane16_swap(plane ? xl[1] : xh[1], plane ? yl[1] : yh[1], false, false);
+                    if (q < q_len && !(xa.dbg & 4))
+                        *reinterpret_cast<uint4*>(Op + (plane ? xa.o_lo : 0) + 32 * e) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+            }
+            if (wave == 0) PP_STAMP(c, 7);
+        }
+    }
+    if (do_stamp && wave == 0) {           // (the loader's last stamps precede its last barrier arrival or follow it by a few instructions)
+        __builtin_amdgcn_s_sleep(100);
+        for (int i = lane; i < 128; i += 64) xa.dbg_buf[bid * 128 + i] = stamps[i];
+    }
+#undef PP_STAMP
+}
+
+static int pp_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// 1 if the pipelined forward takes this problem (the callers fall back to the one-workgroup-per-pair kernels otherwise)
+static int pp_dbg = 0;
+static unsigned long long* pp_dbg_buf = nullptr;
+// timing experiments (tools/dbg/pipe_*.py; never set by the product): bits 1 no LDS-DMA, 2 no arithmetic, 4 no O stores,
+// 16 cycle stamps of workgroups 0-15 into `buf` (16 × 128 u64)
+extern "C" int svpc_attn_pipe_debug(int bits, void* buf) { pp_dbg = bits; pp_dbg_buf = (unsigned long long*)buf; return 0; }
+static int pp_on = -1;
+// tuning / A-B switch: 1 = sequences of ≤ 104 rows take the pipelined forward (default; SVPC_ATTN_PIPE=0 in the environment turns it
+// off), 0 = always the one-workgroup-per-pair kernels.  Returns the previous setting.
+extern "C" int svpc_attn_pipe_enable(int on) {
+    if (pp_on < 0) { const char* e = getenv("SVPC_ATTN_PIPE"); pp_on = e ? atoi(e) : 1; }
+    const int was = pp_on;
+    if (on >= 0) pp_on = on ? 1 : 0;
+    return was;
+}
+bool attn_pipe_supported(const X3AttnArgs& xa, int dh, bool x3) {
+    const int on = (svpc_attn_pipe_enable(-1), pp_on);
+    const MAttnArgs& a = xa.m;
+    const bool al = a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 8 == 0 &&
+                    ((((uintptr_t)a.Q) | ((uintptr_t)a.K) | ((uintptr_t)a.V) | ((uintptr_t)a.O)) & 15) == 0 &&
+                    (!x3 || (xa.q_lo % 8 == 0 && xa.k_lo % 8 == 0 && xa.v_lo % 8 == 0 && xa.o_lo % 8 == 0));
+    return on && dh == 64 && !a.causal && a.max_q <= PP_ROWS && a.max_k <= PP_ROWS && a.max_q > 32 && al && a.n_seq * a.H <= 64 * pp_cus();
+}
+int attn_pipe_fwd_launch(const X3AttnArgs& xa_in, bool x3, hipStream_t stream) {
+    X3AttnArgs xa = xa_in;
+    xa.dbg = pp_dbg; xa.dbg_buf = pp_dbg_buf;
+    if (!xa.dbg_buf) xa.dbg &= ~16;
+    const int n_pairs = xa.m.n_seq * xa.m.H;
+    if (x3) {
+        const size_t lds = (size_t)PP_NSTAGE * (4 * PP_IMG + PP_MT) + 1024;
+        int rc = svpc_raise_lds_once((const void*)attn_pipe_fwd_kernel<true>, "attn_pipe");
+        if (rc) return rc;
+        hipLaunchKernelGGL((attn_pipe_fwd_kernel<true>), dim3(min(n_pairs, pp_cus())), dim3(512), lds, stream, xa, n_pairs);
+    } else {
+        const size_t lds = (size_t)PP_NSTAGE * (2 * PP_IMG + PP_MT) + ((xa.dbg & 16) ? 1024 : 0);
+        int rc = svpc_raise_lds_once((const void*)attn_pipe_fwd_kernel<false>, "attn_pipe");
+        if (rc) return rc;
+        hipLaunchKernelGGL((attn_pipe_fwd_kernel<false>), dim3(min(n_pairs, 2 * pp_cus())), dim3(512), lds, stream, xa, n_pairs);
+    }
+    return svpc_check_launch("attn_pipe_fwd");
+}

@@ -42,9 +42,9 @@ __device__ __forceinline__ float2 q1s_pair(const __bf16* p, int lo) {           
     }
     return r;
 }
-__device__ __forceinline__ float q1s_drop(const Q1sArgs& a, u64 seed, u64 row_base, int key) {
+__device__ __forceinline__ float q1s_drop(const Q1sArgs& a, u64 seed, u64 row, int key) {          // row = index of the probability row (common.h)
     if (a.p_drop <= 0.f) return 1.0f;
-    return drop_scale(seed, a.site, row_base + (u64)key, a.p_drop, 1.0f / (1.0f - a.p_drop));
+    return attn_drop_scale(seed, a.site, row, (uint32_t)key, a.p_drop, 1.0f / (1.0f - a.p_drop));
 }
 
 // scores of this lane's keys (lane, lane + 64) → normalised probabilities p[2] (0 past k_len), returns the log-sum-exp
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void attn_q1s_fwd_kernel(Q1sArgs a) {
     const float lse = q1s_probs<DH, SPLIT>(a, qv, Kp, k_len, a.key_mask ? a.key_mask + k_off : nullptr, lane, p);
     if (lane == 0 && a.LSE) a.LSE[((size_t)s * a.H + h) * a.max_q] = lse;
     const u64 seed = a.p_drop > 0.f ? a.seed[0] : 0ull;
-    const u64 row_base = ((u64)(s * a.H + h) * a.max_q) * a.max_k;
+    const u64 row_base = (u64)(s * a.H + h) * a.max_q;        // the pair's single probability row
     p[0] *= q1s_drop(a, seed, row_base, lane);
     p[1] *= q1s_drop(a, seed, row_base, lane + 64);
     // O[d] = Σ_k p̃[k]·V[k][d]: lanes 0-31 take even keys, lanes 32-63 odd keys, each lane a column pair (DH = 64) / one column (DH = 32)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void attn_q1s_bwd_kernel(Q1sArgs a) {
     float p[2];
     q1s_probs<DH, SPLIT>(a, qv, Kp, k_len, a.key_mask ? a.key_mask + k_off : nullptr, lane, p);
     const u64 seed = a.p_drop > 0.f ? a.seed[0] : 0ull;
-    const u64 row_base = ((u64)(s * a.H + h) * a.max_q) * a.max_k;
+    const u64 row_base = (u64)(s * a.H + h) * a.max_q;        // the pair's single probability row
     float m[2], dpt[2];
     // dP̃[k] = m[k]·(dO·V[k]) with this lane's keys' V rows; dV[k] = p[k]·m[k]·dO (row store)
 #pragma unroll

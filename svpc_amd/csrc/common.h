@@ -91,6 +91,37 @@ __device__ __host__ __forceinline__ uint32_t svpc_hash32(u64 seed, uint32_t site
     const uint32_t hi = (uint32_t)(idx >> 32);
     return svpc_mix32(((uint32_t)idx ^ key) + hi * 0x85EBCA6Bu);
 }
+// ---- dropout draws of the ATTENTION PROBABILITIES (model.py:213): element (row, k) of the (sequence·head·query, key) tensor.
+// The full mixer runs once per ROW, A = mix32(row ^ key); an element costs one add, one xor-shift and ONE full-rate 24-bit multiply:
+//     x = A + k·φ,  y = x ^ (x >> 16),  draw = (y[23:0] · M) >> 16   (16 bits, compared with p·65536).
+// The attention kernels are bound by vector-instruction issue, and the two quarter-rate 32-bit multiplies + three xor-shifts of a
+// per-element lowbias32 were a fifth (bf16x3) to a third (bf16) of the clip-encoder forward's instructions.  Forward kernels keep a
+// query per lane (A once per lane and pair), backward kernels a key per lane (k·φ once per lane, A per register from a per-pair LDS
+// table): the same draw either way.  Statistics (keep rate, row / column variance against the binomial, lag and 2×2 correlations)
+// checked against the lowbias32 draw in tools/dbg/attn_draw_stats.py.
+__device__ __host__ __forceinline__ uint32_t svpc_attn_row_hash(uint32_t key, u64 row) {
+    return svpc_mix32(((uint32_t)row ^ key) + (uint32_t)(row >> 32) * 0x85EBCA6Bu);
+}
+constexpr uint32_t SVPC_ATTN_PHI = 0x9E3779B1u, SVPC_ATTN_M24 = 0xB5297Bu;
+__device__ __host__ __forceinline__ uint32_t svpc_attn_draw16(uint32_t a_plus_kphi) {
+    uint32_t x = a_plus_kphi;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (the xor-shift as ONE sdwa instruction the compiler cannot look into: knowing that the multiply reads 24 bits it otherwise masks x
+    // first — (x & 0xffffff) ^ (x >> 16) — one more instruction per draw)
+    uint32_t y;
+    asm("v_xor_b32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(y) : "v"(x));
+    return __umul24(y, SVPC_ATTN_M24) >> 16;
+#else
+    x ^= x >> 16;
+    return (uint32_t)(((u64)(x & 0xFFFFFFu) * SVPC_ATTN_M24) & 0xFFFFFFFFull) >> 16;
+#endif
+}
+__device__ __host__ __forceinline__ uint32_t svpc_drop_key(u64 seed, uint32_t site) { return (uint32_t)(seed ^ (seed >> 32)) + (site + 1u) * 0x9E3779B9u; }
+// multiplier (0 or 1/(1-p)) of attention-probability element (row, k)
+__device__ __forceinline__ float attn_drop_scale(u64 seed, uint32_t site, u64 row, uint32_t k, float p, float inv_keep) {
+    const uint32_t thr = (uint32_t)(p * 65536.0f);
+    return svpc_attn_draw16(svpc_attn_row_hash(svpc_drop_key(seed, site), row) + k * SVPC_ATTN_PHI) >= thr ? inv_keep : 0.0f;
+}
 // keep-probability 1-p (16-bit resolution); returns the multiplier (0 or 1/(1-p))
 __device__ __forceinline__ float drop_scale(u64 seed, uint32_t site, u64 idx, float p, float inv_keep) {
     const uint32_t thr = (uint32_t)(p * 65536.0f);

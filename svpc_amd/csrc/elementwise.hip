@@ -70,6 +70,18 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ o
         out[i] = drop_scale(seed, site, i, p, 1.0f);
 }
 
+// the keep mask (1 / 0) of the attention kernels' probability dropout: element (row, k) of a (n_rows, max_k) tensor, rows indexed
+// (sequence·H + head)·max_q + query — the row-hash draw of common.h (test infrastructure hands it to the fp32 reference)
+__global__ __launch_bounds__(256) void attn_dropout_mask_kernel(float* __restrict__ out, size_t n_rows, int max_k, float p, uint32_t site,
+                                                                const u64* __restrict__ seed_ptr) {
+    const u64 seed = seed_ptr[0];
+    const size_t n = n_rows * (size_t)max_k;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / (size_t)max_k;
+        out[i] = attn_drop_scale(seed, site, row, (uint32_t)(i - row * (size_t)max_k), p, 1.0f);
+    }
+}
+
 __global__ __launch_bounds__(256) void gumbel_noise_kernel(float* __restrict__ out, size_t n, uint32_t site,
                                                            const u64* __restrict__ seed_ptr) {
     const u64 seed = seed_ptr[0];
@@ -762,6 +774,11 @@ int svpc_dropout_mask(float* out, size_t n, float p, unsigned site, const u64* s
     if (n == 0) return 0;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid1d(n)), dim3(256), 0, s, out, n, p, site, seed);
     return svpc_check_launch("dropout_mask");
+}
+int svpc_attn_dropout_mask(float* out, size_t n_rows, int max_k, float p, unsigned site, const u64* seed, hipStream_t s) {
+    if (n_rows == 0 || max_k <= 0) return 0;
+    hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3(grid1d(n_rows * (size_t)max_k)), dim3(256), 0, s, out, n_rows, max_k, p, site, seed);
+    return svpc_check_launch("attn_dropout_mask");
 }
 int svpc_gumbel_noise(float* out, size_t n, unsigned site, const u64* seed, hipStream_t s) {
     if (n == 0) return 0;

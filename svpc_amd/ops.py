@@ -369,6 +369,12 @@ class Rng:
         _lib.call("dropout_mask", _p(out), n, float(p), int(site), _p(self.seed), _stream())
         return out
 
+    def attn_mask(self, site, n_rows, max_k, p, device):
+        """keep mask of the attention-probability dropout, (n_rows, max_k), rows (sequence·H + head)·max_q + query"""
+        out = torch.empty(n_rows, max_k, dtype=torch.float32, device=device)
+        _lib.call("attn_dropout_mask", _p(out), n_rows, max_k, float(p), int(site), _p(self.seed), _stream())
+        return out
+
 
 _DEFAULT_RNG = {}
 

@@ -114,8 +114,8 @@ def attention(qt, kvt, cols, D, n_heads, seq, key_mask=None, causal=False, drop=
         p = torch.softmax(s, dim=-1)
         if drop is not None and drop[0] > 0:
             pd, rng, site = drop
-            # element index of the mask: ((seq*H + head)*max_q + i)*max_k + j
-            full = rng.mask(site, seq.n * n_heads * seq.max_q * seq.max_k, pd, q.device)
+            # the kernels' own draw for element (row (seq*H + head)*max_q + i, key j)
+            full = rng.attn_mask(site, seq.n * n_heads * seq.max_q, seq.max_k, pd, q.device)
             full = full.view(seq.n, n_heads, seq.max_q, seq.max_k)[i, :, :ql, :kl]
             p = p * full * (1.0 / (1.0 - pd))
         out.append((p @ vi).permute(1, 0, 2).reshape(ql, D))
@@ -358,6 +358,9 @@ class EmulRng:
     def mask(self, site, n, p, device):
         g = torch.Generator().manual_seed(self.seed * 7919 + site)
         return (torch.rand(n, generator=g) >= p).float().to(device)
+
+    def attn_mask(self, site, n_rows, max_k, p, device):
+        return self.mask(site, n_rows * max_k, p, device).view(n_rows, max_k)
 
 
 def greedy_pick(scores, row_c, row_x, lt, pos, unk):

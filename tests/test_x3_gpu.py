@@ -217,6 +217,94 @@ def test_attention_split_vs_torch(n, L, H, dh, drop):
     assert float((qkv.grad.float() - qr.grad).abs().max()) <= 3e-2 * float(qr.grad.abs().max())
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("n,lo,hi,drop", [(60, 33, 104, 0.1), (60, 100, 100, 0.0), (7, 64, 97, 0.1)])
+def test_pipelined_attention_forward_vs_torch_and_vs_one_workgroup_per_pair(mode, n, lo, hi, drop):
+    """attention_pipe.hip — the persistent forward of the clip encoder (a loader wave keeps the next two (sequence, head) pairs' K / V
+    planes in flight by LDS-DMA, seven waves compute the current one): ragged sequences of 33-104 rows, 720 pairs on 256 / 512
+    workgroups (three pairs each and more: every stage of the ring is reused), key-pad mask, dropout — against the fp32 reference (which
+    applies the kernels' own dropout draws) and against the one-workgroup-per-pair kernels it replaces; the backward (which recomputes
+    the probabilities from the forward's LSE and the same draws) against autograd."""
+    from svpc_amd import _lib
+    H, dh = 12, 64
+    D = H * dh
+    O.set_precision(mode)
+    try:
+        g = torch.Generator().manual_seed(5)
+        lens = torch.randint(lo, hi + 1, (n,), generator=g).tolist()
+        lens[0] = hi
+        offs = [sum(lens[:i]) for i in range(n)]
+        R = sum(lens)
+        seq = SeqInfo(offs, lens, offs, lens, DEV)
+        src = _rand(R, 3 * D, seed=60)
+        if mode == "bf16x3":
+            qkv, qkvv = _split(src)
+        else:
+            qkv = src.to(torch.bfloat16)
+            qkvv = qkv.float()
+        km = (torch.rand(R, generator=torch.Generator().manual_seed(6)) > 0.2).float().to(DEV)
+        for o in offs:
+            km[o] = 1.0
+        rng = O.make_rng(DEV, seed=17)
+        d = (drop, rng, 3) if drop > 0 else None
+        ref = E.attention(qkvv, qkvv, (0, D, 2 * D), D, H, seq, key_mask=km, causal=False, drop=d)
+        lib = _lib.load()
+        outs = []
+        for on in (0, 1):
+            was = lib.svpc_attn_pipe_enable(on)
+            try:
+                out = O.attention(qkv, qkv, (0, D, 2 * D), D, H, seq, key_mask=km, causal=False, drop=d)
+                outs.append(_value(out) if mode == "bf16x3" else out.float())
+            finally:
+                lib.svpc_attn_pipe_enable(was)
+        tol = 5e-5 if mode == "bf16x3" else 1.2e-2
+        for o in outs:
+            assert bool(torch.isfinite(o).all())
+            assert float((o - ref).abs().max()) <= tol * float(ref.abs().max())
+        assert float((outs[0] - outs[1]).abs().max()) <= tol * float(ref.abs().max())
+        # backward through the pipelined forward's LSE
+        assert lib.svpc_attn_pipe_enable(-1) == 1
+        qkv.requires_grad_(True)
+        out = O.attention(qkv, qkv, (0, D, 2 * D), D, H, seq, key_mask=km, causal=False, drop=d)
+        gr = _rand(R, D, seed=61).to(torch.bfloat16)
+        out.backward(gr)
+        qr = qkvv.clone().requires_grad_(True)
+        E.attention(qr, qr, (0, D, 2 * D), D, H, seq, key_mask=km, causal=False, drop=d).backward(gr.float())
+        assert float((qkv.grad.float() - qr.grad).abs().max()) <= 3e-2 * float(qr.grad.abs().max())
+    finally:
+        O.set_precision("fp32")
+
+
+@pytest.mark.parametrize("scale_in", [1.0, 3.0])
+def test_bf16_attention_forward_error_statistics(scale_in):
+    """the bf16 clip-encoder forward against an fp64 reference on the same bf16 inputs: the kernel's own rounding (operands of the second
+    product, fp32 accumulation) may add at most half of what the rounding of the bf16 OUTPUT alone costs, and no bias — a bound on
+    the kernel itself, where the whole-model loss deviation of the bf16 mode is the net of millions of such roundings"""
+    import math
+    from svpc_amd import _lib
+    H, dh, B, L = 12, 64, 48, 100
+    D = H * dh
+    seq = SeqInfo.uniform(B, L, L, DEV)
+    qkv = (scale_in * _rand(B * L, 3 * D, seed=70)).to(torch.bfloat16).contiguous()
+    xv = qkv.double()
+    q, k, v = (xv[:, i * D:(i + 1) * D].view(B, L, H, dh).permute(0, 2, 1, 3) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh), -1) @ v).permute(0, 2, 1, 3).reshape(B * L, D)
+    O.set_precision("bf16")
+    try:
+        for on in (1, 0):
+            was = _lib.load().svpc_attn_pipe_enable(on)
+            try:
+                out = O.attention(qkv, qkv, (0, D, 2 * D), D, H, seq, key_mask=None, causal=False, drop=None)
+            finally:
+                _lib.load().svpc_attn_pipe_enable(was)
+            e = out.double() - ref
+            floor = float((ref.to(torch.bfloat16).double() - ref).pow(2).mean().sqrt())
+            assert float(e.pow(2).mean().sqrt()) <= 1.5 * floor, (on, float(e.pow(2).mean().sqrt()), floor)
+            assert abs(float(e.mean())) <= 0.05 * floor, (on, float(e.mean()), floor)
+    finally:
+        O.set_precision("fp32")
+
+
 @pytest.mark.parametrize("n,Lq,Lk,H,dh,causal,drop", [(7, 22, 22, 12, 64, True, 0.0), (7, 22, 22, 12, 64, True, 0.1), (9, 22, 3, 12, 64, False, 0.0),
                                                      (5, 32, 32, 4, 32, True, 0.0), (3, 6, 6, 4, 32, True, 0.0), (4, 22, 1, 12, 64, False, 0.0)])
 def test_attention_short_sequences_split_vs_torch(n, Lq, Lk, H, dh, causal, drop):
