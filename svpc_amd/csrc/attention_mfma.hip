@@ -928,6 +928,8 @@ __global__ __launch_bounds__(256, 2) void attn_small_x3_fwd_kernel(X3AttnArgs xa
 // attention_pipe.hip: the persistent, LDS-DMA-pipelined forward for ≤ 104-row sequences of the bf16 / split streams
 bool attn_pipe_supported(const X3AttnArgs& xa, int dh, bool x3);
 int attn_pipe_fwd_launch(const X3AttnArgs& xa, bool x3, hipStream_t stream);
+bool attn_pipe_bwd_supported(const MAttnArgs& a, int dh);
+int attn_pipe_bwd_launch(const MAttnArgs& a, hipStream_t stream);
 
 static int mattn_set_lds(const void* fn, size_t bytes) { return svpc_raise_lds_once(fn, "attn_mfma"); }   // once per kernel symbol, process-wide table (api.cpp)
 static bool mattn_ok(int dh, int max_q, int max_k, int ldq, int ldk, int ldv, const void* Q, const void* K, const void* V, int dt) {
@@ -984,6 +986,7 @@ static int mattn_fwd_launch(const MAttnArgs& a, int dh, int n_blocks, hipStream_
 template <typename T>
 static int mattn_bwd_launch(const MAttnArgs& a, int dh, int n_blocks, hipStream_t stream) {
     const bool small = a.max_q <= 32 && a.max_k <= 32;
+    if (sizeof(T) == 2 && attn_pipe_bwd_supported(a, dh)) return attn_pipe_bwd_launch(a, stream);
     if (dh == 64) return small ? mattn_bwd_go<T, 64, 32>(a, n_blocks, stream) : mattn_bwd_go<T, 64, 128>(a, n_blocks, stream);
     return small ? mattn_bwd_go<T, 32, 32>(a, n_blocks, stream) : mattn_bwd_go<T, 32, 128>(a, n_blocks, stream);
 }

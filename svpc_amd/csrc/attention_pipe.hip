@@ -356,6 +356,283 @@ __global__ __launch_bounds__(512) void attn_pipe_fwd_kernel(X3AttnArgs xa, int n
 #undef PP_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------------------------- backward
+// dQ, dK, dV of the same attention core for the bf16 streams (in bf16x3 mode: the hi planes), one launch, no atomics, no HBM
+// intermediates — the arithmetic of attn_mfma_bwd_kernel (P recomputed from the forward's LSE and the same dropout draws) on the
+// pipelined skeleton: persistent workgroups, a LOADER wave bringing the Q, K, V, dO images of the next pair into a two-stage LDS ring by
+// LDS-DMA (plus the raw key mask and LSE rows, which it turns into the per-pair tables: mask terms and LSE in the exp2 domain, the
+// dropout row hashes), seven COMPUTE waves on 16-row tiles:
+//   pass 1, wave w = KEY tile w (its K and V fragments stay in registers for the pair): per query tile Sᵀ-layout products
+//     S[q][k] = Q·Kᵀ, dP̃[q][k] = dO·Vᵀ (a key on a lane column, queries over lane groups and registers), P̃ = P ⊙ M and
+//     dS = P ⊙ (dP̃ ⊙ M − δ) in registers; two query tiles at a time are the B operands of dVᵀ += dOᵀ·P̃ and dKᵀ += Qᵀ·dS (A operands:
+//     transposed reads of the dO / Q images); dS also goes to an LDS image [key][query];
+//   pass 2, wave w = QUERY tile w: dQᵀ += Kᵀ·dSᵀ with dSᵀ read back through ds_read_b64_tr_b16 (224-byte rows: conflict-free).
+// δ = rowsum(dO ⊙ O) is computed by the compute waves one pair ahead from rows they request themselves (16 rows per wave).
+// Two workgroup barriers per pair (ring hand-over; dS image complete).  Bound: HBM — (3·Lq + 2·Lk read + Lq + 2·Lk written)·64·2 B per pair.
+constexpr int PB_NSTAGE = 2;
+constexpr int PB_TAB = 4 * 512;                   // per stage: mask terms (keys), LSE·log2e, δ, dropout row hashes (queries): 128 words each
+constexpr int PB_STAGE = 4 * PP_IMG + PB_TAB;     // Q, K, V, dO images + tables
+constexpr int PB_DS_RS = 224;                     // dS image row: 112 queries bf16; 224 = 7·32 → the eight rows of a transposed read
+constexpr int PB_DS = 112 * PB_DS_RS;             // fall on eight different 32-byte bank groups
+
+__global__ __launch_bounds__(512) void attn_pipe_bwd_kernel(MAttnArgs a, int n_pairs) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int NI = 4 * PP_NBLK + 4;           // DMA instructions per pair: four images, key mask, LSE
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bid = blockIdx.x, G = gridDim.x;
+    const int n_my = bid < n_pairs ? (n_pairs - bid + G - 1) / G : 0;
+    char* const ds_img = smem + PB_NSTAGE * PB_STAGE;
+    int m_qoff = 0, m_qlen = 0, m_koff = 0, m_klen = 0;      // (see the forward: segment-table entries by v_readlane)
+    if (lane < n_my) {
+        const int s = (bid + lane * G) / a.H;
+        m_qoff = a.seq[s]; m_qlen = a.seq[a.n_seq + s]; m_koff = a.seq[2 * a.n_seq + s]; m_klen = a.seq[3 * a.n_seq + s];
+    }
+    const DropCtx dctx(a.seed, a.site, a.p_drop);
+    asm volatile("" : "+v"(m_qoff), "+v"(m_qlen), "+v"(m_koff), "+v"(m_klen));
+    (void)NI;
+
+    if (wave == 7) {
+        // ------------------------------------------------------------------------------------------------ loader
+        __builtin_amdgcn_s_setprio(2);
+        const int lrow = lane >> 3, ch0 = (lane & 7) ^ pp_swz(lrow);
+        auto issue = [&](int j) {
+            const int pair = bid + j * G, s = pair / a.H, h = pair - s * a.H;
+            const int q_off = __builtin_amdgcn_readlane(m_qoff, j), q_len = __builtin_amdgcn_readlane(m_qlen, j);
+            const int k_off = __builtin_amdgcn_readlane(m_koff, j), k_len = __builtin_amdgcn_readlane(m_klen, j);
+            char* const st = smem + (j % PB_NSTAGE) * PB_STAGE;
+            const char* const Qp = reinterpret_cast<const char*>((const __bf16*)a.Q + (size_t)q_off * a.ldq + h * 64);
+            const char* const Kp = reinterpret_cast<const char*>((const __bf16*)a.K + (size_t)k_off * a.ldk + h * 64);
+            const char* const Vp = reinterpret_cast<const char*>((const __bf16*)a.V + (size_t)k_off * a.ldv + h * 64);
+            const char* const Dp = reinterpret_cast<const char*>((const __bf16*)a.dO + (size_t)q_off * a.lddo + h * 64);
+#pragma unroll 1
+            for (int b = 0; b < PP_NBLK; ++b) {
+                const int rq = max(min(8 * b + lrow, q_len - 1), 0), rk = max(min(8 * b + lrow, k_len - 1), 0), ch = ch0 ^ ((b & 1) << 1);
+                char* const d = st + b * 1024;
+                __builtin_amdgcn_global_load_lds((pp_gptr)(Qp + ((unsigned)rq * (unsigned)a.ldq + 8u * ch) * 2u), (pp_lptr)d, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((pp_gptr)(Kp + ((unsigned)rk * (unsigned)a.ldk + 8u * ch) * 2u), (pp_lptr)(d + PP_IMG), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((pp_gptr)(Vp + ((unsigned)rk * (unsigned)a.ldv + 8u * ch) * 2u), (pp_lptr)(d + 2 * PP_IMG), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((pp_gptr)(Dp + ((unsigned)rq * (unsigned)a.lddo + 8u * ch) * 2u), (pp_lptr)(d + 3 * PP_IMG), 16, 0, 0);
+            }
+            char* const tab = st + 4 * PP_IMG;       // raw key mask → [0, 512), raw LSE → [512, 1024)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* km = a.key_mask ? a.key_mask + k_off + max(min(lane + 64 * i, k_len - 1), 0) : reinterpret_cast<const float*>(a.seq);
+                __builtin_amdgcn_global_load_lds((pp_gptr)km, (pp_lptr)(tab + 256 * i), 4, 0, 0);
+                const float* ls = a.LSE + ((size_t)s * a.H + h) * a.max_q + max(min(lane + 64 * i, q_len - 1), 0);
+                __builtin_amdgcn_global_load_lds((pp_gptr)ls, (pp_lptr)(tab + 512 + 256 * i), 4, 0, 0);
+            }
+        };
+        if (n_my > 0) issue(0);
+        for (int c = 0; c < n_my; ++c) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // pair c is in LDS (two stages: nothing younger is in flight)
+            {
+                const int pair = bid + c * G, s = pair / a.H, h = pair - s * a.H;
+                const int q_len = __builtin_amdgcn_readlane(m_qlen, c), k_len = __builtin_amdgcn_readlane(m_klen, c);
+                float* const tab = reinterpret_cast<float*>(smem + (c % PB_NSTAGE) * PB_STAGE + 4 * PP_IMG);
+                const u64 row0 = (u64)(s * a.H + h) * a.max_q;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int x = lane + 64 * i;
+                    const float km = a.key_mask ? tab[x] : 1.0f, ls = tab[128 + x];
+                    tab[x] = x < k_len ? (1.0f - km) * (-10000.0f * LOG2E) : -INFINITY;     // mask terms, exp2 domain
+                    tab[128 + x] = x < q_len ? ls * LOG2E : INFINITY;                        // queries past the sequence: P = 0
+                    reinterpret_cast<uint32_t*>(tab)[384 + x] = dctx.row(row0 + x);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (a raw s_barrier does not wait for this wave's LDS stores)
+            __builtin_amdgcn_s_barrier();                    // A_c: pair c and its tables are in LDS; the other stage is free
+            if (c + 1 < n_my) issue(c + 1);
+            __builtin_amdgcn_s_barrier();                    // M_c (the compute waves' mid-pair barrier)
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------------- compute waves
+    const int g = lane >> 4, l15 = lane & 15, t0 = 16 * wave;          // this wave's tile: keys t0 … in pass 1, queries t0 … in pass 2
+    // lane parts of the fragment addresses (see the forward): row fragments of a 16-row tile t (rows 16·t + l15, chunk 4·ks + g) and
+    // transposed fragments (rows 32·u + 16·ab + 4·g + q, chunk 2·dt + (p >> 1)); `…6` / `…3`: the last tile's rows clamped to the image
+    const int kb = l15 * PP_RB + ((g ^ pp_swz(l15)) << 4);
+    const int kr6 = min(96 + l15, PP_ROWS - 1), kb6 = kr6 * PP_RB + ((g ^ pp_swz(kr6)) << 4);
+    const int krw = min(t0 + l15, PP_ROWS - 1), kbw = krw * PP_RB + ((g ^ pp_swz(krw)) << 4);      // this wave's own tile
+    const int vq = l15 >> 2, vp = l15 & 3, vr = 4 * g + vq;
+    const int vb = vr * PP_RB + (((vp >> 1) ^ pp_swz(vr)) << 4) + 8 * (vp & 1);
+    const int vr3 = min(96 + vr, PP_ROWS - 1), vb3 = vr3 * PP_RB + (((vp >> 1) ^ pp_swz(vr3)) << 4) + 8 * (vp & 1);
+    const int dsb = vr * PB_DS_RS + 8 * vp + 2 * t0;                   // dSᵀ fragment of pass 2: rows 4·g + q, columns t0 + 4·p
+    const float cs = a.scale * LOG2E;
+    const uint32_t kphi = (uint32_t)(t0 + l15) * SVPC_ATTN_PHI;
+    // δ one pair ahead: this wave's 16 query rows, 16 head columns per lane group
+    bf16x8 no_[2], nd_[2];
+    auto load_od = [&](int j) {
+        const int pair = bid + j * G, s = pair / a.H, h = pair - s * a.H;
+        const int q_off = __builtin_amdgcn_readlane(m_qoff, j), q_len = __builtin_amdgcn_readlane(m_qlen, j);
+        const int r = max(min(t0 + l15, q_len - 1), 0);
+        const __bf16* op = (const __bf16*)a.O + (size_t)(q_off + r) * a.ldo + h * 64 + 16 * g;
+        const __bf16* dp = (const __bf16*)a.dO + (size_t)(q_off + r) * a.lddo + h * 64 + 16 * g;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { no_[i] = *reinterpret_cast<const bf16x8*>(op + 8 * i); nd_[i] = *reinterpret_cast<const bf16x8*>(dp + 8 * i); }
+    };
+    auto land_od = [&]() {                         // the rows are waited for BEFORE a pair's stores enter the memory queue (see the forward)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(no_[i]), "+v"(nd_[i]));
+    };
+    auto put_delta = [&](int j) {                  // δ of pair j into its stage's table
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d = fmaf((float)no_[i][e], (float)nd_[i][e], d);
+        }
+        d += __shfl_xor(d, 16, 64);
+        d += __shfl_xor(d, 32, 64);
+        if (g == 0) reinterpret_cast<float*>(smem + (j % PB_NSTAGE) * PB_STAGE + 4 * PP_IMG)[256 + t0 + l15] = d;
+    };
+    if (n_my > 0) { load_od(0); land_od(); put_delta(0); }
+    const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const short4v z4 = {0, 0, 0, 0};
+    for (int c = 0; c < n_my; ++c) {
+        const int pair = bid + c * G, s = pair / a.H, h = pair - s * a.H;
+        const int q_off = __builtin_amdgcn_readlane(m_qoff, c), q_len = __builtin_amdgcn_readlane(m_qlen, c);
+        const int k_off = __builtin_amdgcn_readlane(m_koff, c), k_len = __builtin_amdgcn_readlane(m_klen, c);
+        load_od(min(c + 1, n_my - 1));              // (unconditional: see the forward's Q request)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's δ entries are in LDS
+        __builtin_amdgcn_s_barrier();               // A_c
+        const int soff = (c % PB_NSTAGE) * PB_STAGE;
+        const int nkt = (k_len + 15) >> 4, nqt = (q_len + 15) >> 4;      // live 16-row tiles (≤ 7)
+        int qi0 = soff + kb, qi1 = soff + (kb ^ 64), qi60 = soff + kb6, qi61 = soff + (kb6 ^ 64), wi0 = soff + kbw, ti = soff + 4 * PP_IMG + 16 * g;
+        asm volatile("" : "+v"(qi0), "+v"(qi1), "+v"(qi60), "+v"(qi61), "+v"(wi0), "+v"(ti));
+        const char* const tabq = smem + ti;          // + 512: LSE', + 1024: δ, + 1536: row hashes — of queries 4·g …
+        // ---------------------------------------------------------------- pass 1: key tile `wave`
+        if (wave < nkt) {
+            bf16x8 kf[2], vf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                kf[ks] = *reinterpret_cast<const bf16x8*>(smem + (ks ? wi0 ^ 64 : wi0) + PP_IMG);
+                vf[ks] = *reinterpret_cast<const bf16x8*>(smem + (ks ? wi0 ^ 64 : wi0) + 2 * PP_IMG);
+            }
+            const float mt = reinterpret_cast<const float*>(smem + soff + 4 * PP_IMG)[t0 + l15];
+            const int key = t0 + l15;
+            floatx4 dv[4], dk[4];
+            const char* ta[4]; const char* ta3[4];          // transposed fragments of the Q image (dO: + 3·PP_IMG)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                int i0 = soff + (vb ^ (dt << 5)), i3 = soff + (vb3 ^ (dt << 5));
+                asm volatile("" : "+v"(i0), "+v"(i3));
+                ta[dt] = smem + i0; ta3[dt] = smem + i3;
+            }
+            char* const dsw = ds_img + key * PB_DS_RS + 8 * g;          // dS image: row = key, four consecutive queries per 8-byte store
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                uint32_t pp_[4], dd_[4];                   // P̃ and dS of query tiles 2u, 2u+1 as one k-step's B fragment
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int qt = 2 * u + hf;
+                    if (qt >= PP_NT) { pp_[2 * hf] = pp_[2 * hf + 1] = dd_[2 * hf] = dd_[2 * hf + 1] = 0u; continue; }
+                    floatx4 sc, dp;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const char* const o = smem + (qt < 6 ? (ks ? qi1 : qi0) + 2048 * qt : (ks ? qi61 : qi60));
+                        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(o), df = *reinterpret_cast<const bf16x8*>(o + 3 * PP_IMG);
+                        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], ks ? sc : zero4, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[ks], ks ? dp : zero4, 0, 0, 0);
+                    }
+                    // register r ↔ query 16·qt + 4·g + r of this lane's key
+                    const float4 l4 = *reinterpret_cast<const float4*>(tabq + 512 + 64 * qt), d4 = *reinterpret_cast<const float4*>(tabq + 1024 + 64 * qt);
+                    const uint4 a4 = *reinterpret_cast<const uint4*>(tabq + 1536 + 64 * qt);
+                    const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq[4] = {d4.x, d4.y, d4.z, d4.w};
+                    const uint32_t ar[4] = {a4.x, a4.y, a4.z, a4.w};
+                    float pt[4], dsv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(sc[r], cs, mt) - lq[r]);
+                        float m = 1.0f;
+                        if (a.p_drop > 0.f) m = svpc_attn_draw16(ar[r] + kphi) >= dctx.thr ? dctx.ik : 0.0f;
+                        pt[r] = p * m;
+                        dsv[r] = p * fmaf(dp[r], m, -dq[r]);
+                    }
+                    pp_[2 * hf] = pp_cvt2(pt[0], pt[1]); pp_[2 * hf + 1] = pp_cvt2(pt[2], pt[3]);
+                    dd_[2 * hf] = pp_cvt2(dsv[0], dsv[1]); dd_[2 * hf + 1] = pp_cvt2(dsv[2], dsv[3]);
+                    *reinterpret_cast<uint2*>(dsw + 32 * qt) = make_uint2(dd_[2 * hf], dd_[2 * hf + 1]);
+                }
+                const bf16x8 pf = pp_frag(pp_), df8 = pp_frag(dd_);
+                bf16x8 qtr[4], dtr[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const char* const oa = u < 3 ? ta[dt] + 4096 * u : ta3[dt]; const char* const ob = ta[dt] + 4096 * u + 2048;
+                    qtr[dt] = pp_join(__builtin_amdgcn_ds_read_tr16_b64_v4i16((pp_tr_ptr)oa), u < 3 ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((pp_tr_ptr)ob) : z4);
+                    dtr[dt] = pp_join(__builtin_amdgcn_ds_read_tr16_b64_v4i16((pp_tr_ptr)(oa + 3 * PP_IMG)),
+                                      u < 3 ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((pp_tr_ptr)(ob + 3 * PP_IMG)) : z4);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dtr[dt], pf, u ? dv[dt] : zero4, 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], df8, u ? dk[dt] : zero4, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            land_od();
+            // dV, dK rows of this lane's key: tiles 2e, 2e+1 paired by v_permlane16_swap → 8 consecutive head columns per lane
+            __bf16* const vp_ = (__bf16*)a.dV + (size_t)(k_off + key) * a.lddv + h * 64 + 16 * (g & 1) + 8 * (g >> 1);
+            __bf16* const kp_ = (__bf16*)a.dK + (size_t)(k_off + key) * a.lddk + h * 64 + 16 * (g & 1) + 8 * (g >> 1);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint32_t vx0 = pp_cvt2(dv[2 * e][0], dv[2 * e][1]), vx1 = pp_cvt2(dv[2 * e][2], dv[2 * e][3]);
+                const uint32_t vy0 = pp_cvt2(dv[2 * e + 1][0], dv[2 * e + 1][1]), vy1 = pp_cvt2(dv[2 * e + 1][2], dv[2 * e + 1][3]);
+                const uint32_t kx0 = pp_cvt2(dk[2 * e][0] * a.scale, dk[2 * e][1] * a.scale), kx1 = pp_cvt2(dk[2 * e][2] * a.scale, dk[2 * e][3] * a.scale);
+                const uint32_t ky0 = pp_cvt2(dk[2 * e + 1][0] * a.scale, dk[2 * e + 1][1] * a.scale), ky1 = pp_cvt2(dk[2 * e + 1][2] * a.scale, dk[2 * e + 1][3] * a.scale);
+                auto v0 = __builtin_amdgcn_permlane16_swap(vx0, vy0, false, false);
+                auto v1 = __builtin_amdgcn_permlane16_swap(vx1, vy1, false, false);
+                auto k0 = __builtin_amdgcn_permlane16_swap(kx0, ky0, false, false);
+                auto k1 = __builtin_amdgcn_permlane16_swap(kx1, ky1, false, false);
+                if (key < k_len) {
+                    *reinterpret_cast<uint4*>(vp_ + 32 * e) = make_uint4(v0[0], v1[0], v0[1], v1[1]);
+                    *reinterpret_cast<uint4*>(kp_ + 32 * e) = make_uint4(k0[0], k1[0], k0[1], k1[1]);
+                }
+            }
+        }
+        else land_od();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();               // M_c: the dS image is complete
+        // ---------------------------------------------------------------- pass 2: query tile `wave`
+        if (wave < nqt) {
+            floatx4 dqa[4];
+            const char* ka[4]; const char* ka3[4];          // transposed fragments of the K image
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                int i0 = soff + PP_IMG + (vb ^ (dt << 5)), i3 = soff + PP_IMG + (vb3 ^ (dt << 5));
+                asm volatile("" : "+v"(i0), "+v"(i3));
+                ka[dt] = smem + i0; ka3[dt] = smem + i3;
+            }
+            const char* const dsr = ds_img + dsb;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // keys 32·u … +15 (tile 2u) and +16 … +31 (tile 2u + 1); tiles no wave wrote this pair (past the sequence's keys) read as zeros
+                const bool la = 2 * u < nkt, lb = 2 * u + 1 < nkt && u < 3;
+                const bf16x8 sf = pp_join(la ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((pp_tr_ptr)(dsr + 32 * u * PB_DS_RS)) : z4,
+                                          lb ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((pp_tr_ptr)(dsr + (32 * u + 16) * PB_DS_RS)) : z4);
+                bf16x8 ktr[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const char* const oa = u < 3 ? ka[dt] + 4096 * u : ka3[dt]; const char* const ob = ka[dt] + 4096 * u + 2048;
+                    ktr[dt] = pp_join(__builtin_amdgcn_ds_read_tr16_b64_v4i16((pp_tr_ptr)oa), u < 3 ? __builtin_amdgcn_ds_read_tr16_b64_v4i16((pp_tr_ptr)ob) : z4);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dqa[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr[dt], sf, u ? dqa[dt] : zero4, 0, 0, 0);
+            }
+            const int q = t0 + l15;
+            __bf16* const qp_ = (__bf16*)a.dQ + (size_t)(q_off + q) * a.lddq + h * 64 + 16 * (g & 1) + 8 * (g >> 1);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint32_t x0 = pp_cvt2(dqa[2 * e][0] * a.scale, dqa[2 * e][1] * a.scale), x1 = pp_cvt2(dqa[2 * e][2] * a.scale, dqa[2 * e][3] * a.scale);
+                const uint32_t y0 = pp_cvt2(dqa[2 * e + 1][0] * a.scale, dqa[2 * e + 1][1] * a.scale), y1 = pp_cvt2(dqa[2 * e + 1][2] * a.scale, dqa[2 * e + 1][3] * a.scale);
+                auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                if (q < q_len) *reinterpret_cast<uint4*>(qp_ + 32 * e) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            }
+        }
+        // δ of the next pair (its rows were requested before this pair's barrier), into the stage this pair's predecessor has left
+        if (c + 1 < n_my) put_delta(c + 1);
+    }
+}
+
 static int pp_cus() {
     static int n = 0;
     if (!n) {
@@ -406,4 +683,23 @@ int attn_pipe_fwd_launch(const X3AttnArgs& xa_in, bool x3, hipStream_t stream) {
         hipLaunchKernelGGL((attn_pipe_fwd_kernel<false>), dim3(min(n_pairs, 2 * pp_cus())), dim3(512), lds, stream, xa, n_pairs);
     }
     return svpc_check_launch("attn_pipe_fwd");
+}
+
+// ---- backward
+bool attn_pipe_bwd_supported(const MAttnArgs& a, int dh) {
+    const int on = (svpc_attn_pipe_enable(-1), pp_on);
+    const bool al = a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 8 == 0 && a.lddo % 8 == 0 && a.lddq % 8 == 0 &&
+                    a.lddk % 8 == 0 && a.lddv % 8 == 0 &&
+                    ((((uintptr_t)a.Q) | ((uintptr_t)a.K) | ((uintptr_t)a.V) | ((uintptr_t)a.O) | ((uintptr_t)a.dO) | ((uintptr_t)a.dQ) |
+                      ((uintptr_t)a.dK) | ((uintptr_t)a.dV)) & 15) == 0;
+    return on && dh == 64 && !a.causal && a.max_q <= PP_ROWS && a.max_k <= PP_ROWS && a.max_q > 32 && al && a.LSE != nullptr &&
+           a.n_seq * a.H <= 64 * pp_cus();
+}
+int attn_pipe_bwd_launch(const MAttnArgs& a, hipStream_t stream) {
+    const int n_pairs = a.n_seq * a.H;
+    const size_t lds = (size_t)PB_NSTAGE * PB_STAGE + PB_DS;
+    int rc = svpc_raise_lds_once((const void*)attn_pipe_bwd_kernel, "attn_pipe_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_pipe_bwd_kernel, dim3(min(n_pairs, pp_cus())), dim3(512), lds, stream, a, n_pairs);
+    return svpc_check_launch("attn_pipe_bwd");
 }
