@@ -64,13 +64,38 @@ def measured_traffic(precision="bf16"):
     return rec.get("traffic_bytes_per_launch"), rec.get("source")
 
 
-def recorded_parity(precision):
-    """worst loss error of the headline-shape parity test (vivt both weight sets, vi, viv) for this mode, from the committed record"""
+def product_sources_sha16():
+    """hash of the kernel sources and the host package (the same function as tests/helpers.py: the parity records are stamped with it)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "svpc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "svpc_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "svpc_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(ROOT, "svpc_amd", "*.py")))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _load_record(path):
+    """a committed parity record, or (None, reason) when it is missing or was made from other sources than the ones running now"""
     try:
-        with open(PARITY_FILE) as f:
+        with open(path) as f:
             rec = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, "no record"
+    sha = rec.pop("_sources_sha16", None)
+    if sha != product_sources_sha16():
+        return None, "stale: %s was recorded on other sources (%s, now %s) — re-run the GPU parity tests and commit the record" % (
+            os.path.basename(path), sha, product_sources_sha16())
+    return rec, None
+
+
+def recorded_parity(precision):
+    """worst loss error of the headline-shape parity test (vivt both weight sets, vi, viv) for this mode, from the committed record"""
+    rec, why = _load_record(PARITY_FILE)
+    if rec is None:
+        return {"stale": why}
     rows = [v for k, v in rec.items() if k.split("/")[2] == precision]
     if not rows:
         return None
@@ -81,11 +106,9 @@ def recorded_parity(precision):
 
 
 def recorded_config5(precision):
-    try:
-        with open(CONFIG5_PARITY_FILE) as f:
-            rec = json.load(f)
-    except (OSError, ValueError):
-        return None
+    rec, why = _load_record(CONFIG5_PARITY_FILE)
+    if rec is None:
+        return {"stale": why}
     rows = {k: v for k, v in rec.items() if k.split("/")[1] == precision}
     if not rows:
         return None
@@ -117,6 +140,9 @@ def parse_args(argv=None):
     ap.add_argument("--exchange-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="wire format of the gradient buckets: fp32 (default: N ranks == one process with the N-fold batch, exactly) or "
                          "bf16 (half the xGMI bytes for one 2^-9 rounding per rank; error bounded in tests/test_dp_gloo.py)")
+    ap.add_argument("--bucket-timeline", action="store_true",
+                    help="N > 1: record per-bucket issue / completion events of the gradient exchange (exchange.bucket_timeline_ms); off by "
+                         "default — the events are created inside the timed region")
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="run the data-parallel code path (process group, three graphs, bucketed all-reduce) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -457,7 +483,7 @@ def run_train(args, precision, device, world, rank, dist, steps, warmup, instrum
             if state["reducer"] is None:
                 # graph mode: the exchange runs between captured graphs (no hooks); eager mode: overlapped with backward
                 state["reducer"] = GradReducer(arena, overlap=args.no_graph, force=args.rehearse_dp, wire_dtype=args.exchange_dtype,
-                                               timeline=True)
+                                               timeline=args.bucket_timeline)
                 state["reducer"].mark_all_unlaunched()   # first step: hooks were not installed during this backward
             state["reducer"].finish()
         opt.step()
@@ -750,11 +776,15 @@ def _train_main(args, device, world, rank, dist, joined):
                    "gpus_requested": args.gpus},
         "roofline": {"bound": "mfma", "kernel": "%s — every forward projection of the clip-encoder activation stream (M=%d rows: "
                                "Q/K/V, attention-out, FFN, video embedding)" % (kname, r["rows_enc"]),
-                     "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[precision], "unit": "TFLOP/s",
-                     "frac": achieved / MFMA_PEAK_TFLOPS[precision],
+                     # `achieved` / `frac`: SURVEY §8(d)'s algorithmic work (2·M·N·K per launch) ÷ the measured launch time — the roofline
+                     # fraction of the PRODUCT.  The three-term mode issues `mfma_terms_per_product` bf16 MFMA products per algorithmic
+                     # one: `achieved_issued` / `frac_issued` say how busy the matrix pipe is (its utilisation), not useful throughput.
+                     "achieved": achieved / terms, "peak": MFMA_PEAK_TFLOPS[precision], "unit": "TFLOP/s",
+                     "frac": achieved / terms / MFMA_PEAK_TFLOPS[precision],
+                     "achieved_issued": achieved, "frac_issued": achieved / MFMA_PEAK_TFLOPS[precision],
                      "traffic": traffic, "traffic_source": traffic_src,
                      "mfma_terms_per_product": terms,
-                     "algorithmic_flop_per_launch": alg_flop * terms, "algorithmic_product_flop_per_launch": alg_flop,
+                     "algorithmic_flop_per_launch": alg_flop, "issued_mfma_flop_per_launch": alg_flop * terms,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "launches": gsum["launches"], "avg_launch_ms": gsum["ms"] / max(1, gsum["launches"]),
                      "event_pair_overhead_ms": gsum["event_overhead_ms"],

@@ -221,7 +221,8 @@ int svpc_attn_bwd(const float* Q, int ldq, const float* K, int ldk, const float*
                   float scale, float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
 
 /* MFMA (bf16 operands, fp32 softmax/accumulate) form of the same core for ≤128×128 (queries×keys) per sequence, dh 32/64 */
-int svpc_attn_mfma_supported(int dh, int max_q, int max_k, int ldq, int ldk, int ldv);
+int svpc_attn_mfma_supported(int dh, int max_q, int max_k, int ldq, int ldk, int ldv, int dt /* 0 fp32, 1 bf16: the leading dimensions are
+                             checked in 16-byte units of that element type */);
 int svpc_attn_mfma_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, float* LSE,
                        const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,
                        float scale, float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);

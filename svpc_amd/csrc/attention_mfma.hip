@@ -993,9 +993,10 @@ static int mattn_bwd_launch(const MAttnArgs& a, int dh, int n_blocks, hipStream_
 
 extern "C" {
 
-// 1 if the MFMA path supports this problem (head dim 32/64, ≤128 rows per sequence, aligned rows)
-int svpc_attn_mfma_supported(int dh, int max_q, int max_k, int ldq, int ldk, int ldv) {
-    return mattn_ok(dh, max_q, max_k, ldq, ldk, ldv, nullptr, nullptr, nullptr, 0) ? 1 : 0;
+// 1 if the MFMA path supports this problem (head dim 32/64, ≤128 rows per sequence, rows in 16-byte units of the element type dt:
+// 0 = fp32 → leading dimensions % 4, 1 = bf16 → % 8)
+int svpc_attn_mfma_supported(int dh, int max_q, int max_k, int ldq, int ldk, int ldv, int dt) {
+    return mattn_ok(dh, max_q, max_k, ldq, ldk, ldv, nullptr, nullptr, nullptr, dt) ? 1 : 0;
 }
 
 // dt: element type of Q, K, V, O (0 = fp32, 1 = bf16); LSE and the softmax are fp32

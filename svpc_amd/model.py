@@ -354,6 +354,8 @@ class BertDecoderNoMemoryUntied(nn.Module):
         # interior-only row counts in bf16 precision: the sentence activations (and their gradients) stream through HBM as bf16
         stream_bf16 = self.streams_bf16(x.shape[0], x.shape[1])
         x3 = ops.is_x3()
+        ops.require_split_tag(x, "decoder.run")
+        ops.require_split_tag(mem, "decoder.run (memory)")
         if stream_bf16:
             if x.dtype != torch.bfloat16:      # (the caller may have had the embedding LayerNorm write bf16 / split rows already)
                 x = ops.to_split(x) if x3 else x.to(torch.bfloat16)

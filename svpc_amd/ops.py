@@ -485,6 +485,15 @@ def lo_off(t):
     return getattr(t, "_svpc_lo", None)
 
 
+def require_split_tag(t, who):
+    """bf16x3 mode: a bf16 ACTIVATION reaching a forward op must carry its lo-plane tag.  A torch view / cast / detach / cat of a split
+    tensor drops the tag silently, and the op would then compute a one-term bf16 product on the hi plane alone â€” outside the mode's
+    â‰¤ 1e-4 contract with no error anywhere.  Fail instead (use ``to_f32`` to leave the split domain on purpose)."""
+    if _PRECISION == "bf16x3" and t is not None and t.dtype == torch.bfloat16 and lo_off(t) is None:
+        raise _lib.SvpcKernelError("%s: bf16 tensor without its lo-plane tag in bf16x3 mode (a torch view / cast / cat of a split "
+                                   "tensor drops `_svpc_lo`; hand split tensors from op to op, or convert with ops.to_f32)" % who)
+
+
 def new_split(rows, width, device):
     buf = torch.empty(rows, 2 * width, dtype=torch.bfloat16, device=device)
     hi = buf[:, :width]
@@ -854,6 +863,7 @@ def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgr
     (C = dzÂ·W âŠ™ act'(z), svpc_gemm_glds_rg) and the separate activation-backward pass over the stream is skipped.  A second consumer
     is detected in backward and fails loudly."""
     tok_in = getattr(x, "_svpc_act_tok", None)
+    require_split_tag(x, "linear")
     split = lo_off(x) is not None
     if x.dtype == torch.bfloat16:
         n_out = w.shape[1] if trans_w else w.shape[0]
@@ -999,6 +1009,8 @@ def layernorm(x, gamma, beta, eps, residual=None, src_rows=None, pad_row=-1, pre
     """sink=True: the residual tensor's only other consumer is an ops.linear whose backward will absorb this LayerNorm's
     residual-path gradient in its dgrad epilogue (see _RES_SINK).  out_bf16: the output joins an activation stream â€” bf16 in the
     bf16 mode, split (two bf16 planes) in the bf16x3 mode; split inputs always give a split output."""
+    require_split_tag(x, "layernorm")
+    require_split_tag(residual, "layernorm (residual)")
     out_split = bool(out_bf16) and is_x3()
     split = out_split or lo_off(x) is not None or (residual is not None and lo_off(residual) is not None)
     y = _LayerNorm.apply(x, gamma, beta, residual, add2, eps, src_rows, pad_row, pre_drop, post_drop, add1, add1_mod,
@@ -1050,7 +1062,7 @@ class _Attention(Function):
         es = qt.element_size()
         qp, kp, vp = qt.data_ptr() + cols[0] * es, kvt_c.data_ptr() + cols[1] * es, kvt_c.data_ptr() + cols[2] * es
         mfma = (_fast() and ((qp | kp | vp) & 15) == 0 and
-                _lib.load().svpc_attn_mfma_supported(dh, seq.max_q, seq.max_k, qt.stride(0), kvt_c.stride(0), kvt_c.stride(0)) == 1)
+                _lib.load().svpc_attn_mfma_supported(dh, seq.max_q, seq.max_k, qt.stride(0), kvt_c.stride(0), kvt_c.stride(0), _dt(qt)) == 1)
         fwd_done = False
         # incremental decoding (one query per sequence, nothing differentiates through it): a wave per (sequence, head), exact fp32.
         # (grad mode is always off INSIDE a Function.forward: what tells inference from training here is requires_grad of the inputs)
@@ -1167,6 +1179,8 @@ X3_BIG_TILES = int(os.environ.get("SVPC_X3_BIG_TILES", "128"))      # fewer 256Â
 
 
 def attention(qt, kvt, cols, D, n_heads, seq, key_mask=None, causal=False, drop=None):
+    require_split_tag(qt, "attention (queries)")
+    require_split_tag(kvt, "attention (keys / values)")
     if qt.dtype == torch.float32 and kvt.dtype == torch.bfloat16 and kvt is not qt:
         # fp32 queries against bf16 / split keys and values: one query per sequence (the [CLS]-only layer) has its own exact kernels;
         # anything else joins one domain first
@@ -1183,8 +1197,11 @@ def attention(qt, kvt, cols, D, n_heads, seq, key_mask=None, causal=False, drop=
     split = lo_off(qt) is not None or lo_off(kvt) is not None
     if split:
         dh = D // n_heads
+        # (the same conditions _Attention.forward demands of a split stream, 16-byte aligned column blocks included: what fails them
+        # leaves the split domain here instead of raising there)
         ok = ((not causal or (seq.max_q <= 32 and seq.max_k <= 32)) and lo_off(qt) is not None and lo_off(kvt) is not None and
-              _lib.load().svpc_attn_mfma_supported(dh, seq.max_q, seq.max_k, 8, 8, 8) == 1 and qt.stride(0) % 8 == 0 and kvt.stride(0) % 8 == 0)
+              _lib.load().svpc_attn_mfma_supported(dh, seq.max_q, seq.max_k, 8, 8, 8, 1) == 1 and qt.stride(0) % 8 == 0 and kvt.stride(0) % 8 == 0 and
+              ((qt.data_ptr() + cols[0] * 2) | (kvt.data_ptr() + cols[1] * 2) | (kvt.data_ptr() + cols[2] * 2)) % 16 == 0)
         if not ok:          # leave the split domain: exact fp32 attention on fp32 copies
             same = kvt is qt
             qt = to_f32(qt)
@@ -1883,9 +1900,10 @@ class _LossTail(Function):
         w = widths.dev(dev)
         out = torch.empty(5, dtype=torch.float32, device=dev)
         scratch = torch.empty(_lib.load().svpc_loss_tail_ws_floats(cap_rows.numel(), R), dtype=torch.float32, device=dev)
-        counter = _TICKETS.get(dev)
+        tkey = (dev, _stream())   # one counter per (device, stream): launches on one stream are ordered, two streams (or two models on
+        counter = _TICKETS.get(tkey)    # their own streams) must not share the ticket word of a launch in flight
         if counter is None:       # zeroed once; every launch leaves it at zero
-            counter = _TICKETS[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+            counter = _TICKETS[tkey] = torch.zeros(1, dtype=torch.int32, device=dev)
         _lib.call("loss_tail_fwd", _p(cap_rows), cap_rows.numel(), _p(e_p), _p(align), _p(w), R, Ce, _p(a_p), _p(act), Ca, _p(r_e), _p(r_a),
                   float(lam), gneg, gpos, clip, eps, _p(out), _p(scratch), _p(counter), _stream())
         ctx.save_for_backward(e_p, a_p, r_e, r_a, align, act, w)

@@ -516,6 +516,9 @@ class GradReducer:
         else:
             payload = self.arena.flat[s:e]
         if self.timeline:
+            if not self.works and self._stamps and all(st[3] is not None for st in self._stamps):
+                self._stamps = []         # first launch of a step: the previous step's stamps go (a caller that never calls
+                                          # mark_step_start must not grow the list; timeline_ms() then has no origin and returns None)
             self._stamps.append([bi, payload.numel() * payload.element_size(), self._now(), None])
         self.works.append((bi, self.dist.all_reduce(payload, op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True)))
 

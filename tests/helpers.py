@@ -34,3 +34,19 @@ def build_model(case, mt, golden_dir, device="cpu"):
                                                               key=lambda s: int(s.split("/")[1]))]
     model.gumbel_noise = noise or None
     return z, cfg, batch, model
+
+
+def product_sources_sha16():
+    """hash of everything a parity record depends on: the kernel sources and the host-side package (bench.py recomputes it and refuses
+    to quote a record made from other sources)"""
+    import glob
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "svpc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "svpc_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(root, "svpc_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(root, "svpc_amd", "*.py")))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.relpath(f, root).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

@@ -69,7 +69,7 @@ def _config5_case(init):
 
 # floors of the token agreement with the oracle (fraction of the 8 × 12 × 22 emitted ids that are identical).  Greedy decoding
 # feeds every pick back, so ONE flipped arg-max changes the rest of that sentence: the rate measures sentences, not logits.
-FLOOR = {"fp32": 1.0, "bf16x3": 0.99, "bf16": 0.5}
+FLOOR = {"fp32": 1.0, "bf16x3": 1.0, "bf16": 0.5}       # bf16x3: bit-exact at this size since round 3 (2,112 ids, both weight sets)
 
 
 @pytest.mark.timeout(900)
@@ -102,10 +102,13 @@ def test_config5_greedy_decode_at_headline_size(init, precision):
     _REPORT["%s/%s" % (init, precision)] = dict(token_agreement=rate, identical_sentences=sent_same, sentences=sent, tokens=total,
                                                 bit_exact=bool(same == total))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    from helpers import product_sources_sha16
+    _REPORT["_sources_sha16"] = product_sources_sha16()
     with open(os.path.join(ROOT, "gpurun_out", "config5_parity.json"), "w") as f:
         json.dump(_REPORT, f, indent=1)
     print("config 5 (%s weights, %s): %d / %d ids identical (%.4f), %d / %d sentences" % (init, precision, same, total, rate, sent_same, sent))
-    if init == "drawn" or precision == "fp32":
+    # (bf16 with the bench's N(0, .02) weights is only recorded: near-uniform logits there, the agreement rate says nothing about the mode)
+    if init == "drawn" or precision in ("fp32", "bf16x3"):
         assert rate >= FLOOR[precision], (init, precision, rate)
 
 

@@ -163,6 +163,8 @@ def _compare(tag, precision, loss, probs, grads, ref, names, noise=None):
     _REPORT[tag] = rep
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
+    from helpers import product_sources_sha16
+    _REPORT["_sources_sha16"] = product_sources_sha16()       # bench.py quotes the record only for these sources
     with open(os.path.join(out_dir, "headline_parity.json"), "w") as f:
         json.dump(_REPORT, f, indent=1)
     assert rep["loss_rel"] <= tol["loss"], (tag, rep["loss"], rep["ref_loss"], rep["loss_rel"])
@@ -225,3 +227,60 @@ def test_headline_vi_viv_bf16_vs_oracle(mt):
     _run_gpu(mt, "drawn", "bf16")
     _run_gpu(mt, "drawn", "bf16x3")
     _run_gpu(mt, "drawn", "fp32")
+
+
+# ------------------------------------------------------------------------------------------------ the fp32 mode's simulator residue
+@pytest.mark.timeout(1500)
+def test_fp32_mode_simulator_gradients_and_a_float64_oracle():
+    """Round 3 attributed the fp32 mode's 1.5e-3 norm residue on `recipe_reasoner.W2.weight` (test-sensitive weights) to the CPU oracle's
+    own fp32 conditioning (tools/dbg/sim_grad_conditioning.py, synthetic simulator inputs).  The same headline case against the oracle run
+    in FLOAT64 says otherwise, and this test pins what was found (gpurun_out/fp64_oracle_leg.json, committed under profiles/):
+      * the visual simulator's loss IS conditioning-limited in the reference itself: nn.BCELoss(sum) clamps log(1 - e) at -100 once a
+        sigmoid output rounds to exactly 1.0f, so the fp32 and the float64 evaluation of the reference's formulas differ by 17 % in the
+        loss and 16-34 % on `reasoner.*` gradients — parity is defined by the fp32 reference, and the product matches THAT to 3e-4;
+      * on `recipe_reasoner.*` the fp32 and float64 oracles agree to 3e-7: the 2.5e-3 distance of the product's gradient there is the
+        product's own (hand-derived recurrence backward in another summation order), not the oracle's.  Bounded here, listed in DESIGN."""
+    from svpc_amd import ops
+    import copy
+    cfg, model_cpu, batch, noise, ref32 = _case("vivt", "drawn")
+    names = ["recipe_reasoner.W2.weight", "reasoner.W2.weight", "recipe_reasoner.action_selector.3.weight", "reasoner.action_selector.3.weight"]
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        P = {k: (v.detach().clone().double() if v.dtype.is_floating_point else v.detach().clone()) for k, v in model_cpu.state_dict().items()}
+        pn = [n for n, _ in model_cpu.named_parameters()]
+        for n in pn:
+            P[n].requires_grad_(True)
+        b64 = {k: ([t.double() if isinstance(t, torch.Tensor) and t.dtype == torch.float32 else t for t in v] if isinstance(v, list)
+                   else (v.double() if isinstance(v, torch.Tensor) and v.dtype == torch.float32 else v)) for k, v in batch.items()}
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        loss64 = orc.forward(P, cfg, *syn.forward_args(b64), gumbel_noise=[n_.double() for n_ in noise])[0]
+        loss64.backward()
+        g64 = {n: P[n].grad.detach().clone() for n in names}
+    finally:
+        torch.set_default_dtype(old)
+    model = copy.deepcopy(model_cpu).to(DEV)
+    model.eval()
+    model.gumbel_noise = [n_.to(DEV) for n_ in noise]
+    ops.set_precision("fp32")
+    loss = model(*syn.forward_args(_to_dev(batch)))[0]
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(model.named_parameters())
+    rep = {"loss_gpu_vs_oracle32": abs(float(loss) - ref32["loss"]) / abs(ref32["loss"]),
+           "loss_oracle32_vs_oracle64": abs(ref32["loss"] - float(loss64)) / abs(float(loss64)), "tensors": {}}
+    for n in names:
+        g, r64, r32 = named[n].grad.detach().double().cpu().reshape(-1), g64[n].reshape(-1), ref32["grads"][n].double().reshape(-1)
+        rep["tensors"][n] = dict(gpu_vs_oracle32=float((g - r32).norm() / r32.norm()), gpu_vs_oracle64=float((g - r64).norm() / r64.norm()),
+                                 oracle32_vs_oracle64=float((r32 - r64).norm() / r64.norm()))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "fp64_oracle_leg.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    print(json.dumps(rep, indent=1))
+    assert rep["loss_gpu_vs_oracle32"] <= 1e-6
+    for n, d in rep["tensors"].items():
+        assert d["gpu_vs_oracle32"] <= 4e-3, (n, d)                   # parity with the reference's own arithmetic (2× measured worst)
+        if n.startswith("recipe_reasoner."):
+            assert d["oracle32_vs_oracle64"] <= 1e-5, (n, d)          # the reference is well conditioned here …
+            assert d["gpu_vs_oracle64"] <= 5e-3, (n, d)               # … so this distance is the product's: 2.5e-3 measured, bounded at 2×

@@ -378,6 +378,28 @@ def test_one_query_attention_over_stream_rows(n, Lk, H, dh, drop, split):
     assert float((kv.grad.float() - kr.grad).abs().max()) <= 6e-3 * float(kr.grad.abs().max()) + 1e-7
 
 
+def test_untagged_bf16_tensor_fails_loudly_in_x3_mode():
+    """a torch view / cast of a split tensor drops the lo-plane tag; in bf16x3 mode the forward ops refuse such a tensor instead of
+    computing a one-term product on its hi plane (the mode's ≤ 1e-4 contract would break silently)"""
+    from svpc_amd._lib import SvpcKernelError
+    x, _ = _split(_rand(256, 128, seed=80))
+    w, b = _rand(128, 128, seed=81), _rand(128, seed=82)
+    g, be = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
+    assert O.lo_off(x) == 128
+    O.linear(x, w, b)                                    # tagged: fine
+    untagged = x[:, :]                                   # a plain torch view of the hi plane
+    assert O.lo_off(untagged) is None
+    with pytest.raises(SvpcKernelError, match="lo-plane tag"):
+        O.linear(untagged, w, b)
+    with pytest.raises(SvpcKernelError, match="lo-plane tag"):
+        O.layernorm(untagged, g, be, 1e-12)
+    seq = SeqInfo.uniform(2, 128, 128, DEV)
+    qkv, _ = _split(_rand(256, 3 * 128, seed=83))
+    with pytest.raises(SvpcKernelError, match="lo-plane tag"):
+        O.attention(qkv[:, :], qkv[:, :], (0, 128, 256), 128, 2, seq)
+    assert O.to_f32(x).dtype == torch.float32            # the explicit way out of the split domain
+
+
 def test_split_cols_keeps_the_planes_and_gathers_gradients():
     wide, wv = _split(_rand(40, 6 * 128, seed=44))
     wide.requires_grad_(True)
