@@ -140,6 +140,9 @@ def parse_args(argv=None):
     ap.add_argument("--exchange-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="wire format of the gradient buckets: fp32 (default: N ranks == one process with the N-fold batch, exactly) or "
                          "bf16 (half the xGMI bytes for one 2^-9 rounding per rank; error bounded in tests/test_dp_gloo.py)")
+    ap.add_argument("--ragged", type=int, default=20,
+                    help="after the timed region: this many EAGER steps over batches of the structure the reference's loop feeds (S_b ~ U{3..16}, "
+                         "E_b ~ U{1..31}, X_b in {0,1,2}), a different structure every step; printed as the `ragged` field (0 = skip)")
     ap.add_argument("--bucket-timeline", action="store_true",
                     help="N > 1: record per-bucket issue / completion events of the gradient exchange (exchange.bucket_timeline_ms); off by "
                          "default — the events are created inside the timed region")
@@ -457,7 +460,37 @@ def run_decode(cfg, model, args, device, world, rank, dist, steps, warmup):
                        "launch": "eager" if args.decode_eager else "hipGraph replay per batch structure (inputs copied into the captured buffers)"}}
 
 
-def run_train(args, precision, device, world, rank, dist, steps, warmup, instrument=True):
+def ragged_batches(cfg, args, device, n_structs, seed=4242):
+    """``n_structs`` batches with the structure the reference's loop really feeds (src/train.py:91-132 over
+    recursive_caption_dataset.py:528-576): S_b ~ U{3..16} clips per video (the collate pads to the longest), E_b ~ U{1..31} ingredients,
+    X_b in {0, 1, 2} out-of-vocabulary ingredient words, 16 videos; resident in HBM like the headline batch."""
+    import numpy as np
+    import torch
+    from svpc_amd import keep_host_copy, make_batch
+    rng = np.random.RandomState(seed)
+    out, clips = [], []
+    stacked = ("video_features_list", "input_ids_list", "input_masks_list", "input_labels_list", "token_type_ids_list")
+    for i in range(n_structs):
+        S_b = rng.randint(3, 17, size=args.batch).tolist()
+        E_b = rng.randint(1, 32, size=args.batch).tolist()
+        X_b = [int(min(x, e)) for x, e in zip(rng.randint(0, 3, size=args.batch).tolist(), E_b)]
+        b = make_batch(cfg, n_videos=args.batch, max_steps=max(S_b), step_nums=S_b, n_ingr=E_b, n_oov=X_b, seed=seed + 1 + i, full_clips=True)
+        for k in stacked:
+            buf = torch.stack(b[k]).to(device)
+            b[k] = [buf[s_] for s_ in range(buf.shape[0])]
+        for k, v in list(b.items()):
+            if k in stacked:
+                continue
+            if isinstance(v, list) and v and isinstance(v[0], torch.Tensor):
+                b[k] = [t.to(device) for t in v]
+            elif isinstance(v, torch.Tensor):
+                b[k] = keep_host_copy(v.to(device), v) if k == "ingr_sep_masks" else v.to(device)     # the loader built it on the host
+        out.append(b)
+        clips.append(sum(S_b))
+    return out, clips
+
+
+def run_train(args, precision, device, world, rank, dist, steps, warmup, instrument=True, ragged=0):
     """Build model + optimizer in ``precision``, warm up, capture, time ``steps`` steps.  → dict (rank-0 view)."""
     import torch
     from svpc_amd import ops, synthetic as syn
@@ -597,13 +630,47 @@ def run_train(args, precision, device, world, rank, dist, steps, warmup, instrum
             asum["frac_fwd"] = asum["fwd"]["tbps"] / HBM_PEAK_TBPS if "fwd" in asum else None
             asum["frac_bwd"] = asum["bwd"]["tbps"] / HBM_PEAK_TBPS if "bwd" in asum else None
             asum["frac"] = tot_b / (tot_ms * 1e-3) / 1e12 / HBM_PEAK_TBPS if tot_ms > 0 else 0.0
+    # ---- the batches the reference's loop really feeds: a different structure every step (no captured plan can be replayed), eager
+    # launches, the host-side plan of every batch built inside the timed region (the model's plan caches are cleared each step)
+    ragged_res = None
+    if ragged > 0 and world == 1:
+        try:
+            rb, rclips = ragged_batches(cfg, args, device, n_structs=min(8, ragged))
+            rargs = [syn.forward_args(b) for b in rb]
+            st_r = graph.stream if graph is not None else torch.cuda.current_stream()
+
+            def rstep(k):
+                model._plans.clear(); model._ptr_plans.clear(); model._span_cache.clear()
+                opt.zero_grad()
+                l_ = model(*rargs[k % len(rargs)])[0]
+                backward_all(model, l_)
+                opt.step()
+                return l_
+            with torch.cuda.stream(st_r):
+                for k in range(max(3, len(rargs))):          # every structure once: allocator and kernel-image warm-up
+                    rstep(k)
+                torch.cuda.synchronize()
+                th0 = time.perf_counter()
+                for k in range(ragged):
+                    lr_ = rstep(k)
+                host_r = time.perf_counter() - th0
+                torch.cuda.synchronize()
+                el_r = time.perf_counter() - th0
+            avg_clips = sum(rclips[k % len(rclips)] for k in range(ragged)) / float(ragged)
+            ragged_res = {"steps_per_s": ragged / el_r, "ms_per_step": 1000.0 * el_r / ragged, "host_enqueue_ms_per_step": 1000.0 * host_r / ragged,
+                          "steps": ragged, "distinct_structures": len(rargs), "avg_clips_per_step": avg_clips,
+                          "clips_per_s": avg_clips * ragged / el_r, "final_loss": float(lr_.item()), "launch": "eager",
+                          "structure": "16 videos, S_b ~ U{3..16} clips, E_b ~ U{1..31} ingredients, X_b in {0,1,2} OOV words, a different "
+                                       "structure every step (plan caches cleared: the host-side plan is rebuilt inside the timed region)"}
+        except Exception as e:  # noqa: BLE001
+            ragged_res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     ms = 1000.0 * elapsed / steps
     launch = ("hipGraph replay" if not exchange_on else
               "hipGraph replay (fwd + text-side bwd | clip-encoder bwd beside the text-side all-reduce | remaining all-reduce | optimizer)") \
         if graph is not None else ("eager (capture failed: see config.degraded)" if degraded else "eager")
     res = dict(cfg=cfg, model=model, ms=ms, elapsed=elapsed, final_loss=final_loss, host_enqueue_ms=host_enqueue_ms, launch=launch,
                degraded=degraded, gsum=gsum, asum=(asum if instrument else None), glds=glds, bf16_stream=bf16_stream, rows_enc=rows_enc,
-               no_exchange_ms=no_exchange_ms,
+               no_exchange_ms=no_exchange_ms, ragged=ragged_res,
                allreduce_bytes=(reducer.bytes_per_step() if reducer is not None else 0),
                bucket_timeline=(reducer.timeline_ms() if reducer is not None else None),
                n_buckets=(len(reducer.buckets) if reducer is not None else 0))
@@ -692,7 +759,8 @@ def worker(args):
 def _train_main(args, device, world, rank, dist, joined):
     import torch
     from svpc_amd import ops
-    r = run_train(args, args.precision, device, world, rank, dist, args.steps, args.warmup)
+    r = run_train(args, args.precision, device, world, rank, dist, args.steps, args.warmup,
+                  ragged=(args.ragged if (world == 1 and not args.rehearse_dp and not args.no_secondary) else 0))
     cfg, gsum = r["cfg"], r["gsum"]
     extras = {}
     if world == 1 and not args.no_secondary and not args.rehearse_dp:
@@ -805,6 +873,13 @@ def _train_main(args, device, world, rank, dist, joined):
                            "bucket_timeline_ms": r["bucket_timeline"],
                            "ms_per_step_without_exchange": r["no_exchange_ms"],
                            "exposed_exchange_ms": (ms - r["no_exchange_ms"]) if r["no_exchange_ms"] is not None else None}
+    if r.get("ragged") is not None:
+        rg = dict(r["ragged"])
+        if "steps_per_s" in rg:
+            # the uniform figure the ratio refers to is `value` (192 clips per step); a ragged step carries avg_clips_per_step clips
+            rg["vs_uniform_steps_per_s"] = rg["steps_per_s"] / (joined * args.steps / elapsed)
+            rg["vs_uniform_clips_per_s"] = rg["clips_per_s"] / (args.batch * args.clips * joined * args.steps / elapsed)
+        out["ragged"] = rg
     out.update(extras)
     if world == 1 and not args.no_cpu_baseline and not args.rehearse_dp:
         out["cpu_baseline"] = cpu_baseline(cfg, r["model"], args)

@@ -79,11 +79,17 @@ def load():
     return lib
 
 
+_FN = {}
+
+
 def call(name, *args):
     """Invoke ``svpc_<name>``; raise with the library's error string on a non-zero status."""
-    lib = load()
-    rc = getattr(lib, "svpc_" + name)(*args)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), "svpc_" + name)
+    rc = fn(*args)
     if rc != 0:
+        lib = load()
         msg = lib.svpc_last_error()
         raise SvpcKernelError("svpc_%s failed (%d): %s" % (name, rc, msg.decode() if msg else "?"))
     return rc

@@ -20,11 +20,12 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
 import torch
 import torch.nn as nn
 
 from . import ops
-from .ops_common import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, FIdx, Idx
+from .ops_common import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BulkUpload, FIdx, Idx
 
 PAD_ROW = 0  # nn.Embedding(padding_idx=0) in the reference (model.py:492, 519)
 
@@ -588,18 +589,22 @@ class _LSTMParams(nn.LSTM):
 # batch plan: every index map the flattened execution needs, built once per batch shape
 # ------------------------------------------------------------------------------------------------
 class BatchPlan:
+    """Index maps of one batch structure (step counts, ingredient counts): built once per structure on the host, every device
+    array of it sent in ONE copy (ops_common.BulkUpload)."""
+
     def __init__(self, step_nums, ent_nums, n_steps_padded, N, Lv, Lt, L, n_mem, device):
         self.key = (tuple(step_nums), tuple(ent_nums), n_steps_padded, N, Lv, Lt, L, n_mem)
         T = sum(step_nums)
         self.T, self.N = T, N
+        up = BulkUpload(device)
         clip_b, clip_s = [], []
         for b in range(N):
             for s in range(step_nums[b]):
                 clip_b.append(b)
                 clip_s.append(s)
-        src = torch.tensor([s * N + b for b, s in zip(clip_b, clip_s)], dtype=torch.int64)
-        self.video_rows = ((src * L).unsqueeze(1) + torch.arange(Lv)).reshape(-1).to(torch.int32).to(device)
-        self.text_rows = ((src * L + Lv).unsqueeze(1) + torch.arange(Lt)).reshape(-1).to(torch.int32).to(device)
+        src = np.asarray([s * N + b for b, s in zip(clip_b, clip_s)], dtype=np.int64)
+        up.add(((src * L)[:, None] + np.arange(Lv)[None, :]).reshape(-1), sink=lambda t: setattr(self, "video_rows", t))
+        up.add(((src * L + Lv)[:, None] + np.arange(Lt)[None, :]).reshape(-1), sink=lambda t: setattr(self, "text_rows", t))
         self.cls_rows = Idx([c * Lv for c in range(T)])
         self.ones_T = Idx([1] * T)
         self.step_idx = Idx(clip_s)
@@ -616,13 +621,13 @@ class BatchPlan:
         self.ent_off, self.ent_len = Idx(eoff[:-1]), Idx(ent_nums)
         self.e_max = max(ent_nums) if ent_nums else 0
         self.step_ne = Idx([ent_nums[b] for b in clip_b])
-        self.seq_enc = ops.SeqInfo.uniform(T, Lv, Lv, device)
-        self.cls_rows_dev = _i32([c * Lv for c in range(T)], device)
-        self.seq_enc_cls = ops.SeqInfo(list(range(T)), [1] * T, [c * Lv for c in range(T)], [Lv] * T, device)
+        self.seq_enc = ops.SeqInfo.uniform(T, Lv, Lv, None)
+        up.add([c * Lv for c in range(T)], sink=lambda t: setattr(self, "cls_rows_dev", t))
+        self.seq_enc_cls = ops.SeqInfo(list(range(T)), [1] * T, [c * Lv for c in range(T)], [Lv] * T, None)
         self.arange_T = Idx(range(T))
-        self.seq_step = ops.SeqInfo(off[:-1], step_nums, off[:-1], step_nums, device)
-        self.seq_dec_self = ops.SeqInfo.uniform(T, Lt, Lt, device)
-        self.seq_dec_cross = ops.SeqInfo.uniform(T, Lt, n_mem, device)
+        self.seq_step = ops.SeqInfo(off[:-1], step_nums, off[:-1], step_nums, None)
+        self.seq_dec_self = ops.SeqInfo.uniform(T, Lt, Lt, None)
+        self.seq_dec_cross = ops.SeqInfo.uniform(T, Lt, n_mem, None)
         self.row_vid = Idx([b for b in clip_b for _ in range(Lt)])
         self.h_step_off, self.h_step_len = off[:-1], list(step_nums)
         self.h_ent_off, self.h_ent_len = eoff[:-1], list(ent_nums)
@@ -631,16 +636,24 @@ class BatchPlan:
             for s_ in range(step_nums[b]):
                 pick_f.append(s_ * N + b)
                 pick_b.append((step_nums[b] - 1 - s_) * N + b)
-        self.lstm_pick = {"": _i32(pick_f, device), "_reverse": _i32(pick_b, device)}
-        self.step_vid_dev = _i32(clip_b, device)
+        self.lstm_pick = {}
+        up.add(pick_f, sink=lambda t: self.lstm_pick.__setitem__("", t))
+        up.add(pick_b, sink=lambda t: self.lstm_pick.__setitem__("_reverse", t))
+        up.add(clip_b, sink=lambda t: setattr(self, "step_vid_dev", t))
         # reverse-direction LSTM: at time t video b consumes its step S_b-1-t
         S = max(step_nums)
-        self.lstm_fwd_rows, self.lstm_bwd_rows, self.lstm_active = [], [], []
+        self.lstm_fwd_rows, self.lstm_bwd_rows, self.lstm_active = [None] * S, [None] * S, [None] * S
         for t in range(S):
             act = [1.0 if t < step_nums[b] else 0.0 for b in range(N)]
-            self.lstm_fwd_rows.append(_i32([off[b] + min(t, step_nums[b] - 1) for b in range(N)], device))
-            self.lstm_bwd_rows.append(_i32([off[b] + max(step_nums[b] - 1 - t, 0) for b in range(N)], device))
-            self.lstm_active.append(torch.tensor(act, dtype=torch.float32, device=device))
+            up.add([off[b] + min(t, step_nums[b] - 1) for b in range(N)], sink=lambda x, t=t: self.lstm_fwd_rows.__setitem__(t, x))
+            up.add([off[b] + max(step_nums[b] - 1 - t, 0) for b in range(N)], sink=lambda x, t=t: self.lstm_bwd_rows.__setitem__(t, x))
+            up.add_f(act, sink=lambda x, t=t: self.lstm_active.__setitem__(t, x))
+        for v in (self.cls_rows, self.ones_T, self.step_idx, self.step_vid, self.text_starts, self.text_lens, self.step_off, self.step_len,
+                  self.ent_off, self.ent_len, self.step_ne, self.arange_T, self.row_vid):
+            up.add_idx(v)
+        for sq in (self.seq_enc, self.seq_enc_cls, self.seq_step, self.seq_dec_self, self.seq_dec_cross):
+            up.add_seq(sq)
+        up.flush()
         self.sim = (self.step_off, self.step_len, self.ent_off, self.ent_len, self.e_max)
         self._seq_inc = {}
 
@@ -738,7 +751,14 @@ class StateAwareRecursiveTransformer(nn.Module):
             return hit[2]
         if len(self._span_cache) >= 4:
             self._span_cache.clear()
-        spans = self.ingredient_embeddings.spans(ingr_sep_masks.cpu())
+        # A loader that built the mask on the host (the reference's collate does: recursive_caption_dataset.py:528-576) can leave that
+        # copy on the device tensor (``svpc_amd.keep_host_copy``): the step then reads nothing back from the device.  Otherwise the
+        # `.cpu()` below is a synchronous copy on the current stream — the host cannot enqueue this step before the GPU has finished
+        # the previous one, which serialises an eager loop over freshly structured batches (1.8 ms of every 16 ms step, measured).
+        host = getattr(ingr_sep_masks, "_svpc_host", None)
+        if host is None or tuple(host.shape) != tuple(ingr_sep_masks.shape):
+            host = ingr_sep_masks.cpu()
+        spans = self.ingredient_embeddings.spans(host)
         self._span_cache[key] = (ingr_sep_masks, ingr_sep_masks._version, spans)
         return spans
 
@@ -814,7 +834,7 @@ class StateAwareRecursiveTransformer(nn.Module):
         T, e_max, D = bank.shape
         return ops.linear(bank.reshape(T * e_max, D), self.Wing.weight, self.Wing.bias).view(T, e_max, D)
 
-    def _ptr_plan(self, ingr_dicts, c_list, lt, step_ne, row_vid):
+    def _ptr_plan(self, ingr_dicts, c_list, lt, step_ne, row_vid, device=None):
         """CSR of (ingredient → word ids, weight 1/len) per video + per-row class counts; cached by content."""
         key = (tuple(tuple((int(e), tuple(int(i) for i in lst)) for e, lst in d.items()) for d in ingr_dicts),
                tuple(c_list), lt, id(step_ne), id(row_vid))
@@ -829,6 +849,11 @@ class StateAwareRecursiveTransformer(nn.Module):
             off.append(len(ent))
         pl = dict(lt=lt, step_ne=step_ne, row_vid=row_vid, n_vid=len(c_list), csr_off=Idx(off), csr_ent=Idx(ent),
                   csr_id=Idx(ids), csr_w=FIdx(w), row_c=Idx([c_list[b] for b in row_vid.host]), c_max=max(c_list))
+        if device is not None:            # the five tables in one copy (see BatchPlan)
+            up = BulkUpload(device)
+            for k_ in ("csr_off", "csr_ent", "csr_id", "csr_w", "row_c"):
+                up.add_idx(pl[k_])
+            up.flush()
         if len(self._ptr_plans) > 64:
             self._ptr_plans.clear()
         self._ptr_plans[key] = pl
@@ -916,7 +941,7 @@ class StateAwareRecursiveTransformer(nn.Module):
         c_max = max(c_list)
         if mode == "video":
             labels = ops.clamp_labels(labels, V, cfg.unk_id)          # labels ≥ V → UNK (model.py:1013)
-        pl = self._ptr_plan(ingr_id_dict if mode != "video" else [{}] * N, c_list, Lt, plan.step_ne, plan.row_vid)
+        pl = self._ptr_plan(ingr_id_dict if mode != "video" else [{}] * N, c_list, Lt, plan.step_ne, plan.row_vid, device=dev)
         row_c = pl["row_c"]
         P, cap_rows = self._lm_probs(dec, bank, pl, cx, labels=labels)
         # (7) simulator losses, the textual re-simulator, and the sum of all terms (one launch: ops.loss_tail)

@@ -21,8 +21,19 @@ _WS = {}
 _WS_BYTES = 256 << 20
 
 
+_DEV_IDX = [None]
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """raw handle of PyTorch's current stream on the current device.  (torch.cuda.current_stream() builds a Stream object and
+    resolves the device through three Python layers: 9 µs a call, ≈240 calls per eager step — the raw getter is ≈0.3 µs.)"""
+    i = _DEV_IDX[0]
+    if i is None or not _FAST_STREAM:
+        return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(i)
+
+
+_FAST_STREAM = os.environ.get("SVPC_SLOW_STREAM", "") == "" and hasattr(torch._C, "_cuda_getCurrentRawStream")
 
 
 def _p(t):
@@ -31,7 +42,7 @@ def _p(t):
 
 def _ws(device):
     """One scratch arena per (device, stream) (split-K slabs, reduction partials); ops on a stream use it one at a time."""
-    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    key = (device.index if isinstance(device, torch.device) else str(device), _stream())
     w = _WS.get(key)
     if w is None:
         w = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
@@ -330,6 +341,7 @@ class _side_of:
 def _need_gpu(t):
     if not t.is_cuda:
         raise _lib.SvpcKernelError("svpc_amd.ops: tensors must be on the GPU (no CPU fallback exists)")
+    _DEV_IDX[0] = t.device.index          # (the device the following launches go to: see _stream)
 
 
 def _c(t):

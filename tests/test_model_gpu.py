@@ -104,6 +104,73 @@ def test_matches_oracle_on_fresh_seeded_inputs(golden_dir):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=3e-4, atol=1e-6)
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_reference_loop_structures_eager_steps_vs_oracle(golden_dir, precision):
+    """The batches the reference's training loop really feeds (src/train.py:91-132 over recursive_caption_dataset.py:528-576): a
+    DIFFERENT structure every iteration — S_b in 3..16 clips per video, E_b in 1..31 ingredients, 0..2 out-of-vocabulary ingredient
+    words — run eagerly (no captured plan can be replayed), the [SEP] mask's host copy handed along by the loader
+    (svpc_amd.keep_host_copy: no device read-back in the step).  Three consecutive structures through ONE model object, plan caches
+    cold each time, loss / probabilities / parameter gradients against the CPU oracle; the third call repeats the first structure and
+    must reproduce its loss and probabilities bit for bit and its gradients to 1e-5 (a plan rebuilt from scratch ≡ the first one)."""
+    from svpc_amd import keep_host_copy
+    z, cfg, _, model = build_model("c1", "vivt", golden_dir, DEV)          # D=128, L=2, F=3072, V=951; Lv=32
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    names = [n for n, _ in model.named_parameters()]
+    structs = [dict(S=[16, 3, 7, 12, 5], E=[31, 1, 10, 17, 4], X=[2, 0, 1, 2, 0], seed=31),
+               dict(S=[4, 9, 3], E=[2, 25, 8], X=[1, 2, 0], seed=32)]
+    structs.append(structs[0])
+    g = torch.Generator().manual_seed(17)
+    first = None
+    O_ = __import__("svpc_amd.ops", fromlist=["ops"])
+    O_.set_precision(precision)
+    try:
+        for k, st in enumerate(structs):
+            b_cpu = syn.make_batch(cfg, n_videos=len(st["S"]), max_steps=max(st["S"]), step_nums=st["S"], n_ingr=st["E"], n_oov=st["X"],
+                                   seed=st["seed"], full_clips=False)
+            gn = torch.Generator().manual_seed(100 + st["seed"])
+            noise = [-torch.empty(s_, cfg.max_t_len, cfg.vocab_size + x).exponential_(generator=gn).log() for s_, x in zip(st["S"], st["X"])]
+            b = {kk: ([t.to(DEV) if isinstance(t, torch.Tensor) else t for t in v] if isinstance(v, list) else
+                      (v.to(DEV) if isinstance(v, torch.Tensor) else v)) for kk, v in b_cpu.items()}
+            keep_host_copy(b["ingr_sep_masks"], b_cpu["ingr_sep_masks"])
+            model._plans.clear(); model._ptr_plans.clear(); model._span_cache.clear()
+            model.gumbel_noise = [n.to(DEV) for n in noise]
+            model.zero_grad(set_to_none=True)
+            tot, probs, ents, acts = model(*syn.forward_args(b))
+            tot.backward()
+            O_.join_side()
+            torch.cuda.synchronize()
+            res = (float(tot), [p.detach().cpu() for p in probs], {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None})
+            if k == 2:
+                assert res[0] == first[0] and all(torch.equal(a, c) for a, c in zip(res[1], first[1]))
+                # (the forward is bit-reproducible; a few gradient tails — the word-table scatter-add — sum in arrival order)
+                for n in first[2]:
+                    assert float((res[2][n] - first[2][n]).abs().max()) <= 1e-5 * float(first[2][n].abs().max()) + 1e-10, n
+                continue
+            if k == 0:
+                first = res
+            Pk = {n: v.clone() for n, v in P.items()}
+            for n in names:
+                Pk[n].requires_grad_(True)
+            tr, pr, _, _ = orc.forward(Pk, cfg, *syn.forward_args(b_cpu), gumbel_noise=noise)
+            tr.backward()
+            assert abs(res[0] - float(tr)) <= 1e-4 * abs(float(tr)), (k, res[0], float(tr))
+            ptol = dict(rtol=3e-4, atol=1e-6) if precision == "fp32" else dict(rtol=2e-3, atol=2e-5)
+            for a, c in zip(res[1], pr):
+                np.testing.assert_allclose(a.numpy(), c.detach().numpy(), **ptol)
+            # (key biases, `Wing.bias`: zero in exact arithmetic — softmax shift invariance — so both sides hold rounding noise there: an
+            # absolute floor scaled by the largest gradient of the model)
+            gmax = max(float(Pk[n].grad.abs().max()) for n in names if Pk[n].grad is not None)
+            for n in names:
+                if Pk[n].grad is None:
+                    continue
+                r_ = Pk[n].grad
+                gtol = 2e-3 if precision == "fp32" else 4e-2
+                assert float((res[2][n] - r_).abs().max()) <= gtol * float(r_.abs().max()) + (2e-6 if precision == "fp32" else 2e-4) * gmax, (k, n)
+    finally:
+        O_.set_precision("fp32")
+
+
 @pytest.mark.parametrize("incremental", [True, False])
 @pytest.mark.parametrize("case,mt", [("tiny", "v"), ("tiny", "vi"), ("tiny", "viv"), ("tiny", "vivt"), ("c1", "v"), ("c1", "vivt")])
 def test_greedy_decode_ids_bit_exact_vs_reference(golden_dir, case, mt, incremental):
