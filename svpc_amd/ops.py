@@ -869,6 +869,31 @@ class _Linear(Function):
         return dx, dw, db, None, None, None, None, None, None, None, None
 
 
+# ---- bf16x3 ablation experiments (tools/x3_ablation.py; None in the product): which contractions need their lo planes?  One family of
+# projections at a time is degraded — its activation operand's lo plane dropped ("a"), its weight operand's ("b"), its output's ("o": the
+# stored value becomes plain bf16) — by handing the UNCHANGED three-term kernels operands whose lo plane is zero (fp32-storage families:
+# operands rounded to bf16 first), forward only, under no_grad.  ABLATE = {"match": f(param_name) -> str of "abo" flags or "", "names":
+# {data_ptr: parameter name}}.
+ABLATE = None
+
+
+def _ablate_flags(w):
+    if ABLATE is None:
+        return ""
+    name = ABLATE["names"].get(w.data_ptr())
+    return ABLATE["match"](name) if name is not None else ""
+
+
+def _zero_lo_copy(t):
+    lo = lo_off(t)
+    if lo is None:
+        return t.to(torch.bfloat16).float() if t.dtype == torch.float32 else t
+    c = new_split(t.shape[0], t.shape[1], t.device)
+    c.copy_(t.detach())
+    _lo_view(c).zero_()
+    return c
+
+
 def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgrad=None, w16=None, fuse_act_bwd=False):
     """fuse_act_bwd=True (with an activation, no dropout): the caller promises that the returned tensor is consumed by exactly ONE
     ops.linear; on a bf16 stream that projection's dgrad then writes the gradient of this projection's pre-activation directly
@@ -876,6 +901,20 @@ def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgr
     is detected in backward and fails loudly."""
     tok_in = getattr(x, "_svpc_act_tok", None)
     require_split_tag(x, "linear")
+    abl = _ablate_flags(w) if ABLATE is not None else ""
+    if abl:
+        assert not torch.is_grad_enabled(), "ablation experiments are forward-only"
+        if "a" in abl:
+            x = _zero_lo_copy(x)
+        if "b" in abl:
+            if w16 is None:
+                w16 = _shadow(w)
+            if w16 is not None and lo_off(w16) is not None:          # (a weight shadow keeps its lo plane numel-strided, like _transient_split)
+                buf = torch.zeros(2, *w16.shape, dtype=torch.bfloat16, device=w16.device)
+                buf[0].copy_(w16)
+                w16 = buf[0]
+                w16._svpc_lo = w16.numel()
+            w = w.detach().to(torch.bfloat16).float()
     split = lo_off(x) is not None
     if x.dtype == torch.bfloat16:
         n_out = w.shape[1] if trans_w else w.shape[0]
@@ -908,6 +947,11 @@ def linear(x, w, b=None, act=ACT_NONE, trans_w=False, drop=None, wgrad=None, bgr
     y = _Linear.apply(x, w, b, act, trans_w, drop, wgrad, bgrad, w16, tok_out, tok_in)
     if split:
         y._svpc_lo = y.shape[1]        # (a split activation yields a split output: see _Linear.forward)
+    if abl and "o" in abl:
+        if split:
+            _lo_view(y).zero_()
+        else:
+            y = y.to(torch.bfloat16).float()
     if tok_out is not None:
         y._svpc_act_tok = tok_out
     return y
@@ -1029,6 +1073,11 @@ def layernorm(x, gamma, beta, eps, residual=None, src_rows=None, pad_row=-1, pre
                          add2_idx, out_bf16, sink, out_split)
     if split:
         y._svpc_lo = y.shape[1]
+    if ABLATE is not None and "o" in _ablate_flags(gamma):          # (experiments: the normalised rows stored as plain bf16)
+        if split:
+            _lo_view(y).zero_()
+        else:
+            y = y.to(torch.bfloat16).float()
     return y
 
 
@@ -1207,6 +1256,20 @@ def attention(qt, kvt, cols, D, n_heads, seq, key_mask=None, causal=False, drop=
         else:
             qt = qt.to(torch.bfloat16)
     split = lo_off(qt) is not None or lo_off(kvt) is not None
+    if ABLATE is not None and split and kvt is qt and ABLATE.get("attn"):      # (experiments: Q / K or V operands of the clip encoder's core
+        flags = ABLATE["attn"] if seq.max_q > 32 else ""                      # without their lo planes)
+        if flags:
+            assert not torch.is_grad_enabled()
+            c = new_split(qt.shape[0], qt.shape[1], qt.device)
+            c.copy_(qt.detach()); _lo_view(c).copy_(_lo_view(qt))
+            lo = _lo_view(c)
+            if "q" in flags:
+                lo[:, cols[0]:cols[0] + D].zero_()
+            if "k" in flags:
+                lo[:, cols[1]:cols[1] + D].zero_()
+            if "v" in flags:
+                lo[:, cols[2]:cols[2] + D].zero_()
+            qt = kvt = c
     if split:
         dh = D // n_heads
         # (the same conditions _Attention.forward demands of a split stream, 16-byte aligned column blocks included: what fails them
