@@ -215,6 +215,14 @@ int svpc_attn_fwd(const float* Q, int ldq, const float* K, int ldk, const float*
  * has exactly one query row; fp32, forward only */
 int svpc_attn_q1_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, float* LSE,
                      const int* seq, int n_seq, int H, int dh, int max_k, const float* key_mask, float scale, svpc_stream_t stream);
+/* one decoding step of an attention block of the decoder layer (src/rtransformer/model.py:620-663 evaluated for ONE new position per
+ * sentence, as src/translator.py:88-112 needs): O[t] = LayerNorm(X[t] + Attention(Q[t]; rows t·k_stride … t·k_stride+n_keys−1 of K / V)),
+ * heads of dh = 64, fp32.  newK / newV (both or neither): the token's own key / value row, stored as row t·k_stride+n_keys−1 of the cache
+ * before it is attended to (incremental self-attention); without them K / V are only read (cross-attention over the memory rows). */
+int svpc_attn_q1_ln_supported(int D, int dh, int n_keys, int ldq, int ldkv, int ldnew, int ldx, int ldo);
+int svpc_attn_q1_ln_fwd(const float* Q, int ldq, float* K, float* V, int ldkv, int k_stride, int n_keys, const float* newK, const float* newV,
+                        int ldnew, const float* X, int ldx, const float* gamma, const float* beta, float eps, float* O, int ldo, int T, int D,
+                        int dh, float scale, svpc_stream_t stream);
 int svpc_attn_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                   const float* LSE, const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
                   float* delta, const int* seq, int n_seq, int H, int dh, int max_q, int max_k, const float* key_mask, int causal,

@@ -278,6 +278,95 @@ __global__ __launch_bounds__(256) void attn_q1_kernel(AttnArgs a) {
     if (a.LSE && lane == 0) a.LSE[((size_t)s * a.H + h) * a.max_q] = m + logf(l);
 }
 
+// ---- one decoding step of an attention block in ONE launch (incremental greedy decoding, translator.py:88-112 through the decoder
+// layer model.py:620-663): per sentence t,  out[t] = LayerNorm( x[t] + Attention(q[t]; K, V of the sentence) ), optionally after
+// APPENDING the token's new key / value row to the sentence's cache (the causal mask lets position pos see exactly the pos+1 rows
+// written so far).  Replaces cache copy + attn_q1 + LayerNorm (self-attention) and attn_q1 + LayerNorm (cross-attention over the 1-3
+// memory rows).  One workgroup per sentence, a thread owns 4 consecutive dimensions (16 lanes = one head of 64): every key row of the
+// sentence is requested before the first is used (MAXK 16-byte loads per thread), scores by row-of-16 DPP sums, softmax in registers,
+// the normalisation statistics by two block reductions (mean, then the centred second moment, as the reference's BertLayerNorm).
+// fp32 throughout; forward only.
+struct Q1LnArgs {
+    const float* Q; int ldq; float* K; float* V; int ldkv; int k_stride; int n_keys;
+    const float* newK; const float* newV; int ldnew;
+    const float* X; int ldx; const float* gamma; const float* beta; float eps; float* O; int ldo;
+    int T, D; float scale;
+};
+__device__ __forceinline__ float row16_sum(float v) {
+    v = dpp_add_<0xB1>(v); v = dpp_add_<0x4E>(v); v = dpp_add_<0x141>(v); v = dpp_add_<0x140>(v);
+    return v;
+}
+template <int MAXK>
+__global__ __launch_bounds__(256) void attn_q1_ln_kernel(Q1LnArgs a) {
+    __shared__ float red[2][4];
+    const int t = blockIdx.x, tid = threadIdx.x, d0 = 4 * tid;
+    const int nw = blockDim.x >> 6;
+    const bool app = a.newK != nullptr;
+    const int nc = app ? a.n_keys - 1 : a.n_keys;                   // rows read from the cache
+    const size_t row0 = (size_t)t * a.k_stride;
+    float4 q = *reinterpret_cast<const float4*>(a.Q + (size_t)t * a.ldq + d0);
+    const float4 xr = *reinterpret_cast<const float4*>(a.X + (size_t)t * a.ldx + d0);
+    const float4 gm = *reinterpret_cast<const float4*>(a.gamma + d0), bt = *reinterpret_cast<const float4*>(a.beta + d0);
+    float4 kn = make_float4(0.f, 0.f, 0.f, 0.f), vn = kn;
+    if (app) {
+        kn = *reinterpret_cast<const float4*>(a.newK + (size_t)t * a.ldnew + d0);
+        vn = *reinterpret_cast<const float4*>(a.newV + (size_t)t * a.ldnew + d0);
+    }
+    float4 kr[MAXK];
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j)      // (rows past the end re-read the last one — unconditional loads, all in flight; nc == 0 reads row 0 of the sentence's own cache block)
+        kr[j] = *reinterpret_cast<const float4*>(a.K + (row0 + min(j, max(nc - 1, 0))) * a.ldkv + d0);
+    q.x *= a.scale; q.y *= a.scale; q.z *= a.scale; q.w *= a.scale;
+    float sc[MAXK], sn = -INFINITY, mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+        const float d = row16_sum(q.x * kr[j].x + q.y * kr[j].y + q.z * kr[j].z + q.w * kr[j].w);
+        sc[j] = j < nc ? d : -INFINITY;
+        mx = fmaxf(mx, sc[j]);
+    }
+    float4 vr[MAXK];
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j)
+        vr[j] = *reinterpret_cast<const float4*>(a.V + (row0 + min(j, max(nc - 1, 0))) * a.ldkv + d0);
+    if (app) {
+        sn = row16_sum(q.x * kn.x + q.y * kn.y + q.z * kn.z + q.w * kn.w);
+        mx = fmaxf(mx, sn);
+        *reinterpret_cast<float4*>(a.K + (row0 + nc) * a.ldkv + d0) = kn;
+        *reinterpret_cast<float4*>(a.V + (row0 + nc) * a.ldkv + d0) = vn;
+    }
+    float l = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+        const float p = expf(sc[j] - mx);              // 0 past the end
+        l += p;
+        acc.x += p * vr[j].x; acc.y += p * vr[j].y; acc.z += p * vr[j].z; acc.w += p * vr[j].w;
+    }
+    if (app) {
+        const float p = expf(sn - mx);
+        l += p;
+        acc.x += p * vn.x; acc.y += p * vn.y; acc.z += p * vn.z; acc.w += p * vn.w;
+    }
+    const float il = 1.0f / l;
+    float4 y = make_float4(acc.x * il + xr.x, acc.y * il + xr.y, acc.z * il + xr.z, acc.w * il + xr.w);
+    // LayerNorm over the D values of the row (model.py:150-166: u = mean, s = mean((x-u)^2), (x-u)/sqrt(s+eps)·w + b)
+    float ps = wave_sum((y.x + y.y) + (y.z + y.w));
+    if ((tid & 63) == 0) red[0][tid >> 6] = ps;
+    __syncthreads();
+    float tot = 0.f;
+    for (int w = 0; w < nw; ++w) tot += red[0][w];
+    const float mean = tot / (float)a.D;
+    y.x -= mean; y.y -= mean; y.z -= mean; y.w -= mean;
+    float pq = wave_sum((y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w));
+    if ((tid & 63) == 0) red[1][tid >> 6] = pq;
+    __syncthreads();
+    float tq = 0.f;
+    for (int w = 0; w < nw; ++w) tq += red[1][w];
+    const float rstd = 1.0f / sqrtf(tq / (float)a.D + a.eps);
+    float4 o = make_float4(y.x * rstd * gm.x + bt.x, y.y * rstd * gm.y + bt.y, y.z * rstd * gm.z + bt.z, y.w * rstd * gm.w + bt.w);
+    *reinterpret_cast<float4*>(a.O + (size_t)t * a.ldo + d0) = o;
+}
+
 extern "C" {
 
 // one query row per sequence (q_len == 1 for every sequence), no dropout, not causal-masked beyond k_len: forward only
@@ -292,6 +381,35 @@ int svpc_attn_q1_fwd(const float* Q, int ldq, const float* K, int ldk, const flo
     if (max_k <= 8) hipLaunchKernelGGL(attn_q1_kernel<8>, dim3(ceil_div(n_seq * H, 4)), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_q1_kernel<32>, dim3(ceil_div(n_seq * H, 4)), dim3(256), 0, stream, a);
     return svpc_check_launch("attn_q1_fwd");
+}
+
+// 1 if svpc_attn_q1_ln_fwd takes the shape: heads of 64, D a multiple of 256 up to 1024, at most 32 key rows per sentence, 16-byte rows
+int svpc_attn_q1_ln_supported(int D, int dh, int n_keys, int ldq, int ldkv, int ldnew, int ldx, int ldo) {
+    if (dh != 64 || D % 256 != 0 || D > 1024 || n_keys < 1 || n_keys > 32) return 0;
+    if ((ldq | ldkv | ldnew | ldx | ldo) & 3) return 0;
+    return 1;
+}
+// out[t] = LayerNorm(X[t] + Attention(Q[t]; keys / values = rows t·k_stride … t·k_stride + n_keys − 1 of K / V)), T sentences, one query
+// each; with newK / newV (both or neither; row t, leading dimension ldnew) the token's key / value row is FIRST stored as row
+// t·k_stride + n_keys − 1 of K / V (the cache append of incremental decoding) — it is the last of the n_keys rows attended to.
+int svpc_attn_q1_ln_fwd(const float* Q, int ldq, float* K, float* V, int ldkv, int k_stride, int n_keys, const float* newK, const float* newV,
+                        int ldnew, const float* X, int ldx, const float* gamma, const float* beta, float eps, float* O, int ldo, int T, int D,
+                        int dh, float scale, hipStream_t stream) {
+    if (T == 0) return 0;
+    SVPC_REQUIRE(svpc_attn_q1_ln_supported(D, dh, n_keys, ldq, ldkv, newK ? ldnew : 0, ldx, ldo) == 1 && (newK == nullptr) == (newV == nullptr) &&
+                     k_stride >= n_keys &&
+                     ((((uintptr_t)Q) | ((uintptr_t)K) | ((uintptr_t)V) | ((uintptr_t)newK) | ((uintptr_t)newV) | ((uintptr_t)X) | ((uintptr_t)gamma) |
+                       ((uintptr_t)beta) | ((uintptr_t)O)) & 15) == 0,
+                 "attn_q1_ln: needs heads of 64, D % 256 == 0, D <= 1024, 1..32 key rows per sentence, 16-byte aligned rows");
+    Q1LnArgs a{Q, ldq, K, V, ldkv, k_stride, n_keys, newK, newV, ldnew, X, ldx, gamma, beta, eps, O, ldo, T, D, scale};
+    const int nc = newK ? n_keys - 1 : n_keys;
+    const dim3 grid(T), block(D / 4);
+    if (nc <= 4) hipLaunchKernelGGL(attn_q1_ln_kernel<4>, grid, block, 0, stream, a);
+    else if (nc <= 8) hipLaunchKernelGGL(attn_q1_ln_kernel<8>, grid, block, 0, stream, a);
+    else if (nc <= 16) hipLaunchKernelGGL(attn_q1_ln_kernel<16>, grid, block, 0, stream, a);
+    else if (nc <= 24) hipLaunchKernelGGL(attn_q1_ln_kernel<24>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(attn_q1_ln_kernel<32>, grid, block, 0, stream, a);
+    return svpc_check_launch("attn_q1_ln_fwd");
 }
 
 int svpc_attn_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, float* LSE,

@@ -850,7 +850,9 @@ static int gemm_l32_x(const float* A, int lda, int a_kc, const float* B, int ldb
     if (remap < 0) { const char* e = getenv("SVPC_GEMM_REMAP"); remap = e ? atoi(e) : 1; }
     static int env_skinny = -1;
     if (env_skinny < 0) { const char* e = getenv("SVPC_L32_SKINNY"); env_skinny = e ? atoi(e) : 1; }
-    if (env_skinny && a_kc && M <= 256 && N >= 32 && (K & 15) == 0 && (lda & 3) == 0 && (!b_kc || (ldb & 3) == 0)) {
+    static int skinny_m = -1;
+    if (skinny_m < 0) { const char* e = getenv("SVPC_L32_SKINNY_M"); skinny_m = e ? atoi(e) : 256; }
+    if (env_skinny && a_kc && M <= skinny_m && N >= 32 && (K & 15) == 0 && (lda & 3) == 0 && (!b_kc || (ldb & 3) == 0)) {
         const int tn_ = ceil_div(N, 32);
         dim3 grids(ceil_div(M, 32) * tn_);
         if (x3) {

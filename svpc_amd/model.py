@@ -313,13 +313,19 @@ class BertDecoderLayerNoMemoryUntied(nn.Module):
         T, D = x.shape
         w, b, _, _, _ = self.self_attention.packed()
         qkv = ops.linear(x, w, b)
-        cache.view(T, lt, 2 * D)[:, pos].copy_(qkv[:, D:])
-        sa = ops.attention(qkv, cache, (0, 0, D), D, cx.H, seq_self, key_mask=None, causal=False)
-        x1 = ops.layernorm(sa, self.norm1.weight, self.norm1.bias, cx.eps, residual=x)
+        # cache append + one-query attention + residual + LayerNorm in one launch where the shape allows (fp32 rows, heads of 64)
+        x1 = ops.attn_q1_ln(qkv, cache, lt, pos + 1, x, self.norm1.weight, self.norm1.bias, cx.eps, cx.H, new_kv=qkv[:, D:])
+        if x1 is None:
+            cache.view(T, lt, 2 * D)[:, pos].copy_(qkv[:, D:])
+            sa = ops.attention(qkv, cache, (0, 0, D), D, cx.H, seq_self, key_mask=None, causal=False)
+            x1 = ops.layernorm(sa, self.norm1.weight, self.norm1.bias, cx.eps, residual=x)
         ca_m = self.dec_enc_attention
         qc = ops.linear(x1, ca_m.query.weight, ca_m.query.bias)
-        ca = ops.attention(qc, mem_kv, (0, 0, D), D, cx.H, seq_cross, key_mask=None, causal=False)
-        x2 = ops.layernorm(ca, self.norm2.weight, self.norm2.bias, cx.eps, residual=x1)
+        n_mem = mem_kv.shape[0] // T
+        x2 = ops.attn_q1_ln(qc, mem_kv, n_mem, n_mem, x1, self.norm2.weight, self.norm2.bias, cx.eps, cx.H)
+        if x2 is None:
+            ca = ops.attention(qc, mem_kv, (0, 0, D), D, cx.H, seq_cross, key_mask=None, causal=False)
+            x2 = ops.layernorm(ca, self.norm2.weight, self.norm2.bias, cx.eps, residual=x1)
         o = ops.linear(x2, self.output.dense.weight, self.output.dense.bias)
         return ops.layernorm(o, self.output.LayerNorm.weight, self.output.LayerNorm.bias, cx.eps, residual=x2)
 

@@ -1312,6 +1312,32 @@ class _SplitCols(Function):
         return g, None, None
 
 
+def attn_q1_ln(q, kv, k_stride, n_keys, residual, gamma, beta, eps, n_heads, new_kv=None):
+    """One decoding step of an attention block (reference decoder layer model.py:620-663 for one new position per sentence,
+    translator.py:88-112): LayerNorm(residual + Attention(q; the sentence's key / value rows)), one launch.  ``q``: (T, ≥D) fp32, the
+    query in its first D columns; ``kv``: (rows, 2D) fp32, K | V, sentence t owning rows t·k_stride … t·k_stride + n_keys − 1;
+    ``new_kv`` (T, 2D view): the token's own K | V, stored as the sentence's row n_keys − 1 first (the cache append).  Forward only.
+    Returns None when the shape is not taken (the caller then runs copy / attention / layernorm separately)."""
+    T, D = residual.shape
+    if torch.is_grad_enabled() and (q.requires_grad or residual.requires_grad):
+        return None
+    ts = (q, kv, residual) + ((new_kv,) if new_kv is not None else ())
+    if not all(t.is_cuda and t.dtype == torch.float32 and lo_off(t) is None and t.stride(1) == 1 for t in ts) or D % n_heads:
+        return None
+    lib = _lib.load()
+    ldn = new_kv.stride(0) if new_kv is not None else 0
+    if lib.svpc_attn_q1_ln_supported(D, D // n_heads, n_keys, q.stride(0), kv.stride(0), ldn, residual.stride(0), D) != 1:
+        return None
+    if any(t.data_ptr() % 16 for t in ts) or kv.shape[1] != 2 * D or k_stride < n_keys:
+        return None
+    out = torch.empty(T, D, dtype=torch.float32, device=q.device)
+    nk = new_kv.data_ptr() if new_kv is not None else None
+    _lib.call("attn_q1_ln_fwd", _p(q), q.stride(0), kv.data_ptr(), kv.data_ptr() + 4 * D, kv.stride(0), k_stride, n_keys, nk,
+              (nk + 4 * D) if nk is not None else None, ldn, _p(residual), residual.stride(0), _p(gamma), _p(beta), float(eps), _p(out), D, T, D,
+              D // n_heads, 1.0 / math.sqrt(D // n_heads), _stream())
+    return out
+
+
 def split_cols(wide, n):
     """→ n column blocks of ``wide`` (R, n·w) whose gradients are gathered in place (see _SplitCols).  A split ``wide`` gives split
     blocks: the lo plane of a block lies the same number of columns behind it as the lo plane of the whole row."""

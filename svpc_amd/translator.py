@@ -37,6 +37,11 @@ class Translator(object):
         model.load_state_dict(checkpoint["model"])
         self.model = model
         self.model.eval()
+        if next(model.parameters()).is_cuda:
+            # inference without an optimizer: adopt the parameters in a WeightStore, so the packed [Wq Wk Wv] / stacked memory K|V blocks
+            # and the bf16 (+ lo plane) weight shadows are resident — without one every packed projection concatenates its weights per call
+            from .optim import WeightStore
+            WeightStore.for_model(model)
 
     @classmethod
     def prepare_video_only_inputs(cls, input_ids, input_masks, segment_ids):
