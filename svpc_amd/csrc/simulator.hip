@@ -8,6 +8,7 @@
 // Backward walks t in reverse with the gradient of E carried in registers (thread-owned columns), recomputing alpha, k
 // from the saved e / ē / E_t; the 2·E_b+1 per-step scalars (dα pieces, dw) are reduced once per step through LDS.
 #include "common.h"
+#include <stdlib.h>
 
 constexpr int SIM_EMAX = 32;
 
@@ -128,7 +129,10 @@ __device__ __forceinline__ void sim_dma(const float* __restrict__ src, float* __
 }
 
 // MODE 2: DMA double-buffered (4 images in LDS) · MODE 1: both images staged synchronously (2 images) · MODE 0: only the state is
-// staged, the upstream gradient is read from HBM inside the loops (1 image: up to 32 entities × 768)
+// staged, the upstream gradient is read from HBM inside the loops (1 image: up to 32 entities × 768) · MODE 3 (the 1-image case when
+// D % 256 == 0: 17-32 entities at D = 768, what the reference's batches with up to 31 ingredients need): the state image by DMA and the
+// thread's column of the upstream gradient in registers, every entity requested at the top of the step — ONE memory round trip per step
+// where MODE 0 made one per entity inside the loop (conditional loads serialise) plus a staged copy: 850 → ≈120 µs at 16 steps × 31 entities
 // EM = compile-time bound on the entities per video (16 or 32): the per-entity scalars and gradient columns are register arrays
 // unrolled to EM, so the smaller bound halves the register pressure and the predicated code when the batch allows it.
 template <int CPT, int NT, int MODE, int EM>
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
     const int img = ((em * D + 255) / 256) * 256;  // floats per image, 1-KiB aligned
     float* Ebuf = smem;                            // DMA: [2][img] state BEFORE step t;  else [img]
     float* Ubuf = Ebuf + (DMA ? 2 : 1) * img;      // same shape: upstream gradient of the state AFTER step t (zeros if absent)
-    float* red = Ubuf + (MODE == 0 ? 0 : (DMA ? 2 : 1)) * img;       // (2*32+1) × NW wave partials
+    constexpr bool ONE = MODE == 0 || MODE == 3;      // one image: the state only
+    float* red = Ubuf + (ONE ? 0 : (DMA ? 2 : 1)) * img;       // (2*32+1) × NW wave partials
     float* sc = red + (2 * EM + 1) * NW;     // scalars: ds[32]
     float* dprev = sc + EM;                  // 32: gradient flowing into e_{t-1} through "prev"
     float* tot = dprev + EM;                 // 2·EM + 1 block totals of the wave partials in `red`
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
 #pragma unroll
         for (int u = 0; u < CPT; ++u) dE[e][u] = 0.f;
     if (threadIdx.x < EM) dprev[threadIdx.x] = 0.f;
-    if (MODE != 0 && !a.deall)
+    if (!ONE && !a.deall)
         for (int i = threadIdx.x; i < (DMA ? 2 : 1) * img; i += NT) Ubuf[i] = 0.f;
 
     auto state_before = [&](int t) -> const float* {
@@ -180,6 +185,11 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
         }
     };
     if (S > 0) fetch(S - 1);
+    float upv[MODE == 3 ? EM : 1][CPT];
+#pragma unroll
+    for (int e = 0; e < (MODE == 3 ? EM : 1); ++e)
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) upv[e][u] = 0.f;
     for (int t = S - 1; t >= 0; --t) {
         const int j = s0 + t;
         const int cur = DMA ? ((S - 1 - t) & 1) : 0;
@@ -192,6 +202,18 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
                 sim_dma<NT>(state_before(t - 1), Ebuf + (cur ^ 1) * img, E * D, wave, lane);
                 if (a.deall) sim_dma<NT>(a.deall + (size_t)(j - 1) * em * D, Ubuf + (cur ^ 1) * img, E * D, wave, lane);
             }
+        } else if (MODE == 3) {
+            __syncthreads();                                       // everyone is done with the image of step t+1
+            sim_dma<NT>(state_before(t), Es, E * D, wave, lane);
+            if (a.deall) {
+#pragma unroll
+                for (int e = 0; e < EM; ++e)
+#pragma unroll
+                    for (int u = 0; u < CPT; ++u)                   // (rows / columns past the end re-read the last: unconditional, all in flight)
+                        upv[e][u] = a.deall[((size_t)j * em + min(e, E - 1)) * D + min((int)threadIdx.x + NT * u, D - 1)];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         } else {
             __syncthreads();
             const float* sb = state_before(t);
@@ -233,7 +255,8 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
 #pragma unroll
                 for (int e = 0; e < EM; ++e) {
                     if (e < E) {
-                        const float up = MODE != 0 ? Us[(size_t)e * D + d] : (a.deall ? a.deall[((size_t)j * em + e) * D + d] : 0.f);
+                        const float up = MODE == 3 ? upv[MODE == 3 ? e : 0][u]
+                                                   : (MODE != 0 ? Us[(size_t)e * D + d] : (a.deall ? a.deall[((size_t)j * em + e) * D + d] : 0.f));
                         const float g = dE[e][u] + up;
                         const float Ev = Es[(size_t)e * D + d];
                         pA[e] += g * (k - Ev);
@@ -336,6 +359,152 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
     }
 }
 
+// ---- the backward for 17-32 entities per video at D = NT ∈ {256, 512, 768, 1024} (one column per thread, one state image in LDS:
+// the reference's batches carry up to 31 ingredients).  Same arithmetic and summation order as sim_recur_bwd_kernel; what differs is
+// where things live.  The generic kernel keeps nine 32-entry per-entity arrays in registers (α, e, e_prev, de, the two partial sums, dαβ,
+// dα, ds — unrolled to EM): at 768 threads (168 VGPRs) that is 540 bytes of scratch per lane, touched inside every step of the dependent
+// chain, and with one image its loads of the upstream gradient sat inside the entity loop, one memory round trip per entity (850 µs for
+// 16 steps × 31 entities).  Here: (1) the per-entity scalars live in LDS (written by the first 32 threads from values requested one
+// step ahead, read back as broadcasts), (2) the two per-entity partial sums are wave-reduced as they are produced, (3) the scalar
+// algebra is done once by thread e instead of redundantly by all, (4) the state image comes by LDS-DMA and the thread's column of the
+// upstream gradient — all entities — is requested at the top of the step: one memory round trip per step.  Registers per thread: the
+// carried gradient column dE[32] and that upstream column.
+template <int NT>
+__global__ __launch_bounds__(NT) void sim_recur_bwd_lean_kernel(SimArgs a) {
+    constexpr int NW = NT / 64, EM = SIM_EMAX;
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    const int b = blockIdx.x, D = a.D, em = a.e_max;            // D == NT (host check)
+    const int s0 = a.step_off[b], S = a.step_len[b], e0 = a.ent_off[b], E = a.ent_len[b];
+    const int img = ((em * D + 255) / 256) * 256;
+    float* Es = smem;
+    float* red = Es + img;                   // (2·EM + 1) × NW wave partials
+    float* dprev = red + (2 * EM + 1) * NW;  // EM: gradient flowing into e_{t-1} through "prev"
+    float* tot = dprev + EM;                 // 2·EM + 1 block totals
+    float* al_s = tot + (2 * EM + 1);        // EM each: α, e, e_prev, upstream de, dα, ds
+    float* ev_s = al_s + EM;
+    float* pv_s = ev_s + EM;
+    float* dv_s = pv_s + EM;
+    float* dal_s = dv_s + EM;
+    float* ds_s = dal_s + EM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = tid;
+    float dE[EM], upv[EM];
+#pragma unroll
+    for (int e = 0; e < EM; ++e) { dE[e] = 0.f; upv[e] = 0.f; }
+    if (tid < EM) dprev[tid] = 0.f;
+    auto state_before = [&](int t) -> const float* {
+        return t == 0 ? a.E0 + (size_t)e0 * D : a.eall + (size_t)(s0 + t - 1) * em * D;
+    };
+    // operands of step t-1 that do not depend on the recurrence, requested during step t
+    float n_c0 = 0.f, n_c1 = 0.f, n_w = 0.f, n_eb = 0.f, n_deb = 0.f, n_q = 0.f, n_ev = 0.f, n_pv = 0.f, n_dv = 0.f;
+    const int ecl = min(tid, max(E - 1, 0));
+    auto fetch = [&](int tt) {
+        const int jj = s0 + tt;
+        n_c0 = a.c[(size_t)jj * 3]; n_c1 = a.c[(size_t)jj * 3 + 1]; n_w = a.w4f[jj];
+        n_eb = a.ebar[(size_t)jj * D + d];
+        n_deb = a.debar ? a.debar[(size_t)jj * D + d] : 0.f;
+        n_q = a.q[(size_t)jj * D + d];
+        // (every thread loads — clamped — so that the loads are not predicated; threads ≥ E do not use them)
+        n_ev = a.e_out[(size_t)jj * em + ecl];
+        n_pv = a.e_out[(size_t)max(jj - 1, 0) * em + ecl];
+        n_dv = a.de ? a.de[(size_t)jj * em + ecl] : 0.f;
+    };
+    if (S > 0) fetch(S - 1);
+    for (int t = S - 1; t >= 0; --t) {
+        const int j = s0 + t;
+        __syncthreads();                                       // everyone is done with the image and the scalars of step t+1
+        sim_dma<NT>(state_before(t), Es, E * D, wave, lane);
+        if (a.deall) {
+#pragma unroll
+            for (int e = 0; e < EM; ++e)                        // (rows past the end re-read the last: unconditional, all in flight)
+                upv[e] = a.deall[((size_t)j * em + min(e, E - 1)) * D + d];
+        }
+        const float c0 = n_c0, c1 = n_c1, w = n_w, eb = n_eb, debv = n_deb, qv = n_q;
+        if (tid < EM) {
+            const bool on = tid < E;
+            const float ev = on ? n_ev : 0.f, pv = (on && t > 0) ? n_pv : 0.f;
+            ev_s[tid] = ev; pv_s[tid] = pv; dv_s[tid] = on ? n_dv : 0.f;
+            al_s[tid] = on ? c0 * ev + c1 * pv : 0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t > 0) fetch(t - 1);
+        const float k = fmaxf(w * eb, 0.f);
+        float dk = 0.f, Z = 0.f;
+#pragma unroll
+        for (int e = 0; e < EM; ++e) {
+            if (e < E) {
+                const float al = al_s[e];
+                const float g = dE[e] + upv[e];
+                const float Ev = Es[(size_t)e * D + d];
+                const float ra = wave_sum(g * (k - Ev));
+                if (lane == 0) red[e * NW + wave] = ra;
+                dk += g * al;
+                dE[e] = g * (1.f - al);
+                Z += al;
+            }
+        }
+        const float invZ = 1.0f / Z;
+        const float dpre = k > 0.f ? dk : 0.f;
+        const float deb = dpre * w + debv;
+#pragma unroll
+        for (int e = 0; e < EM; ++e) {
+            if (e < E) {
+                const float rb = wave_sum(deb * Es[(size_t)e * D + d]);
+                if (lane == 0) red[(EM + e) * NW + wave] = rb;
+                dE[e] += al_s[e] * invZ * deb;
+            }
+        }
+        const float pw = wave_sum(dpre * eb);
+        if (lane == 0) red[(2 * EM) * NW + wave] = pw;
+        __syncthreads();
+        if (tid < 2 * EM + 1) {                                // wave order: deterministic
+            const float* rp = red + tid * NW;
+            float t_ = rp[0];
+#pragma unroll
+            for (int w_ = 1; w_ < NW; ++w_) t_ += rp[w_];
+            tot[tid] = t_;
+        }
+        __syncthreads();
+        if (tid < EM) {
+            float mix = 0.f;
+#pragma unroll
+            for (int e = 0; e < EM; ++e)
+                if (e < E) mix += tot[EM + e] * al_s[e] * invZ;
+            float dal = 0.f, dsv = 0.f;
+            if (tid < E) {
+                dal = tot[tid] + (tot[EM + tid] - mix) * invZ;
+                const float ev = ev_s[tid];
+                const float de_tot = c0 * dal + dv_s[tid] + dprev[tid];
+                dsv = de_tot * ev * (1.f - ev);
+            }
+            dal_s[tid] = dal; ds_s[tid] = dsv;
+            dprev[tid] = tid < E ? c1 * dal : 0.f;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float dc0 = 0.f, dc1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < EM; ++e)
+                if (e < E) { dc0 += dal_s[e] * ev_s[e]; dc1 += dal_s[e] * pv_s[e]; }
+            a.dc[(size_t)j * 3] = dc0; a.dc[(size_t)j * 3 + 1] = dc1; a.dc[(size_t)j * 3 + 2] = 0.f;
+            a.dw4f[j] = tot[2 * EM];
+        }
+        float dqv = 0.f;
+#pragma unroll
+        for (int e = 0; e < EM; ++e) {
+            if (e < E) {
+                const float dsv = ds_s[e];
+                dqv += dsv * Es[(size_t)e * D + d];
+                dE[e] += dsv * qv;
+            }
+        }
+        a.dq[(size_t)j * D + d] = dqv;
+    }
+#pragma unroll
+    for (int e = 0; e < EM; ++e)
+        if (e < E) a.dE0[((size_t)e0 + e) * D + d] = dE[e];
+}
+
 static int sim_set_lds(const void* fn, size_t bytes) { return svpc_raise_lds_once(fn, "sim_recur"); }   // once per kernel symbol, process-wide table (api.cpp)
 
 extern "C" {
@@ -373,6 +542,7 @@ int svpc_sim_recur_bwd(const float* q, const float* c, const float* w4f, const f
     int mode = 0;
     if (D % 256 == 0 && aligned && 4 * img * sizeof(float) + tail <= budget) mode = 2;
     else if (2 * img * sizeof(float) + tail <= budget) mode = 1;
+    else if (D % 256 == 0 && aligned) mode = 3;
     const size_t lds = (mode == 2 ? 4 : (mode == 1 ? 2 : 1)) * img * sizeof(float) + tail;
     SVPC_REQUIRE(lds <= budget, "sim_recur: entity state does not fit LDS");
     SimArgs a{};
@@ -381,13 +551,30 @@ int svpc_sim_recur_bwd(const float* q, const float* c, const float* w4f, const f
     a.eall = const_cast<float*>(eall); a.e_max = e_max; a.D = D; a.de = de; a.debar = debar; a.deall = deall;
     a.dq = dq; a.dc = dc; a.dw4f = dw4f; a.dE0 = dE0;
     int rc;
+    static int lean_env = -1;
+    if (lean_env < 0) { const char* e = getenv("SVPC_SIM_LEAN"); lean_env = e ? atoi(e) : 1; }
+    if (mode == 3 && EMv == 32 && nt == D && lean_env) {
+        const size_t lds_lean = img * sizeof(float) + ((2 * SIM_EMAX + 1) * (nt / 64) + SIM_EMAX + (2 * SIM_EMAX + 1) + 6 * SIM_EMAX) * sizeof(float);
+        SVPC_REQUIRE(lds_lean <= budget, "sim_recur: entity state does not fit LDS");
+#define SIM_LEAN_GO(NTV)                                                                                             \
+    do {                                                                                                             \
+        rc = sim_set_lds((const void*)sim_recur_bwd_lean_kernel<NTV>, lds_lean); if (rc) return rc;                   \
+        hipLaunchKernelGGL((sim_recur_bwd_lean_kernel<NTV>), dim3(n_videos), dim3(NTV), lds_lean, stream, a);         \
+    } while (0)
+        if (nt == 256) SIM_LEAN_GO(256);
+        else if (nt == 512) SIM_LEAN_GO(512);
+        else if (nt == 768) SIM_LEAN_GO(768);
+        else SIM_LEAN_GO(1024);
+#undef SIM_LEAN_GO
+        return svpc_check_launch("sim_recur_bwd");
+    }
 #define SIM_BWD_GO2(NTV, MV, EMV)                                                                                  \
     do {                                                                                                           \
         rc = sim_set_lds((const void*)sim_recur_bwd_kernel<1, NTV, MV, EMV>, lds); if (rc) return rc;               \
         hipLaunchKernelGGL((sim_recur_bwd_kernel<1, NTV, MV, EMV>), dim3(n_videos), dim3(NTV), lds, stream, a);     \
     } while (0)
 #define SIM_BWD_GO(NTV, MV) do { if (EMv == 16) SIM_BWD_GO2(NTV, MV, 16); else SIM_BWD_GO2(NTV, MV, 32); } while (0)
-#define SIM_BWD_NT(NTV) do { if (mode == 2) SIM_BWD_GO(NTV, 2); else if (mode == 1) SIM_BWD_GO(NTV, 1); else SIM_BWD_GO(NTV, 0); } while (0)
+#define SIM_BWD_NT(NTV) do { if (mode == 2) SIM_BWD_GO(NTV, 2); else if (mode == 1) SIM_BWD_GO(NTV, 1); else if (mode == 3) SIM_BWD_GO(NTV, 3); else SIM_BWD_GO(NTV, 0); } while (0)
     if (nt == 256) SIM_BWD_NT(256);
     else if (nt == 512) SIM_BWD_NT(512);
     else if (nt == 768) SIM_BWD_NT(768);

@@ -765,6 +765,13 @@ class StateAwareRecursiveTransformer(nn.Module):
         if host is None or tuple(host.shape) != tuple(ingr_sep_masks.shape):
             host = ingr_sep_masks.cpu()
         spans = self.ingredient_embeddings.spans(host)
+        if ingr_sep_masks.is_cuda:
+            # the three span tables in one asynchronous copy: created lazily (Idx.dev) each is a pageable, SYNCHRONOUS host→device copy —
+            # the host then waits for the GPU to drain before it can enqueue the step (3 × 0.75 ms per freshly structured batch, measured)
+            up = BulkUpload(ingr_sep_masks.device)
+            for ix in spans[:3]:
+                up.add_idx(ix)
+            up.flush()
         self._span_cache[key] = (ingr_sep_masks, ingr_sep_masks._version, spans)
         return spans
 
@@ -805,8 +812,9 @@ class StateAwareRecursiveTransformer(nn.Module):
         ve = self.video_embeddings
         # training forward at interior-only shapes: the clip-encoder activation stream lives in HBM as bf16
         # (bf16x3 mode: the split stream also carries the reference-shaped forward_step — the greedy decoder's encoder side)
+        n_rows = video_rows.numel() if video_rows is not None else feats_flat.shape[0]       # (None: the rows are already compact)
         stream_bf16 = (cls_only is not None or ops.is_x3()) and ops.bf16_stream_ok(
-            video_rows.numel(), self.config.hidden_size, self.config.video_feature_size, self.config.intermediate_size)
+            n_rows, self.config.hidden_size, self.config.video_feature_size, self.config.intermediate_size)
         h = ve.video_embeddings.run(feats_flat, cx.eps, src_rows=video_rows, drop=cx.drop(cx.p_h),
                                     add1=ve.position_embeddings_video.pe[:Lv].contiguous(), add1_mod=Lv,
                                     add2=self.token_type_embeddings.weight, add2_idx=ids_v, out_bf16=stream_bf16)
@@ -906,16 +914,23 @@ class StateAwareRecursiveTransformer(nn.Module):
         ents = self.ingredient_embeddings.run(ingr_ids, spans, cx)
 
         # (2) clip encoder over all valid clips at once (reference loops S × forward_step, :1038-1042)
-        cls = self._encode_clips(feats, plan.video_rows, ids_v, mask_v, plan.seq_enc, cx,
-                                 cls_only=(plan.cls_rows_dev, plan.seq_enc_cls))                  # (T, D): [CLS] rows only
-        # Optional two-phase backward for data parallelism (svpc_amd/graph.py): the [CLS] rows are the ONLY tensor through which
-        # the loss reaches the clip encoder, so cutting the autograd graph here lets the caller run the text-side backward,
-        # start exchanging those gradients (74 % of the bytes), then run ``split_boundary[0].backward(split_boundary[1].grad)``.
         self.split_boundary = None
-        if getattr(self, "split_backward", False) and torch.is_grad_enabled() and cls.requires_grad:
-            cut = cls.detach().requires_grad_(True)
-            self.split_boundary = (cls, cut)
-            cls = cut
+        cg = getattr(self, "clip_graphs", None)
+        if cg is not None and cg.usable(feats):
+            # batches whose structure changes every step: the clip encoder depends on it only through T, so its forward and backward
+            # replay hipGraphs captured per clip count (svpc_amd/clip_graphs.py).  Sets ``split_boundary``: the caller's backward
+            # must be ``graph.backward_all``.
+            cls = cg.run(feats, plan.video_rows, ids_v, mask_v, T, cx)
+        else:
+            cls = self._encode_clips(feats, plan.video_rows, ids_v, mask_v, plan.seq_enc, cx,
+                                     cls_only=(plan.cls_rows_dev, plan.seq_enc_cls))              # (T, D): [CLS] rows only
+            # Optional two-phase backward for data parallelism (svpc_amd/graph.py): the [CLS] rows are the ONLY tensor through which
+            # the loss reaches the clip encoder, so cutting the autograd graph here lets the caller run the text-side backward,
+            # start exchanging those gradients (74 % of the bytes), then run ``split_boundary[0].backward(split_boundary[1].grad)``.
+            if getattr(self, "split_backward", False) and torch.is_grad_enabled() and cls.requires_grad:
+                cut = cls.detach().requires_grad_(True)
+                self.split_boundary = (cls, cut)
+                cls = cut
 
         # (3) [CLS] rows + step PE → step-wise encoder over ragged per-video step sequences (:1062-1065)
         x = ops.span_mean(cls, plan.arange_T, plan.ones_T, add=self.step_positional_encoding.pe, add_idx=plan.step_idx)
@@ -940,7 +955,11 @@ class StateAwareRecursiveTransformer(nn.Module):
 
         # (5) decoder over all T sentences at once (reference: per video, :1086/:925-1015)
         xt = self.text_embeddings.run(text_ids, Lt, cx, out_bf16=self.decoder.streams_bf16(T * Lt, D))
-        dec = self.decoder.run(xt, text_mask, mem, plan.seq_dec_self, plan.seq_dec_cross, None, cx)
+        dg = getattr(self, "decoder_graphs", None)
+        if dg is not None and dg.usable(xt, mem):         # (structure enters the decoder only through T: svpc_amd/clip_graphs.py)
+            dec = dg.run(xt, text_mask, mem, T, cx)
+        else:
+            dec = self.decoder.run(xt, text_mask, mem, plan.seq_dec_self, plan.seq_dec_cross, None, cx)
 
         # (6) head + pointer-generator + label-smoothed KL
         c_list = [V + (extra_zeros[b] if mode != "video" else 0) for b in range(N)]

@@ -12,7 +12,7 @@ import math
 import os
 
 import torch
-from torch.autograd import Function
+from torch.autograd import Function as _TorchFunction
 
 from . import _lib
 from .ops_common import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, FIdx, Idx, SeqInfo, as_idx  # noqa: F401
@@ -34,6 +34,16 @@ def _stream():
 
 
 _FAST_STREAM = os.environ.get("SVPC_SLOW_STREAM", "") == "" and hasattr(torch._C, "_cuda_getCurrentRawStream")
+
+
+class Function(_TorchFunction):
+    """autograd.Function whose ``apply`` goes straight to the C++ binding: the stock classmethod first walks every argument looking for
+    dead functorch wrappers (≈12 Python calls per argument — 0.6 ms of an eager step's 1,500 ops); no functorch transform is ever active
+    around these ops and none of them defines ``setup_context``."""
+
+    @classmethod
+    def apply(cls, *args):
+        return super(_TorchFunction, cls).apply(*args)
 
 
 def _p(t):

@@ -8,6 +8,16 @@ import torch
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
 
 
+def _upload(values, dtype, device):
+    """host list → device tensor without draining the stream: ``torch.tensor(list, device=cuda)`` copies from pageable memory
+    synchronously (the host waits for everything queued before it); a pinned staging tensor and a non-blocking copy do not (the caching
+    host allocator keeps the staging block until the copy has run)"""
+    t = torch.tensor(values, dtype=dtype)
+    if torch.device(device).type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 class Idx:
     """An int32 index array with a host copy (python list) and a lazily created, cached HBM copy.
     Built once per batch shape inside ``BatchPlan`` so that steady-state steps issue no H2D copies."""
@@ -26,7 +36,7 @@ class Idx:
         key = str(device)
         t = self._dev.get(key)
         if t is None:
-            t = torch.tensor(self.host, dtype=torch.int32, device=device)
+            t = _upload(self.host, torch.int32, device)
             self._dev[key] = t
         return t
 
@@ -47,7 +57,7 @@ class FIdx:
         key = str(device)
         t = self._dev.get(key)
         if t is None:
-            t = torch.tensor(self.host, dtype=torch.float32, device=device)
+            t = _upload(self.host, torch.float32, device)
             self._dev[key] = t
         return t
 

@@ -1,0 +1,64 @@
+"""Clip-encoder hipGraphs per clip count (svpc_amd/clip_graphs.py) under batches whose structure changes every step (reference loop:
+src/train.py:91-132 over recursive_caption_dataset.py:528-576): a step whose clip encoder is replayed ≡ the eager step."""
+import pytest
+import torch
+
+from helpers import build_model
+from svpc_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_replayed_clip_encoder_step_equals_eager_step(golden_dir, precision):
+    from svpc_amd import keep_host_copy, ops
+    from svpc_amd import clip_graphs
+    from svpc_amd.graph import backward_all, ops_stream
+    from svpc_amd.optim import FusedBertAdam
+    z, cfg, _, model = build_model("c1", "vivt", golden_dir, DEV)          # D=128, L=2, F=3072; Lv=32; eval mode: no dropout
+    structs = [dict(S=[16, 3, 7, 12, 5], E=[31, 1, 10, 17, 4], X=[2, 0, 1, 2, 0], seed=31),
+               dict(S=[4, 9, 3], E=[2, 25, 8], X=[1, 2, 0], seed=32)]
+    batches = []
+    for st in structs:
+        b_cpu = syn.make_batch(cfg, n_videos=len(st["S"]), max_steps=max(st["S"]), step_nums=st["S"], n_ingr=st["E"], n_oov=st["X"],
+                               seed=st["seed"], full_clips=False)
+        gn = torch.Generator().manual_seed(100 + st["seed"])
+        noise = [-torch.empty(s_, cfg.max_t_len, cfg.vocab_size + x).exponential_(generator=gn).log().to(DEV) for s_, x in zip(st["S"], st["X"])]
+        b = {kk: ([t.to(DEV) if isinstance(t, torch.Tensor) else t for t in v] if isinstance(v, list) else
+                  (v.to(DEV) if isinstance(v, torch.Tensor) else v)) for kk, v in b_cpu.items()}
+        keep_host_copy(b["ingr_sep_masks"], b_cpu["ingr_sep_masks"])
+        batches.append((syn.forward_args(b), noise))
+    ops.set_precision(precision)
+    try:
+        opt = FusedBertAdam(list(model.named_parameters()), lr=0.0, warmup=0.1, t_total=1000, weight_decay=0.0, grad_clip=1.0)
+
+        def run(k):
+            args, noise = batches[k % 2]
+            model._plans.clear(); model._ptr_plans.clear(); model._span_cache.clear()
+            model.gumbel_noise = noise
+            opt.zero_grad()
+            tot, probs, _, _ = model(*args)
+            backward_all(model, tot)
+            ops.join_side()
+            torch.cuda.synchronize()
+            opt.ensure_built()                       # (first call: the gradient arena; lr = 0, no optimizer step is taken)
+            return float(tot.detach()), [p.detach().clone() for p in probs], opt.arena.flat.clone()
+        with torch.cuda.stream(ops_stream()):
+            run(0)
+            clip_graphs.enable(model, False)
+            eager = [run(k) for k in range(4)]
+            cg, dg = clip_graphs.enable(model)
+            graphed = [run(k) for k in range(4)]
+        assert cg.stats["captures"] == 2 and cg.stats["hits"] == 2, cg.stats
+        assert dg.stats["captures"] == 2 and dg.stats["hits"] == 2, dg.stats
+        for k, (e, g) in enumerate(zip(eager, graphed)):
+            # the replayed forward runs the same kernels on the same values (the frame rows gathered beforehand instead of inside the
+            # first LayerNorm): loss and probabilities bit for bit; gradient tails that sum in arrival order to 1e-5
+            assert e[0] == g[0], (k, e[0], g[0])
+            assert all(torch.equal(a, c) for a, c in zip(e[1], g[1])), k
+            assert float((e[2] - g[2]).abs().max()) <= 1e-5 * float(e[2].abs().max()), k
+            assert float(g[2].abs().max()) > 0
+    finally:
+        clip_graphs.enable(model, False)
+        ops.set_precision("fp32")

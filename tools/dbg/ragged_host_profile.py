@@ -15,6 +15,9 @@ rb, clips = bench.ragged_batches(cfg, args, dev, 8)
 rargs = [syn.forward_args(b) for b in rb]
 opt = FusedBertAdam(list(model.named_parameters()), lr=1e-4, warmup=0.1, t_total=100000, weight_decay=0.01, grad_clip=1.0)
 st = torch.cuda.Stream()
+if os.environ.get("GRAPHS", "1") != "0":
+    from svpc_amd import clip_graphs
+    clip_graphs.enable(model)
 def step(k):
     model._plans.clear(); model._ptr_plans.clear(); model._span_cache.clear()
     opt.zero_grad(); loss = model(*rargs[k % 8])[0]; backward_all(model, loss); opt.step(); return loss
@@ -28,4 +31,4 @@ with torch.cuda.stream(st):
     pr = cProfile.Profile(); pr.enable()
     for k in range(8): step(k)
     pr.disable(); torch.cuda.synchronize()
-ps = pstats.Stats(pr); ps.sort_stats("tottime").print_stats(45)
+ps = pstats.Stats(pr); ps.sort_stats("tottime").print_stats(30); ps.sort_stats("cumtime").print_stats(40)
