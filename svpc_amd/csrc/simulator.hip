@@ -553,7 +553,7 @@ int svpc_sim_recur_bwd(const float* q, const float* c, const float* w4f, const f
     int rc;
     static int lean_env = -1;
     if (lean_env < 0) { const char* e = getenv("SVPC_SIM_LEAN"); lean_env = e ? atoi(e) : 1; }
-    if (mode == 3 && EMv == 32 && nt == D && lean_env) {
+    if (((mode == 3 && EMv == 32 && lean_env) || (lean_env == 2 && D % 256 == 0 && aligned)) && nt == D) {      // (2: experiments — every entity count)
         const size_t lds_lean = img * sizeof(float) + ((2 * SIM_EMAX + 1) * (nt / 64) + SIM_EMAX + (2 * SIM_EMAX + 1) + 6 * SIM_EMAX) * sizeof(float);
         SVPC_REQUIRE(lds_lean <= budget, "sim_recur: entity state does not fit LDS");
 #define SIM_LEAN_GO(NTV)                                                                                             \

@@ -5,6 +5,7 @@ from svpc_amd import ops as O
 O.set_precision("bf16x3")
 DEV = "cuda:0"
 SPLIT = len(sys.argv) > 1 and sys.argv[1] == "split"
+RD = False
 for M, N, K in [(768, 768, 768), (768, 2304, 768), (768, 951, 768), (192, 768, 768), (264, 768, 768), (192, 2304, 768)]:
     x = torch.randn(M, K, device=DEV)
     x0 = x
@@ -12,7 +13,7 @@ for M, N, K in [(768, 768, 768), (768, 2304, 768), (768, 951, 768), (192, 768, 7
     if SPLIT:
         x = O.to_split(x)
     w = torch.randn(N, K, device=DEV) / math.sqrt(K); b = torch.randn(N, device=DEV)
-    if SPLIT:
+    if SPLIT or RD:
         w16 = O._transient_split(w)
     with torch.no_grad():
         for _ in range(5):
