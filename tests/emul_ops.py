@@ -279,7 +279,7 @@ def bce_rows(p, y, widths):
     cols = torch.arange(p.shape[1], device=p.device).unsqueeze(0)
     valid = (cols < torch.as_tensor(_h(widths), device=p.device).unsqueeze(1)).float()
     pp = torch.where(valid > 0, p, torch.full_like(p, 0.5))
-    l = -(y * torch.log(pp).clamp(min=-100) + (1 - y) * torch.log(1 - pp).clamp(min=-100))
+    l = torch.nn.functional.binary_cross_entropy(pp, y, reduction="none")      # (torch's own backward: (p - y) / max(p(1-p), 1e-12))
     return (l * valid).sum(1)
 
 
