@@ -181,24 +181,36 @@ class Translator(object):
                                ingr_input_ids, ingr_masks, ingr_sep_masks, ingr_id_dict, oov_word_dict, alignments, actions,
                                batch_step_num, rt_model):
         model = rt_model
-        input_ids_list, input_masks_list = self.prepare_video_only_inputs(input_ids_list, input_masks_list, token_type_ids_list)
         dev = video_features_list[0].device
+        # the text half of every step's ids / masks is blanked in place, as the reference does (translator.py:205-228).  When the per-step
+        # tensors are consecutive slices of one buffer (the usual collate output; model._stacked sees it) that is three launches on the
+        # stacked views instead of three per step
+        stk = None
+        if isinstance(input_ids_list, list) and dev.type == "cuda":
+            views = [model._stacked(l) for l in (input_ids_list, input_masks_list, token_type_ids_list)]
+            if all(v.data_ptr() == l[0].data_ptr() for v, l in zip(views, (input_ids_list, input_masks_list, token_type_ids_list))):
+                stk = views
+        if stk is not None:
+            self.prepare_video_only_inputs(*stk)
+        else:
+            input_ids_list, input_masks_list = self.prepare_video_only_inputs(input_ids_list, input_masks_list, token_type_ids_list)
         N, L, F = video_features_list[0].shape
         S_pad = len(input_ids_list)
         prep = self._prepare(model, batch_step_num, ingr_sep_masks, ingr_id_dict, oov_word_dict, S_pad, N, L, dev)
         plan = prep["plan"]
         feats = model._stacked(video_features_list).reshape(S_pad * N * L, F)
-        ids_all = torch.stack(input_ids_list).reshape(-1).to(torch.int32)
-        masks_all = torch.stack(input_masks_list).reshape(-1).float()
+        ids_all = (stk[0] if stk is not None else torch.stack(input_ids_list)).reshape(-1).to(torch.int32)
+        masks_all = (stk[1] if stk is not None else torch.stack(input_masks_list)).reshape(-1).float()
         ingr_flat = torch.as_tensor(ingr_input_ids).to(dev).reshape(-1).to(torch.int32)
         if not self.graph or dev.type != "cuda":
             out = self._decode_core(model, prep, feats, ids_all, masks_all, ingr_flat)
         else:
             out = self._decode_graphed(model, prep, feats, ids_all, masks_all, ingr_flat)
+        out = out.to(torch.int64)                      # (one cast for the batch: the per-video results are views of it)
         res = []
         for b in range(N):
             o, n = plan.h_step_off[b], plan.h_step_len[b]
-            res.append(out[o:o + n].to(torch.int64))
+            res.append(out[o:o + n])
         return res, oov_word_dict
 
     def _decode_graphed(self, model, prep, feats, ids_all, masks_all, ingr_flat):
