@@ -387,6 +387,8 @@ def run_decode(cfg, model, args, device, world, rank, dist, steps, warmup):
     from svpc_amd.translator import Translator
     n_vid = args.decode_videos
     b = make_batch(cfg, n_videos=n_vid, max_steps=args.clips, n_ingr=10, n_oov=0, seed=2019 + rank, full_clips=True)
+    # the three ingredient arrays reach translate_batch as host lists, as the reference's collate hands them (src/translator.py:181-183)
+    b["_ingr_host_lists"] = (b["ingr_input_ids"].tolist(), b["ingr_masks"].tolist(), b["ingr_sep_masks"].tolist())
     for k, v in list(b.items()):
         if isinstance(v, list) and v and isinstance(v[0], torch.Tensor):
             b[k] = [t.to(device) for t in v]

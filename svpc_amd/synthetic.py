@@ -207,9 +207,9 @@ def translate_inputs(batch):
             batch["video_features_list"],
             [x.clone() for x in batch["input_masks_list"]],
             batch["token_type_ids_list"],
-            batch["ingr_input_ids"].tolist(),
-            batch["ingr_masks"].tolist(),
-            batch["ingr_sep_masks"].tolist(),
+            *(batch["_ingr_host_lists"] if "_ingr_host_lists" in batch else      # (the reference's collate hands these three as host lists,
+              (batch["ingr_input_ids"].tolist(), batch["ingr_masks"].tolist(),  #  translator.py:181-183; a caller holding them on the device
+               batch["ingr_sep_masks"].tolist())),                              #  pays three synchronous read-backs per call here)
             batch["ingr_id_dict"],
             batch["oov_word_dict"],
             batch["alignments"],
