@@ -62,3 +62,55 @@ def test_replayed_clip_encoder_step_equals_eager_step(golden_dir, precision):
     finally:
         clip_graphs.enable(model, False)
         ops.set_precision("fp32")
+
+
+def test_eviction_recapture_and_training_mode_dropout(golden_dir):
+    """more clip counts than cache entries (LRU eviction, recapture into the shared pool), in TRAINING mode with dropout on: every step
+    finite, the captured encoder / decoder draw fresh masks per replay (two replays of one structure give different losses), and with the
+    graphs switched off again the eager path still reproduces itself from the same seed state"""
+    from svpc_amd import keep_host_copy, ops, clip_graphs
+    from svpc_amd.graph import backward_all, ops_stream
+    from svpc_amd.optim import FusedBertAdam
+    z, cfg, _, model = build_model("c1", "vivt", golden_dir, DEV)
+    model.train()
+    structs = [dict(S=[5, 3, 7], E=[3, 1, 10], X=[0, 0, 1], seed=41), dict(S=[4, 9, 3], E=[2, 25, 8], X=[1, 2, 0], seed=42),
+               dict(S=[16, 3], E=[31, 4], X=[2, 0], seed=43), dict(S=[6, 6, 6, 6], E=[5, 5, 5, 5], X=[0, 0, 0, 0], seed=44)]
+    batches = []
+    for st in structs:
+        b_cpu = syn.make_batch(cfg, n_videos=len(st["S"]), max_steps=max(st["S"]), step_nums=st["S"], n_ingr=st["E"], n_oov=st["X"],
+                               seed=st["seed"], full_clips=False)
+        b = {kk: ([t.to(DEV) if isinstance(t, torch.Tensor) else t for t in v] if isinstance(v, list) else
+                  (v.to(DEV) if isinstance(v, torch.Tensor) else v)) for kk, v in b_cpu.items()}
+        keep_host_copy(b["ingr_sep_masks"], b_cpu["ingr_sep_masks"])
+        batches.append(syn.forward_args(b))
+    ops.set_precision("bf16x3")
+    try:
+        opt = FusedBertAdam(list(model.named_parameters()), lr=0.0, warmup=0.1, t_total=1000, weight_decay=0.0, grad_clip=1.0)   # (weights stay put)
+        model.gumbel_noise = None
+
+        def run(k):
+            model._plans.clear(); model._ptr_plans.clear(); model._span_cache.clear()
+            opt.zero_grad()
+            tot = model(*batches[k % len(batches)])[0]
+            backward_all(model, tot)
+            opt.step()
+            return float(tot.detach())
+        with torch.cuda.stream(ops_stream()):
+            run(0)
+            cg, dg = clip_graphs.enable(model)
+            cg.max_entries = dg.max_entries = 2
+            losses = [run(k) for k in range(12)]          # 4 clip counts through 2 entries: every step after the first pass recaptures
+            torch.cuda.synchronize()
+        assert all(l == l and abs(l) < 1e9 for l in losses), losses
+        assert len(cg.entries) == 2 and len(dg.entries) == 2
+        assert cg.stats["captures"] >= 8 and dg.stats["captures"] >= 8, (cg.stats, dg.stats)
+        cg.max_entries = dg.max_entries = 8
+        with torch.cuda.stream(ops_stream()):
+            warm = [run(k) for k in range(4)]
+            a = [run(0) for _ in range(3)]                  # same structure and weights, replayed: only the dropout / Gumbel seeds move on
+            torch.cuda.synchronize()
+        assert cg.stats["hits"] >= 3
+        assert len({round(v, 3) for v in a}) == 3, a      # three different dropout draws
+    finally:
+        clip_graphs.enable(model, False)
+        ops.set_precision("fp32")
