@@ -291,6 +291,8 @@ def test_fp32_mode_simulator_gradients_and_a_float64_oracle():
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, "fp64_oracle_leg.json"), "w") as f:
+        from helpers import product_sources_sha16
+        rep["_sources_sha16"] = product_sources_sha16()
         json.dump(rep, f, indent=1)
     print(json.dumps(rep, indent=1))
     assert rep["loss_gpu_vs_oracle32"] <= 1e-6

@@ -106,6 +106,8 @@ def test_twenty_captured_steps_follow_the_oracle(golden_dir, precision):
     rec[precision] = dict(loss_gpu=losses, loss_oracle=ref_losses, loss_rel=rel, worst_rel=max(rel), first_rel=rel[0], last_rel=rel[-1],
                           param_drift_over_travel=(num / max(den, 1e-300)) ** 0.5, steps=STEPS, lr=LR, shape="config 1 (c1), vivt")
     with open(rec_path, "w") as f:
+        from helpers import product_sources_sha16
+        rec["_sources_sha16"] = product_sources_sha16()
         json.dump(rec, f, indent=1)
     print("%s: loss %.4f -> %.4f (oracle %.4f -> %.4f), worst rel %.2e, last rel %.2e, parameter drift / travel %.2e" %
           (precision, losses[0], losses[-1], ref_losses[0], ref_losses[-1], max(rel), rel[-1], rec[precision]["param_drift_over_travel"]))
