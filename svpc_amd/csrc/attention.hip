@@ -292,6 +292,13 @@ struct Q1LnArgs {
     const float* X; int ldx; const float* gamma; const float* beta; float eps; float* O; int ldo;
     int T, D; float scale;
 };
+// 16 bytes of the key / value cache with the non-temporal hint: the cache (up to 104 MB per layer and iteration) is read once per
+// iteration and must not push the decoder's weights (71 MB, re-read every iteration) out of the Infinity Cache
+typedef float q1_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 q1_stream4(const float* p) {
+    const q1_f4 v = __builtin_nontemporal_load(reinterpret_cast<const q1_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ float row16_sum(float v) {
     v = dpp_add_<0xB1>(v); v = dpp_add_<0x4E>(v); v = dpp_add_<0x141>(v); v = dpp_add_<0x140>(v);
     return v;
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(256) void attn_q1_ln_kernel(Q1LnArgs a) {
     float4 kr[MAXK];
 #pragma unroll
     for (int j = 0; j < MAXK; ++j)      // (rows past the end re-read the last one — unconditional loads, all in flight; nc == 0 reads row 0 of the sentence's own cache block)
-        kr[j] = *reinterpret_cast<const float4*>(a.K + (row0 + min(j, max(nc - 1, 0))) * a.ldkv + d0);
+        kr[j] = q1_stream4(a.K + (row0 + min(j, max(nc - 1, 0))) * a.ldkv + d0);
     q.x *= a.scale; q.y *= a.scale; q.z *= a.scale; q.w *= a.scale;
     float sc[MAXK], sn = -INFINITY, mx = -INFINITY;
 #pragma unroll
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(256) void attn_q1_ln_kernel(Q1LnArgs a) {
     float4 vr[MAXK];
 #pragma unroll
     for (int j = 0; j < MAXK; ++j)
-        vr[j] = *reinterpret_cast<const float4*>(a.V + (row0 + min(j, max(nc - 1, 0))) * a.ldkv + d0);
+        vr[j] = q1_stream4(a.V + (row0 + min(j, max(nc - 1, 0))) * a.ldkv + d0);
     if (app) {
         sn = row16_sum(q.x * kn.x + q.y * kn.y + q.z * kn.z + q.w * kn.w);
         mx = fmaxf(mx, sn);
