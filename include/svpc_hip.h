@@ -393,6 +393,10 @@ int svpc_lstm_pair_bwd_parts(const float* const* dh_out, const float* const* dh_
 /* greedy decoding step: argmax with the UNK column suppressed + OOV→UNK remap, src/translator.py:104-112 */
 int svpc_greedy_pick(const float* scores, int ld, const int* row_c, const int* row_x, int n_sent, int lt, int pos, int unk,
                      int* next_ext, int* next_model, svpc_stream_t stream);
+/* … and the picked ids also stored as column `col` of the sentence-major (n_sent, ld_out) id matrices the decoding loop keeps
+ * (text_out: model-side ids, ext_out: extended ids; src/translator.py:96-99 writes them at the top of the next iteration) */
+int svpc_greedy_pick_append(const float* scores, int ld, const int* row_c, const int* row_x, int n_sent, int lt, int pos, int unk,
+                            int* next_ext, int* next_model, int* text_out, int* ext_out, int ld_out, int col, svpc_stream_t stream);
 int svpc_add(const float* a, const float* b, float* c, size_t n, svpc_stream_t stream);
 int svpc_sum_all(const float* x, size_t n, float* out, float scale, svpc_stream_t stream);
 int svpc_fill_from(float* x, size_t n, const float* v, svpc_stream_t stream);

@@ -715,7 +715,8 @@ __global__ __launch_bounds__(256) void lstm_pair_bwd_kernel(LstmPair a, int N, i
 // side sees UNK for copied out-of-vocabulary words (id >= C_j - X_j).
 __global__ __launch_bounds__(256) void greedy_pick_kernel(const float* __restrict__ scores, int ld, const int* __restrict__ row_c,
                                                           const int* __restrict__ row_x, int lt, int pos, int unk,
-                                                          int* __restrict__ next_ext, int* __restrict__ next_model) {
+                                                          int* __restrict__ next_ext, int* __restrict__ next_model,
+                                                          int* __restrict__ text_out, int* __restrict__ ext_out, int ld_out, int col) {
     __shared__ float sval[4];
     __shared__ int sidx[4];
     const int j = blockIdx.x, r = j * lt + pos;
@@ -737,8 +738,13 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(const float* __restric
         best = sval[0]; bi = sidx[0];
         for (int w = 1; w < 4; ++w)
             if (sval[w] > best || (sval[w] == best && sidx[w] < bi)) { best = sval[w]; bi = sidx[w]; }
+        const int mod = bi >= C - X ? unk : bi;
         next_ext[j] = bi;
-        next_model[j] = bi >= C - X ? unk : bi;
+        next_model[j] = mod;
+        if (text_out) {                  // the picked token is also the sentence's entry at position `col` of the two id matrices
+            text_out[(size_t)j * ld_out + col] = mod;
+            ext_out[(size_t)j * ld_out + col] = bi;
+        }
     }
 }
 
@@ -929,11 +935,18 @@ int svpc_clamp_labels(const int* in, int* out, int n, int vocab, int unk, hipStr
     hipLaunchKernelGGL(clamp_labels_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, out, n, vocab, unk);
     return svpc_check_launch("clamp_labels");
 }
+int svpc_greedy_pick_append(const float* scores, int ld, const int* row_c, const int* row_x, int n_sent, int lt, int pos, int unk,
+                            int* next_ext, int* next_model, int* text_out, int* ext_out, int ld_out, int col, hipStream_t s) {
+    if (n_sent == 0) return 0;
+    SVPC_REQUIRE((text_out == nullptr) == (ext_out == nullptr) && (text_out == nullptr || (col >= 0 && col < ld_out)),
+                 "greedy_pick_append: both id matrices or neither, column inside the matrices");
+    hipLaunchKernelGGL(greedy_pick_kernel, dim3(n_sent), dim3(256), 0, s, scores, ld, row_c, row_x, lt, pos, unk, next_ext, next_model,
+                       text_out, ext_out, ld_out, col);
+    return svpc_check_launch("greedy_pick");
+}
 int svpc_greedy_pick(const float* scores, int ld, const int* row_c, const int* row_x, int n_sent, int lt, int pos, int unk,
                      int* next_ext, int* next_model, hipStream_t s) {
-    if (n_sent == 0) return 0;
-    hipLaunchKernelGGL(greedy_pick_kernel, dim3(n_sent), dim3(256), 0, s, scores, ld, row_c, row_x, lt, pos, unk, next_ext, next_model);
-    return svpc_check_launch("greedy_pick");
+    return svpc_greedy_pick_append(scores, ld, row_c, row_x, n_sent, lt, pos, unk, next_ext, next_model, nullptr, nullptr, 0, 0, s);
 }
 int svpc_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, const float* h_prev, const float* active, float* h,
                        float* c, float* gates_act, int N, int D, hipStream_t s) {

@@ -2042,13 +2042,20 @@ def loss_tail(cap_rows, e_p, a_p, r_e, r_a, align, act, widths, lam, gamma_neg=4
                            float(clip), float(eps))
 
 
-def greedy_pick(scores, row_c, row_x, lt, pos, unk):
-    """scores (T*lt, ≥C): → (next_ext, next_model) int32 (T,), see svpc_greedy_pick."""
+def greedy_pick(scores, row_c, row_x, lt, pos, unk, append=None):
+    """scores (T*lt, ≥C): → (next_ext, next_model) int32 (T,), see svpc_greedy_pick.  ``append`` = (text, ext, col): the picked ids are
+    also stored as column ``col`` of the two (T, Lt) int32 id matrices of the decoding loop (one launch instead of three)."""
     scores = _c(scores)
     dev = scores.device
     n = scores.shape[0] // lt
     ext = torch.empty(n, dtype=torch.int32, device=dev)
     mod = torch.empty(n, dtype=torch.int32, device=dev)
+    if append is not None:
+        tm, em, col = append
+        assert tm.dtype == em.dtype == torch.int32 and tm.is_contiguous() and em.is_contiguous() and tm.shape == em.shape and tm.shape[0] == n
+        _lib.call("greedy_pick_append", _p(scores), scores.stride(0), _p(as_idx(row_c).dev(dev)), _p(as_idx(row_x).dev(dev)), n, lt, int(pos),
+                  int(unk), _p(ext), _p(mod), _p(tm), _p(em), tm.shape[1], int(col), _stream())
+        return ext, mod
     _lib.call("greedy_pick", _p(scores), scores.stride(0), _p(as_idx(row_c).dev(dev)), _p(as_idx(row_x).dev(dev)), n, lt, int(pos),
               int(unk), _p(ext), _p(mod), _stream())
     return ext, mod

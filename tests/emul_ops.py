@@ -372,7 +372,7 @@ class EmulRng:
         return self.mask(site, n_rows * max_k, p, device).view(n_rows, max_k)
 
 
-def greedy_pick(scores, row_c, row_x, lt, pos, unk):
+def greedy_pick(scores, row_c, row_x, lt, pos, unk, append=None):
     row_c, row_x = _h(row_c), _h(row_x)
     n = scores.shape[0] // lt
     ext, mod = [], []
@@ -384,6 +384,9 @@ def greedy_pick(scores, row_c, row_x, lt, pos, unk):
         ext.append(i)
         mod.append(unk if i >= row_c[r] - row_x[r] else i)
     t = lambda v: torch.tensor(v, dtype=torch.int32, device=scores.device)
+    if append is not None:
+        append[0][:, append[2]] = t(mod)
+        append[1][:, append[2]] = t(ext)
     return t(ext), t(mod)
 
 
