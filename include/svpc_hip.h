@@ -288,6 +288,10 @@ int svpc_sim_recur_bwd(const float* q, const float* c, const float* w4f, const f
 /* ---- pointer-generator + caption loss: model.py:896-923, :37-55 */
 int svpc_ptr_attn_fwd(const float* dec, const float* proj, const float* bank, const int* step_ne, float* pi, float* att, int T,
                       int lt, int e_max, int D, svpc_stream_t stream);
+/* … with the generation gate p_gen = sigmoid([dec ; att]·w + b) (src/rtransformer/model.py:905-908) of every row computed in the same launch
+ * (w: 2·D floats, b: one; att may be null): what a decoding iteration needs of the pointer, lt = 1 */
+int svpc_ptr_attn_pgen_fwd(const float* dec, const float* proj, const float* bank, const int* step_ne, float* pi, float* att,
+                           const float* pgen_w, const float* pgen_b, float* pgen, int T, int lt, int e_max, int D, svpc_stream_t stream);
 int svpc_ptr_attn_bwd(const float* dec, const float* proj, const float* bank, const int* step_ne, const float* pi, const float* dpi,
                       const float* datt, float* ddec, float* dproj, float* dbank, int T, int lt, int e_max, int D,
                       svpc_stream_t stream);

@@ -53,7 +53,9 @@ __device__ __forceinline__ void ptr_dots(const float* __restrict__ rows_t, const
 // one workgroup per step and one round of workgroups, so the time of a launch is the latency of ONE workgroup)
 __global__ __launch_bounds__(768) void ptr_attn_fwd_kernel(const float* __restrict__ dec, const float* __restrict__ proj,
                                                            const float* __restrict__ bank, const int* __restrict__ step_ne,
-                                                           float* __restrict__ pi, float* __restrict__ att, int lt, int em, int D) {
+                                                           float* __restrict__ pi, float* __restrict__ att, int lt, int em, int D,
+                                                           const float* __restrict__ pgen_w, const float* __restrict__ pgen_b,
+                                                           float* __restrict__ pgen) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
     float* rows = psm;                         // lt × D
     float* ent = rows + (size_t)lt * D;        // PTR_EC × D
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(768) void ptr_attn_fwd_kernel(const float* __restri
     }
     __syncthreads();
     // att[t][d] = Σ_e pi[t][e]·bank[e][d]: a thread owns column d, the E bank values of the column sit in registers
+    float gp = 0.f;                            // (the gate is taken for lt = 1 only: host check)
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
         float bv[PTR_EMAX];
 #pragma unroll
@@ -98,7 +101,23 @@ __global__ __launch_bounds__(768) void ptr_attn_fwd_kernel(const float* __restri
                     acc += p4.x * bv[4 * q4] + p4.y * bv[4 * q4 + 1] + p4.z * bv[4 * q4 + 2] + p4.w * bv[4 * q4 + 3];
                 }
             }
-            att[((size_t)j * lt + t) * D + d] = acc;
+            if (att) att[((size_t)j * lt + t) * D + d] = acc;
+            // the generation gate of the row, p_gen = sigmoid([dec ; att]·w + b) (model.py:905-908), while its operands are here: the
+            // decoding iterations take it from this launch instead of a concatenation and a 1,536-deep one-column projection
+            if (pgen_w) gp += rows[(size_t)t * D + d] * pgen_w[d] + acc * pgen_w[D + d];
+        }
+    }
+    if (pgen_w) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+        const float ws = wave_sum(gp);
+        __syncthreads();                       // every thread is done with the pi rows in `sc`: its first words take the wave partials
+        float* gred = sc;
+        if (lane == 0) gred[wave] = ws;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = gred[0];
+            for (int w = 1; w < NW; ++w) tot += gred[w];
+            pgen[j] = 1.0f / (1.0f + expf(-(tot + pgen_b[0])));
         }
     }
 }
@@ -460,8 +479,24 @@ int svpc_ptr_attn_fwd(const float* dec, const float* proj, const float* bank, co
     int rc = ptr_set_lds((const void*)ptr_attn_fwd_kernel);
     if (rc) return rc;
     const int nt = D >= 768 ? 768 : (D >= 512 ? 512 : 256);
-    hipLaunchKernelGGL(ptr_attn_fwd_kernel, dim3(T), dim3(nt), lds, s, dec, proj, bank, step_ne, pi, att, lt, e_max, D);
+    hipLaunchKernelGGL(ptr_attn_fwd_kernel, dim3(T), dim3(nt), lds, s, dec, proj, bank, step_ne, pi, att, lt, e_max, D, (const float*)nullptr,
+                       (const float*)nullptr, (float*)nullptr);
     return svpc_check_launch("ptr_attn_fwd");
+}
+// the same with the generation gate p_gen = sigmoid([dec ; att]·w + b) per row (w: 2D floats, b: 1) computed in the launch; att may be
+// null (forward only: the decoding iterations need pi and p_gen); lt = 1 (one new position per sentence), D ≤ 768
+int svpc_ptr_attn_pgen_fwd(const float* dec, const float* proj, const float* bank, const int* step_ne, float* pi, float* att,
+                           const float* pgen_w, const float* pgen_b, float* pgen, int T, int lt, int e_max, int D, hipStream_t s) {
+    if (T == 0) return 0;
+    SVPC_REQUIRE(e_max <= PTR_EMAX, "ptr_attn: at most 32 entities");
+    SVPC_REQUIRE(D % 4 == 0 && ((((uintptr_t)dec) | ((uintptr_t)proj) | ((uintptr_t)bank)) & 15) == 0, "ptr_attn: rows must be 16-byte aligned");
+    SVPC_REQUIRE(pgen_w && pgen_b && pgen && lt == 1 && D <= 768, "ptr_attn_pgen: one position per step row, D <= 768");
+    const size_t lds = ((size_t)(lt + PTR_EC) * D + (size_t)lt * PTR_EMAX) * sizeof(float);
+    int rc = ptr_set_lds((const void*)ptr_attn_fwd_kernel);
+    if (rc) return rc;
+    const int nt = D >= 768 ? 768 : (D >= 512 ? 512 : 256);
+    hipLaunchKernelGGL(ptr_attn_fwd_kernel, dim3(T), dim3(nt), lds, s, dec, proj, bank, step_ne, pi, att, lt, e_max, D, pgen_w, pgen_b, pgen);
+    return svpc_check_launch("ptr_attn_pgen_fwd");
 }
 int svpc_ptr_attn_bwd(const float* dec, const float* proj, const float* bank, const int* step_ne, const float* pi, const float* dpi,
                       const float* datt, float* ddec, float* dproj, float* dbank, int T, int lt, int e_max, int D, hipStream_t s) {

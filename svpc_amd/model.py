@@ -837,8 +837,13 @@ class StateAwareRecursiveTransformer(nn.Module):
         T, e_max, D = bank.shape
         if proj is None:
             proj = self.bank_projection(bank)
-        pi, att = ops.ptr_attn(dec, proj, bank, plan_like["step_ne"], lt)
-        g = ops.linear(torch.cat([dec, att], 1), self.pgen_linear[0].weight, self.pgen_linear[0].bias, act=ACT_SIGMOID)
+        fused = ops.ptr_attn_pgen(dec, proj, bank, plan_like["step_ne"], self.pgen_linear[0].weight, self.pgen_linear[0].bias) \
+            if (lt == 1 and not torch.is_grad_enabled()) else None
+        if fused is not None:           # decoding iteration: pointer attention and generation gate in one launch
+            pi, g = fused
+        else:
+            pi, att = ops.ptr_attn(dec, proj, bank, plan_like["step_ne"], lt)
+            g = ops.linear(torch.cat([dec, att], 1), self.pgen_linear[0].weight, self.pgen_linear[0].bias, act=ACT_SIGMOID)
         return ops.ptr_mix_loss(logits, g, pi, labels, plan_like["row_c"], plan_like["row_vid"], plan_like["csr_off"],
                                 plan_like["csr_ent"], plan_like["csr_id"], plan_like["csr_w"], plan_like["c_max"],
                                 self.label_smoothing)

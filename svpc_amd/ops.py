@@ -1608,6 +1608,21 @@ def ptr_attn(dec, proj, bank, step_ne, lt):
     return _PtrAttn.apply(dec, proj, bank, as_idx(step_ne), int(lt))
 
 
+def ptr_attn_pgen(dec, proj, bank, step_ne, w, b):
+    """Decoding iteration (one position per step row, no gradients): (pi, p_gen) with p_gen = sigmoid([dec ; att]·w + b) computed inside
+    the pointer-attention launch — replaces ptr_attn + concatenation + the 1,536-deep one-column projection.  None if not applicable."""
+    T, e_max, D = bank.shape
+    if (torch.is_grad_enabled() or not dec.is_cuda or dec.dtype != torch.float32 or D > 768 or D % 4 or w.shape != (1, 2 * D)
+            or dec.shape != (T, D) or not (dec.is_contiguous() and proj.is_contiguous() and bank.is_contiguous() and w.is_contiguous())):
+        return None
+    dev = dec.device
+    pi = torch.empty(T, e_max, dtype=torch.float32, device=dev)
+    g = torch.empty(T, 1, dtype=torch.float32, device=dev)
+    _lib.call("ptr_attn_pgen_fwd", _p(dec), _p(proj), _p(bank), _p(as_idx(step_ne).dev(dev)), _p(pi), None, _p(w), _p(b), _p(g), T, 1, e_max, D,
+              _stream())
+    return pi, g
+
+
 class _PtrMixLoss(Function):
     @staticmethod
     def forward(ctx, logits, g, pi, labels, row_c, row_vid, csr_off, csr_ent, csr_id, csr_w, c_max, smoothing):

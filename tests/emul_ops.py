@@ -191,6 +191,10 @@ def ptr_attn(dec, proj, bank, step_ne, lt):
     return pi.reshape(T * lt, e_max), att.reshape(T * lt, D)
 
 
+def ptr_attn_pgen(dec, proj, bank, step_ne, w, b):
+    return None          # (decoding-iteration fusion: GPU only; the callers fall back to ptr_attn + linear)
+
+
 def ptr_mix_loss(logits, g, pi, labels, row_c, row_vid, csr_off, csr_ent, csr_id, csr_w, c_max, smoothing,
                  dp_ext_hook=None):
     """Rows r: P = g*softmax(logits) over V columns, zeros up to C_r, copy mass (1-g)*pi[e]*w scattered to

@@ -68,3 +68,21 @@ def test_shapes_outside_the_kernel_are_declined():
     assert ops.attn_q1_ln(q, kv, 2, 2, x, torch.ones(96, device=dev), torch.zeros(96, device=dev), 1e-12, 3) is None      # heads of 32
     q = torch.randn(4, 768, device=dev); kv = torch.randn(4 * 40, 1536, device=dev); x = torch.randn(4, 768, device=dev)
     assert ops.attn_q1_ln(q, kv, 40, 40, x, torch.ones(768, device=dev), torch.zeros(768, device=dev), 1e-12, 12) is None  # 40 key rows
+
+
+def test_pointer_attention_with_the_generation_gate_in_one_launch():
+    """svpc_ptr_attn_pgen_fwd (decoding iteration: pi and p_gen = sigmoid([dec ; att]·w + b)) against the separate kernels"""
+    from svpc_amd import ops
+    from svpc_amd.ops_common import ACT_SIGMOID, Idx
+    torch.manual_seed(11)
+    dev, T, E, D = "cuda:0", 45, 10, 768
+    dec = torch.randn(T, D, device=dev); bank = torch.randn(T, E, D, device=dev); proj = torch.randn(T, E, D, device=dev) * 0.05
+    w = torch.randn(1, 2 * D, device=dev) * 0.05; b = torch.randn(1, device=dev)
+    ne = Idx([1 + (i * 7) % E for i in range(T)])
+    with torch.no_grad():
+        pi, g = ops.ptr_attn_pgen(dec, proj, bank, ne, w, b)
+        pi0, att0 = ops.ptr_attn(dec, proj, bank, ne, 1)
+        g0 = ops.linear(torch.cat([dec, att0], 1), w, b, act=ACT_SIGMOID)
+    assert torch.equal(pi, pi0)
+    ref = torch.sigmoid(torch.cat([dec, att0], 1).double() @ w.double().t() + b.double())
+    assert (g.double() - ref).abs().max().item() <= 2e-6 and (g0.double() - ref).abs().max().item() <= 2e-6
