@@ -115,4 +115,6 @@ class GraphedTrainStep:
             self.exchange.finish()
             self.graph_opt.replay()
         self.opt.step_count += 1
+        from .optim import WEIGHTS_EPOCH
+        WEIGHTS_EPOCH[0] += 1         # (the replay ran the optimizer kernels: see optim.WEIGHTS_EPOCH)
         return self.loss

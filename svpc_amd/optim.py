@@ -28,6 +28,12 @@ def warmup_linear(progress, warmup):
     return max((progress - 1.0) / (warmup - 1.0), 0.0)
 
 
+# Bumped whenever parameter VALUES change without autograd's version counters noticing (the fused optimizer kernels, a replayed step
+# graph, the EMA swap).  Whoever caches something derived from the weights (Translator's per-checkpoint embedding table and its decode
+# graphs) keys it on this counter beside the tensors' own versions.
+WEIGHTS_EPOCH = [0]
+
+
 class _Meta(ctypes.Structure):
     _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
                 ("ema", ctypes.c_void_p), ("n", ctypes.c_longlong), ("wd", ctypes.c_float), ("pad", ctypes.c_int),
@@ -336,6 +342,7 @@ class FusedBertAdam:
     def launch(self):
         """The three kernels only (graph-capturable)."""
         from . import ops
+        WEIGHTS_EPOCH[0] += 1         # (the kernels rewrite the parameters behind autograd's version counters)
         ops.join_side()        # parameter-gradient kernels forked onto side streams
         stream = torch.cuda.current_stream().cuda_stream
         _lib.call("opt_step", self.meta.data_ptr(), self.chunk_tid.data_ptr(), self.chunk_start.data_ptr(),
@@ -351,12 +358,14 @@ class FusedBertAdam:
     # -- EMA evaluation swap (optimization.py:205-216: assign the shadow weights for validation, resume afterwards)
     def ema_assign(self):
         assert self.ema is not None and self.arena is not None
+        WEIGHTS_EPOCH[0] += 1
         self._backup = self.weights.flat.clone()
         with torch.no_grad():
             self.weights.flat.copy_(self.ema)
         self.weights.refresh()
 
     def ema_resume(self):
+        WEIGHTS_EPOCH[0] += 1
         with torch.no_grad():
             self.weights.flat.copy_(self._backup)
         self._backup = None

@@ -100,7 +100,8 @@ class Translator(object):
             return None
         te = model.text_embeddings
         ps = [te.word_embeddings.weight] + list(te.word_fc.parameters())
-        key = (tuple((p.data_ptr(), p._version) for p in ps), ops.get_precision(), Lt)
+        from .optim import WEIGHTS_EPOCH
+        key = (tuple((p.data_ptr(), p._version) for p in ps), WEIGHTS_EPOCH[0], ops.get_precision(), Lt)
         if self._ttab is None or self._ttab[0] != key:
             V = te.word_embeddings.weight.shape[0]
             ids = torch.arange(V, dtype=torch.int32, device=dev)
@@ -241,8 +242,9 @@ class Translator(object):
         # a captured graph holds raw pointers: it is valid only while the parameters (and, on the bf16 path, their shadow) live where
         # they lived at capture time — a weight store built later (optimizer start, WeightStore.for_model) re-points them
         from . import ops as _ops
+        from .optim import WEIGHTS_EPOCH
         sig = (tuple(p.data_ptr() for p in list(model.parameters())[:8]), _ops.get_precision(),
-               id(getattr(model, "_svpc_weight_store", None)))
+               id(getattr(model, "_svpc_weight_store", None)), WEIGHTS_EPOCH[0])      # (epoch: the graph holds the embedding table's address)
         g = prep["graph"]
         if g is not None and g[3] != sig:
             g = prep["graph"] = None

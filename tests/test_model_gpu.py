@@ -604,3 +604,35 @@ def test_overlapped_reducer_with_bf16_sink_mid_backward():
             red.close()
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_translator_sees_weights_changed_by_the_fused_optimizer(golden_dir, graph):
+    """One Translator object decodes, the fused optimizer changes the parameters in place (its kernels do not touch autograd's version
+    counters), the same object decodes again: the per-checkpoint text-embedding table and the captured decode graph are keyed on
+    optim.WEIGHTS_EPOCH, so the second result is what a fresh Translator gives — not a mix of new weights and a stale table."""
+    from svpc_amd import ops
+    from svpc_amd.graph import backward_all, ops_stream
+    from svpc_amd.optim import FusedBertAdam
+    from svpc_amd.translator import Translator
+    z, cfg, batch, model = build_model("c1", "vivt", golden_dir, DEV)
+    O = type("O", (), {"cuda": True})
+    with torch.cuda.stream(ops_stream()):
+        tr = Translator(O(), {"model_cfg": cfg, "model": model.state_dict()}, model=model, graph=graph)
+        d0, _ = tr.translate_batch(syn.translate_inputs(batch))
+        d0b, _ = tr.translate_batch(syn.translate_inputs(batch))
+        opt = FusedBertAdam(list(model.named_parameters()), lr=5e-2, weight_decay=0.0, grad_clip=1.0)      # (t_total = -1: constant rate)
+        model.train()
+        for _ in range(3):
+            opt.zero_grad()
+            loss = model(*syn.forward_args(batch))[0]
+            backward_all(model, loss)
+            opt.step()
+        model.eval()
+        d1, _ = tr.translate_batch(syn.translate_inputs(batch))
+        fresh = Translator(O(), {"model_cfg": cfg, "model": model.state_dict()}, model=model, graph=False)
+        d2, _ = fresh.translate_batch(syn.translate_inputs(batch))
+        torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(d0, d0b))
+    assert all(torch.equal(a, b) for a, b in zip(d1, d2))
+    assert any(not torch.equal(a, b) for a, b in zip(d0, d1)), "three steps at lr 5e-2 should change at least one emitted token"
