@@ -240,7 +240,7 @@ def test_fp32_mode_simulator_gradients_and_a_float64_oracle():
         loss and 16-34 % on `reasoner.*` gradients — parity is defined by the fp32 reference, and the product matches THAT to 5e-4;
       * on `recipe_reasoner.*` the fp32 and float64 oracles agree to 3e-7, so the 2.5e-3 the product showed there was the product's:
         torch's BCE backward is (p - y) / max(p(1-p), 1e-12), not the derivative of the clamped forward the kernels used; a handful of
-        re-simulated entity probabilities of 1e-12…1e-13 with label 1 made the difference (tools/dbg/recipe_residue_full.py).  With the
+        re-simulated entity probabilities of 1e-12…1e-13 with label 1 made the difference (tests/tools/recipe_residue_full.py).  With the
         reference's formula in `bce_rows_bwd` / `loss_tail_bwd` the distance is 4e-7 — asserted here at 5e-6."""
     from svpc_amd import ops
     import copy
@@ -298,7 +298,7 @@ def test_fp32_mode_simulator_gradients_and_a_float64_oracle():
     assert rep["loss_gpu_vs_oracle32"] <= 1e-6
     assert len(well) >= 100
     # (Went.0.*: ONE of the 147,456 pre-activations of went = relu(Went·ē) is 3.9e-7 from zero and falls on the other side with the
-    # kernel's ē, which is 3.4e-6 from the oracle's — a ReLU flip, i.e. rounding: tools/dbg/went_residue.py)
+    # kernel's ē, which is 3.4e-6 from the oracle's — a ReLU flip, i.e. rounding: tests/tools/went_residue.py)
     flip = {"Went.0.bias": 5e-3, "Went.0.weight": 2e-3}
     for a in well:
         assert a[1] <= flip.get(a[0], 5e-5), a

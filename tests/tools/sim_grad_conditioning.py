@@ -4,9 +4,11 @@ fp32 and in fp64 on the same inputs, differs by that much on these tensors — n
 (model.py:871, :810: 23 % of the entity probabilities are > 0.999 or < 0.001 with n/sqrt(fan_in) weights) differentiates through
 1/(1-e)·e(1-e) evaluated from the ROUNDED probability, whose last ulp (different exp implementations on CPU and GPU) moves a
 saturated entry's gradient by up to ulp/(1-e).  With the bench weights (N(0, 0.02)) nothing saturates and the residue is 1e-6.
-usage: python tools/dbg/sim_grad_conditioning.py   (CPU only)"""
+usage: python tests/tools/sim_grad_conditioning.py   (CPU only)"""
 import sys, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import bench
 from oracle import svpc_oracle as orc
 from svpc_amd import synthetic as syn

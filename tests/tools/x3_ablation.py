@@ -5,9 +5,9 @@ bf16") — or one family of STORED tensors loses its lo plane (plain bf16 storag
 worst / mean probability error, the arg-max agreement, the Gumbel arg-max flips and (test-sensitive weights) the agreement of the
 greedy ids at config 5's size are recorded.  The degraded operands go through the UNCHANGED three-term kernels with a zero lo plane
 (svpc_amd.ops.ABLATE), forward only.  → profiles/r04_x3_ablation.json (written under gpurun_out/ on the GPU box).
-usage: python tools/x3_ablation.py [--no-decode] [--init drawn|bench|both]"""
+usage: python tests/tools/x3_ablation.py [--no-decode] [--init drawn|bench|both]"""
 import argparse, copy, json, os, re, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
