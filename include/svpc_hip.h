@@ -302,6 +302,18 @@ int svpc_ptr_mix_loss_bwd(const float* logits, const float* g, const float* pi, 
                           const int* row_vid, const int* csr_off, const int* csr_ent, const int* csr_id, const float* csr_w,
                           const float* P, const float* dP_ext, const float* dloss, float* dlogits, float* dg, float* dpi, int R, int V,
                           int c_max, int e_max, float smoothing, svpc_stream_t stream);
+/* label_smoothing == 0: the reference then applies nn.CrossEntropyLoss(ignore_index=-1) to the PROBABILITIES (src/rtransformer/model.py:869-870
+ * used at :960,982,1002,1014) — per video the mean over its non-ignored rows of logsumexp_{v<C}(P_v) − P_y.  row_w[r] = 1 / (valid rows of
+ * row r's video), from svpc_ce_row_weights; loss_rows[r] = row_w[r]·(…) so that their sum is Σ_videos mean.  row_w == NULL: the
+ * label-smoothed KL above (smoothing > 0 required). */
+int svpc_ce_row_weights(const int* labels, const int* row_vid, int R, int n_vid, float* row_w, svpc_stream_t stream);
+int svpc_ptr_mix_ce_fwd(const float* logits, const float* g, const float* pi, const int* labels, const int* row_c,
+                        const int* row_vid, const int* csr_off, const int* csr_ent, const int* csr_id, const float* csr_w, float* P,
+                        float* loss_rows, int R, int V, int c_max, int e_max, float smoothing, const float* row_w, svpc_stream_t stream);
+int svpc_ptr_mix_ce_bwd(const float* logits, const float* g, const float* pi, const int* labels, const int* row_c,
+                        const int* row_vid, const int* csr_off, const int* csr_ent, const int* csr_id, const float* csr_w,
+                        const float* P, const float* dP_ext, const float* dloss, float* dlogits, float* dg, float* dpi, int R, int V,
+                        int c_max, int e_max, float smoothing, const float* row_w, svpc_stream_t stream);
 
 /* ---- Gumbel-softmax (hard) re-sampling of the caption: reconstruct model.py:1018 */
 int svpc_gumbel_noise(float* out, size_t n, unsigned site, const svpc_u64* seed, svpc_stream_t stream);

@@ -9,7 +9,7 @@ by ``svpc_amd.synthetic``; the fixtures hold parameters, Gumbel noise and the re
          (2) ``torch.Tensor.cuda`` → identity (the model hard-codes .cuda(), e.g. model.py:50,123,783-790),
          (3) a stub ``nltk`` (recursive_caption_dataset.py:5 imports it; only needed for src.translator).
 
-Usage:  python oracle/make_golden.py            (writes tests/golden/)
+Usage:  python oracle/make_golden.py [case …]   (writes tests/golden/; no argument: every case of oracle/cases.py)
 """
 from __future__ import annotations
 
@@ -60,7 +60,7 @@ def install_shims():
     return EasyDict
 
 
-from oracle.cases import CASES, MODES  # noqa: E402
+from oracle.cases import CASES, CASE_MODES, MODES  # noqa: E402
 
 
 def build_reference_model(EasyDict, Model, cfg_kw, model_type, seed=7):
@@ -184,11 +184,14 @@ def main():
     from src.translator import Translator
     gdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
+    only = sys.argv[1:]          # optional case names: regenerate those fixtures only
     for case in CASES:
+        if only and case not in only:
+            continue
         for mt in MODES:
-            if case == "c1" and mt not in ("v", "vivt"):
+            if mt not in CASE_MODES.get(case, MODES):
                 continue
-            out = run_case(EasyDict, Model, Translator, case, mt, full_dump=(case == "tiny"))
+            out = run_case(EasyDict, Model, Translator, case, mt, full_dump=case.startswith("tiny"))
             if case == "c1":  # parameters are re-drawn from the seed by the tests (too large to commit)
                 out = {k: v for k, v in out.items() if not k.startswith("param/")}
             path = os.path.join(gdir, "%s_%s.npz" % (case, mt))

@@ -231,6 +231,16 @@ def label_smoothing_kl(probs, target, smoothing):
     return F.kl_div(logp, q, reduction="sum")
 
 
+def caption_criterion(cfg):
+    """src/rtransformer/model.py:869-870 — LabelSmoothingLoss when config.label_smoothing > 0, else nn.CrossEntropyLoss(ignore_index=-1);
+    either is applied to the PROBABILITIES (:960, :982, :1002, :1014), once per video: the cross-entropy is a mean over the video's
+    non-ignored rows of log_softmax(P)[y] — a softmax of probabilities, reproduced as the reference computes it."""
+    ls = cfg.label_smoothing if "label_smoothing" in cfg else 0.0
+    if ls > 0:
+        return lambda probs, target: label_smoothing_kl(probs, target, ls)
+    return lambda probs, target: F.cross_entropy(probs, target, ignore_index=-1)
+
+
 def asymmetric_loss(p, y, gamma_neg=4.0, gamma_pos=1.0, clip=0.05, eps=1e-8):
     """libs/ASL/src/loss_functions/losses.py:15-50 (probabilities in, focal weights differentiated)."""
     p_neg = (1 - p + clip).clamp(max=1)
@@ -315,7 +325,7 @@ def forward(P, cfg, input_ids_list, video_features_list, input_masks_list, token
             labels[labels >= cfg.vocab_size] = cfg.unk_id                             # :1013
         else:
             probs = pointer_generator(P, dec, bank, ingr_id_dict[b], extra_zeros[b], cfg)
-        cap = cap + label_smoothing_kl(probs.reshape(-1, probs.shape[-1]), labels.reshape(-1), cfg.label_smoothing)
+        cap = cap + caption_criterion(cfg)(probs.reshape(-1, probs.shape[-1]), labels.reshape(-1))
         probs_list.append(probs)
         if mode in ("full", "reason_copy"):
             any_act = (actions[b] == 1).any(dim=1)

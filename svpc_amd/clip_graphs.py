@@ -27,11 +27,29 @@ import torch
 from . import ops
 
 
+_OWNERS = []        # every ClipEncoderGraphs alive in this process (weak): the optimizer asks them whether a backward is still owed
+
+
+def check_consumed(who="optimizer step"):
+    """Raise if a clip-encoder forward replay is still waiting for its backward replay: the training loop called ``loss.backward()``
+    instead of ``svpc_amd.graph.backward_all`` (the clip encoder's gradients of this step would silently be missing)."""
+    for ref in list(_OWNERS):
+        cg = ref()
+        if cg is None:
+            _OWNERS.remove(ref)
+        elif cg.pending is not None:
+            cg.pending = None
+            raise RuntimeError("clip_graphs: %s with the clip encoder's backward replay still pending — the step's backward must be "
+                               "svpc_amd.graph.backward_all(model, loss), not loss.backward() (the clip-encoder gradients of this step "
+                               "were never computed)" % who)
+
+
 class _Entry:
-    __slots__ = ("T", "g_fwd", "g_bwd", "feats", "ids", "mask", "seq", "cls_rows", "seq_cls", "cls", "gout", "n_sites", "replays")
+    __slots__ = ("T", "g_fwd", "g_bwd", "feats", "ids", "mask", "seq", "cls_rows", "seq_cls", "cls", "gout", "n_sites", "replays", "owner")
 
     def backward(self, grad):
         """the second phase of the step's backward (see ``svpc_amd.graph.backward_all``)"""
+        self.owner.pending = None
         if grad is None:
             return
         self.gout.copy_(grad)
@@ -47,6 +65,9 @@ class ClipEncoderGraphs:
         self.pool = None
         self.feats_cap = self.ids_cap = self.mask_cap = None
         self.stats = {"hits": 0, "captures": 0, "bypassed": 0}
+        self.pending = None                 # the entry whose forward has been replayed and whose backward has not (see check_consumed)
+        import weakref
+        _OWNERS.append(weakref.ref(self))
 
     # -------------------------------------------------------------------------------------------------------------------------
     def usable(self, feats):
@@ -56,6 +77,8 @@ class ClipEncoderGraphs:
             return False
         if torch.cuda.is_current_stream_capturing() or ops.GRAD_READY_HOOK is not None:
             return False
+        if torch.cuda.current_stream() == torch.cuda.default_stream():      # (a capture cannot run on the legacy default stream:
+            return False                                                   #  run the loop under ``graph.ops_stream()``)
         w = self.model.video_embeddings.video_embeddings[2].weight
         return getattr(w, "_svpc_direct", False)
 
@@ -75,6 +98,11 @@ class ClipEncoderGraphs:
         Lv, F = cfg.max_v_len, feats.shape[1]
         rows = T * Lv
         dev = feats.device
+        if self.pending is not None:
+            self.pending = None
+            raise RuntimeError("clip_graphs: a second forward before the previous step's clip-encoder backward was replayed (its saved "
+                               "activations live in the shared graph pool and would be overwritten) — run svpc_amd.graph.backward_all "
+                               "after every forward that wants gradients, or call the model under torch.no_grad()")
         self._buffers(rows, F, dev)
         key = (T, Lv, F, ops._PRECISION, cx.training, cx.p_h, cx.p_a, torch.cuda.current_stream().cuda_stream)
         e = self.entries.get(key)
@@ -91,6 +119,7 @@ class ClipEncoderGraphs:
         cx.rng._site += e.n_sites
         cut = e.cls.detach().requires_grad_(True)
         model.split_boundary = (e, cut)
+        self.pending = e
         return cut
 
     def _capture(self, key, T, cx):
@@ -99,7 +128,7 @@ class ClipEncoderGraphs:
         Lv, D = cfg.max_v_len, cfg.hidden_size
         dev = self.feats_cap.device
         e = _Entry()
-        e.T, e.replays = T, 0
+        e.T, e.replays, e.owner = T, 0, self
         rows = T * Lv
         e.feats, e.ids, e.mask = self.feats_cap[:rows], self.ids_cap[:rows], self.mask_cap[:rows]
         e.seq = ops.SeqInfo.uniform(T, Lv, Lv, dev)
@@ -110,6 +139,14 @@ class ClipEncoderGraphs:
             self.pool = torch.cuda.graph_pool_handle()
         stream = torch.cuda.current_stream()
         site0 = cx.rng._site
+        # one EAGER pass at this clip count first: anything a first call does besides launching kernels (the 256 MB kernel workspace of
+        # this stream, lazily uploaded index tables) must not be baked into the graph.  Its backward runs on a zero output gradient:
+        # every parameter gradient it accumulates into the optimizer's arena is an exact zero.
+        warm = model._encode_clips(e.feats, None, e.ids, e.mask, e.seq, cx, cls_only=(e.cls_rows, e.seq_cls))
+        warm.backward(e.gout)
+        ops.join_side()
+        del warm
+        cx.rng._site = site0
         e.g_fwd, e.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(e.g_fwd, pool=self.pool, stream=stream):
             cls = model._encode_clips(e.feats, None, e.ids, e.mask, e.seq, cx, cls_only=(e.cls_rows, e.seq_cls))
@@ -177,6 +214,8 @@ class DecoderGraphs:
             return False
         if torch.cuda.is_current_stream_capturing() or ops.GRAD_READY_HOOK is not None:
             return False
+        if torch.cuda.current_stream() == torch.cuda.default_stream():
+            return False
         w = self.model.decoder.layer[0].output.dense.weight
         return getattr(w, "_svpc_direct", False)
 
@@ -223,6 +262,13 @@ class DecoderGraphs:
         e.mem, e.mem_leaf = self._like(mem)
         e.mask = torch.zeros_like(text_mask)
         e.gout = torch.zeros(xt.shape[0], cfg.hidden_size, dtype=torch.float32, device=dev)
+        # (one eager pass first, backward on a zero gradient: see ClipEncoderGraphs._capture)
+        warm = model.decoder.run(e.xt_leaf, e.mask, e.mem_leaf, e.seq_self, e.seq_cross, None, cx)
+        warm.backward(e.gout)
+        ops.join_side()
+        del warm
+        e.xt_leaf.grad = e.mem_leaf.grad = None
+        cx.rng._site = site0
         with torch.cuda.graph(e.g_fwd, pool=self.pool, stream=stream):
             out = model.decoder.run(e.xt_leaf, e.mask, e.mem_leaf, e.seq_self, e.seq_cross, None, cx)
         assert out.shape == e.gout.shape and out.dtype == e.gout.dtype

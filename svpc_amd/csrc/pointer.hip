@@ -221,7 +221,31 @@ struct MixArgs {
     float* P; float* loss_rows; int V; int c_max; int em; float smoothing;
     // backward
     const float* dP_ext; const float* dloss; float* dlogits; float* dg; float* dpi;
+    // label_smoothing == 0 (reference model.py:869-870: nn.CrossEntropyLoss(ignore_index=-1) applied to the PROBABILITIES): row weight
+    // 1 / (valid rows of the row's video) — the criterion is a mean per video; non-null selects that branch
+    const float* row_w;
 };
+
+// row_w[r] = 1 / #{r' of r's video with label != -1}: one workgroup, counts in LDS (videos in chunks of 1024).  A video without a valid
+// row gets 1/0 = inf on rows that are all ignored (weight never used); torch's mean over an empty selection is NaN there as well.
+__global__ __launch_bounds__(1024) void ce_row_weights_kernel(const int* __restrict__ labels, const int* __restrict__ row_vid, int R,
+                                                               int n_vid, float* __restrict__ row_w) {
+    __shared__ int cnt[1024];
+    for (int v0 = 0; v0 < n_vid; v0 += 1024) {
+        cnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (int r = threadIdx.x; r < R; r += 1024) {
+            const int b = row_vid[r] - v0;
+            if (b >= 0 && b < 1024 && labels[r] >= 0) atomicAdd(&cnt[b], 1);
+        }
+        __syncthreads();
+        for (int r = threadIdx.x; r < R; r += 1024) {
+            const int b = row_vid[r] - v0;
+            if (b >= 0 && b < 1024) row_w[r] = 1.0f / (float)cnt[b];
+        }
+        __syncthreads();
+    }
+}
 
 // grid: R rows. LDS: c_max floats.
 __global__ __launch_bounds__(256) void ptr_mix_loss_fwd_kernel(MixArgs a) {
@@ -247,6 +271,21 @@ __global__ __launch_bounds__(256) void ptr_mix_loss_fwd_kernel(MixArgs a) {
     }
     const int y = a.labels[r];
     float loss = 0.f;
+    if (a.row_w) {
+        // cross-entropy OF THE PROBABILITIES (the reference's label_smoothing == 0 branch): w_r · (logsumexp_{v<C} P_v − P_y)
+        float pm = -INFINITY;
+        for (int v = threadIdx.x; v < a.c_max; v += 256) {
+            const float p = row[v];
+            a.P[(size_t)r * a.c_max + v] = p;
+            if (v < C) pm = fmaxf(pm, p);
+        }
+        pm = block_max_256(pm, red);
+        float se = 0.f;
+        for (int v = threadIdx.x; v < C; v += 256) se += expf(row[v] - pm);
+        se = block_sum_256(se, red);
+        if (threadIdx.x == 0) a.loss_rows[r] = y >= 0 ? a.row_w[r] * (pm + logf(se) - row[y]) : 0.f;
+        return;
+    }
     const float qs = a.smoothing / (float)(C - 1), conf = 1.0f - a.smoothing;
     for (int v = threadIdx.x; v < a.c_max; v += 256) {
         const float p = row[v];
@@ -279,11 +318,25 @@ __global__ __launch_bounds__(256) void ptr_mix_loss_bwd_kernel(MixArgs a) {
     for (int v = threadIdx.x; v < V; v += 256) { const float e = expf(lg[v] - m); smx[v] = e; s += e; }
     s = block_sum_256(s, red);
     const float inv = 1.0f / s;
+    float ce_m = 0.f, ce_inv = 0.f;
+    if (a.row_w && y >= 0) {          // softmax of the PROBABILITIES over the row's C classes (see the forward)
+        float pm = -INFINITY;
+        for (int v = threadIdx.x; v < C; v += 256) pm = fmaxf(pm, a.P[(size_t)r * a.c_max + v]);
+        pm = block_max_256(pm, red);
+        float se = 0.f;
+        for (int v = threadIdx.x; v < C; v += 256) se += expf(a.P[(size_t)r * a.c_max + v] - pm);
+        se = block_sum_256(se, red);
+        ce_m = pm; ce_inv = go * a.row_w[r] / se;
+    }
     for (int v = threadIdx.x; v < a.c_max; v += 256) {
         float d = a.dP_ext ? a.dP_ext[(size_t)r * a.c_max + v] : 0.f;
         if (y >= 0 && v < C) {
-            const float qv = v == y ? conf : (v == C - 1 ? 0.f : qs);
-            if (qv > 0.f) d -= go * qv / (a.P[(size_t)r * a.c_max + v] + 1e-12f);
+            if (a.row_w) {
+                d += ce_inv * expf(a.P[(size_t)r * a.c_max + v] - ce_m) - (v == y ? go * a.row_w[r] : 0.f);
+            } else {
+                const float qv = v == y ? conf : (v == C - 1 ? 0.f : qs);
+                if (qv > 0.f) d -= go * qv / (a.P[(size_t)r * a.c_max + v] + 1e-12f);
+            }
         }
         dP[v] = d;
         if (v < V) smx[v] *= inv;
@@ -521,20 +574,50 @@ int svpc_ptr_mix_loss_fwd(const float* logits, const float* g, const float* pi, 
     a.logits = logits; a.g = g; a.pi = pi; a.labels = labels; a.row_c = row_c; a.row_vid = row_vid; a.csr_off = csr_off;
     a.csr_ent = csr_ent; a.csr_id = csr_id; a.csr_w = csr_w; a.P = P; a.loss_rows = loss_rows; a.V = V; a.c_max = c_max;
     a.em = e_max; a.smoothing = smoothing;
+    SVPC_REQUIRE(smoothing > 0.f, "ptr_mix_loss: label_smoothing == 0 is the cross-entropy branch (svpc_ptr_mix_ce_fwd)");
     hipLaunchKernelGGL(ptr_mix_loss_fwd_kernel, dim3(R), dim3(256), (size_t)c_max * sizeof(float), s, a);
     return svpc_check_launch("ptr_mix_loss_fwd");
 }
+int svpc_ptr_mix_ce_bwd(const float* logits, const float* g, const float* pi, const int* labels, const int* row_c,
+                        const int* row_vid, const int* csr_off, const int* csr_ent, const int* csr_id, const float* csr_w,
+                        const float* P, const float* dP_ext, const float* dloss, float* dlogits, float* dg, float* dpi, int R, int V,
+                        int c_max, int e_max, float smoothing, const float* row_w, hipStream_t s);
 int svpc_ptr_mix_loss_bwd(const float* logits, const float* g, const float* pi, const int* labels, const int* row_c,
                           const int* row_vid, const int* csr_off, const int* csr_ent, const int* csr_id, const float* csr_w,
                           const float* P, const float* dP_ext, const float* dloss, float* dlogits, float* dg, float* dpi, int R, int V,
                           int c_max, int e_max, float smoothing, hipStream_t s) {
+    return svpc_ptr_mix_ce_bwd(logits, g, pi, labels, row_c, row_vid, csr_off, csr_ent, csr_id, csr_w, P, dP_ext, dloss, dlogits, dg, dpi, R,
+                               V, c_max, e_max, smoothing, nullptr, s);
+}
+int svpc_ptr_mix_ce_fwd(const float* logits, const float* g, const float* pi, const int* labels, const int* row_c,
+                        const int* row_vid, const int* csr_off, const int* csr_ent, const int* csr_id, const float* csr_w, float* P,
+                        float* loss_rows, int R, int V, int c_max, int e_max, float smoothing, const float* row_w, hipStream_t s) {
     if (R == 0) return 0;
+    SVPC_REQUIRE(row_w != nullptr || smoothing > 0.f, "ptr_mix_loss: label_smoothing == 0 needs the per-row weights (svpc_ce_row_weights)");
+    MixArgs a{};
+    a.logits = logits; a.g = g; a.pi = pi; a.labels = labels; a.row_c = row_c; a.row_vid = row_vid; a.csr_off = csr_off;
+    a.csr_ent = csr_ent; a.csr_id = csr_id; a.csr_w = csr_w; a.P = P; a.loss_rows = loss_rows; a.V = V; a.c_max = c_max;
+    a.em = e_max; a.smoothing = smoothing; a.row_w = row_w;
+    hipLaunchKernelGGL(ptr_mix_loss_fwd_kernel, dim3(R), dim3(256), (size_t)c_max * sizeof(float), s, a);
+    return svpc_check_launch("ptr_mix_loss_fwd");
+}
+int svpc_ptr_mix_ce_bwd(const float* logits, const float* g, const float* pi, const int* labels, const int* row_c,
+                        const int* row_vid, const int* csr_off, const int* csr_ent, const int* csr_id, const float* csr_w,
+                        const float* P, const float* dP_ext, const float* dloss, float* dlogits, float* dg, float* dpi, int R, int V,
+                        int c_max, int e_max, float smoothing, const float* row_w, hipStream_t s) {
+    if (R == 0) return 0;
+    SVPC_REQUIRE(row_w != nullptr || smoothing > 0.f, "ptr_mix_loss: label_smoothing == 0 needs the per-row weights (svpc_ce_row_weights)");
     MixArgs a{};
     a.logits = logits; a.g = g; a.pi = pi; a.labels = labels; a.row_c = row_c; a.row_vid = row_vid; a.csr_off = csr_off;
     a.csr_ent = csr_ent; a.csr_id = csr_id; a.csr_w = csr_w; a.P = const_cast<float*>(P); a.V = V; a.c_max = c_max; a.em = e_max;
-    a.smoothing = smoothing; a.dP_ext = dP_ext; a.dloss = dloss; a.dlogits = dlogits; a.dg = dg; a.dpi = dpi;
+    a.smoothing = smoothing; a.dP_ext = dP_ext; a.dloss = dloss; a.dlogits = dlogits; a.dg = dg; a.dpi = dpi; a.row_w = row_w;
     hipLaunchKernelGGL(ptr_mix_loss_bwd_kernel, dim3(R), dim3(256), (size_t)2 * c_max * sizeof(float), s, a);
     return svpc_check_launch("ptr_mix_loss_bwd");
+}
+int svpc_ce_row_weights(const int* labels, const int* row_vid, int R, int n_vid, float* row_w, hipStream_t s) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(ce_row_weights_kernel, dim3(1), dim3(1024), 0, s, labels, row_vid, R, n_vid, row_w);
+    return svpc_check_launch("ce_row_weights");
 }
 int svpc_gumbel_fwd(const float* P, const float* noise, const int* row_c, const float* emb, float* bow, int* idx, float* stats, int R,
                     int c_max, int V, int W, float tau, hipStream_t s) {

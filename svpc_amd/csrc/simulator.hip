@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
                 for (int e = 0; e < EM; ++e)
 #pragma unroll
                     for (int u = 0; u < CPT; ++u)                   // (rows / columns past the end re-read the last: unconditional, all in flight)
-                        upv[e][u] = a.deall[((size_t)j * em + min(e, E - 1)) * D + min((int)threadIdx.x + NT * u, D - 1)];
+                        upv[e][u] = a.deall[((size_t)j * em + max(min(e, E - 1), 0)) * D + min((int)threadIdx.x + NT * u, D - 1)];
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_lean_kernel(SimArgs a) {
         if (a.deall) {
 #pragma unroll
             for (int e = 0; e < EM; ++e)                        // (rows past the end re-read the last: unconditional, all in flight)
-                upv[e] = a.deall[((size_t)j * em + min(e, E - 1)) * D + d];
+                upv[e] = a.deall[((size_t)j * em + max(min(e, E - 1), 0)) * D + d];
         }
         const float c0 = n_c0, c1 = n_c1, w = n_w, eb = n_eb, debv = n_deb, qv = n_q;
         if (tid < EM) {

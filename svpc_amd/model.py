@@ -701,9 +701,11 @@ class StateAwareRecursiveTransformer(nn.Module):
         self.eps = 1e-12
         self.recipe_encoder = _LSTMParams(config.word_vec_size, D, batch_first=True, bidirectional=True)
         self.recipe_reasoner = EntitiyReasoningNetwork(config)
+        # (> 0: LabelSmoothingLoss; else nn.CrossEntropyLoss(ignore_index=-1) applied to the probabilities, a mean per video —
+        # reference model.py:869-870; both live in ops.ptr_mix_loss)
         self.label_smoothing = config.label_smoothing if "label_smoothing" in config else 0.0
         if not self.label_smoothing > 0:
-            raise NotImplementedError("the hot path is built for label_smoothing > 0 (scripts/train.sh default 0.1)")
+            self.label_smoothing = 0.0
         self.apply(self.init_bert_weights)
         self._plans = {}
         self._ptr_plans = {}

@@ -1637,16 +1637,21 @@ class _PtrMixLoss(Function):
         co, ce, ci, cw = csr_off.dev(dev), csr_ent.dev(dev), csr_id.dev(dev), csr_w.dev(dev)
         P = torch.empty(R, c_max, dtype=torch.float32, device=dev)
         loss_rows = torch.empty(R, dtype=torch.float32, device=dev)
-        _lib.call("ptr_mix_loss_fwd", _p(logits), _p(g), _p(pi), _p(labels), _p(rc), _p(rv), _p(co), _p(ce), _p(ci), _p(cw), _p(P),
-                  _p(loss_rows), R, V, c_max, e_max, float(smoothing), _stream())
-        ctx.save_for_backward(logits, g, pi, labels, rc, rv, co, ce, ci, cw, P)
+        row_w = None
+        if not smoothing > 0:
+            # label_smoothing == 0 (reference model.py:869-870): cross-entropy of the probabilities, a mean per video → per-row weights
+            row_w = torch.empty(R, dtype=torch.float32, device=dev)
+            _lib.call("ce_row_weights", _p(labels), _p(rv), R, len(csr_off) - 1, _p(row_w), _stream())
+        _lib.call("ptr_mix_ce_fwd", _p(logits), _p(g), _p(pi), _p(labels), _p(rc), _p(rv), _p(co), _p(ce), _p(ci), _p(cw), _p(P),
+                  _p(loss_rows), R, V, c_max, e_max, float(smoothing), _p(row_w), _stream())
+        ctx.save_for_backward(logits, g, pi, labels, rc, rv, co, ce, ci, cw, P, row_w)
         ctx.cfg = (R, V, c_max, e_max, float(smoothing))
         ctx.set_materialize_grads(False)
         return P, loss_rows
 
     @staticmethod
     def backward(ctx, dP, dloss):
-        logits, g, pi, labels, rc, rv, co, ce, ci, cw, P = ctx.saved_tensors
+        logits, g, pi, labels, rc, rv, co, ce, ci, cw, P, row_w = ctx.saved_tensors
         R, V, c_max, e_max, smoothing = ctx.cfg
         dev = logits.device
         dP = _c(dP) if dP is not None else None
@@ -1656,8 +1661,8 @@ class _PtrMixLoss(Function):
         dlogits = torch.empty_like(logits)
         dg = torch.empty_like(g) if g is not None else None
         dpi = torch.empty_like(pi) if pi is not None else None
-        _lib.call("ptr_mix_loss_bwd", _p(logits), _p(g), _p(pi), _p(labels), _p(rc), _p(rv), _p(co), _p(ce), _p(ci), _p(cw), _p(P),
-                  _p(dP), _p(dloss), _p(dlogits), _p(dg), _p(dpi), R, V, c_max, e_max, smoothing, _stream())
+        _lib.call("ptr_mix_ce_bwd", _p(logits), _p(g), _p(pi), _p(labels), _p(rc), _p(rv), _p(co), _p(ce), _p(ci), _p(cw), _p(P),
+                  _p(dP), _p(dloss), _p(dlogits), _p(dg), _p(dpi), R, V, c_max, e_max, smoothing, _p(row_w), _stream())
         return dlogits, dg, dpi, None, None, None, None, None, None, None, None, None
 
 

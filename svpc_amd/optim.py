@@ -184,6 +184,7 @@ class WeightStore:
                 view.copy_(p.detach())
                 p.data = view
                 p._svpc_bf16 = tag(self.shadow[o:o + n].view_as(p))
+                p._svpc_store = self        # (the owner: ``for_model`` never adopts a parameter that already lives in a store)
         for q, ids, kinds in _packed_groups(self.names, self.params, self.offsets):
             D_out, D_in = q.shape
             fw = _packed_views(self.flat, self.offsets, ids, D_out, D_in, kinds)
@@ -200,11 +201,22 @@ class WeightStore:
 
     @classmethod
     def for_model(cls, model):
-        """Inference-time use (no optimizer): adopt every parameter of ``model``."""
-        store = getattr(model, "_svpc_weight_store", None)
-        if store is None:
+        """Inference-time use: the store that owns ``model``'s parameters — the fused optimizer's when one has been built (the
+        reference builds a Translator on the live training model after every epoch, src/train.py:284: adopting the parameters a
+        second time would re-point ``p.data`` away from the addresses the optimizer's tensor table, the EMA swap and any captured
+        step graph hold, and training would silently continue on an orphaned copy) — else a new one over every parameter.
+        Parameters outside the owning store (frozen embedding tables, modules unused in the model's mode) stay where they are:
+        a captured graph may hold their addresses too."""
+        owners = {}
+        for p in model.parameters():
+            st = getattr(p, "_svpc_store", None)
+            if st is not None and p.data_ptr() >= st.flat.data_ptr() and p.data_ptr() < st.flat.data_ptr() + 4 * st.numel:
+                owners.setdefault(id(st), [st, 0])[1] += p.numel()
+        if owners:
+            store = max(owners.values(), key=lambda e: e[1])[0]
+        else:
             store = cls(list(model.named_parameters()))
-            model._svpc_weight_store = store
+        model._svpc_weight_store = store
         return store
 
     def refresh(self):
@@ -341,7 +353,8 @@ class FusedBertAdam:
 
     def launch(self):
         """The three kernels only (graph-capturable)."""
-        from . import ops
+        from . import clip_graphs, ops
+        clip_graphs.check_consumed()  # (a replayed clip-encoder forward whose backward replay was never requested: loud, not silent)
         WEIGHTS_EPOCH[0] += 1         # (the kernels rewrite the parameters behind autograd's version counters)
         ops.join_side()        # parameter-gradient kernels forked onto side streams
         stream = torch.cuda.current_stream().cuda_stream

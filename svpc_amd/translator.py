@@ -243,8 +243,12 @@ class Translator(object):
         # they lived at capture time — a weight store built later (optimizer start, WeightStore.for_model) re-points them
         from . import ops as _ops
         from .optim import WEIGHTS_EPOCH
+        # (epoch + the embedding parameters' version counters: the graph holds the address of the per-checkpoint text-embedding table,
+        # which ``_text_table`` rebuilds — elsewhere — when either moves: load_state_dict / copy_ into the same tensors bump only the versions)
+        te = model.text_embeddings
         sig = (tuple(p.data_ptr() for p in list(model.parameters())[:8]), _ops.get_precision(),
-               id(getattr(model, "_svpc_weight_store", None)), WEIGHTS_EPOCH[0])      # (epoch: the graph holds the embedding table's address)
+               id(getattr(model, "_svpc_weight_store", None)), WEIGHTS_EPOCH[0],
+               tuple(p._version for p in [te.word_embeddings.weight] + list(te.word_fc.parameters())))
         g = prep["graph"]
         if g is not None and g[3] != sig:
             g = prep["graph"] = None

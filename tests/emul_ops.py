@@ -218,12 +218,21 @@ def ptr_mix_loss(logits, g, pi, labels, row_c, row_vid, csr_off, csr_ent, csr_id
                 add = add.index_add(0, rows, contrib)
         P = P + add
     losses = []
+    if not smoothing > 0:
+        # the reference's label_smoothing == 0 branch: nn.CrossEntropyLoss(ignore_index=-1) applied to the probabilities, a MEAN per video
+        n_valid = {}
+        for r in range(R):
+            if int(labels[r]) != -1:
+                n_valid[int(row_vid[r])] = n_valid.get(int(row_vid[r]), 0) + 1
     for r in range(R):
         y = int(labels[r])
         if y == -1:
             losses.append(P[r].sum() * 0.0)
             continue
         C = int(row_c[r])
+        if not smoothing > 0:
+            losses.append((torch.logsumexp(P[r, :C], 0) - P[r, y]) / n_valid[int(row_vid[r])])
+            continue
         qv = torch.full((C,), smoothing / (C - 1), device=logits.device)
         qv[C - 1] = 0
         qv[y] = 1.0 - smoothing

@@ -21,7 +21,7 @@ def build_model(case, mt, golden_dir, device="cpu"):
         model.reasoner.set_pretrained_embedding(torch.zeros(A, W), freeze=False)
     if mt == "vivt":
         model.recipe_reasoner.set_pretrained_embedding(torch.zeros(A, W), freeze=False)
-    if case == "tiny":
+    if case.startswith("tiny"):
         sd = {k[len("param/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")}
     else:
         sd = syn.draw_parameters([(n, torch.empty(s)) for n, s in parameter_shapes(cfg, mt).items()], seed=7)

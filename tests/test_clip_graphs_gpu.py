@@ -114,3 +114,54 @@ def test_eviction_recapture_and_training_mode_dropout(golden_dir):
     finally:
         clip_graphs.enable(model, False)
         ops.set_precision("fp32")
+
+
+def test_guards_plain_backward_second_forward_and_default_stream(golden_dir):
+    """the three unguarded ways to misuse the replayed clip encoder fail loudly — (1) ``loss.backward()`` instead of
+    ``graph.backward_all`` (the clip encoder's gradients would silently be missing) raises at the optimizer step, (2) a second forward
+    with gradients before the owed backward replay raises, (3) on the legacy default stream (where a capture cannot run) the model
+    takes the eager path instead of raising mid-step."""
+    from svpc_amd import keep_host_copy, ops, clip_graphs
+    from svpc_amd.graph import backward_all, ops_stream
+    from svpc_amd.optim import FusedBertAdam
+    z, cfg, _, model = build_model("c1", "vivt", golden_dir, DEV)
+    b_cpu = syn.make_batch(cfg, n_videos=3, max_steps=7, step_nums=[5, 3, 7], n_ingr=[3, 1, 10], n_oov=[0, 0, 1], seed=51, full_clips=False)
+    b = {kk: ([t.to(DEV) if isinstance(t, torch.Tensor) else t for t in v] if isinstance(v, list) else
+              (v.to(DEV) if isinstance(v, torch.Tensor) else v)) for kk, v in b_cpu.items()}
+    keep_host_copy(b["ingr_sep_masks"], b_cpu["ingr_sep_masks"])
+    args = syn.forward_args(b)
+    model.gumbel_noise = None
+    try:
+        opt = FusedBertAdam(list(model.named_parameters()), lr=0.0, weight_decay=0.0, grad_clip=1.0)
+        with torch.cuda.stream(ops_stream()):
+            opt.zero_grad()
+            backward_all(model, model(*args)[0])
+            opt.step()
+            cg, dg = clip_graphs.enable(model)
+            # (1) plain backward: the optimizer refuses to step on gradients that lack the clip encoder's part
+            opt.zero_grad()
+            model(*args)[0].backward()
+            with pytest.raises(RuntimeError, match="backward_all"):
+                opt.step()
+            assert cg.pending is None
+            # (2) two forwards, no backward in between
+            opt.zero_grad()
+            model(*args)
+            with pytest.raises(RuntimeError, match="second forward"):
+                model(*args)
+            # … and the loop recovers: a correct step afterwards works
+            opt.zero_grad()
+            backward_all(model, model(*args)[0])
+            opt.step()
+            hits = cg.stats["hits"]
+            torch.cuda.synchronize()
+        # (3) default stream: eager path, no capture attempted, gradients complete
+        torch.cuda.synchronize()
+        opt.zero_grad()
+        backward_all(model, model(*args)[0])
+        ops.join_side()
+        torch.cuda.synchronize()
+        assert cg.stats["hits"] == hits and model.split_boundary is None
+        assert float(model.video_embeddings.video_embeddings[2].weight.grad.abs().max()) > 0
+    finally:
+        clip_graphs.enable(model, False)

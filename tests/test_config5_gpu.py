@@ -112,6 +112,82 @@ def test_config5_greedy_decode_at_headline_size(init, precision):
         assert rate >= FLOOR[precision], (init, precision, rate)
 
 
+def _slice_batch(batch, lo, hi):
+    """videos lo..hi-1 of a batch as a batch of their own (the per-step tensors are (N, …): videos are independent)"""
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, list) and v and isinstance(v[0], torch.Tensor) and k.endswith("_list"):
+            out[k] = [t[lo:hi].contiguous() for t in v]
+        elif isinstance(v, torch.Tensor):
+            out[k] = v[lo:hi].contiguous()
+        else:
+            out[k] = list(v[lo:hi])
+    return out
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_config5_at_64_videos_equals_eight_decodes_of_eight(precision):
+    """BASELINE.json config 5 is quoted on 64 videos; the id-exactness test above decodes 8.  At 64 videos × 12 clips the decoding
+    iterations run T = 768 sentence rows — other GEMM / attention / LayerNorm instances than T = 96.  Videos are independent
+    (src/translator.py:175-191 decodes them one by one), so decode(64 videos) must equal the concatenation of eight decodes of eight
+    videos BIT FOR BIT — with ragged ingredient counts and out-of-vocabulary words in the mix — and one of the chunks is checked against
+    ``oracle.greedy_decode``.  Eager and replayed (hipGraph) decodes of the 64 both take part."""
+    import copy
+    import bench
+    from svpc_amd.optim import WeightStore
+    from svpc_amd.translator import Translator
+    args = bench.parse_args([])
+    cfg, model_cpu = bench.build(args, "cpu", model_type="vivt")
+    drawn = syn.draw_parameters(list(model_cpu.named_parameters()), seed=7)
+    with torch.no_grad():
+        for n, p in model_cpu.named_parameters():
+            p.copy_(drawn[n])
+    model_cpu.eval()
+    n_ingr = [(10, 7, 12, 3, 31, 1, 9, 17)[b % 8] for b in range(64)]
+    n_oov = [(0, 1, 0, 2, 0, 0, 1, 0)[(b + b // 8) % 8] for b in range(64)]
+    batch = syn.make_batch(cfg, n_videos=64, max_steps=12, n_ingr=n_ingr, n_oov=[min(a, b) for a, b in zip(n_oov, n_ingr)], seed=2064,
+                           full_clips=True)
+    key = "oracle_chunk3"
+    if key not in _C5:
+        c = _slice_batch(batch, 24, 32)
+        P = {k: v.detach().clone() for k, v in model_cpu.state_dict().items()}
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        _C5[key] = orc.greedy_decode(P, cfg, c["input_ids_list"], c["video_features_list"], c["input_masks_list"], c["ingr_input_ids"],
+                                     c["ingr_sep_masks"], c["batch_step_num"], c["ingr_id_dict"], c["oov_word_dict"])
+    ref3 = _C5[key]
+    ops.set_precision(precision)
+    try:
+        model = copy.deepcopy(model_cpu).to(DEV)
+        model.eval()
+        WeightStore.for_model(model)
+        O = type("O", (), {"cuda": True})
+        tr = Translator(O(), {"model_cfg": cfg, "model": model.state_dict()}, model=model, graph=True)
+        b64 = _to_dev(batch)
+        full, _ = tr.translate_batch(syn.translate_inputs(b64))
+        full2, _ = tr.translate_batch(syn.translate_inputs(b64))          # the replayed graph
+        chunks = []
+        for c in range(8):
+            d, _ = tr.translate_batch(syn.translate_inputs(_to_dev(_slice_batch(batch, 8 * c, 8 * c + 8))))
+            chunks.extend(d)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision("fp32")
+    assert len(full) == 64 and len(chunks) == 64
+    bad = [b for b in range(64) if not torch.equal(full[b], chunks[b])]
+    assert not bad, "decode(64 videos) differs from the decodes of 8 for videos %s" % bad
+    assert all(torch.equal(a, b) for a, b in zip(full, full2)), "hipGraph replay of the 64-video decode differs from its eager run"
+    for b in range(8):
+        assert torch.equal(full[24 + b].cpu(), ref3[b]), ("video %d differs from the oracle" % (24 + b))
+    _REPORT["64_videos/%s" % precision] = dict(videos=64, sentences=768, equals_8x8=True, chunk_vs_oracle_bit_exact=True,
+                                               copied_oov_ids=int(sum(int((d >= cfg.vocab_size).sum()) for d in full)))
+    from helpers import product_sources_sha16
+    _REPORT["_sources_sha16"] = product_sources_sha16()
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "config5_parity.json"), "w") as f:
+        json.dump(_REPORT, f, indent=1)
+
+
 # ------------------------------------------------------------------------------------------------ the reference caller's call surface
 # bf16x3: every stored value carries 2⁻¹⁷ ≈ 8e-6 relative to its row's magnitude (O(1) after a LayerNorm), a few stages deep
 TOLS = {"fp32": dict(rtol=1e-4, atol=2e-6), "bf16x3": dict(rtol=3e-4, atol=6e-5)}

@@ -72,6 +72,47 @@ TOL = {"fp32": dict(loss=1e-4, prob=5e-5, prob_mean=1e-6, gnorm=2e-3, cos=0.9999
 TOL_TENSOR = {("bf16", "Wing.weight"): dict(gnorm=2e-1)}
 
 _REPORT = {}
+# the wider bf16 bars (loss 3e-3 instead of 1.5e-3, the `Wing.weight` exception) are justified only by "the pipelined
+# attention forward re-draws the rounding pattern, it is not less accurate".  That claim is now CHECKED on the device before the wider
+# bars apply: both forward kernels on the same bf16 inputs against an fp64 reference — the pipelined kernel's rms error and bias must be
+# no worse than the one-workgroup-per-pair kernel's.  If the check fails the previous bars (1.5e-3, no per-tensor exception) are used.
+_PREV_BF16 = dict(loss=1.5e-3)
+_AB = {}
+
+
+def _attn_ab():
+    """→ dict(rms_pipe, rms_old, bias_pipe, bias_old, floor, ok) — clip-encoder attention forward, bf16, 100 × 100 × 64, fp64 reference"""
+    if _AB:
+        return _AB
+    import math
+    from svpc_amd import _lib, ops
+    from svpc_amd.ops_common import SeqInfo
+    H, dh, B, L = 12, 64, 48, 100
+    D = H * dh
+    g = torch.Generator().manual_seed(70)
+    qkv = (1.5 * torch.randn(B * L, 3 * D, generator=g)).to(DEV).to(torch.bfloat16).contiguous()
+    xv = qkv.double()
+    q, k, v = (xv[:, i * D:(i + 1) * D].view(B, L, H, dh).permute(0, 2, 1, 3) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh), -1) @ v).permute(0, 2, 1, 3).reshape(B * L, D)
+    seq = SeqInfo.uniform(B, L, L, DEV)
+    prev = ops.get_precision()
+    ops.set_precision("bf16")
+    st = {}
+    try:
+        for on, tag in ((1, "pipe"), (0, "old")):
+            was = _lib.load().svpc_attn_pipe_enable(on)
+            try:
+                out = ops.attention(qkv, qkv, (0, D, 2 * D), D, H, seq, key_mask=None, causal=False, drop=None)
+            finally:
+                _lib.load().svpc_attn_pipe_enable(was)
+            e = out.double() - ref
+            st["rms_" + tag], st["bias_" + tag] = float(e.pow(2).mean().sqrt()), float(e.mean())
+    finally:
+        ops.set_precision(prev)
+    st["floor"] = float((ref.to(torch.bfloat16).double() - ref).pow(2).mean().sqrt())
+    st["ok"] = bool(st["rms_pipe"] <= 1.02 * st["rms_old"] and abs(st["bias_pipe"]) <= max(abs(st["bias_old"]), 0.02 * st["floor"]))
+    _AB.update(st)
+    return _AB
 
 
 def _build(mt, init):
@@ -143,7 +184,14 @@ def _gumbel_flips(probs, ref_probs, noise, tau):
 
 
 def _compare(tag, precision, loss, probs, grads, ref, names, noise=None):
-    tol = TOL[precision]
+    tol = dict(TOL[precision])
+    tol_tensor = dict(TOL_TENSOR)
+    if precision == "bf16":
+        ab = _attn_ab()
+        _REPORT["_attention_ab_vs_fp64"] = dict(ab)
+        if not ab["ok"]:         # the pipelined forward is NOT "the same error, re-drawn": the previous bars apply
+            tol.update(_PREV_BF16)
+            tol_tensor = {}
     rep = {"loss": loss, "ref_loss": ref["loss"], "loss_rel": abs(loss - ref["loss"]) / abs(ref["loss"])}
     if noise is not None:
         rep["gumbel_flips"], rep["gumbel_positions"] = _gumbel_flips(probs, ref["probs"], noise, None)
@@ -173,7 +221,7 @@ def _compare(tag, precision, loss, probs, grads, ref, names, noise=None):
     assert rep["argmax_agreement"] >= tol["argmax"], (tag, rep["argmax_agreement"])
     assert len(rep["grads"]) >= 12
     for n, d in rep["grads"].items():
-        t = dict(tol, **TOL_TENSOR.get((precision, n), {}))
+        t = dict(tol, **tol_tensor.get((precision, n), {}))
         assert d["norm_rel"] <= t["gnorm"], (tag, n, d)
         assert d["cos"] >= t["cos"], (tag, n, d)
 

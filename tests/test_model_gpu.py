@@ -14,9 +14,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.mark.parametrize("mt", ["v", "vi", "viv", "vivt"])
-def test_tiny_forward_backward_vs_reference_golden(golden_dir, mt):
-    z, cfg, batch, model = build_model("tiny", mt, golden_dir, DEV)
+@pytest.mark.parametrize("case,mt", [("tiny", "v"), ("tiny", "vi"), ("tiny", "viv"), ("tiny", "vivt"),
+                                     ("tiny_ls0", "v"), ("tiny_ls0", "vivt")])   # (_ls0: the label_smoothing == 0 criterion, model.py:869-870)
+def test_tiny_forward_backward_vs_reference_golden(golden_dir, case, mt):
+    z, cfg, batch, model = build_model(case, mt, golden_dir, DEV)
     loss, probs, ents, acts = model(*syn.forward_args(batch))
     ref = float(z["loss"])
     assert abs(loss.item() - ref) <= 1e-4 * abs(ref), (loss.item(), ref)
@@ -636,3 +637,60 @@ def test_translator_sees_weights_changed_by_the_fused_optimizer(golden_dir, grap
     assert all(torch.equal(a, b) for a, b in zip(d0, d0b))
     assert all(torch.equal(a, b) for a, b in zip(d1, d2))
     assert any(not torch.equal(a, b) for a, b in zip(d0, d1)), "three steps at lr 5e-2 should change at least one emitted token"
+
+
+def test_translator_built_after_the_optimizer_does_not_orphan_training(golden_dir):
+    """The reference's order (src/train.py:284: a Translator on the LIVE training model after every epoch): optimizer steps, then a
+    first Translator, then more optimizer steps — eager and through a captured step graph.  The Translator must reuse the store the
+    fused optimizer moved the parameters into (a second ``WeightStore`` re-pointed ``p.data`` away from the addresses the
+    optimizer's tensor table and a captured graph hold, and training silently continued on an orphaned copy)."""
+    from svpc_amd.graph import GraphedTrainStep, backward_all, ops_stream
+    from svpc_amd.optim import FusedBertAdam, WeightStore
+    from svpc_amd.translator import Translator
+    z, cfg, batch, model = build_model("c1", "vivt", golden_dir, DEV)
+    O = type("O", (), {"cuda": True})
+    args = syn.forward_args(batch)
+
+    def eager_step(opt):
+        opt.zero_grad()
+        loss = model(*args)[0]
+        backward_all(model, loss)
+        opt.step()
+
+    with torch.cuda.stream(ops_stream()):
+        opt = FusedBertAdam(list(model.named_parameters()), lr=5e-2, weight_decay=0.0, grad_clip=1.0, ema_decay=0.9)
+        model.train()
+        for _ in range(2):
+            eager_step(opt)
+        store = opt.weights
+        ptrs = [p.data_ptr() for p in store.params]
+        model.eval()
+        tr = Translator(O(), {"model_cfg": cfg, "model": model.state_dict()}, model=model, graph=True)
+        assert WeightStore.for_model(model) is store and model._svpc_weight_store is store
+        assert [p.data_ptr() for p in store.params] == ptrs, "the Translator re-pointed parameters that live in the optimizer's store"
+        d0, _ = tr.translate_batch(syn.translate_inputs(batch))
+        model.train()
+        before = store.flat.clone()
+        eager_step(opt)
+        torch.cuda.synchronize()
+        assert not torch.equal(before, store.flat), "an optimizer step after the first Translator no longer changes the weights"
+        for p, o in zip(store.params, store.offsets):          # model parameters ARE the store (what state_dict() saves)
+            assert p.data_ptr() == store.flat.data_ptr() + 4 * o
+        # a captured step keeps training the same addresses, and the EMA swap reaches the model
+        step = GraphedTrainStep(model, opt, args, warmup=1)
+        before = store.flat.clone()
+        step()
+        torch.cuda.synchronize()
+        assert not torch.equal(before, store.flat)
+        w = model.decoder.layer[0].output.dense.weight
+        live = w.detach().clone()
+        opt.ema_assign()
+        assert not torch.equal(w.detach(), live), "ema_assign did not reach the model's parameters"
+        opt.ema_resume()
+        assert torch.equal(w.detach(), live)
+        model.eval()
+        d1, _ = tr.translate_batch(syn.translate_inputs(batch))
+        fresh = Translator(O(), {"model_cfg": cfg, "model": model.state_dict()}, model=model, graph=False)
+        d2, _ = fresh.translate_batch(syn.translate_inputs(batch))
+        torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(d1, d2))

@@ -38,9 +38,9 @@ def test_state_dict_names_match_reference(golden_dir, mt):
             np.testing.assert_allclose(model.state_dict()[k].numpy(), z["param/" + k], atol=1e-6)
 
 
-@pytest.mark.parametrize("mt", ["v", "vi", "viv", "vivt"])
-def test_batched_forward_backward_matches_reference(golden_dir, mt):
-    z, cfg, batch, model = build("tiny", mt, golden_dir)
+@pytest.mark.parametrize("case,mt", [("tiny", "v"), ("tiny", "vi"), ("tiny", "viv"), ("tiny", "vivt"), ("tiny_ls0", "v"), ("tiny_ls0", "vivt")])
+def test_batched_forward_backward_matches_reference(golden_dir, case, mt):
+    z, cfg, batch, model = build(case, mt, golden_dir)
     loss, probs, ents, acts = model(*syn.forward_args(batch))
     assert abs(loss.item() - float(z["loss"])) <= 2e-5 * abs(float(z["loss"]))
     for b, p in enumerate(probs):
