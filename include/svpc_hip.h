@@ -285,6 +285,23 @@ int svpc_sim_recur_bwd(const float* q, const float* c, const float* w4f, const f
                        const float* ebar, const float* eall, const float* de, const float* debar, const float* deall, float* dq,
                        float* dc, float* dw4f, float* dE0, svpc_stream_t stream);
 
+/* ---- decoder cross-attention over the <= 3 memory rows of a sentence + residual LayerNorm, one launch forward and one backward per
+ * layer: src/rtransformer/model.py:657-658 (BertDecoderLayerNoMemoryUntied.forward), attention core :194-219, BertLayerNorm :143-156.
+ * The query projection is folded into the keys per head, U[j,h] = Wq_h^T k[j,h] (a small grouped GEMM over the memory rows, done by the
+ * caller): scores = (x1·U + <bq_h, k>)/sqrt(dh).  x_dt / y_dt: 0 fp32, 1 bf16, 2 split (two bf16 planes, the lo plane lox / loy columns
+ * behind); probs (T·lt, H, 4), mean / rstd (T·lt) are saved for the backward.  Backward returns dx1 (dense), dU, the layer's [dK | dV]
+ * block (dV complete, dK = the bias part: the caller's grouped GEMM adds Wq_h·dU[j,h]) and per-sentence partial sums of
+ * [dgamma | dbeta] (T, 2D) and d bq (T, D) for svpc_multi_finalize. */
+int svpc_cross_attn_ln_supported(int D, int H, int lt, int nm);
+int svpc_cross_attn_ln_fwd(const void* x1, int x_dt, int ldx, int lox, const float* U, const float* kv, int ld_kv, const float* bq,
+                           const float* gamma, const float* beta, float eps, void* y, int y_dt, int ldy, int loy, float* probs, float* mean,
+                           float* rstd, int T, int lt, int nm, int D, int H, float scale, float p_drop, unsigned site, const svpc_u64* seed,
+                           svpc_stream_t stream);
+int svpc_cross_attn_ln_bwd(const void* x1, int x_dt, int ldx, int lox, const float* U, const float* kv, int ld_kv, const float* bq,
+                           const float* gamma, const float* probs, const float* mean, const float* rstd, const void* dy, int dy_dt,
+                           int lddy, void* dx1, int dx_dt, int lddx, float* dU, float* dkv, int ld_dkv, float* part_ln, float* part_bq, int T,
+                           int lt, int nm, int D, int H, float scale, float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
+
 /* ---- pointer-generator + caption loss: model.py:896-923, :37-55 */
 int svpc_ptr_attn_fwd(const float* dec, const float* proj, const float* bank, const int* step_ne, float* pi, float* att, int T,
                       int lt, int e_max, int D, svpc_stream_t stream);
@@ -295,6 +312,14 @@ int svpc_ptr_attn_pgen_fwd(const float* dec, const float* proj, const float* ban
 int svpc_ptr_attn_bwd(const float* dec, const float* proj, const float* bank, const int* step_ne, const float* pi, const float* dpi,
                       const float* datt, float* ddec, float* dproj, float* dbank, int T, int lt, int e_max, int D,
                       svpc_stream_t stream);
+/* training form: pointer attention AND the generation gate of every row in one launch, forward and backward (model.py:899-908).  The
+ * attended vector feeds only the gate, so it never reaches HBM; backward returns the per-step partial sums of [d pgen_w | d pgen_b] in
+ * wpart (T rows of 2·D + 1 floats) for the table-driven finalizer (svpc_multi_finalize). */
+int svpc_ptr_attn_gate_fwd(const float* dec, const float* proj, const float* bank, const int* step_ne, float* pi, const float* pgen_w,
+                           const float* pgen_b, float* pgen, int T, int lt, int e_max, int D, svpc_stream_t stream);
+int svpc_ptr_attn_gate_bwd(const float* dec, const float* proj, const float* bank, const int* step_ne, const float* pi, const float* dpi,
+                           const float* pgen, const float* dpgen, const float* pgen_w, float* ddec, float* dproj, float* dbank,
+                           float* wpart, int T, int lt, int e_max, int D, svpc_stream_t stream);
 int svpc_ptr_mix_loss_fwd(const float* logits, const float* g, const float* pi, const int* labels, const int* row_c,
                           const int* row_vid, const int* csr_off, const int* csr_ent, const int* csr_id, const float* csr_w, float* P,
                           float* loss_rows, int R, int V, int c_max, int e_max, float smoothing, svpc_stream_t stream);

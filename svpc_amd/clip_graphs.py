@@ -237,7 +237,11 @@ class DecoderGraphs:
     def _like(t):
         """a buffer of t's layout (split tensors keep their lo plane) and a leaf over it for the captured autograd graph"""
         lo = ops.lo_off(t)
-        buf = ops.new_split(t.shape[0], t.shape[1], t.device) if lo is not None else torch.zeros_like(t)
+        if lo is not None:          # (zero-filled: the eager warm-up pass before the capture reads it, and 0 × garbage is NaN)
+            buf = torch.zeros(t.shape[0], 2 * t.shape[1], dtype=torch.bfloat16, device=t.device)[:, :t.shape[1]]
+            buf._svpc_lo = t.shape[1]
+        else:
+            buf = torch.zeros_like(t)
         leaf = buf.detach().requires_grad_(True)
         if lo is not None:
             leaf._svpc_lo = buf._svpc_lo

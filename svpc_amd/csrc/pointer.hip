@@ -214,6 +214,206 @@ __global__ __launch_bounds__(768) void ptr_attn_bwd_kernel(const float* __restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ ptr_attn with the generation gate (training)
+// The pointer attention of a step together with the generation gate of its lt rows, p_gen[t] = sigmoid([dec_t ; att_t]·w + b)
+// (reference: src/rtransformer/model.py:899-908).  In the training forward the attended vector att feeds NOTHING but that gate, so it never
+// goes to HBM: forward writes pi and p_gen; backward takes d pi and d p_gen and uses
+//     datt_t = dz_t·w2 (dz_t = dg_t·g_t(1-g_t), w2 = w[D:])   ⇒   datt_t·bank_e = dz_t·<w2, bank_e>: E dot products instead of lt·E,
+//     dbank_e = (Σ_t pi[t,e]·dz_t)·w2 + [softmax path through proj: none — proj has its own gradient],
+//     dw = Σ_t dz_t·[dec_t ; att_t] with Σ_t dz_t·att_t = Σ_e c_e·bank_e, c_e = Σ_t dz_t·pi[t,e];  db = Σ_t dz_t
+// (per-step partial sums of dw | db go to `wpart` (T × (2D+1)), added up by the table-driven finalizer).  Replaces, per step of the
+// model, the concatenation [dec ; att] (16 MB), a 1,536-deep one-column projection and its dgrad / wgrad / bias-sum launches.
+__global__ __launch_bounds__(768) void ptr_attn_gate_fwd_kernel(const float* __restrict__ dec, const float* __restrict__ proj,
+                                                                const float* __restrict__ bank, const int* __restrict__ step_ne,
+                                                                float* __restrict__ pi, int lt, int em, int D,
+                                                                const float* __restrict__ pgen_w, const float* __restrict__ pgen_b,
+                                                                float* __restrict__ pgen) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    float* rows = psm;                         // lt × D
+    float* ent = rows + (size_t)lt * D;        // PTR_EC × D
+    float* sc = ent + (size_t)PTR_EC * D;      // lt × PTR_EMAX
+    float* gred = sc + lt * PTR_EMAX;          // (waves) × PTR_LTMAX partial gate sums
+    const int j = blockIdx.x, E = step_ne[j];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    const float* pj = proj + (size_t)j * em * D;
+    const float* bj = bank + (size_t)j * em * D;
+    ptr_stage(rows, dec + (size_t)j * lt * D, lt * D);
+    for (int i = threadIdx.x; i < NW * PTR_LTMAX; i += blockDim.x) gred[i] = 0.f;
+    for (int e0 = 0; e0 < E; e0 += PTR_EC) {
+        const int ec = min(PTR_EC, E - e0);
+        __syncthreads();
+        ptr_stage(ent, pj + (size_t)e0 * D, ec * D);
+        __syncthreads();
+        ptr_dots(rows, ent, sc, lt, ec, e0, D);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < lt; t += blockDim.x) {
+        float m = -INFINITY;
+        for (int e = 0; e < E; ++e) m = fmaxf(m, sc[t * PTR_EMAX + e]);
+        float s = 0.f;
+        for (int e = 0; e < E; ++e) { const float v = expf(sc[t * PTR_EMAX + e] - m); sc[t * PTR_EMAX + e] = v; s += v; }
+        const float inv = 1.0f / s;
+        for (int e = 0; e < em; ++e) {
+            const float v = e < E ? sc[t * PTR_EMAX + e] * inv : 0.f;
+            if (e < E) sc[t * PTR_EMAX + e] = v;
+            pi[((size_t)j * lt + t) * em + e] = v;
+        }
+        for (int e = E; e < ((E + 3) & ~3); ++e) sc[t * PTR_EMAX + e] = 0.f;
+    }
+    __syncthreads();
+    // column phase (wave-uniform trip count: the per-row gate sums are wave reductions): a thread owns column d
+    for (int d0 = 0; d0 < D; d0 += blockDim.x) {
+        const int d = d0 + threadIdx.x;
+        const bool on = d < D;
+        const int dc = on ? d : D - 1;
+        float bv[PTR_EMAX];
+#pragma unroll
+        for (int e = 0; e < PTR_EMAX; ++e) bv[e] = (e < E && on) ? bj[(size_t)e * D + dc] : 0.f;
+        const float w1 = on ? pgen_w[dc] : 0.f, w2 = on ? pgen_w[D + dc] : 0.f;
+        for (int t = 0; t < lt; ++t) {
+            float acc = 0.f;
+#pragma unroll
+            for (int q4 = 0; q4 < PTR_EMAX / 4; ++q4) {
+                if (4 * q4 < E) {
+                    const float4 p4 = *reinterpret_cast<const float4*>(sc + t * PTR_EMAX + 4 * q4);
+                    acc += p4.x * bv[4 * q4] + p4.y * bv[4 * q4 + 1] + p4.z * bv[4 * q4 + 2] + p4.w * bv[4 * q4 + 3];
+                }
+            }
+            const float gs = wave_sum(rows[(size_t)t * D + dc] * w1 + acc * w2);
+            if (lane == 0) gred[wave * PTR_LTMAX + t] += gs;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < lt; t += blockDim.x) {
+        float tot = pgen_b[0];
+        for (int w = 0; w < NW; ++w) tot += gred[w * PTR_LTMAX + t];
+        pgen[(size_t)j * lt + t] = 1.0f / (1.0f + expf(-tot));
+    }
+}
+
+// LDS: (1 + PTR_EC)·D floats (w2 row, entity chunk) + 2·lt·32 + 2·32·32 + 3·32 floats
+__global__ __launch_bounds__(768) void ptr_attn_gate_bwd_kernel(const float* __restrict__ dec, const float* __restrict__ proj,
+                                                                const float* __restrict__ bank, const int* __restrict__ step_ne,
+                                                                const float* __restrict__ pi, const float* __restrict__ dpi,
+                                                                const float* __restrict__ pgen, const float* __restrict__ dpgen,
+                                                                const float* __restrict__ pgen_w, float* __restrict__ ddec,
+                                                                float* __restrict__ dproj, float* __restrict__ dbank,
+                                                                float* __restrict__ wpart, int lt, int em, int D) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    float* w2row = psm;                        // D: w[D:]
+    float* ent = w2row + D;                    // PTR_EC × D
+    float* dsc = ent + (size_t)PTR_EC * D;     // lt × PTR_EMAX
+    float* pis = dsc + lt * PTR_EMAX;          // lt × PTR_EMAX
+    float* dscT = pis + lt * PTR_EMAX;         // PTR_EMAX × PTR_LTMAX
+    float* pisT = dscT + PTR_EMAX * PTR_LTMAX; // PTR_EMAX × PTR_LTMAX (kept for the layout's sake: c_e is taken from it)
+    float* ue = pisT + PTR_EMAX * PTR_LTMAX;   // PTR_EMAX: <w2, bank_e>   (ptr_dots writes row 0 of a lt×32 image)
+    float* dzs = ue + PTR_EMAX;                // PTR_LTMAX: dz_t
+    float* ces = dzs + PTR_LTMAX;              // PTR_EMAX: c_e
+    const int j = blockIdx.x, E = step_ne[j];
+    const float* pj = proj + (size_t)j * em * D;
+    const float* bj = bank + (size_t)j * em * D;
+    const float* dj = dec + (size_t)j * lt * D;
+    ptr_stage(w2row, pgen_w + D, D);
+    for (int t = threadIdx.x; t < PTR_LTMAX; t += blockDim.x) {
+        float dz = 0.f;
+        if (t < lt) { const float g = pgen[(size_t)j * lt + t]; dz = (dpgen ? dpgen[(size_t)j * lt + t] : 0.f) * g * (1.0f - g); }
+        dzs[t] = dz;
+    }
+    for (int e0 = 0; e0 < E; e0 += PTR_EC) {
+        const int ec = min(PTR_EC, E - e0);
+        __syncthreads();
+        ptr_stage(ent, bj + (size_t)e0 * D, ec * D);
+        __syncthreads();
+        ptr_dots(w2row, ent, ue, 1, ec, e0, D);          // u_e = <w2, bank_e>
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < lt * E; i += blockDim.x) {
+        const int t = i / E, e = i - t * E;
+        const size_t o = ((size_t)j * lt + t) * em + e;
+        dsc[t * PTR_EMAX + e] = dzs[t] * ue[e] + (dpi ? dpi[o] : 0.f);
+        pis[t * PTR_EMAX + e] = pi[o];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < lt; t += blockDim.x) {
+        float mix = 0.f;
+        for (int e = 0; e < E; ++e) mix += pis[t * PTR_EMAX + e] * dsc[t * PTR_EMAX + e];
+        for (int e = 0; e < E; ++e) {
+            const float v = pis[t * PTR_EMAX + e] * (dsc[t * PTR_EMAX + e] - mix);
+            dsc[t * PTR_EMAX + e] = v;
+            dscT[e * PTR_LTMAX + t] = v;
+        }
+        for (int e = E; e < ((E + 3) & ~3); ++e) dsc[t * PTR_EMAX + e] = 0.f;
+    }
+    for (int i = threadIdx.x; i < E * PTR_LTMAX; i += blockDim.x) {
+        const int e = i / PTR_LTMAX, t = i - e * PTR_LTMAX;
+        if (t >= lt) dscT[e * PTR_LTMAX + t] = 0.f;
+    }
+    for (int e = threadIdx.x; e < PTR_EMAX; e += blockDim.x) {        // c_e = Σ_t dz_t·pi[t,e]
+        float c = 0.f;
+        if (e < E) for (int t = 0; t < lt; ++t) c += dzs[t] * pis[t * PTR_EMAX + e];
+        ces[e] = c;
+    }
+    __syncthreads();
+    float* wp = wpart + (size_t)j * (2 * D + 1);
+    if (threadIdx.x == 0) {
+        float sb = 0.f;
+        for (int t = 0; t < lt; ++t) sb += dzs[t];
+        wp[2 * D] = sb;
+    }
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float pv[PTR_EMAX];
+#pragma unroll
+        for (int e = 0; e < PTR_EMAX; ++e) pv[e] = e < E ? pj[(size_t)e * D + d] : 0.f;
+        float dv[PTR_LTMAX];
+#pragma unroll
+        for (int t = 0; t < PTR_LTMAX; ++t) dv[t] = t < lt ? dj[(size_t)t * D + d] : 0.f;
+        const float w1 = pgen_w[d], w2 = w2row[d];
+        // ddec[t][d] = Σ_e dsc[t][e]·proj[e][d] + dz_t·w1[d]
+        for (int t = 0; t < lt; ++t) {
+            float acc = dzs[t] * w1;
+#pragma unroll
+            for (int q4 = 0; q4 < PTR_EMAX / 4; ++q4) {
+                if (4 * q4 < E) {
+                    const float4 p4 = *reinterpret_cast<const float4*>(dsc + t * PTR_EMAX + 4 * q4);
+                    acc += p4.x * pv[4 * q4] + p4.y * pv[4 * q4 + 1] + p4.z * pv[4 * q4 + 2] + p4.w * pv[4 * q4 + 3];
+                }
+            }
+            ddec[((size_t)j * lt + t) * D + d] = acc;
+        }
+        // dw1[d] partial = Σ_t dz_t·dec[t][d]
+        float s1 = 0.f;
+#pragma unroll
+        for (int q4 = 0; q4 < PTR_LTMAX / 4; ++q4) {
+            if (4 * q4 < lt) {
+                const float4 z4 = *reinterpret_cast<const float4*>(dzs + 4 * q4);
+                s1 += z4.x * dv[4 * q4] + z4.y * dv[4 * q4 + 1] + z4.z * dv[4 * q4 + 2] + z4.w * dv[4 * q4 + 3];
+            }
+        }
+        wp[d] = s1;
+        // dproj[e][d] = Σ_t dsc[t][e]·dec[t][d];  dbank[e][d] = c_e·w2[d];  dw2[d] partial = Σ_e c_e·bank[e][d]
+        float s2 = 0.f;
+        for (int e = 0; e < em; ++e) {
+            float ap = 0.f, ab = 0.f;
+            if (e < E) {
+#pragma unroll
+                for (int q4 = 0; q4 < PTR_LTMAX / 4; ++q4) {
+                    if (4 * q4 < lt) {
+                        const float4 d4 = *reinterpret_cast<const float4*>(dscT + e * PTR_LTMAX + 4 * q4);
+                        ap += d4.x * dv[4 * q4] + d4.y * dv[4 * q4 + 1] + d4.z * dv[4 * q4 + 2] + d4.w * dv[4 * q4 + 3];
+                    }
+                }
+                const float c = ces[e];
+                ab = c * w2;
+                s2 += c * bj[(size_t)e * D + d];
+            }
+            dproj[((size_t)j * em + e) * D + d] = ap;
+            dbank[((size_t)j * em + e) * D + d] = ab;
+        }
+        wp[D + d] = s2;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ ptr_mix_loss
 struct MixArgs {
     const float* logits; const float* g; const float* pi; const int* labels; const int* row_c; const int* row_vid;
@@ -565,6 +765,41 @@ int svpc_ptr_attn_bwd(const float* dec, const float* proj, const float* bank, co
     hipLaunchKernelGGL(ptr_attn_bwd_kernel, dim3(T), dim3(nt), lds, s, dec, proj, bank, step_ne, pi, dpi, datt, ddec, dproj, dbank, lt,
                        e_max, D);
     return svpc_check_launch("ptr_attn_bwd");
+}
+
+// pointer attention + generation gate of every row, training form (see ptr_attn_gate_*_kernel): forward → pi (T·lt, e_max), pgen (T·lt);
+// backward ← dpi, dpgen → ddec, dproj, dbank and the per-step partial sums wpart (T, 2D+1) of [d pgen_w | d pgen_b]
+int svpc_ptr_attn_gate_fwd(const float* dec, const float* proj, const float* bank, const int* step_ne, float* pi, const float* pgen_w,
+                           const float* pgen_b, float* pgen, int T, int lt, int e_max, int D, hipStream_t s) {
+    if (T == 0) return 0;
+    SVPC_REQUIRE(e_max <= PTR_EMAX, "ptr_attn: at most 32 entities");
+    SVPC_REQUIRE(lt <= PTR_LTMAX, "ptr_attn: at most 32 tokens per sentence");
+    SVPC_REQUIRE(pgen_w && pgen_b && pgen, "ptr_attn_gate: gate weights missing");
+    SVPC_REQUIRE(D % 4 == 0 && ((((uintptr_t)dec) | ((uintptr_t)proj) | ((uintptr_t)bank)) & 15) == 0, "ptr_attn: rows must be 16-byte aligned");
+    const int nt = D >= 768 ? 768 : (D >= 512 ? 512 : 256);
+    const size_t lds = ((size_t)(lt + PTR_EC) * D + (size_t)lt * PTR_EMAX + (size_t)(nt / 64) * PTR_LTMAX) * sizeof(float);
+    SVPC_REQUIRE(lds <= 150 * 1024, "ptr_attn: sentence rows do not fit LDS");
+    int rc = ptr_set_lds((const void*)ptr_attn_gate_fwd_kernel);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ptr_attn_gate_fwd_kernel, dim3(T), dim3(nt), lds, s, dec, proj, bank, step_ne, pi, lt, e_max, D, pgen_w, pgen_b, pgen);
+    return svpc_check_launch("ptr_attn_gate_fwd");
+}
+int svpc_ptr_attn_gate_bwd(const float* dec, const float* proj, const float* bank, const int* step_ne, const float* pi, const float* dpi,
+                           const float* pgen, const float* dpgen, const float* pgen_w, float* ddec, float* dproj, float* dbank,
+                           float* wpart, int T, int lt, int e_max, int D, hipStream_t s) {
+    if (T == 0) return 0;
+    SVPC_REQUIRE(e_max <= PTR_EMAX, "ptr_attn: at most 32 entities");
+    SVPC_REQUIRE(lt <= PTR_LTMAX, "ptr_attn: at most 32 tokens per sentence");
+    SVPC_REQUIRE(D % 4 == 0 && ((((uintptr_t)pgen_w) | ((uintptr_t)proj) | ((uintptr_t)bank)) & 15) == 0, "ptr_attn: rows must be 16-byte aligned");
+    const size_t lds = ((size_t)(1 + PTR_EC) * D + (size_t)2 * lt * PTR_EMAX + (size_t)2 * PTR_EMAX * PTR_LTMAX + 2 * PTR_EMAX + PTR_LTMAX) *
+                       sizeof(float);
+    SVPC_REQUIRE(lds <= 150 * 1024, "ptr_attn: entity rows do not fit LDS");
+    int rc = ptr_set_lds((const void*)ptr_attn_gate_bwd_kernel);
+    if (rc) return rc;
+    const int nt = D >= 768 ? 768 : (D >= 512 ? 512 : 256);
+    hipLaunchKernelGGL(ptr_attn_gate_bwd_kernel, dim3(T), dim3(nt), lds, s, dec, proj, bank, step_ne, pi, dpi, pgen, dpgen, pgen_w, ddec, dproj,
+                       dbank, wpart, lt, e_max, D);
+    return svpc_check_launch("ptr_attn_gate_bwd");
 }
 int svpc_ptr_mix_loss_fwd(const float* logits, const float* g, const float* pi, const int* labels, const int* row_c,
                           const int* row_vid, const int* csr_off, const int* csr_ent, const int* csr_id, const float* csr_w, float* P,

@@ -191,6 +191,16 @@ def ptr_attn(dec, proj, bank, step_ne, lt):
     return pi.reshape(T * lt, e_max), att.reshape(T * lt, D)
 
 
+def cross_attn_ln_usable(*a, **k):
+    return False          # (the fused decoder cross-attention is a GPU kernel pair: the emulated model takes the unfused path)
+
+
+def ptr_attn_gate(dec, proj, bank, step_ne, lt, w, b):
+    """pointer attention + generation gate (model.py:899-908): (pi, sigmoid([dec ; att]·wᵀ + b))"""
+    pi, att = ptr_attn(dec, proj, bank, step_ne, lt)
+    return pi, torch.sigmoid(torch.cat([dec, att], 1) @ w.t() + b)
+
+
 def ptr_attn_pgen(dec, proj, bank, step_ne, w, b):
     return None          # (decoding-iteration fusion: GPU only; the callers fall back to ptr_attn + linear)
 

@@ -101,7 +101,7 @@ def test_eviction_recapture_and_training_mode_dropout(golden_dir):
             cg.max_entries = dg.max_entries = 2
             losses = [run(k) for k in range(12)]          # 4 clip counts through 2 entries: every step after the first pass recaptures
             torch.cuda.synchronize()
-        assert all(l == l and abs(l) < 1e9 for l in losses), losses
+        assert all(l == l and abs(l) < 1e9 for l in losses), "losses: %r" % (losses,)
         assert len(cg.entries) == 2 and len(dg.entries) == 2
         assert cg.stats["captures"] >= 8 and dg.stats["captures"] >= 8, (cg.stats, dg.stats)
         cg.max_entries = dg.max_entries = 8

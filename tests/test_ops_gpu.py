@@ -256,6 +256,89 @@ def test_ptr_attn_entity_chunks_and_full_width():
                 name="ptr_attn wide")
 
 
+@pytest.mark.parametrize("T,lt,nm,D,H,kind,p", [(5, 22, 3, 768, 12, "f32", 0.0), (5, 22, 3, 768, 12, "x3", 0.1), (3, 22, 2, 768, 12, "bf16", 0.0),
+                                                (4, 6, 3, 128, 4, "f32", 0.1), (2, 22, 1, 768, 12, "x3", 0.0), (3, 9, 3, 256, 4, "x3", 0.1)])
+def test_cross_attn_ln_fused_vs_projection_attention_layernorm(T, lt, nm, D, H, kind, p):
+    """ops.cross_u + ops.cross_attn_ln (the decoder's cross-attention with the query projection folded into the keys, residual and LayerNorm
+    in the same launch, round 5) against the plain statement of reference model.py:657-658: q = x1·Wqᵀ + bq, softmax(q·kᵀ/√dh)·v over the
+    sentence's n_mem memory rows, LayerNorm(x1 + ·) — outputs and the gradients of x1, [K | V], Wq, bq, gamma, beta; split / bf16 / fp32 rows,
+    with and without dropout of the probabilities (same counter-based draw on both sides)."""
+    import math
+    dh = D // H
+    Rm, R = T * nm, T * lt
+    x1 = rnd(R, D, seed=1)
+    kv = rnd(Rm, 2 * D, seed=2, scale=0.7)
+    wq = rnd(D, D, seed=3, scale=1.0 / math.sqrt(D))
+    bq, gamma, beta = rnd(D, seed=4, scale=0.1), (1.0 + 0.1 * rnd(D, seed=5, grad=False)).requires_grad_(True), rnd(D, seed=6, scale=0.1)
+    rng = O.make_rng(DEV)
+    site = 7
+    drop = (p, rng, site) if p > 0 else None
+    gout = torch.randn(R, D, generator=torch.Generator().manual_seed(9)).to(DEV)
+    O.set_precision("bf16" if kind == "bf16" else "bf16x3")
+    try:
+        if kind == "x3":
+            xin = O.to_split(x1)
+        elif kind == "bf16":
+            xin = x1.to(torch.bfloat16)
+        else:
+            xin = x1
+        assert O.cross_attn_ln_usable(D, H, lt, nm)
+        us = O.cross_u([kv], [wq], H)
+        y = O.cross_attn_ln(xin, us[0], kv, bq, gamma, beta, 1e-12, H, lt, nm, drop=drop)
+        yf = O.to_f32(y)
+        (yf * gout).sum().backward()
+        got = [t.grad.clone() for t in (x1, kv, wq, bq, gamma, beta)]
+        for t in (x1, kv, wq, bq, gamma, beta):
+            t.grad = None
+    finally:
+        O.set_precision("fp32")
+    # reference in fp32 torch
+    xr = (x1.detach().to(torch.bfloat16).float() if kind == "bf16" else x1.detach()).requires_grad_(True)
+    q = (xr @ wq.t() + bq).view(T, lt, H, dh)
+    k = kv[:, :D].view(T, nm, H, dh)
+    v = kv[:, D:].view(T, nm, H, dh)
+    sc = torch.einsum("sthc,sjhc->shtj", q, k) / math.sqrt(dh)
+    pr = torch.softmax(sc, -1)
+    if p > 0:
+        mask = rng.attn_mask(site, T * H * lt, nm, p, DEV).view(T, H, lt, nm)
+        pr = pr * mask / (1.0 - p)
+    o = torch.einsum("shtj,sjhc->sthc", pr, v).reshape(R, D)
+    ref = torch.nn.functional.layer_norm(xr + o, (D,), gamma, beta, 1e-12)
+    (ref * gout).sum().backward()
+    want = [xr.grad, kv.grad, wq.grad, bq.grad, gamma.grad, beta.grad]
+    tol = 4e-2 if kind == "bf16" else 2e-4
+    assert float((yf.detach() - ref.detach()).abs().max()) <= tol * max(1.0, float(ref.abs().max())), float((yf - ref).abs().max())
+    gtol = 5e-2 if kind == "bf16" else 2e-2          # (the backward contractions are one-term bf16 products in every fast mode)
+    for name, g, w in zip(("x1", "kv", "wq", "bq", "gamma", "beta"), got, want):
+        err = float((g.float() - w).abs().max())
+        assert err <= gtol * float(w.abs().max()) + 1e-5, (name, err, float(w.abs().max()))
+
+
+@pytest.mark.parametrize("T,lt,em,D,ne", [(3, 22, 20, 768, [20, 17, 3]), (5, 6, 4, 64, [3, 3, 4, 2, 2]), (4, 1, 5, 128, [5, 1, 4, 2]),
+                                          (2, 22, 31, 768, [31, 1]), (3, 7, 6, 200, [6, 2, 5])])
+def test_ptr_attn_gate_forward_backward(T, lt, em, D, ne):
+    """pointer attention + generation gate in one launch (training form, round 5) against ptr_attn → cat → linear → sigmoid: both outputs
+    and the gradients of dec, proj, bank, the gate weight and bias — through autograd and through arena-style direct gradients"""
+    step_ne = Idx(ne)
+    dec, proj, bank = rnd(T * lt, D, seed=1, scale=0.2), rnd(T, em, D, seed=2, scale=0.2), rnd(T, em, D, seed=3)
+    w, b = rnd(1, 2 * D, seed=4, scale=0.1), rnd(1, seed=5)
+    compare(lambda d, p, bk, w_, b_: O.ptr_attn_gate(d, p, bk, step_ne, lt, w_, b_), lambda d, p, bk, w_, b_: E.ptr_attn_gate(d, p, bk, step_ne, lt, w_, b_),
+            [dec, proj, bank, w, b], grad_rtol=1e-3, grad_atol=1e-4, name="ptr_attn_gate")
+    # direct (arena-style) gate gradients through the deferred finalizer: accumulate onto what is already there
+    wl, bl = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    wl.grad, bl.grad = torch.full_like(wl, 0.5), torch.full_like(bl, -0.25)
+    wl._svpc_direct = bl._svpc_direct = True
+    pi, g = O.ptr_attn_gate(dec.detach(), proj.detach(), bank.detach(), step_ne, lt, wl, bl)
+    gw = torch.randn(g.shape, generator=torch.Generator().manual_seed(3)).to(DEV)
+    (g * gw).sum().backward()
+    O.join_side()
+    wr, br = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    _, gr = E.ptr_attn_gate(dec.detach(), proj.detach(), bank.detach(), step_ne, lt, wr, br)
+    (gr * gw).sum().backward()
+    assert float((wl.grad - 0.5 - wr.grad).abs().max()) <= 1e-4 + 1e-3 * float(wr.grad.abs().max())
+    assert float((bl.grad + 0.25 - br.grad).abs().max()) <= 1e-4 + 1e-3 * float(br.grad.abs().max())
+
+
 def test_ptr_attn_and_mix_loss_and_gumbel():
     T, lt, em, D, V = 5, 6, 4, 64, 50
     step_ne = Idx([3, 3, 4, 2, 2])
@@ -279,6 +362,9 @@ def test_ptr_attn_and_mix_loss_and_gumbel():
     def mk(mod):
         return lambda logits, g, pi: mod.ptr_mix_loss(logits, g, pi, labels, row_c, row_vid, csr_off, csr_ent, csr_id, csr_w, c_max, 0.1)
     compare(mk(O), mk(E), [logits, g, pi], grad_rtol=1e-3, name="ptr_mix_loss")
+    # label_smoothing == 0: cross-entropy of the probabilities, a mean per video (reference model.py:869-870)
+    mk0 = lambda mod: (lambda logits, g, pi: mod.ptr_mix_loss(logits, g, pi, labels, row_c, row_vid, csr_off, csr_ent, csr_id, csr_w, c_max, 0.0))
+    compare(mk0(O), mk0(E), [logits, g, pi], grad_rtol=1e-3, name="ptr_mix_loss (cross-entropy branch)")
     # MODEL_TYPE=v: plain softmax + loss
     empty = Idx([])
     mkv = lambda mod: (lambda logits: mod.ptr_mix_loss(logits, None, None, labels.clamp(max=V - 1), Idx([V] * R), row_vid, Idx([0, 0, 0, 0]),
