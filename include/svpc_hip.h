@@ -287,20 +287,21 @@ int svpc_sim_recur_bwd(const float* q, const float* c, const float* w4f, const f
 
 /* ---- decoder cross-attention over the <= 3 memory rows of a sentence + residual LayerNorm, one launch forward and one backward per
  * layer: src/rtransformer/model.py:657-658 (BertDecoderLayerNoMemoryUntied.forward), attention core :194-219, BertLayerNorm :143-156.
- * The query projection is folded into the keys per head, U[j,h] = Wq_h^T k[j,h] (a small grouped GEMM over the memory rows, done by the
- * caller): scores = (x1·U + <bq_h, k>)/sqrt(dh).  x_dt / y_dt: 0 fp32, 1 bf16, 2 split (two bf16 planes, the lo plane lox / loy columns
- * behind); probs (T·lt, H, 4), mean / rstd (T·lt) are saved for the backward.  Backward returns dx1 (dense), dU, the layer's [dK | dV]
- * block (dV complete, dK = the bias part: the caller's grouped GEMM adds Wq_h·dU[j,h]) and per-sentence partial sums of
- * [dgamma | dbeta] (T, 2D) and d bq (T, D) for svpc_multi_finalize. */
+ *   y = LayerNorm(x1 + MHA(query rows q; keys / values = the sentence's nm memory rows))
+ * q, x1: T·lt rows; k, v: T·nm rows (the layer's key / value column blocks of the memory projection).  dt codes: 0 fp32, 1 bf16, 2 split (two
+ * bf16 planes, the lo plane lo* columns behind).  probs (T·lt, H, 4), mean / rstd (T·lt) are saved for the backward, which returns the
+ * gradients of the query rows and of the residual rows (dense, dg_dt), of the key / value rows (dense, dkv_dt, row stride ld_dkv) and the
+ * per-sentence partial sums of [dgamma | dbeta] (T, 2D) for svpc_multi_finalize. */
 int svpc_cross_attn_ln_supported(int D, int H, int lt, int nm);
-int svpc_cross_attn_ln_fwd(const void* x1, int x_dt, int ldx, int lox, const float* U, const float* kv, int ld_kv, const float* bq,
-                           const float* gamma, const float* beta, float eps, void* y, int y_dt, int ldy, int loy, float* probs, float* mean,
-                           float* rstd, int T, int lt, int nm, int D, int H, float scale, float p_drop, unsigned site, const svpc_u64* seed,
-                           svpc_stream_t stream);
-int svpc_cross_attn_ln_bwd(const void* x1, int x_dt, int ldx, int lox, const float* U, const float* kv, int ld_kv, const float* bq,
-                           const float* gamma, const float* probs, const float* mean, const float* rstd, const void* dy, int dy_dt,
-                           int lddy, void* dx1, int dx_dt, int lddx, float* dU, float* dkv, int ld_dkv, float* part_ln, float* part_bq, int T,
-                           int lt, int nm, int D, int H, float scale, float p_drop, unsigned site, const svpc_u64* seed, svpc_stream_t stream);
+int svpc_cross_attn_ln_fwd(const void* q, int q_dt, int ldq, int loq, const void* x1, int x_dt, int ldx, int lox, const void* k, const void* v,
+                           int kv_dt, int ld_kv, int lokv, const float* gamma, const float* beta, float eps, void* y, int y_dt, int ldy, int loy,
+                           float* probs, float* mean, float* rstd, int T, int lt, int nm, int D, int H, float scale, float p_drop, unsigned site,
+                           const svpc_u64* seed, svpc_stream_t stream);
+int svpc_cross_attn_ln_bwd(const void* q, int q_dt, int ldq, int loq, const void* x1, int x_dt, int ldx, int lox, const void* k, const void* v,
+                           int kv_dt, int ld_kv, int lokv, const float* gamma, const float* probs, const float* mean, const float* rstd,
+                           const void* dy, int dy_dt, int lddy, void* dq, void* dres, int dg_dt, int lddg, void* dk, void* dv, int dkv_dt,
+                           int ld_dkv, float* part_ln, int T, int lt, int nm, int D, int H, float scale, float p_drop, unsigned site,
+                           const svpc_u64* seed, svpc_stream_t stream);
 
 /* ---- pointer-generator + caption loss: model.py:896-923, :37-55 */
 int svpc_ptr_attn_fwd(const float* dec, const float* proj, const float* bank, const int* step_ne, float* pi, float* att, int T,

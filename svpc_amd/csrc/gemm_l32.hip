@@ -701,8 +701,6 @@ int svpc_gemm_l32_preferred(int a_kc, int b_kc, int lda, int ldb, int M, int N, 
     static int env_w = -1;
     if (env_w < 0) { const char* e = getenv("SVPC_L32_WAVESPLIT"); env_w = e ? atoi(e) : 1; }
     if (K % L32_BK != 0) return (t128 <= 300) ? 1 : 0;                         // k tail: the tiled form only
-    if (K >= 4096 && t64 <= 256) return 0;      // a very long reduction on few tiles (the stacked memory projection's dgrad, K = L·2D = 9,216
-                                                // at 576 rows): one workgroup per tile would stream megabytes through one CU — split-K slabs
     if (env_w && t64 <= 256 && K >= 4 * L32_BK && t64 * 4 >= 32) return 1;      // wave-split-K form, any K
     return (t128 <= 300 && K < 2048) ? 1 : 0;
 }

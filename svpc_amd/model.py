@@ -279,10 +279,8 @@ class BertDecoderLayerNoMemoryUntied(nn.Module):
         self.norm2 = BertLayerNorm(config.hidden_size, eps=config.layer_norm_eps)
         self.output = BertOutput(config)
 
-    def run(self, x, text_mask, mem, seq_self, seq_cross, mem_mask, cx, kvc=None, u=None):
-        """``kvc``: this layer's K|V rows of the memory when the stack has projected them for all layers at once.  ``u``: the layer's
-        folded keys U[j, h] = Wq_hᵀ·k[j, h] (ops.cross_u): cross-attention + residual + LayerNorm then run as ONE launch, forward and
-        backward, and the (T·Lt, D) query projection is never formed (svpc_amd/csrc/cross_attn.hip)."""
+    def run(self, x, text_mask, mem, seq_self, seq_cross, mem_mask, cx, kvc=None):
+        """``kvc``: this layer's K|V rows of the memory when the stack has projected them for all layers at once."""
         D = x.shape[1]
         w, b, wg, bg, w16 = self.self_attention.packed()
         qkv = ops.linear(x, w, b, wgrad=wg, bgrad=bg, w16=w16)
@@ -290,21 +288,24 @@ class BertDecoderLayerNoMemoryUntied(nn.Module):
                            drop=cx.drop(cx.p_a))
         x1 = ops.layernorm(sa, self.norm1.weight, self.norm1.bias, cx.eps, residual=x, sink=True)
         ca_m = self.dec_enc_attention
-        if u is not None:
-            n_seq = seq_self.n
-            x2 = ops.cross_attn_ln(x1, u, kvc, ca_m.query.bias, self.norm2.weight, self.norm2.bias, cx.eps, cx.H, x1.shape[0] // n_seq,
-                                   kvc.shape[0] // n_seq, drop=cx.drop(cx.p_a))
-            o = ops.linear(x2, self.output.dense.weight, self.output.dense.bias)
-            return ops.layernorm(o, self.output.LayerNorm.weight, self.output.LayerNorm.bias, cx.eps,
-                                 residual=x2, pre_drop=cx.drop(cx.p_h), sink=True)
         qc = ops.linear(x1, ca_m.query.weight, ca_m.query.bias)
         if kvc is None:
             wkv, bkv, wg, bg, w16 = ca_m.packed("kv")
             kvc = ops.linear(mem, wkv, bkv, wgrad=wg, bgrad=bg, w16=w16)
         if kvc.dtype != qc.dtype:          # (memory rows handed over in another storage type than the sentence stream)
             kvc = kvc.to(qc.dtype)
-        ca = ops.attention(qc, kvc, (0, 0, D), D, cx.H, seq_cross, key_mask=mem_mask, causal=False, drop=cx.drop(cx.p_a))
-        x2 = ops.layernorm(ca, self.norm2.weight, self.norm2.bias, cx.eps, residual=x1, sink=True)
+        n_seq = seq_cross.n
+        lt = x1.shape[0] // max(n_seq, 1)
+        if (n_seq > 0 and x1.shape[0] == n_seq * seq_cross.max_q and kvc.shape[0] == n_seq * seq_cross.max_k and x1.is_cuda
+                and (ops.lo_off(qc) is None) == (ops.lo_off(kvc) is None) and (ops.lo_off(qc) is None) == (ops.lo_off(x1) is None)
+                and qc.dtype == x1.dtype and ops.cross_attn_ln_usable(D, cx.H, lt, seq_cross.max_k, mem_mask)):
+            # uniform sentences over ≤ 3 memory rows each: attention + residual + LayerNorm in one launch, forward and backward
+            # (svpc_amd/csrc/cross_attn.hip)
+            x2 = ops.cross_attn_ln(qc, x1, kvc, self.norm2.weight, self.norm2.bias, cx.eps, cx.H, lt, seq_cross.max_k,
+                                   drop=cx.drop(cx.p_a), sink=True)
+        else:
+            ca = ops.attention(qc, kvc, (0, 0, D), D, cx.H, seq_cross, key_mask=mem_mask, causal=False, drop=cx.drop(cx.p_a))
+            x2 = ops.layernorm(ca, self.norm2.weight, self.norm2.bias, cx.eps, residual=x1, sink=True)
         o = ops.linear(x2, self.output.dense.weight, self.output.dense.bias)
         return ops.layernorm(o, self.output.LayerNorm.weight, self.output.LayerNorm.bias, cx.eps,
                              residual=x2, pre_drop=cx.drop(cx.p_h), sink=True)
@@ -372,53 +373,24 @@ class BertDecoderNoMemoryUntied(nn.Module):
         x3 = ops.is_x3()
         ops.require_split_tag(x, "decoder.run")
         ops.require_split_tag(mem, "decoder.run (memory)")
-        mem0 = mem
-        fused_cross = self._fused_cross_ok(x, mem0, mem_mask, seq_self)
         if stream_bf16:
             if x.dtype != torch.bfloat16:      # (the caller may have had the embedding LayerNorm write bf16 / split rows already)
                 x = ops.to_split(x) if x3 else x.to(torch.bfloat16)
             # the memory rows join the stream once, not per layer: each layer's K|V projection then reads bf16 and writes bf16
             # (one cast instead of six casts forward and six backward; its weight gradients join the grouped bf16 launch)
-            if not fused_cross and mem.dtype == torch.float32 and ops.bf16_stream_ok(mem.shape[0], mem.shape[1], 2 * mem.shape[1]):
+            if mem.dtype == torch.float32 and ops.bf16_stream_ok(mem.shape[0], mem.shape[1], 2 * mem.shape[1]):
                 mem = ops.to_split(mem) if x3 else mem.to(torch.bfloat16)
         # Every layer projects the SAME memory rows to its keys and values (reference model.py:643-651): one (R, D) x (D, L·2D)
         # projection for the stack instead of L, each layer reads its 2D columns in place; backward likewise gathers the L
         # key / value gradients in one buffer and runs one dgrad (contraction L·2D) and one wgrad.
         kvs = [None] * len(self.layer)
-        us = [None] * len(self.layer)
-        if fused_cross:
-            # cross-attention over the ≤ 3 memory rows folded into the keys (ops.cross_u / ops.cross_attn_ln): the memory rows stay fp32,
-            # ONE fp32 projection gives every layer's [K | V], one grouped GEMM every layer's U
-            w, b, wg, bg, _ = self.stacked_memory_kv()
-            kvs = ops.split_cols(ops.linear(mem0, w, b, wgrad=wg, bgrad=bg), len(self.layer))
-            us = ops.cross_u(kvs, [l.dec_enc_attention.query.weight for l in self.layer], cx.H)
-        else:
-            st = self.stacked_memory_kv() if mem.dtype == x.dtype else None
-            if st is not None:
-                w, b, wg, bg, w16 = st
-                kvs = ops.split_cols(ops.linear(mem, w, b, wgrad=wg, bgrad=bg, w16=w16), len(self.layer))
-        for layer, kvc, u in zip(self.layer, kvs, us):
-            x = layer.run(x, text_mask, mem, seq_self, seq_cross, mem_mask, cx, kvc=kvc, u=u)
+        st = self.stacked_memory_kv() if mem.dtype == x.dtype else None
+        if st is not None:
+            w, b, wg, bg, w16 = st
+            kvs = ops.split_cols(ops.linear(mem, w, b, wgrad=wg, bgrad=bg, w16=w16), len(self.layer))
+        for layer, kvc in zip(self.layer, kvs):
+            x = layer.run(x, text_mask, mem, seq_self, seq_cross, mem_mask, cx, kvc=kvc)
         return ops.to_f32(x) if stream_bf16 else x
-
-    def _fused_cross_ok(self, x, mem, mem_mask, seq_self):
-        """whether ``run`` takes the fused cross-attention path: shape taken by the kernels, fp32 memory rows, the stack's key / value
-        projections contiguous in a weight store, and — when gradients are wanted — every parameter the path differentiates writing
-        straight into the optimizer's arena (Wq through the grouped weight gradient, bq / LayerNorm through the finalizer)"""
-        T = seq_self.n
-        if T <= 0 or mem.dtype != torch.float32 or x.shape[0] != T * seq_self.max_q or mem.shape[0] % T:      # (uniform sentences only)
-            return False
-        cfg = self.config
-        if not ops.cross_attn_ln_usable(x.shape[1], cfg.num_attention_heads, x.shape[0] // T, mem.shape[0] // T, mem_mask):
-            return False
-        if self.stacked_memory_kv() is None:
-            return False
-        if torch.is_grad_enabled() and (x.requires_grad or mem.requires_grad):
-            for l in self.layer:
-                ps = (l.dec_enc_attention.query.weight, l.dec_enc_attention.query.bias, l.norm2.weight, l.norm2.bias)
-                if any(p.requires_grad and ops._direct(p) is None for p in ps):
-                    return False
-        return True
 
     def forward(self, dec_hidden_states, dec_mask, enc_outputs, enc_mask, diagonal_mask=True,
                 output_all_encoded_layers=False):

@@ -1389,190 +1389,99 @@ class _ToSplit(Function):
 
 # ------------------------------------------------------------------------------------------------ decoder cross-attention, fused
 # Cross-attention of every sentence row to the ≤ 3 memory rows of its sentence + residual + LayerNorm in ONE launch, forward and backward
-# (svpc_amd/csrc/cross_attn.hip; reference model.py:657-658 in :630-663).  The query projection is folded into the keys per head:
-# U[j, h] = Wq_hᵀ·k[j, h] — ``cross_u`` computes it for ALL decoder layers with grouped GEMMs over the memory rows (T·n_mem rows instead of
-# T·Lt) and, in backward, turns the dU the row kernels return into dWq (a grouped weight gradient over the memory rows) and dK.
+# (svpc_amd/csrc/cross_attn.hip; reference model.py:657-658 in :630-663; SURVEY §2.3 K6 "trivial; fuse").
 USE_XATTN = os.environ.get("SVPC_NO_XATTN", "") == ""
 
 
 def cross_attn_ln_usable(D, H, lt, nm, mem_mask=None):
-    return (USE_XATTN and _fast() and mem_mask is None and H > 0 and D % H == 0
+    return (USE_XATTN and mem_mask is None and H > 0 and D % H == 0
             and _lib.load().svpc_cross_attn_ln_supported(int(D), int(H), int(lt), int(nm)) == 1)
 
 
-def _group_gemm(probs_list, a_kc, b_kc, accumulate, x3):
-    """probs_list: [(A_ptr, B_ptr, C_ptr, M, N, K, lda, ldb, ldc)] → grouped launches of ≤ 32 problems"""
-    st = _stream()
-    for k in range(0, len(probs_list), 32):
-        part = probs_list[k:k + 32]
-        arr = (_GemmProblem * len(part))()
-        for i, q in enumerate(part):
-            arr[i] = _GemmProblem(*q)
-        _lib.call("gemm_group_x3" if x3 else "gemm_group", ctypes.addressof(arr), len(part), a_kc, b_kc, accumulate, st)
-
-
-class _CrossU(Function):
-    """(kv block of layer 0 … L-1, Wq of layer 0 … L-1) → U of every layer, (T·nm, H, D) each (views of ONE (L, T·nm, H, D) buffer).
-    Backward: dWq_l[h·dh:(h+1)·dh, :] += k_l[:, head h]ᵀ · dU_l[:, h, :] (grouped weight gradient, K = T·nm rows) into the optimizer's
-    arena, and dk_l[:, head h] += dU_l[:, h, :] · Wq_l[head h rows]ᵀ accumulated INTO the gradient block of the memory projection that
-    the row kernels have already written (``_svpc_grad_into`` of the kv block: no autograd add, no copy)."""
-
-    @staticmethod
-    def forward(ctx, L, H, dU_all, *tensors):
-        kvs, wqs = tensors[:L], tensors[L:2 * L]
-        Rm = kvs[0].shape[0]
-        D = wqs[0].shape[1]
-        dh = D // H
-        dev = kvs[0].device
-        U = torch.empty(L, Rm, H, D, dtype=torch.float32, device=dev)
-        probs = []
-        for l in range(L):
-            kv, wq = kvs[l], wqs[l]
-            for h in range(H):
-                probs.append((kv.data_ptr() + 4 * h * dh, wq.data_ptr() + 4 * h * dh * D, U[l].data_ptr() + 4 * h * D, Rm, D, dh,
-                              kv.stride(0), D, H * D))
-        _group_gemm(probs, 1, 0, 0, is_x3())
-        ctx.save_for_backward(*kvs, *wqs)
-        ctx.cfg = (L, H, D, dh, Rm)
-        ctx.dU_all = dU_all
-        ctx.into = [getattr(kv, "_svpc_grad_into", None) for kv in kvs]
-        ctx.direct = [_direct(w) for w in wqs]
-        return tuple(U[l] for l in range(L))
-
-    @staticmethod
-    def backward(ctx, *grads):
-        saved = ctx.saved_tensors
-        L, H, D, dh, Rm = ctx.cfg
-        kvs, wqs = saved[:L], saved[L:]
-        dU_all = ctx.dU_all
-        for l, g in enumerate(grads):              # (the row kernels wrote their dU straight into dU_all[l] and returned that view)
-            if g is None:
-                dU_all[l].zero_()
-            elif g.data_ptr() != dU_all[l].data_ptr():
-                dU_all[l].copy_(g)
-        # dK: accumulate onto the bias part the row kernels stored in the memory projection's gradient block
-        probs, dkv_out = [], []
-        for l in range(L):
-            into = ctx.into[l]
-            if into is None:            # (no shared gradient buffer: op-level tests) a dense [dK | dV]-shaped gradient of our own, dK part only
-                into = torch.zeros(Rm, 2 * D, dtype=torch.float32, device=dU_all.device)
-                dkv_out.append(into)
-            else:
-                dkv_out.append(None)
-            for h in range(H):
-                probs.append((dU_all[l].data_ptr() + 4 * h * D, wqs[l].data_ptr() + 4 * h * dh * D, into.data_ptr() + 4 * h * dh, Rm, dh, D,
-                              H * D, D, into.stride(0)))
-        _group_gemm(probs, 1, 1, 1, False)
-        # dWq: grouped weight gradients over the memory rows
-        dws = []
-        wp = []
-        for l in range(L):
-            wg = ctx.direct[l]
-            if wg is None:
-                wg = torch.zeros_like(wqs[l])
-                dws.append(wg)
-            else:
-                dws.append(None)
-            for h in range(H):
-                wp.append((kvs[l].data_ptr() + 4 * h * dh, dU_all[l].data_ptr() + 4 * h * D, wg.data_ptr() + 4 * h * dh * D, None, dh, D, Rm,
-                           kvs[l].stride(0), H * D, D))
-        mx = _lib.load().svpc_gemm_group_wgrad_max()
-        for k in range(0, len(wp), mx):
-            part = wp[k:k + mx]
-            arr = (_WgradProblem * len(part))()
-            for i, q in enumerate(part):
-                arr[i] = _WgradProblem(*q)
-            _lib.call("gemm_group_wgrad", ctypes.addressof(arr), len(part), _stream())
-        # (no ops._ready here: Wq is an autograd input of this node, so its post-accumulate hook — which fires when this backward returns —
-        # is the data-parallel reducer's signal that the write above has been enqueued; a pointer report as well would count twice)
-        ctx.dU_all = None
-        return (None, None, None) + tuple(dkv_out) + tuple(dws)
-
-
-def cross_u(kvs, wqs, n_heads):
-    """kvs: the L [K | V] blocks (T·nm, 2D) fp32 of the stacked memory projection; wqs: the L cross-attention query weights (D, D)
-    → list of L tensors U_l (T·nm, H, D); U_l carries ``_svpc_grad_into`` (where the fused row kernel's backward writes dU_l)."""
-    L = len(kvs)
-    Rm, D = kvs[0].shape[0], wqs[0].shape[1]
-    need = torch.is_grad_enabled() and any(t.requires_grad for t in list(kvs) + list(wqs))
-    dU_all = torch.empty(L, Rm, n_heads, D, dtype=torch.float32, device=kvs[0].device) if need else None
-    outs = _CrossU.apply(L, n_heads, dU_all, *kvs, *wqs)
-    if need:
-        for l, o in enumerate(outs):
-            o._svpc_grad_into = dU_all[l]
-    return list(outs)
+def _kind(t):
+    """storage code of the C-ABI: 0 fp32, 1 bf16, 2 split"""
+    return 2 if lo_off(t) is not None else _dt(t)
 
 
 class _CrossAttnLn(Function):
     @staticmethod
-    def forward(ctx, x1, U, kv, bq, gamma, beta, eps, H, lt, nm, drop, out_kind):
-        _need_gpu(x1)
-        x_lo = lo_off(x1)
-        T = U.shape[0] // nm
+    def forward(ctx, q, x1, kv, gamma, beta, eps, H, lt, nm, drop, sink):
+        _need_gpu(q)
         D = gamma.shape[0]
-        R = T * lt
-        dev = x1.device
-        x_dt = 2 if x_lo is not None else _dt(x1)
+        R = q.shape[0]
+        T = R // lt
+        dev = q.device
+        out_kind = _kind(x1)
         if out_kind == 2:
             y = new_split(R, D, dev)
             loy = y._svpc_lo
         else:
-            y = torch.empty(R, D, dtype=torch.bfloat16 if out_kind == 1 else torch.float32, device=dev)
+            y = torch.empty(R, D, dtype=x1.dtype, device=dev)
             loy = 0
         probs = torch.empty(R, H, 4, dtype=torch.float32, device=dev)
         mean = torch.empty(R, dtype=torch.float32, device=dev)
         rstd = torch.empty(R, dtype=torch.float32, device=dev)
         p, site, seed = _drop_args(drop)
         scale = 1.0 / math.sqrt(D // H)
-        _lib.call("cross_attn_ln_fwd", _p(x1), x_dt, x1.stride(0), x_lo or 0, _p(U), _p(kv), kv.stride(0), _p(bq), _p(gamma), _p(beta), float(eps),
+        es = kv.element_size()
+        _lib.call("cross_attn_ln_fwd", _p(q), _kind(q), q.stride(0), lo_off(q) or 0, _p(x1), out_kind, x1.stride(0), lo_off(x1) or 0,
+                  kv.data_ptr(), kv.data_ptr() + D * es, _kind(kv), kv.stride(0), lo_off(kv) or 0, _p(gamma), _p(beta), float(eps),
                   _p(y), out_kind, y.stride(0), loy, _p(probs), _p(mean), _p(rstd), T, lt, nm, D, H, scale, p, site, _p(seed), _stream())
-        ctx.save_for_backward(x1, U, kv, bq, gamma, probs, mean, rstd, seed)
-        ctx.cfg = (T, lt, nm, D, H, scale, p, site, x_dt, x_lo or 0)
-        ctx.into = (getattr(U, "_svpc_grad_into", None), getattr(kv, "_svpc_grad_into", None))
-        ctx.direct = (_direct(bq), _direct(gamma), _direct(beta))
+        ctx.save_for_backward(q, x1, kv, gamma, probs, mean, rstd, seed)
+        ctx.cfg = (T, lt, nm, D, H, scale, p, site, _kind(q), lo_off(q) or 0, out_kind, lo_off(x1) or 0, _kind(kv), lo_off(kv) or 0)
+        ctx.kv_into = getattr(kv, "_svpc_grad_into", None)
+        ctx.direct = (_direct(gamma), _direct(beta))
+        ctx.sink = bool(sink)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x1, U, kv, bq, gamma, probs, mean, rstd, seed = ctx.saved_tensors
-        T, lt, nm, D, H, scale, p, site, x_dt, x_lo = ctx.cfg
+        q, x1, kv, gamma, probs, mean, rstd, seed = ctx.saved_tensors
+        T, lt, nm, D, H, scale, p, site, q_dt, q_lo, x_dt, x_lo, kv_dt, kv_lo = ctx.cfg
         dev = dy.device
         dy = _c(dy)
         R = T * lt
-        dx1 = torch.empty(R, D, dtype=dy.dtype, device=dev)
-        u_into, kv_into = ctx.into
-        dU = u_into if u_into is not None else torch.empty_like(U)
-        dkv = kv_into if (kv_into is not None and kv_into.shape == kv.shape) else torch.empty(kv.shape, dtype=torch.float32, device=dev)
+        dq = torch.empty(R, D, dtype=dy.dtype, device=dev)
+        dres = torch.empty(R, D, dtype=dy.dtype, device=dev)
+        into = ctx.kv_into
+        if into is not None and into.shape == kv.shape and into.dtype == kv.dtype:
+            dkv = into                                 # the layer's block of the stacked projection's gradient buffer: written in place
+        else:
+            dkv = torch.empty(kv.shape, dtype=kv.dtype, device=dev)
         part_ln = torch.empty(T, 2 * D, dtype=torch.float32, device=dev)
-        part_bq = torch.empty(T, D, dtype=torch.float32, device=dev)
-        _lib.call("cross_attn_ln_bwd", _p(x1), x_dt, x1.stride(0), x_lo, _p(U), _p(kv), kv.stride(0), _p(bq), _p(gamma), _p(probs), _p(mean),
-                  _p(rstd), _p(dy), _dt(dy), dy.stride(0), _p(dx1), _dt(dx1), dx1.stride(0), _p(dU), _p(dkv), dkv.stride(0), _p(part_ln),
-                  _p(part_bq), T, lt, nm, D, H, scale, p, site, _p(seed), _stream())
-        bq_d, g_d, b_d = ctx.direct
-        dbq = dgamma = dbeta = None
-        if bq_d is not None and g_d is not None and b_d is not None and USE_MULTI_FINALIZE and not SIDE_WGRAD:
+        es = dkv.element_size()
+        _lib.call("cross_attn_ln_bwd", _p(q), q_dt, q.stride(0), q_lo, _p(x1), x_dt, x1.stride(0), x_lo, kv.data_ptr(),
+                  kv.data_ptr() + D * kv.element_size(), kv_dt, kv.stride(0), kv_lo, _p(gamma), _p(probs), _p(mean), _p(rstd), _p(dy), _dt(dy),
+                  dy.stride(0), _p(dq), _p(dres), _dt(dq), dq.stride(0), dkv.data_ptr(), dkv.data_ptr() + D * es, _dt(dkv), dkv.stride(0),
+                  _p(part_ln), T, lt, nm, D, H, scale, p, site, _p(seed), _stream())
+        g_d, b_d = ctx.direct
+        dgamma = dbeta = None
+        if g_d is not None and b_d is not None and USE_MULTI_FINALIZE and not SIDE_WGRAD:
             defer_finalize(part_ln, T, 2 * D, g_d, b_d, D)
-            defer_finalize(part_bq, T, D, bq_d)
         else:
             sl = _colsum(part_ln).view(-1)
             dgamma, dbeta = sl[:D].clone(), sl[D:].clone()
-            dbq = _colsum(part_bq).view(-1)
-            for tgt, val in ((g_d, dgamma), (b_d, dbeta), (bq_d, dbq)):
-                if tgt is not None:
-                    tgt.add_(val)
-            dgamma = None if g_d is not None else dgamma
-            dbeta = None if b_d is not None else dbeta
-            dbq = None if bq_d is not None else dbq
-        return dx1, dU, dkv, dbq, dgamma, dbeta, None, None, None, None, None, None
+            if g_d is not None:
+                g_d.add_(dgamma); dgamma = None
+            if b_d is not None:
+                b_d.add_(dbeta); dbeta = None
+        if ctx.sink and USE_RES_SINK and (dres.dtype == torch.bfloat16 or (_fast() and USE_L32)):
+            _RES_SINK[x1.data_ptr()] = dres            # joins the dgrad of the query projection, the other consumer of x1 (see _RES_SINK)
+            SINK_STATS[0] += 1
+            _queue_end_of_backward_join()
+            dres = None
+        return dq, dres, dkv, dgamma, dbeta, None, None, None, None, None, None
 
 
-def cross_attn_ln(x1, U, kv, bq, gamma, beta, eps, n_heads, lt, nm, drop=None):
-    """LayerNorm(x1 + CrossAttention(x1; the sentence's nm memory rows)) — x1 (T·lt, D) fp32 / bf16 / split; U (T·nm, H, D) from
-    ``cross_u``; kv (T·nm, 2D) fp32 [K | V] block (may be a column block of the stacked projection).  Output in x1's storage kind."""
-    require_split_tag(x1, "cross_attn_ln")
-    kind = 2 if lo_off(x1) is not None else _dt(x1)
-    y = _CrossAttnLn.apply(x1, U, kv, bq, gamma, beta, float(eps), int(n_heads), int(lt), int(nm), drop, kind)
-    if kind == 2:
+def cross_attn_ln(q, x1, kv, gamma, beta, eps, n_heads, lt, nm, drop=None, sink=False):
+    """LayerNorm(x1 + CrossAttention(q; the sentence's nm memory rows)) in one launch — q, x1 (T·lt, D) fp32 / bf16 / split; kv (T·nm, 2D)
+    [K | V] rows of the same storage family (may be a column block of the stacked memory projection).  Output in x1's storage kind.
+    sink=True: x1's only other consumer is the ops.linear that produced q — its dgrad absorbs the residual-path gradient (_RES_SINK)."""
+    require_split_tag(q, "cross_attn_ln (queries)")
+    require_split_tag(x1, "cross_attn_ln (residual)")
+    require_split_tag(kv, "cross_attn_ln (memory rows)")
+    y = _CrossAttnLn.apply(q, x1, kv, gamma, beta, float(eps), int(n_heads), int(lt), int(nm), drop, sink)
+    if lo_off(x1) is not None:
         y._svpc_lo = y.shape[1]
     return y
 

@@ -447,6 +447,8 @@ class GradReducer:
                 packed = getattr(p, "_svpc_packed", None)
                 if packed is not None:
                     for which, (wg, bg) in packed.items():
+                        if which == "q":       # the one-member view IS the query parameter, which reaches autograd (and its hook) whenever it is
+                            continue           # used: a pointer report for it would count the same write twice (fused cross-attention, round 5)
                         mem = p._svpc_packed_members[which]
                         half = len(mem) // 2
                         self._by_pack[("w", wg.data_ptr(), wg.numel())] = [(j, bucket_of[j]) for j in mem[:half]]

@@ -257,61 +257,55 @@ def test_ptr_attn_entity_chunks_and_full_width():
 
 
 @pytest.mark.parametrize("T,lt,nm,D,H,kind,p", [(5, 22, 3, 768, 12, "f32", 0.0), (5, 22, 3, 768, 12, "x3", 0.1), (3, 22, 2, 768, 12, "bf16", 0.0),
-                                                (4, 6, 3, 128, 4, "f32", 0.1), (2, 22, 1, 768, 12, "x3", 0.0), (3, 9, 3, 256, 4, "x3", 0.1)])
-def test_cross_attn_ln_fused_vs_projection_attention_layernorm(T, lt, nm, D, H, kind, p):
-    """ops.cross_u + ops.cross_attn_ln (the decoder's cross-attention with the query projection folded into the keys, residual and LayerNorm
-    in the same launch, round 5) against the plain statement of reference model.py:657-658: q = x1·Wqᵀ + bq, softmax(q·kᵀ/√dh)·v over the
-    sentence's n_mem memory rows, LayerNorm(x1 + ·) — outputs and the gradients of x1, [K | V], Wq, bq, gamma, beta; split / bf16 / fp32 rows,
-    with and without dropout of the probabilities (same counter-based draw on both sides)."""
+                                                (4, 6, 3, 128, 4, "f32", 0.1), (2, 22, 1, 768, 12, "x3", 0.0), (3, 9, 3, 256, 4, "x3", 0.1),
+                                                (2, 24, 3, 512, 8, "bf16", 0.1)])
+def test_cross_attn_ln_fused_vs_attention_then_layernorm(T, lt, nm, D, H, kind, p):
+    """ops.cross_attn_ln (the decoder's cross-attention over the sentence's n_mem memory rows + residual + LayerNorm in one launch, forward
+    and backward, round 5) against the plain statement of reference model.py:657-658 / :194-219 / :143-156 — outputs and the gradients of the
+    query rows, the residual rows, [K | V], gamma, beta; split / bf16 / fp32 rows, with and without dropout of the probabilities (the same
+    counter-based draw on both sides), gradients through the residual-gradient sink too."""
     import math
     dh = D // H
     Rm, R = T * nm, T * lt
-    x1 = rnd(R, D, seed=1)
+    q, x1 = rnd(R, D, seed=1, scale=0.5), rnd(R, D, seed=7)
     kv = rnd(Rm, 2 * D, seed=2, scale=0.7)
-    wq = rnd(D, D, seed=3, scale=1.0 / math.sqrt(D))
-    bq, gamma, beta = rnd(D, seed=4, scale=0.1), (1.0 + 0.1 * rnd(D, seed=5, grad=False)).requires_grad_(True), rnd(D, seed=6, scale=0.1)
+    gamma, beta = (1.0 + 0.1 * rnd(D, seed=5, grad=False)).requires_grad_(True), rnd(D, seed=6, scale=0.1)
     rng = O.make_rng(DEV)
     site = 7
     drop = (p, rng, site) if p > 0 else None
     gout = torch.randn(R, D, generator=torch.Generator().manual_seed(9)).to(DEV)
-    O.set_precision("bf16" if kind == "bf16" else "bf16x3")
+    conv = {"x3": O.to_split, "bf16": lambda t: t.to(torch.bfloat16), "f32": lambda t: t}[kind]
+    O.set_precision("bf16" if kind == "bf16" else ("bf16x3" if kind == "x3" else "fp32"))
     try:
-        if kind == "x3":
-            xin = O.to_split(x1)
-        elif kind == "bf16":
-            xin = x1.to(torch.bfloat16)
-        else:
-            xin = x1
         assert O.cross_attn_ln_usable(D, H, lt, nm)
-        us = O.cross_u([kv], [wq], H)
-        y = O.cross_attn_ln(xin, us[0], kv, bq, gamma, beta, 1e-12, H, lt, nm, drop=drop)
+        y = O.cross_attn_ln(conv(q), conv(x1), conv(kv), gamma, beta, 1e-12, H, lt, nm, drop=drop)
         yf = O.to_f32(y)
         (yf * gout).sum().backward()
-        got = [t.grad.clone() for t in (x1, kv, wq, bq, gamma, beta)]
-        for t in (x1, kv, wq, bq, gamma, beta):
+        O.join_side()
+        got = [t.grad.clone() for t in (q, x1, kv, gamma, beta)]
+        for t in (q, x1, kv, gamma, beta):
             t.grad = None
     finally:
         O.set_precision("fp32")
-    # reference in fp32 torch
-    xr = (x1.detach().to(torch.bfloat16).float() if kind == "bf16" else x1.detach()).requires_grad_(True)
-    q = (xr @ wq.t() + bq).view(T, lt, H, dh)
-    k = kv[:, :D].view(T, nm, H, dh)
-    v = kv[:, D:].view(T, nm, H, dh)
-    sc = torch.einsum("sthc,sjhc->shtj", q, k) / math.sqrt(dh)
+    # reference in fp32 torch on the values the kernels saw (bf16 kinds: the rounded inputs)
+    rd = (lambda t: t.detach().to(torch.bfloat16).float()) if kind == "bf16" else (lambda t: t.detach())
+    qr, xr, kvr = (rd(t).requires_grad_(True) for t in (q, x1, kv))
+    k = kvr[:, :D].view(T, nm, H, dh)
+    v = kvr[:, D:].view(T, nm, H, dh)
+    sc = torch.einsum("sthc,sjhc->shtj", qr.view(T, lt, H, dh), k) / math.sqrt(dh)
     pr = torch.softmax(sc, -1)
     if p > 0:
-        mask = rng.attn_mask(site, T * H * lt, nm, p, DEV).view(T, H, lt, nm)
-        pr = pr * mask / (1.0 - p)
+        pr = pr * rng.attn_mask(site, T * H * lt, nm, p, DEV).view(T, H, lt, nm) / (1.0 - p)
     o = torch.einsum("shtj,sjhc->sthc", pr, v).reshape(R, D)
     ref = torch.nn.functional.layer_norm(xr + o, (D,), gamma, beta, 1e-12)
     (ref * gout).sum().backward()
-    want = [xr.grad, kv.grad, wq.grad, bq.grad, gamma.grad, beta.grad]
-    tol = 4e-2 if kind == "bf16" else 2e-4
-    assert float((yf.detach() - ref.detach()).abs().max()) <= tol * max(1.0, float(ref.abs().max())), float((yf - ref).abs().max())
-    gtol = 5e-2 if kind == "bf16" else 2e-2          # (the backward contractions are one-term bf16 products in every fast mode)
-    for name, g, w in zip(("x1", "kv", "wq", "bq", "gamma", "beta"), got, want):
+    want = [qr.grad, xr.grad, kvr.grad, gamma.grad, beta.grad]
+    tol = 2e-2 if kind == "bf16" else 2e-5          # (bf16: the rounding of the stored output)
+    assert float((yf.detach() - ref.detach()).abs().max()) <= tol * max(1.0, float(ref.detach().abs().max())), float((yf.detach() - ref.detach()).abs().max())
+    gtol = 2e-2 if kind != "f32" else 1e-4          # (bf16 / split streams: the gradients arrive and leave as dense bf16 rows)
+    for name, g, w in zip(("q", "x1", "kv", "gamma", "beta"), got, want):
         err = float((g.float() - w).abs().max())
-        assert err <= gtol * float(w.abs().max()) + 1e-5, (name, err, float(w.abs().max()))
+        assert err <= gtol * float(w.abs().max()) + 1e-6, (name, err, float(w.abs().max()))
 
 
 @pytest.mark.parametrize("T,lt,em,D,ne", [(3, 22, 20, 768, [20, 17, 3]), (5, 6, 4, 64, [3, 3, 4, 2, 2]), (4, 1, 5, 128, [5, 1, 4, 2]),
