@@ -439,6 +439,14 @@ int svpc_greedy_pick(const float* scores, int ld, const int* row_c, const int* r
  * (text_out: model-side ids, ext_out: extended ids; src/translator.py:96-99 writes them at the top of the next iteration) */
 int svpc_greedy_pick_append(const float* scores, int ld, const int* row_c, const int* row_x, int n_sent, int lt, int pos, int unk,
                             int* next_ext, int* next_model, int* text_out, int* ext_out, int ld_out, int col, svpc_stream_t stream);
+/* rows between storage kinds in one launch (data movement): dst[r] = convert(src[idx ? idx[r] : r]); kinds 0 fp32, 1 bf16, 2 split (two bf16
+ * planes, the lo plane lo_* columns behind the hi plane).  Where rows join or leave an activation stream: the decoder's memory rows
+ * (src/rtransformer/model.py:939-947) entering the split stream, its output leaving it (:1086), the [CLS] rows of the clip stream (:1062-1064). */
+int svpc_rows_move(const void* src, int src_kind, int ld_src, int lo_src, const int* idx, void* dst, int dst_kind, int ld_dst, int lo_dst,
+                   int R, int W, svpc_stream_t stream);
+/* table[idx[r]] += rows[r], fp32 rows into a dense bf16 table (distinct idx): the gradient of gathered stream rows joins the stream's
+ * gradient in place */
+int svpc_scatter_add_rows_bf16(const float* rows, const int* idx, void* table, int ld_table, int R, int W, svpc_stream_t stream);
 int svpc_add(const float* a, const float* b, float* c, size_t n, svpc_stream_t stream);
 int svpc_sum_all(const float* x, size_t n, float* out, float scale, svpc_stream_t stream);
 int svpc_fill_from(float* x, size_t n, const float* v, svpc_stream_t stream);

@@ -750,6 +750,41 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(const float* __restric
 
 static inline unsigned grid1d(size_t n) { size_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
+
+// ---- rows between storage kinds in ONE launch (data movement: hi + lo of a split row is exact in fp32, fp32 → split is the two roundings
+// that define the planes).  dst[r][:] = convert(src[idx ? idx[r] : r][:]); kinds: 0 fp32, 1 bf16, 2 split (lo plane `lo` columns behind).
+// Replaces the ATen chains of the few places where rows change domain (decoder memory rows fp32 → split: 4 launches; decoder output
+// split → fp32: 3; the [CLS] rows of the clip stream gathered as fp32: 5).
+template <int SK, int DK>
+__global__ __launch_bounds__(256) void rows_move_kernel(const void* __restrict__ src, int lds_, int slo, const int* __restrict__ idx,
+                                                        void* __restrict__ dst, int ldd, int dlo, int W) {
+    const int r = blockIdx.x;
+    const size_t so = (size_t)(idx ? idx[r] : r) * lds_, dofs = (size_t)r * ldd;
+    for (int c = threadIdx.x; c < W; c += 256) {
+        float v;
+        if constexpr (SK == 0) v = reinterpret_cast<const float*>(src)[so + c];
+        else {
+            const __bf16* b = reinterpret_cast<const __bf16*>(src);
+            v = (float)b[so + c];
+            if constexpr (SK == 2) v += (float)b[so + slo + c];
+        }
+        if constexpr (DK == 0) reinterpret_cast<float*>(dst)[dofs + c] = v;
+        else {
+            __bf16* b = reinterpret_cast<__bf16*>(dst);
+            const __bf16 h = (__bf16)v;
+            b[dofs + c] = h;
+            if constexpr (DK == 2) b[dofs + dlo + c] = (__bf16)(v - (float)h);
+        }
+    }
+}
+// table[idx[r]][:] += rows[r][:] for a dense bf16 table and fp32 rows (fp32 add, one rounding; distinct idx: no atomics needed)
+__global__ __launch_bounds__(256) void scatter_add_rows_bf16_kernel(const float* __restrict__ rows, const int* __restrict__ idx,
+                                                                    __bf16* __restrict__ table, int ldt, int W) {
+    const int r = blockIdx.x;
+    const size_t to = (size_t)idx[r] * ldt;
+    for (int c = threadIdx.x; c < W; c += 256) table[to + c] = (__bf16)((float)table[to + c] + rows[(size_t)r * W + c]);
+}
+
 extern "C" {
 
 int svpc_act_bwd_t(const void* dy, const void* aux, void* dz, int dt, size_t n, int act, float p, unsigned site, const u64* seed,
@@ -768,6 +803,20 @@ int svpc_act_bwd_t(const void* dy, const void* aux, void* dz, int dt, size_t n, 
 int svpc_act_bwd(const float* dy, const float* aux, float* dz, size_t n, int act, float p, unsigned site, const u64* seed,
                  hipStream_t s) {
     return svpc_act_bwd_t(dy, aux, dz, 0, n, act, p, site, seed, s);
+}
+int svpc_rows_move(const void* src, int src_kind, int ld_src, int lo_src, const int* idx, void* dst, int dst_kind, int ld_dst, int lo_dst,
+                   int R, int W, hipStream_t s) {
+    if (R == 0 || W == 0) return 0;
+    SVPC_REQUIRE(src_kind >= 0 && src_kind <= 2 && dst_kind >= 0 && dst_kind <= 2, "rows_move: storage kinds are 0 (fp32), 1 (bf16), 2 (split)");
+#define RM(SK, DK) if (src_kind == SK && dst_kind == DK) hipLaunchKernelGGL((rows_move_kernel<SK, DK>), dim3(R), dim3(256), 0, s, src, ld_src, lo_src, idx, dst, ld_dst, lo_dst, W)
+    RM(0, 0); RM(0, 1); RM(0, 2); RM(1, 0); RM(1, 1); RM(1, 2); RM(2, 0); RM(2, 1); RM(2, 2);
+#undef RM
+    return svpc_check_launch("rows_move");
+}
+int svpc_scatter_add_rows_bf16(const float* rows, const int* idx, void* table, int ld_table, int R, int W, hipStream_t s) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(scatter_add_rows_bf16_kernel, dim3(R), dim3(256), 0, s, rows, idx, (__bf16*)table, ld_table, W);
+    return svpc_check_launch("scatter_add_rows_bf16");
 }
 int svpc_add(const float* a, const float* b, float* c, size_t n, hipStream_t s) {
     if (n == 0) return 0;

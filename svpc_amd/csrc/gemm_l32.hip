@@ -585,8 +585,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restric
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
     skinny_tile<B_KC, 4, X3>(part, A, lda, B, ldb, C, ldc, M, N, K, epi, tm, tn);
 }
-// grouped form (both operands k-contiguous), NW waves per 32×32 tile: 8 for the long reductions of the LSTM dgrad (K = 3072)
-template <int NW, bool X3 = false>
+// grouped form (A k-contiguous; B k-contiguous, or — B_KC = false — k-strided [K][ldb]: the LSTM's recurrent dgrad reads W_hh (4D, D) in
+// place, no transposed copy per step), NW waves per 32×32 tile: 8 for the long reductions of the LSTM dgrad (K = 3072)
+template <int NW, bool X3 = false, bool B_KC = true>
 __global__ __launch_bounds__(64 * NW) void gemm_group_skinny_kernel(GemmGroupArgs g) {
     __shared__ float part[NW][16][64];
     int pi = 0;
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_group_skinny_kernel(GemmGroupArg
     const int tile = blockIdx.x - q.tile0;
     const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
     Epi epi{nullptr, ACT_NONE, 0.f, 0u, nullptr, g.accumulate, nullptr};
-    skinny_tile<true, NW, X3>(part, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, epi, tm, tn);
+    skinny_tile<B_KC, NW, X3>(part, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, epi, tm, tn);
 }
 
 // ---- one time step of BOTH LSTM directions, recurrent projection and cell in one launch (reference: nn.LSTM inside
@@ -720,7 +721,8 @@ static int gemm_group_x(const void* problems, int n, int a_kc, int b_kc, int acc
     int tiles = 0;
     static int env_skinny = -1;
     if (env_skinny < 0) { const char* e = getenv("SVPC_L32_SKINNY"); env_skinny = e ? atoi(e) : 1; }
-    bool skinny = env_skinny && a_kc && b_kc;       // every problem a few rows tall: 32×32 tiles with register-direct operands
+    bool skinny = env_skinny && a_kc;               // every problem a few rows tall: 32×32 tiles with register-direct operands
+    if (!b_kc && x3) skinny = false;                // (the k-strided B form exists for the one-term products of the backward)
     int kmax = 0;
     for (int i = 0; i < n; ++i) {
         if (hp[i].M > 256 || hp[i].N < 32 || (hp[i].K & 15) || (hp[i].lda & 3) || (hp[i].ldb & 3)) skinny = false;
@@ -735,6 +737,11 @@ static int gemm_group_x(const void* problems, int n, int a_kc, int b_kc, int acc
         q.A = h.A; q.B = h.B; q.C = h.C; q.M = h.M; q.N = h.N; q.K = h.K; q.lda = h.lda; q.ldb = h.ldb; q.ldc = h.ldc;
         q.tile0 = tiles; q.tiles_n = ceil_div(h.N, T);
         tiles += ceil_div(h.M, T) * q.tiles_n;
+    }
+    if (skinny && !b_kc) {
+        if (kmax >= 1536) hipLaunchKernelGGL((gemm_group_skinny_kernel<8, false, false>), dim3(tiles), dim3(512), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_group_skinny_kernel<4, false, false>), dim3(tiles), dim3(256), 0, stream, g);
+        return svpc_check_launch("gemm_group_skinny");
     }
     if (skinny) {
         if (x3) {

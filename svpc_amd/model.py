@@ -226,7 +226,9 @@ class BertLayerNoMemoryUntied(nn.Module):
         the selected rows are bit-for-bit what ``run`` produces for them (in eval mode)."""
         D = h.shape[1]
         att = self.attention.self
-        hq = ops.take_rows_f32(h, sel_rows)          # the few selected rows leave the bf16 / split stream here (no-op in fp32 storage)
+        # the few selected rows leave the bf16 / split stream here (no-op in fp32 storage); the key / value projection — the stream's only
+        # other consumer — takes the alias, so the rows' gradient joins the stream gradient in place (ops.take_rows_f32_alias)
+        hq, h = ops.take_rows_f32_alias(h, sel_rows)
         q = ops.linear(hq, att.query.weight, att.query.bias)
         wkv, bkv, wg, bg, w16 = att.packed("kv")
         kv = ops.linear(h, wkv, bkv, wgrad=wg, bgrad=bg, w16=w16)

@@ -527,13 +527,24 @@ def _lo_view(t):
     return torch.as_strided(t.detach(), t.shape, t.stride(), t.storage_offset() + t._svpc_lo)
 
 
+def _rows_move(src, src_lo, idx, dst, dst_lo, R, W):
+    """dst[r] = convert(src[idx ? idx[r] : r]) between storage kinds in one launch (svpc_rows_move; data movement)"""
+    sk = 2 if src_lo is not None else _dt(src)
+    dk = 2 if dst_lo is not None else _dt(dst)
+    _lib.call("rows_move", _p(src), sk, src.stride(0), src_lo or 0, _p(idx), _p(dst), dk, dst.stride(0), dst_lo or 0, R, W, _stream())
+
+
 class _ToF32(Function):
     @staticmethod
     def forward(ctx, t, lo):
+        ctx.dt = t.dtype
+        if t.dim() == 2 and t.is_cuda and t.stride(1) == 1:
+            out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+            _rows_move(t, lo, None, out, None, t.shape[0], t.shape[1])
+            return out
         out = t.float()
         if lo is not None:
             out += torch.as_strided(t, t.shape, t.stride(), t.storage_offset() + lo).float()
-        ctx.dt = t.dtype
         return out
 
     @staticmethod
@@ -553,7 +564,20 @@ def take_rows_f32(t, idx):
     lo = lo_off(t)
     if lo is None:
         return torch.index_select(t, 0, idx).float()
-    return _TakeSplit.apply(t, idx, lo)
+    return _TakeSplit.apply(t, idx, lo)[0]
+
+
+def take_rows_f32_alias(t, idx):
+    """(fp32 rows ``idx`` of ``t``, an alias of ``t``) for a stream tensor with exactly ONE other consumer: that consumer takes the alias,
+    and the gradient of the gathered rows is added into the alias's gradient IN PLACE (one small scatter launch) instead of a zero-filled
+    stream-sized tensor, an index_add and autograd's stream-sized sum.  Plain tensors: (rows, t)."""
+    lo = lo_off(t)
+    if (lo is None and t.dtype != torch.bfloat16) or not t.is_cuda or idx.dtype != torch.int32 or t.dim() != 2:
+        return take_rows_f32(t, idx), t
+    rows, alias = _TakeSplit.apply(t, idx, lo)
+    if lo is not None:
+        alias._svpc_lo = lo
+    return rows, alias
 
 
 class _TakeSplit(Function):
@@ -561,14 +585,31 @@ class _TakeSplit(Function):
     def forward(ctx, t, idx, lo):
         ctx.save_for_backward(idx)
         ctx.shape, ctx.dt = t.shape, t.dtype
-        low = torch.as_strided(t, t.shape, t.stride(), t.storage_offset() + lo)
-        return torch.index_select(t, 0, idx).float() + torch.index_select(low, 0, idx).float()
+        ctx.set_materialize_grads(False)         # (an unused alias must reach backward as None, not as a stream-sized tensor of zeros)
+        if t.is_cuda and idx.dtype == torch.int32 and t.stride(1) == 1:
+            out = torch.empty(idx.numel(), t.shape[1], dtype=torch.float32, device=t.device)
+            _rows_move(t, lo, idx, out, None, idx.numel(), t.shape[1])
+        elif lo is not None:
+            low = torch.as_strided(t, t.shape, t.stride(), t.storage_offset() + lo)
+            out = torch.index_select(t, 0, idx).float() + torch.index_select(low, 0, idx).float()
+        else:
+            out = torch.index_select(t, 0, idx).float()
+        return out, t.view_as(t)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_alias):
         idx, = ctx.saved_tensors
+        if g is None:
+            return g_alias, None, None
+        if (g_alias is not None and g_alias.is_cuda and g_alias.dtype == torch.bfloat16 and g_alias.is_contiguous() and idx.dtype == torch.int32
+                and tuple(g_alias.shape) == tuple(ctx.shape)):
+            g = _c(g.float())
+            _lib.call("scatter_add_rows_bf16", _p(g), _p(idx), _p(g_alias), g_alias.stride(0), idx.numel(), g.shape[1], _stream())
+            return g_alias, None, None
         out = torch.zeros(ctx.shape, dtype=ctx.dt, device=g.device)
         out.index_add_(0, idx.long(), g.to(ctx.dt))
+        if g_alias is not None:
+            out = out + g_alias
         return out, None, None
 
 
@@ -1378,6 +1419,9 @@ class _ToSplit(Function):
     @staticmethod
     def forward(ctx, t):
         out = new_split(t.shape[0], t.shape[1], t.device)
+        if t.is_cuda and t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32:
+            _rows_move(t, None, None, out, out._svpc_lo, t.shape[0], t.shape[1])
+            return out
         out.copy_(t)
         torch.as_strided(out, out.shape, out.stride(), out.storage_offset() + out._svpc_lo).copy_(t - out.float())
         return out
@@ -2062,7 +2106,8 @@ class _BiLstmSeq(Function):
         dc = [tail[2], tail[3]]
         dh2, dc2 = [mk(N, D) for _ in range(2)], [mk(N, D) for _ in range(2)]
         st = _stream()
-        wt = [w[z].t().contiguous() for z in range(2)]        # (D, 4D): k-contiguous operand of the per-step dgrad
+        # (the per-step dgrad dh = dG·W_hh reads W_hh (4D, D) k-strided IN PLACE — svpc_gemm_group with b_kc = 0 — instead of a transposed
+        # copy of both directions' weights made every step: 2 × 14 µs of ATen copies at D = 768)
         # the per-step dgrad (N × D over K = 4D) is bound by how fast ONE workgroup can pull its weight columns: cut K into
         # LSTM_DGRAD_PARTS k-parts (separate problems of the grouped launch, each writing a slab) that the next cell launch adds
         P = LSTM_DGRAD_PARTS if (4 * D) % (32 * LSTM_DGRAD_PARTS) == 0 else 1
@@ -2080,12 +2125,13 @@ class _BiLstmSeq(Function):
                     probs = (_GemmProblem * (2 * P))()
                     for z in range(2):
                         for k in range(P):
-                            probs[z * P + k] = _GemmProblem(dG[z][t].data_ptr() + 4 * k * Kp, wt[z].data_ptr() + 4 * k * Kp,
-                                                            slabs[z][k].data_ptr(), N, D, Kp, 4 * D, 4 * D, D)
-                    _lib.call("gemm_group", ctypes.addressof(probs), 2 * P, 1, 1, 0, st)
+                            probs[z * P + k] = _GemmProblem(dG[z][t].data_ptr() + 4 * k * Kp, w[z].data_ptr() + 4 * k * Kp * D,
+                                                            slabs[z][k].data_ptr(), N, D, Kp, 4 * D, D, D)
+                    _lib.call("gemm_group", ctypes.addressof(probs), 2 * P, 1, 0, 0, st)
                     have_parts = True
             else:
                 _lib.call("lstm_pair_bwd", a[0][0], a[1][0], a[2][0], a[3][0], a[4][0], _p(active_t[t]), a[6][0], a[7][0], a[8][0], N, D, st)
+                wt = [w[z].t().contiguous() for z in range(2)] if t == S - 1 else wt      # (unsplit fallback: a transposed copy, once)
                 _gemm_pair([dG[0][t], dG[1][t]], wt, dh2, N, D, 4 * D, accumulate=1)      # dh_{t-1} = pass-through + dgates · W_hh
             dh, dh2 = dh2, dh
             dc, dc2 = dc2, dc

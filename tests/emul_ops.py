@@ -191,6 +191,10 @@ def ptr_attn(dec, proj, bank, step_ne, lt):
     return pi.reshape(T * lt, e_max), att.reshape(T * lt, D)
 
 
+def take_rows_f32_alias(t, idx):
+    return take_rows_f32(t, idx), t
+
+
 def cross_attn_ln_usable(*a, **k):
     return False          # (the fused decoder cross-attention is a GPU kernel pair: the emulated model takes the unfused path)
 
