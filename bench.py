@@ -462,22 +462,34 @@ def run_decode(cfg, model, args, device, world, rank, dist, steps, warmup):
                        "launch": "eager" if args.decode_eager else "hipGraph replay per batch structure (inputs copied into the captured buffers)"}}
 
 
-def ragged_batches(cfg, args, device, n_structs, seed=4242):
+def ragged_batches(cfg, args, device, n_structs, seed=4242, shared_features=False):
     """``n_structs`` batches with the structure the reference's loop really feeds (src/train.py:91-132 over
     recursive_caption_dataset.py:528-576): S_b ~ U{3..16} clips per video (the collate pads to the longest), E_b ~ U{1..31} ingredients,
-    X_b in {0, 1, 2} out-of-vocabulary ingredient words, 16 videos; resident in HBM like the headline batch."""
+    X_b in {0, 1, 2} out-of-vocabulary ingredient words, 16 videos; resident in HBM like the headline batch.  shared_features: every batch
+    reads its frame features from ONE resident (16, N, L, F) buffer (drawn once) — what differs from batch to batch is the STRUCTURE
+    (ids, masks, labels, ingredients, step counts), which is what the cold leg measures; a hundred batches then cost seconds to build."""
     import numpy as np
     import torch
     from svpc_amd import keep_host_copy, make_batch
     rng = np.random.RandomState(seed)
     out, clips = [], []
     stacked = ("video_features_list", "input_ids_list", "input_masks_list", "input_labels_list", "token_type_ids_list")
+    bank_h = bank_d = None
+    if shared_features:
+        L_, F_ = cfg.max_v_len + cfg.max_t_len, cfg.video_feature_size
+        bank_h = np.zeros((16, args.batch, L_, F_), np.float32)
+        bank_h[:, :, 1:cfg.max_v_len - 1] = np.random.RandomState(seed).rand(16, args.batch, cfg.max_v_len - 2, F_).astype(np.float32)
+        bank_d = torch.from_numpy(bank_h).to(device)
     for i in range(n_structs):
         S_b = rng.randint(3, 17, size=args.batch).tolist()
         E_b = rng.randint(1, 32, size=args.batch).tolist()
         X_b = [int(min(x, e)) for x, e in zip(rng.randint(0, 3, size=args.batch).tolist(), E_b)]
-        b = make_batch(cfg, n_videos=args.batch, max_steps=max(S_b), step_nums=S_b, n_ingr=E_b, n_oov=X_b, seed=seed + 1 + i, full_clips=True)
+        b = make_batch(cfg, n_videos=args.batch, max_steps=max(S_b), step_nums=S_b, n_ingr=E_b, n_oov=X_b, seed=seed + 1 + i, full_clips=True,
+                       feature_bank=bank_h)
         for k in stacked:
+            if k == "video_features_list" and bank_d is not None:
+                b[k] = [bank_d[s_] for s_ in range(max(S_b))]
+                continue
             buf = torch.stack(b[k]).to(device)
             b[k] = [buf[s_] for s_ in range(buf.shape[0])]
         for k, v in list(b.items()):
@@ -677,7 +689,42 @@ def run_train(args, precision, device, world, rank, dist, steps, warmup, instrum
                 graph_leg = rleg()
             finally:
                 clip_graphs.enable(model, False)
+            # (c) COLD: what the first epoch sees — a new structure every step from EMPTY graph caches, every capture inside the timed region
+            # (clip counts are bucketed to multiples of 8, so at most 27 captures per family ever happen: svpc_amd/clip_graphs.py)
+            cold = None
+            n_cold = int(os.environ.get("SVPC_BENCH_COLD_STEPS", "100"))
+            if n_cold > 0:
+                cb, cclips = ragged_batches(cfg, args, device, n_structs=n_cold, seed=777, shared_features=True)
+                cargs = [syn.forward_args(b) for b in cb]
+                cg2, dg2 = clip_graphs.enable(model)          # fresh, empty caches
+                try:
+                    def cstep(k):
+                        model._plans.clear(); model._ptr_plans.clear(); model._span_cache.clear()
+                        opt.zero_grad()
+                        l_ = model(*cargs[k])[0]
+                        backward_all(model, l_)
+                        opt.step()
+                        return l_
+                    with torch.cuda.stream(st_r):
+                        torch.cuda.synchronize()
+                        tc0 = time.perf_counter()
+                        for k in range(n_cold):
+                            lc_ = cstep(k)
+                        host_c = time.perf_counter() - tc0
+                        torch.cuda.synchronize()
+                        el_c = time.perf_counter() - tc0
+                    cold = dict(steps=n_cold, steps_per_s=n_cold / el_c, ms_per_step=1000.0 * el_c / n_cold,
+                                host_enqueue_ms_per_step=1000.0 * host_c / n_cold, final_loss=float(lc_.item()),
+                                captures=dict(clip_encoder=cg2.stats["captures"], decoder=dg2.stats["captures"]),
+                                hits=dict(clip_encoder=cg2.stats["hits"], decoder=dg2.stats["hits"]),
+                                distinct_clip_counts=len(set(cclips)), clip_count_buckets=len(set(-(-c // clip_graphs.T_BUCKET) for c in cclips)),
+                                avg_clips_per_step=sum(cclips) / float(n_cold),
+                                note="100 different structures in a row from empty graph caches, captures inside the timed region")
+                finally:
+                    clip_graphs.enable(model, False)
+                del cb, cargs
             ragged_res = dict(graph_leg)
+            ragged_res["cold"] = cold
             ragged_res.update({"steps": ragged, "distinct_structures": len(rargs), "distinct_clip_counts": len(set(rclips)),
                                "avg_clips_per_step": avg_clips, "clips_per_s": avg_clips * ragged_res["steps_per_s"],
                                "launch": "clip encoder and caption decoder: hipGraph replay per clip count T; step encoder, simulators, pointer, "
@@ -904,6 +951,8 @@ def _train_main(args, device, world, rank, dist, joined):
             # the uniform figure the ratio refers to is `value` (192 clips per step); a ragged step carries avg_clips_per_step clips
             rg["vs_uniform_steps_per_s"] = rg["steps_per_s"] / (joined * args.steps / elapsed)
             rg["vs_uniform_clips_per_s"] = rg["clips_per_s"] / (args.batch * args.clips * joined * args.steps / elapsed)
+            if rg.get("cold"):
+                rg["cold"]["vs_uniform_steps_per_s"] = rg["cold"]["steps_per_s"] / (joined * args.steps / elapsed)
         out["ragged"] = rg
     out.update(extras)
     if world == 1 and not args.no_cpu_baseline and not args.rehearse_dp:

@@ -45,15 +45,34 @@ def check_consumed(who="optimizer step"):
 
 
 class _Entry:
-    __slots__ = ("T", "g_fwd", "g_bwd", "feats", "ids", "mask", "seq", "cls_rows", "seq_cls", "cls", "gout", "n_sites", "replays", "owner")
+    __slots__ = ("T", "g_fwd", "g_bwd", "feats", "ids", "mask", "seq", "cls_rows", "seq_cls", "cls", "gout", "n_sites", "replays", "owner", "t_valid")
 
     def backward(self, grad):
         """the second phase of the step's backward (see ``svpc_amd.graph.backward_all``)"""
         self.owner.pending = None
         if grad is None:
             return
-        self.gout.copy_(grad)
+        n = self.t_valid
+        self.gout[:n].copy_(grad)
+        if n < self.T:
+            self.gout[n:].zero_()          # the padding clips of the bucket: zero output gradient → exact zeros in every parameter gradient
         self.g_bwd.replay()
+
+
+T_BUCKET = 8       # clip counts are rounded up to a multiple of this: ≤ 27 graphs per family cover every batch of 16 videos × 3..16 clips
+
+
+def _bucket(T):
+    return -(-T // T_BUCKET) * T_BUCKET
+
+
+def _rows(t, n):
+    """the first n rows of a (possibly split) 2-D buffer, still tagged with its lo-plane offset"""
+    v = t[:n]
+    lo = ops.lo_off(t)
+    if lo is not None:
+        v._svpc_lo = lo
+    return v
 
 
 class ClipEncoderGraphs:
@@ -66,16 +85,19 @@ class ClipEncoderGraphs:
         self.feats_cap = self.ids_cap = self.mask_cap = None
         self.stats = {"hits": 0, "captures": 0, "bypassed": 0}
         self.pending = None                 # the entry whose forward has been replayed and whose backward has not (see check_consumed)
+        self._warmed = set()
         import weakref
         _OWNERS.append(weakref.ref(self))
 
     # -------------------------------------------------------------------------------------------------------------------------
     def usable(self, feats):
-        """eager fallback: no gradients wanted, inside a whole-step capture, a gradient-ready hook installed (the data-parallel
-        reducer starts its buckets from the eager backward), parameters not yet in the optimizer's arena"""
+        """eager fallback: no gradients wanted, inside a whole-step capture, parameters not yet in the optimizer's arena.  (A data-parallel
+        reducer may be attached: its hooks are paused while a graph is captured — ``ops.hooks_paused`` — and the parameters of a replayed
+        part, which never fire a hook, are exchanged by ``graph.backward_all(..., exchange=reducer)``: text-side buckets after the eager
+        backward, the clip encoder's after its replay — the cut of the three-graph step.)"""
         if not (torch.is_grad_enabled() and feats.is_cuda):
             return False
-        if torch.cuda.is_current_stream_capturing() or ops.GRAD_READY_HOOK is not None:
+        if torch.cuda.is_current_stream_capturing():
             return False
         if torch.cuda.current_stream() == torch.cuda.default_stream():      # (a capture cannot run on the legacy default stream:
             return False                                                   #  run the loop under ``graph.ops_stream()``)
@@ -103,21 +125,26 @@ class ClipEncoderGraphs:
             raise RuntimeError("clip_graphs: a second forward before the previous step's clip-encoder backward was replayed (its saved "
                                "activations live in the shared graph pool and would be overwritten) — run svpc_amd.graph.backward_all "
                                "after every forward that wants gradients, or call the model under torch.no_grad()")
-        self._buffers(rows, F, dev)
-        key = (T, Lv, F, ops._PRECISION, cx.training, cx.p_h, cx.p_a, torch.cuda.current_stream().cuda_stream)
+        # the graph is captured for the clip count rounded UP to a multiple of T_BUCKET: the padding clips are whatever finite rows the
+        # capacity buffers hold, their [CLS] rows are dropped and their output gradient is zero, so they contribute exact zeros to every
+        # parameter gradient (masked work is exact under the summed loss) — ≤ 27 graphs instead of ≈100 clip counts
+        Tb = _bucket(T)
+        self._buffers(Tb * Lv, F, dev)
+        key = (Tb, Lv, F, ops._PRECISION, cx.training, cx.p_h, cx.p_a, torch.cuda.current_stream().cuda_stream)
         e = self.entries.get(key)
         if e is None:
-            e = self._capture(key, T, cx)
+            e = self._capture(key, Tb, cx)
         else:
             self.entries.move_to_end(key)
             self.stats["hits"] += 1
-        torch.index_select(feats, 0, video_rows.long(), out=e.feats)
-        e.ids.copy_(ids_v)
-        e.mask.copy_(mask_v)
+        torch.index_select(feats, 0, video_rows.long(), out=e.feats[:rows])
+        e.ids[:rows].copy_(ids_v)
+        e.mask[:rows].copy_(mask_v)
         e.g_fwd.replay()
         e.replays += 1
+        e.t_valid = T
         cx.rng._site += e.n_sites
-        cut = e.cls.detach().requires_grad_(True)
+        cut = e.cls[:T].detach().requires_grad_(True)
         model.split_boundary = (e, cut)
         self.pending = e
         return cut
@@ -128,7 +155,7 @@ class ClipEncoderGraphs:
         Lv, D = cfg.max_v_len, cfg.hidden_size
         dev = self.feats_cap.device
         e = _Entry()
-        e.T, e.replays, e.owner = T, 0, self
+        e.T, e.replays, e.owner, e.t_valid = T, 0, self, T
         rows = T * Lv
         e.feats, e.ids, e.mask = self.feats_cap[:rows], self.ids_cap[:rows], self.mask_cap[:rows]
         e.seq = ops.SeqInfo.uniform(T, Lv, Lv, dev)
@@ -142,20 +169,24 @@ class ClipEncoderGraphs:
         # one EAGER pass at this clip count first: anything a first call does besides launching kernels (the 256 MB kernel workspace of
         # this stream, lazily uploaded index tables) must not be baked into the graph.  Its backward runs on a zero output gradient:
         # every parameter gradient it accumulates into the optimizer's arena is an exact zero.
-        warm = model._encode_clips(e.feats, None, e.ids, e.mask, e.seq, cx, cls_only=(e.cls_rows, e.seq_cls))
-        warm.backward(e.gout)
-        ops.join_side()
-        del warm
-        cx.rng._site = site0
-        e.g_fwd, e.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(e.g_fwd, pool=self.pool, stream=stream):
-            cls = model._encode_clips(e.feats, None, e.ids, e.mask, e.seq, cx, cls_only=(e.cls_rows, e.seq_cls))
-        e.cls = cls
-        e.n_sites = cx.rng._site - site0
-        cx.rng._site = site0                        # (the replay that follows advances the counter)
-        with torch.cuda.graph(e.g_bwd, pool=self.pool, stream=stream):
-            cls.backward(e.gout)
-            ops.join_side()
+        with ops.hooks_paused():                    # (a data-parallel reducer must not see the warm-up's / the capture's parameter writes)
+            wkey = (stream.cuda_stream, ops._PRECISION, cx.training)
+            if wkey not in self._warmed:            # (once per stream and mode: later clip counts meet the workspace and the kernels' LDS limits set up)
+                warm = model._encode_clips(e.feats, None, e.ids, e.mask, e.seq, cx, cls_only=(e.cls_rows, e.seq_cls))
+                warm.backward(e.gout)
+                ops.join_side()
+                del warm
+                cx.rng._site = site0
+                self._warmed.add(wkey)
+            e.g_fwd, e.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(e.g_fwd, pool=self.pool, stream=stream, capture_error_mode="thread_local"):
+                cls = model._encode_clips(e.feats, None, e.ids, e.mask, e.seq, cx, cls_only=(e.cls_rows, e.seq_cls))
+            e.cls = cls
+            e.n_sites = cx.rng._site - site0
+            cx.rng._site = site0                        # (the replay that follows advances the counter)
+            with torch.cuda.graph(e.g_bwd, pool=self.pool, stream=stream, capture_error_mode="thread_local"):
+                cls.backward(e.gout)
+                ops.join_side()
         e.cls = cls.detach()
         self.entries[key] = e
         self.stats["captures"] += 1
@@ -173,7 +204,7 @@ class ClipEncoderGraphs:
 # pool of their own — the clip encoder's saved activations must survive from its forward replay to its backward replay at the end of the
 # step, with the decoder's replays in between.
 class _DecEntry:
-    __slots__ = ("g_fwd", "g_bwd", "xt", "xt_leaf", "mem", "mem_leaf", "mask", "out", "gout", "seq_self", "seq_cross", "n_sites")
+    __slots__ = ("g_fwd", "g_bwd", "xt", "xt_leaf", "mem", "mem_leaf", "mask", "out", "gout", "seq_self", "seq_cross", "n_sites", "T", "lt", "nm")
 
 
 def _copy_rows(dst, src):
@@ -186,19 +217,25 @@ def _copy_rows(dst, src):
 class _DecoderReplay(ops.Function):
     @staticmethod
     def forward(ctx, xt, mem, text_mask, e):
-        _copy_rows(e.xt, xt)
-        _copy_rows(e.mem, mem)
-        e.mask.copy_(text_mask)
+        nx, nmr = xt.shape[0], mem.shape[0]
+        _copy_rows(_rows(e.xt, nx), xt)
+        _copy_rows(_rows(e.mem, nmr), mem)
+        e.mask[:nx].copy_(text_mask)
+        if nx < e.mask.shape[0]:
+            e.mask[nx:].zero_()                    # the padding sentences of the bucket: all positions masked
         e.g_fwd.replay()
-        ctx.e = e
-        return e.out.detach()
+        ctx.e, ctx.n = e, (nx, nmr)
+        return e.out[:nx].detach()
 
     @staticmethod
     def backward(ctx, g):
         e = ctx.e
-        e.gout.copy_(g)
+        nx, nmr = ctx.n
+        e.gout[:nx].copy_(g)
+        if nx < e.gout.shape[0]:
+            e.gout[nx:].zero_()                    # zero output gradient for the padding sentences: exact zeros downstream
         e.g_bwd.replay()
-        return e.xt_leaf.grad, e.mem_leaf.grad, None, None
+        return e.xt_leaf.grad[:nx], e.mem_leaf.grad[:nmr], None, None
 
 
 class DecoderGraphs:
@@ -208,11 +245,12 @@ class DecoderGraphs:
         self.entries = collections.OrderedDict()
         self.pool = None
         self.stats = {"hits": 0, "captures": 0}
+        self._warmed = set()
 
     def usable(self, xt, mem):
         if not (torch.is_grad_enabled() and xt.is_cuda and xt.requires_grad and mem.requires_grad):
             return False
-        if torch.cuda.is_current_stream_capturing() or ops.GRAD_READY_HOOK is not None:
+        if torch.cuda.is_current_stream_capturing():
             return False
         if torch.cuda.current_stream() == torch.cuda.default_stream():
             return False
@@ -221,11 +259,13 @@ class DecoderGraphs:
 
     def run(self, xt, text_mask, mem, T, cx):
         cfg = self.model.config
-        key = (T, tuple(xt.shape), str(xt.dtype), ops.lo_off(xt), tuple(mem.shape), str(mem.dtype), ops.lo_off(mem), ops._PRECISION, cx.training,
+        Tb = _bucket(T)          # (captured for the sentence count rounded up to a multiple of T_BUCKET: see ClipEncoderGraphs.run)
+        lt, nm = xt.shape[0] // T, mem.shape[0] // T
+        key = (Tb, lt, xt.shape[1], str(xt.dtype), ops.lo_off(xt), nm, mem.shape[1], str(mem.dtype), ops.lo_off(mem), ops._PRECISION, cx.training,
                cx.p_h, cx.p_a, torch.cuda.current_stream().cuda_stream)
         e = self.entries.get(key)
         if e is None:
-            e = self._capture(key, xt, text_mask, mem, T, cx)
+            e = self._capture(key, xt, text_mask, mem, Tb, lt, nm, cx)
         else:
             self.entries.move_to_end(key)
             self.stats["hits"] += 1
@@ -234,26 +274,26 @@ class DecoderGraphs:
         return out
 
     @staticmethod
-    def _like(t):
-        """a buffer of t's layout (split tensors keep their lo plane) and a leaf over it for the captured autograd graph"""
+    def _like(t, rows):
+        """a zero-filled buffer of ``rows`` rows in t's layout (split tensors keep their lo plane) and a leaf over it for the captured
+        autograd graph (zero-filled: the eager warm-up pass before the capture reads it, and 0 × garbage is NaN)"""
         lo = ops.lo_off(t)
-        if lo is not None:          # (zero-filled: the eager warm-up pass before the capture reads it, and 0 × garbage is NaN)
-            buf = torch.zeros(t.shape[0], 2 * t.shape[1], dtype=torch.bfloat16, device=t.device)[:, :t.shape[1]]
+        if lo is not None:
+            buf = torch.zeros(rows, 2 * t.shape[1], dtype=torch.bfloat16, device=t.device)[:, :t.shape[1]]
             buf._svpc_lo = t.shape[1]
         else:
-            buf = torch.zeros_like(t)
+            buf = torch.zeros(rows, t.shape[1], dtype=t.dtype, device=t.device)
         leaf = buf.detach().requires_grad_(True)
         if lo is not None:
             leaf._svpc_lo = buf._svpc_lo
         return buf, leaf
 
-    def _capture(self, key, xt, text_mask, mem, T, cx):
+    def _capture(self, key, xt, text_mask, mem, T, Lt, n_mem, cx):
         model = self.model
         cfg = model.config
-        Lt = cfg.max_t_len
         dev = xt.device
-        n_mem = mem.shape[0] // T
         e = _DecEntry()
+        e.T, e.lt, e.nm = T, Lt, n_mem
         e.seq_self = ops.SeqInfo.uniform(T, Lt, Lt, dev)
         e.seq_cross = ops.SeqInfo.uniform(T, Lt, n_mem, dev)
         if self.pool is None:
@@ -262,25 +302,29 @@ class DecoderGraphs:
         site0 = cx.rng._site
         e.g_fwd, e.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # (the graph's input / output-gradient buffers are made BEFORE the capture: an allocation-with-fill inside it would be replayed)
-        e.xt, e.xt_leaf = self._like(xt)
-        e.mem, e.mem_leaf = self._like(mem)
-        e.mask = torch.zeros_like(text_mask)
-        e.gout = torch.zeros(xt.shape[0], cfg.hidden_size, dtype=torch.float32, device=dev)
-        # (one eager pass first, backward on a zero gradient: see ClipEncoderGraphs._capture)
-        warm = model.decoder.run(e.xt_leaf, e.mask, e.mem_leaf, e.seq_self, e.seq_cross, None, cx)
-        warm.backward(e.gout)
-        ops.join_side()
-        del warm
-        e.xt_leaf.grad = e.mem_leaf.grad = None
-        cx.rng._site = site0
-        with torch.cuda.graph(e.g_fwd, pool=self.pool, stream=stream):
-            out = model.decoder.run(e.xt_leaf, e.mask, e.mem_leaf, e.seq_self, e.seq_cross, None, cx)
-        assert out.shape == e.gout.shape and out.dtype == e.gout.dtype
-        e.n_sites = cx.rng._site - site0
-        cx.rng._site = site0
-        with torch.cuda.graph(e.g_bwd, pool=self.pool, stream=stream):
-            out.backward(e.gout)
-            ops.join_side()
+        e.xt, e.xt_leaf = self._like(xt, T * Lt)
+        e.mem, e.mem_leaf = self._like(mem, T * n_mem)
+        e.mask = torch.zeros(T * Lt, dtype=text_mask.dtype, device=dev)
+        e.gout = torch.zeros(T * Lt, cfg.hidden_size, dtype=torch.float32, device=dev)
+        with ops.hooks_paused():
+            # (one eager pass first — per stream and mode —, backward on a zero gradient: see ClipEncoderGraphs._capture)
+            wkey = (stream.cuda_stream, ops._PRECISION, cx.training, str(xt.dtype), ops.lo_off(xt) is not None)
+            if wkey not in self._warmed:
+                warm = model.decoder.run(e.xt_leaf, e.mask, e.mem_leaf, e.seq_self, e.seq_cross, None, cx)
+                warm.backward(e.gout)
+                ops.join_side()
+                del warm
+                e.xt_leaf.grad = e.mem_leaf.grad = None
+                cx.rng._site = site0
+                self._warmed.add(wkey)
+            with torch.cuda.graph(e.g_fwd, pool=self.pool, stream=stream, capture_error_mode="thread_local"):
+                out = model.decoder.run(e.xt_leaf, e.mask, e.mem_leaf, e.seq_self, e.seq_cross, None, cx)
+            assert out.shape == e.gout.shape and out.dtype == e.gout.dtype
+            e.n_sites = cx.rng._site - site0
+            cx.rng._site = site0
+            with torch.cuda.graph(e.g_bwd, pool=self.pool, stream=stream, capture_error_mode="thread_local"):
+                out.backward(e.gout)
+                ops.join_side()
         e.out = out.detach()
         assert e.xt_leaf.grad is not None and e.mem_leaf.grad is not None
         self.entries[key] = e

@@ -35,12 +35,18 @@ def ops_stream(device=None):
     return st
 
 
-def backward_all(model, loss):
-    """``loss.backward()`` plus, when the model cut its autograd graph at the [CLS] rows (``model.split_backward``), the second
-    phase through the clip encoder."""
+def backward_all(model, loss, exchange=None):
+    """``loss.backward()`` plus, when the model cut its autograd graph at the [CLS] rows (``model.split_backward``, or the clip encoder
+    replayed from a per-clip-count hipGraph: svpc_amd/clip_graphs.py), the second phase through the clip encoder.  ``exchange``: the
+    data-parallel ``GradReducer`` — between the two phases every bucket without a clip-encoder member is started (the text side's
+    gradients, ≈74 % of the bytes, are final: those of eager parts were reported by their hooks during the backward, those of replayed
+    parts — which fire no hook — are complete because their replay ran inside it), so they travel while the clip encoder's backward
+    runs: the cut of the three-graph step.  The caller then calls ``exchange.finish()`` and the optimizer."""
     loss.backward()
     cut = getattr(model, "split_boundary", None)
     if cut is not None:
+        if exchange is not None:
+            exchange.start_early()
         cut[0].backward(cut[1].grad)
         model.split_boundary = None
 

@@ -739,8 +739,24 @@ def _direct(p):
     return g if (g is not None and getattr(p, "_svpc_direct", False)) else None
 
 
+HOOKS_PAUSED = [0]         # > 0: gradient-ready notifications (pointer reports here, the reducer's post-accumulate hooks) are ignored
+
+
+class hooks_paused:
+    """``with ops.hooks_paused():`` — while a part of the step is warmed up / captured into a hipGraph (svpc_amd/clip_graphs.py) the
+    data-parallel reducer must not count the parameter writes of that pass (nor issue a collective from inside a capture)."""
+
+    def __enter__(self):
+        HOOKS_PAUSED[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        HOOKS_PAUSED[0] -= 1
+        return False
+
+
 def _ready(t, kind=None):
-    if GRAD_READY_HOOK is not None and t is not None:
+    if GRAD_READY_HOOK is not None and t is not None and not HOOKS_PAUSED[0]:
         GRAD_READY_HOOK(t.data_ptr(), t.numel(), kind)
 
 

@@ -581,8 +581,11 @@ class GradReducer:
             self._done(i, bi)
 
     def _make_hook(self, i, bi):
+        from . import ops
+
         def hook(param):
-            self._done(i, bi)
+            if not ops.HOOKS_PAUSED[0]:          # (a warm-up / capture pass of a replayed part of the step: clip_graphs._capture)
+                self._done(i, bi)
         return hook
 
     CLIP_SIDE = ("video_embeddings.", "encoder.", "token_type_embeddings.")

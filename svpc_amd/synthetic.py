@@ -87,7 +87,7 @@ def _as_list(v, n):
 
 
 def make_batch(cfg, n_videos, max_steps, step_nums=None, n_ingr=10, n_oov=0, seed=2019,
-               full_clips=True, p_align=0.15, p_action=None, device="cpu"):
+               full_clips=True, p_align=0.15, p_action=None, device="cpu", feature_bank=None):
     """Build the 13 positional arguments of ``StateAwareRecursiveTransformer.forward``.
 
     Returns a dict with keys named after the forward signature (model.py:1027-1030) plus
@@ -139,7 +139,10 @@ def make_batch(cfg, n_videos, max_steps, step_nums=None, n_ingr=10, n_oov=0, see
     labels = np.full((S, N, L), IGNORE, np.int64)
     tt = np.zeros((S, N, L), np.int64)
     tt[:, :, Lv:] = 1
-    feats = np.zeros((S, N, L, F), np.float32)
+    # feature_bank: a pre-drawn (≥ S, N, L, F) array of frame features reused for every batch (rows 1..Lv-2 of every clip are U[0,1) draws;
+    # full_clips only) — drawing 77 M uniforms per batch is what makes a hundred differently STRUCTURED batches slow to build
+    bank = feature_bank is not None and full_clips
+    feats = feature_bank[:S] if bank else np.zeros((S, N, L, F), np.float32)
     for s in range(S):
         for b in range(N):
             valid = Lv - 2 if full_clips else int(rng.randint(max(1, (Lv - 2) // 2), Lv - 1))
@@ -147,7 +150,8 @@ def make_batch(cfg, n_videos, max_steps, step_nums=None, n_ingr=10, n_oov=0, see
             ids[s, b, 1:1 + valid] = VID
             ids[s, b, 1 + valid] = SEP
             masks[s, b, :valid + 2] = 1
-            feats[s, b, 1:1 + valid] = rng.rand(valid, F).astype(np.float32)
+            if not bank:
+                feats[s, b, 1:1 + valid] = rng.rand(valid, F).astype(np.float32)
             n_w = int(rng.randint(min(5, Lt - 2), min(20, Lt - 2) + 1)) if Lt > 4 else Lt - 2
             words = rng.randint(N_SPECIAL, V, size=n_w)
             ext = words.copy()

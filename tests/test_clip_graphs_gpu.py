@@ -73,8 +73,9 @@ def test_eviction_recapture_and_training_mode_dropout(golden_dir):
     from svpc_amd.optim import FusedBertAdam
     z, cfg, _, model = build_model("c1", "vivt", golden_dir, DEV)
     model.train()
-    structs = [dict(S=[5, 3, 7], E=[3, 1, 10], X=[0, 0, 1], seed=41), dict(S=[4, 9, 3], E=[2, 25, 8], X=[1, 2, 0], seed=42),
-               dict(S=[16, 3], E=[31, 4], X=[2, 0], seed=43), dict(S=[6, 6, 6, 6], E=[5, 5, 5, 5], X=[0, 0, 0, 0], seed=44)]
+    # (clip counts 15, 25, 19, 40: four different buckets of 8 — the graphs are captured per clip count rounded up to a multiple of 8)
+    structs = [dict(S=[5, 3, 7], E=[3, 1, 10], X=[0, 0, 1], seed=41), dict(S=[4, 9, 12], E=[2, 25, 8], X=[1, 2, 0], seed=42),
+               dict(S=[16, 3], E=[31, 4], X=[2, 0], seed=43), dict(S=[6, 6, 6, 6, 9, 7], E=[5, 5, 5, 5, 3, 8], X=[0, 0, 0, 0, 1, 0], seed=44)]
     batches = []
     for st in structs:
         b_cpu = syn.make_batch(cfg, n_videos=len(st["S"]), max_steps=max(st["S"]), step_nums=st["S"], n_ingr=st["E"], n_oov=st["X"],
@@ -165,3 +166,74 @@ def test_guards_plain_backward_second_forward_and_default_stream(golden_dir):
         assert float(model.video_embeddings.video_embeddings[2].weight.grad.abs().max()) > 0
     finally:
         clip_graphs.enable(model, False)
+
+
+def test_bucketed_clip_counts_and_the_dp_reducer(golden_dir):
+    """(a) two batches whose clip counts fall into the SAME bucket of 8 share one pair of graphs (the padding clips
+    contribute exact zeros); (b) the graphs stay in use with the data-parallel reducer attached — one rank over gloo, SUM over one rank is
+    the identity — through ``backward_all(model, loss, exchange=reducer)``: text-side buckets are started between the eager backward and
+    the clip encoder's replay, the rest by ``finish()``; the exchanged gradients equal the plain eager step's."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from svpc_amd import keep_host_copy, ops, clip_graphs
+    from svpc_amd.graph import backward_all, ops_stream
+    from svpc_amd.optim import FusedBertAdam, GradReducer
+    z, cfg, _, model = build_model("c1", "vivt", golden_dir, DEV)
+    structs = [dict(S=[5, 3, 7], E=[3, 1, 10], X=[0, 0, 1], seed=61), dict(S=[4, 6, 3], E=[2, 25, 8], X=[1, 2, 0], seed=62)]      # T = 15, 13
+    batches = []
+    for st in structs:
+        b_cpu = syn.make_batch(cfg, n_videos=len(st["S"]), max_steps=max(st["S"]), step_nums=st["S"], n_ingr=st["E"], n_oov=st["X"],
+                               seed=st["seed"], full_clips=False)
+        gn = torch.Generator().manual_seed(100 + st["seed"])
+        noise = [-torch.empty(s_, cfg.max_t_len, cfg.vocab_size + x).exponential_(generator=gn).log().to(DEV) for s_, x in zip(st["S"], st["X"])]
+        b = {kk: ([t.to(DEV) if isinstance(t, torch.Tensor) else t for t in v] if isinstance(v, list) else
+                  (v.to(DEV) if isinstance(v, torch.Tensor) else v)) for kk, v in b_cpu.items()}
+        keep_host_copy(b["ingr_sep_masks"], b_cpu["ingr_sep_masks"])
+        batches.append((syn.forward_args(b), noise))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    ops.set_precision("bf16x3")
+    red = None
+    try:
+        opt = FusedBertAdam(list(model.named_parameters()), lr=0.0, warmup=0.1, t_total=1000, weight_decay=0.0, grad_clip=1.0)
+
+        def run(k, exchange=None):
+            args, noise = batches[k % 2]
+            model._plans.clear(); model._ptr_plans.clear(); model._span_cache.clear()
+            model.gumbel_noise = noise
+            opt.zero_grad()
+            tot = model(*args)[0]
+            backward_all(model, tot, exchange=exchange)
+            if exchange is not None:
+                exchange.finish()
+            ops.join_side()
+            torch.cuda.synchronize()
+            arena = opt.ensure_built()
+            return float(tot.detach()), arena.flat.clone()
+        with torch.cuda.stream(ops_stream()):
+            run(0)
+            eager = [run(k) for k in range(2)]
+            cg, dg = clip_graphs.enable(model)
+            graphed = [run(k) for k in range(4)]
+            assert cg.stats["captures"] == 1 and cg.stats["hits"] == 3, cg.stats          # 15 and 13 clips: one bucket (16)
+            assert dg.stats["captures"] == 1 and dg.stats["hits"] == 3, dg.stats
+            red = GradReducer(opt.arena, bucket_bytes=256 << 10, overlap=True, force=True)
+            assert red.active and red.overlap
+            with_dp = [run(k, exchange=red) for k in range(4)]
+            assert cg.stats["hits"] == 7 and cg.stats["bypassed"] == 0, cg.stats          # the graphs stayed in use under the reducer
+        for k in range(4):
+            e = eager[k % 2]
+            for tag, g in (("graphs", graphed[k]), ("graphs + reducer", with_dp[k])):
+                assert abs(e[0] - g[0]) <= 1e-6 * abs(e[0]), (tag, k, e[0], g[0])
+                assert float((e[1] - g[1]).abs().max()) <= 2e-5 * float(e[1].abs().max()), (tag, k)
+    finally:
+        clip_graphs.enable(model, False)
+        ops.set_precision("fp32")
+        if red is not None:
+            red.close()
+        if created:
+            dist.destroy_process_group()
