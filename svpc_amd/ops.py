@@ -145,7 +145,7 @@ def defer_wgrad(dz, x, wgrad, bgrad):
     if USE_GROUPED_WGRAD and GROUP_BF16 and _fast() and wgrad is not None and not SIDE_WGRAD and \
             dz.dtype == torch.bfloat16 and x.dtype == torch.bfloat16:
         return _defer_wgrad16(dz, x, wgrad, bgrad)
-    if not (USE_GROUPED_WGRAD and _fast() and wgrad is not None and dz.dtype == torch.float32 and x.dtype == torch.float32):
+    if not (USE_GROUPED_WGRAD and _fast() and wgrad is not None and dz.dtype == torch.float32 and x.dtype == torch.float32) or BWD_EXACT:
         return False
     rows, n_out = dz.shape
     n_in = x.shape[1]
@@ -636,6 +636,15 @@ def bf16_stream_ok(rows, *dims):
     return rows % 128 == 0 and all(d % 128 == 0 for d in dims)
 
 
+# ---- backward ablation switches (tests/tools/bwd_ablation.py; all False in the product): which part of the bf16 backward of the bf16x3
+# mode moves a training trajectory away from the fp32 one?  BWD_EXACT: every contraction on fp32 storage that is NOT a three-term forward
+# product (i.e. the dgrads / wgrads of the text / step-level side) runs on the exact f32 MFMA, ungrouped; ATTN_BWD_EXACT: attention on
+# fp32 storage takes the exact fp32 backward kernel instead of the matrix-core one.  (The third switch is ``BF16_STREAM`` below: False
+# keeps every activation — and so every gradient — in fp32 storage.)
+BWD_EXACT = False
+ATTN_BWD_EXACT = False
+
+
 def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NONE, p=0.0, site=0, seed=None, accumulate=0, R=None, G=None,
           x3=False):
     """C = epi(A·B) (+ R: an addend of C's type and layout, only on the bf16 direct-to-LDS path; other paths add it afterwards).
@@ -648,7 +657,10 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, M, N, K, Z=None, bias=None, act=ACT_NON
           if GEMM_TIMER is not None else None)
     if ev:
         ev[0].record()
-    if x3 and A.dtype == B.dtype == C.dtype == torch.float32:
+    if BWD_EXACT and not x3 and A.dtype == B.dtype == C.dtype == torch.float32:
+        _lib.call("gemm_f32", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), M, N, K, _p(bias), act, p, site,
+                  _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
+    elif x3 and A.dtype == B.dtype == C.dtype == torch.float32:
         if (A.data_ptr() | B.data_ptr()) % 16 == 0 and _lib.load().svpc_gemm_l32_supported(a_kc, b_kc, lda, ldb, M, N, K) == 1:
             _lib.call("gemm_l32_x3", _p(A), lda, a_kc, _p(B), ldb, b_kc, _p(C), C.stride(0), _p(Z), None, M, N, K, _p(bias), act, p, site,
                       _p(seed), accumulate, _p(ws), ws.numel() * 4, _stream())
@@ -1235,7 +1247,7 @@ class _Attention(Function):
         ctx.save_for_backward(qt, kvt_c, out, lse, key_mask, seed, tbl)
         ctx.cfg = (cols, D, H, seq.n, seq.max_q, seq.max_k, causal, p, site, same)
         ctx.kv_into = None if same else getattr(kvt, "_svpc_grad_into", None)     # a column block of a shared gradient buffer
-        ctx.mfma = mfma
+        ctx.mfma = mfma and not (ATTN_BWD_EXACT and qt.dtype == torch.float32)
         ctx.n_k_rows = seq.n_k_rows
         return out
 
@@ -2171,7 +2183,7 @@ class _BiLstmSeq(Function):
 
 def bilstm_sequences(gx_f, gx_b, w_f, w_b, rows_f, rows_b, active_t, pick_f, pick_b):
     """Both LSTM directions (see lstm_sequence for the arguments) → (out_f, out_b), each (T, D)."""
-    if _fast() and gx_f.is_cuda:
+    if _fast() and gx_f.is_cuda and not BWD_EXACT:
         return _BiLstmSeq.apply(gx_f, gx_b, w_f, w_b, rows_f, rows_b, active_t, pick_f, pick_b, _direct(w_f), _direct(w_b))
     return lstm_sequence(gx_f, w_f, rows_f, active_t, pick_f), lstm_sequence(gx_b, w_b, rows_b, active_t, pick_b)
 

@@ -30,7 +30,15 @@ NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")          # src/train.p
 # summation order — reaches 9e-3 by step 16 after staying below 1e-6 for eight steps.  The headline mode (three-term forward, bf16
 # BACKWARD: gradient norms within 0.3 %, cosines ≥ 0.9999 per step) starts at the forward's 3e-7 and sits ≈ 7× above the fp32 run
 # from step 8 on; both descend to within 4 % of the oracle's final loss.  `early` bounds steps 0-6, `all` every step.
-BOUND = {"fp32": dict(early=2e-6, all=2e-2, final=1.5e-2, drift=4e-2), "bf16x3": dict(early=6e-4, all=1.3e-1, final=8e-2, drift=3.2e-1)}
+# Round 5: bounds at 1.3× what THIS build measures (profiles/trajectory_parity.json: fp32 worst 9.5e-3 / drift 0.018;
+# bf16x3 worst 1.8e-2 / final 5.4e-3 / drift 0.075) — a backward that got 1.3× worse now fails.  What the bound cannot do is stay put across
+# kernel changes: the trajectory is chaotic (Adam's m/√v turns rounding into full-size steps), so a mere RE-DRAW of the rounding pattern
+# moves it by 2× — round 4's kernels gave worst 6.3e-2 / drift 0.155 with the same arithmetic; tests/tools/bwd_ablation.py
+# (profiles/r05_bwd_ablation.json) shows the same on two seeds and two shapes: no single family of the bf16 backward carries the drift
+# (exact text-side GEMMs, exact attention, fp32 stream storage each leave it where it was; only ALL of them together — a 4× slower
+# step — bring the config-1 run to the fp32 run's 0.001–0.017, and at the headline shape even that nearly exact backward, step-0 gradient
+# cosine 1.000000, drifts 0.17–0.24 from the fp32 mode in 20 steps).  Re-measure and re-state these numbers when the arithmetic changes.
+BOUND = {"fp32": dict(early=2e-6, all=1.25e-2, final=7.7e-3, drift=2.4e-2), "bf16x3": dict(early=6.6e-4, all=2.3e-2, final=7.1e-3, drift=9.8e-2)}
 
 _ORACLE = {}
 
