@@ -35,6 +35,18 @@ def ops_stream(device=None):
     return st
 
 
+_STREAMS_B = {}
+
+
+def ops_stream_b(device=None):
+    """a second capture / replay stream per device: the other half of a batch decoded beside the first (svpc_amd.translator)"""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    st = _STREAMS_B.get(dev)
+    if st is None:
+        st = _STREAMS_B[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def backward_all(model, loss, exchange=None):
     """``loss.backward()`` plus, when the model cut its autograd graph at the [CLS] rows (``model.split_backward``, or the clip encoder
     replayed from a per-clip-count hipGraph: svpc_amd/clip_graphs.py), the second phase through the clip encoder.  ``exchange``: the

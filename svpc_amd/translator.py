@@ -27,6 +27,12 @@ class Translator(object):
         self.opt = opt
         self.incremental = incremental
         self.graph = graph          # replay the decode of a recurring batch structure as one hipGraph (see _decode_graphed)
+        # graph mode, ≥ 2·min_half videos: the two halves of the batch as two graphs on two streams.  OFF: measured once on the MI355X
+        # (round 5, 64 videos × 12 clips, bf16x3) the two replays did not overlap — 36.3 ms per batch against 27.3 ms for the one graph
+        # (encoder side 13.3 ms + 2 × 22 iterations of ≈0.5 ms: every half's iterations cost what the whole batch's cost, and the
+        # second half's ran after the first's) — DESIGN §0.  Kept as an option because the ids are identical either way (tested).
+        self.two_streams = False
+        self.min_half = 8
         self.phase_events = None    # bench.py: a list → _decode_core (eager) appends three HIP events: start, encoder side done, end
         self._preps = {}
         self._ttab = None
@@ -217,28 +223,59 @@ class Translator(object):
             input_ids_list, input_masks_list = self.prepare_video_only_inputs(input_ids_list, input_masks_list, token_type_ids_list)
         N, L, F = video_features_list[0].shape
         S_pad = len(input_ids_list)
-        prep = self._prepare(model, batch_step_num, ingr_sep_masks, ingr_id_dict, oov_word_dict, S_pad, N, L, dev)
-        plan = prep["plan"]
-        feats = model._stacked(video_features_list).reshape(S_pad * N * L, F)
-        ids_all = (stk[0] if stk is not None else torch.stack(input_ids_list)).reshape(-1).to(torch.int32)
-        masks_all = (stk[1] if stk is not None else torch.stack(input_masks_list)).reshape(-1).float()
-        ingr_flat = torch.as_tensor(ingr_input_ids).to(dev).reshape(-1).to(torch.int32)
-        if not self.graph or dev.type != "cuda":
-            out = self._decode_core(model, prep, feats, ids_all, masks_all, ingr_flat)
+        feats4 = model._stacked(video_features_list)                                             # (S, N, L, F): zero-copy for a stacked loader
+        ids3 = (stk[0] if stk is not None else torch.stack(input_ids_list))                      # (S, N, L)
+        masks3 = (stk[1] if stk is not None else torch.stack(input_masks_list))
+        ingr_all = torch.as_tensor(ingr_input_ids).to(dev).to(torch.int32)                       # (N, Li)
+        sep_all = torch.as_tensor(ingr_sep_masks)
+
+        def part(lo, hi, stream=None):
+            n = hi - lo
+            prep = self._prepare(model, list(batch_step_num[lo:hi]), sep_all[lo:hi], list(ingr_id_dict[lo:hi]), list(oov_word_dict[lo:hi]),
+                                 S_pad, n, L, dev)
+            src = (feats4[:, lo:hi], ids3[:, lo:hi], masks3[:, lo:hi], ingr_all[lo:hi])
+            if not self.graph or dev.type != "cuda":
+                out = self._decode_core(model, prep, src[0].reshape(S_pad * n * L, F), src[1].reshape(-1).to(torch.int32),
+                                        src[2].reshape(-1).float(), src[3].reshape(-1))
+            else:
+                out = self._decode_graphed(model, prep, src, (S_pad, n, L, F), stream)
+            return prep["plan"], out
+
+        # Two halves on two streams: the encoder side of a batch is bound by the matrix cores, the Lt decoding
+        # iterations are chains of small dependent launches that leave the chip idle — two independent chains interleave.  Videos are
+        # independent (the reference decodes them one by one, translator.py:175-191), so the ids are those of the unsplit decode bit for
+        # bit (tests/test_config5_gpu.py).  Two replayed graphs on two streams, not one forked graph.
+        halves = [(0, N)]
+        if self.graph and self.two_streams and dev.type == "cuda" and N >= 2 * self.min_half:
+            halves = [(0, N // 2), (N // 2, N)]
+        if len(halves) == 1:
+            plans_outs = [part(0, N)]
         else:
-            out = self._decode_graphed(model, prep, feats, ids_all, masks_all, ingr_flat)
-        out = out.to(torch.int64)                      # (one cast for the batch: the per-video results are views of it)
+            from .graph import ops_stream, ops_stream_b
+            cur = torch.cuda.current_stream()
+            sa = cur if cur != torch.cuda.default_stream() else ops_stream()
+            sb = ops_stream_b()
+            plans_outs = []
+            for (lo, hi), st in zip(halves, (sa, sb)):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    plans_outs.append(part(lo, hi, st))
+            for st in (sa, sb):
+                cur.wait_stream(st)
         res = []
-        for b in range(N):
-            o, n = plan.h_step_off[b], plan.h_step_len[b]
-            res.append(out[o:o + n])
+        for plan, out in plans_outs:
+            out = out.to(torch.int64)                  # (one cast per part: the per-video results are views of it)
+            for b in range(plan.N):
+                o, n_ = plan.h_step_off[b], plan.h_step_len[b]
+                res.append(out[o:o + n_])
         return res, oov_word_dict
 
-    def _decode_graphed(self, model, prep, feats, ids_all, masks_all, ingr_flat):
+    def _decode_graphed(self, model, prep, src, shape, stream=None):
         """The ≈2,000 launches of a batch's decode (encoder side + Lt iterations × 6 layers) replayed as ONE hipGraph.  The graph
         is tied to the batch structure (step / ingredient / OOV counts: ``_prepare``'s key): the first batch of a structure runs
         eagerly twice (warm-up: index tables reach the device, kernels set their attributes) and is then captured; later batches of
-        the same structure copy their tensors into the captured inputs and replay."""
+        the same structure copy their tensors into the captured inputs and replay.  ``src``: (features (S, n, L, F), ids (S, n, L),
+        masks (S, n, L), ingredient ids (n, Li)) — possibly strided views of the whole batch (the copy into the captured inputs gathers them)."""
         # a captured graph holds raw pointers: it is valid only while the parameters (and, on the bf16 path, their shadow) live where
         # they lived at capture time — a weight store built later (optimizer start, WeightStore.for_model) re-points them
         from . import ops as _ops
@@ -246,31 +283,44 @@ class Translator(object):
         # (epoch + the embedding parameters' version counters: the graph holds the address of the per-checkpoint text-embedding table,
         # which ``_text_table`` rebuilds — elsewhere — when either moves: load_state_dict / copy_ into the same tensors bump only the versions)
         te = model.text_embeddings
+        S_pad, n, L, F = shape
+        from .graph import ops_stream
+        cur = torch.cuda.current_stream()
+        side = stream if stream is not None else (cur if cur != torch.cuda.default_stream() else ops_stream())
         sig = (tuple(p.data_ptr() for p in list(model.parameters())[:8]), _ops.get_precision(),
                id(getattr(model, "_svpc_weight_store", None)), WEIGHTS_EPOCH[0],
-               tuple(p._version for p in [te.word_embeddings.weight] + list(te.word_fc.parameters())))
-        g = prep["graph"]
+               tuple(p._version for p in [te.word_embeddings.weight] + list(te.word_fc.parameters())), side.cuda_stream)
+        if not isinstance(prep["graph"], dict):
+            prep["graph"] = {}                       # one graph per replay stream: two halves of ONE structure must not share captured buffers
+        gkey = side.cuda_stream
+        g = prep["graph"].get(gkey)
         if g is not None and g[3] != sig:
-            g = prep["graph"] = None
+            g = None
+            prep["graph"].pop(gkey, None)
+
+        def flat(st):
+            return (st[0].view(S_pad * n * L, F), st[1].view(-1), st[2].view(-1), st[3].view(-1))
         if g is None:
-            self._decode_core(model, prep, feats, ids_all, masks_all, ingr_flat)
-            static = [feats.clone(), ids_all.clone(), masks_all.clone(), ingr_flat.clone()]
-            # warm-up and capture on the process's one capture stream (svpc_amd.graph.ops_stream): a fresh stream per batch
+            static = [torch.empty(S_pad, n, L, F, dtype=torch.float32, device=src[0].device),
+                      torch.empty(S_pad, n, L, dtype=torch.int32, device=src[0].device),
+                      torch.empty(S_pad, n, L, dtype=torch.float32, device=src[0].device),
+                      torch.empty(src[3].shape, dtype=torch.int32, device=src[0].device)]
+            for dst, s_ in zip(static, src):
+                dst.copy_(s_)
+            # warm-up and capture on ONE stream per half (svpc_amd.graph.ops_stream / ops_stream_b): a fresh stream per batch
             # structure would pin another 256 MB kernel workspace each (ops._ws is per (device, stream))
-            from .graph import ops_stream
-            cur = torch.cuda.current_stream()
-            side = cur if cur != torch.cuda.default_stream() else ops_stream()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                self._decode_core(model, prep, *static)
+                self._decode_core(model, prep, *flat(static))
+                self._decode_core(model, prep, *flat(static))
             cur.wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
-                out = self._decode_core(model, prep, *static)
-            g = prep["graph"] = (graph, static, out, sig)
+                out = self._decode_core(model, prep, *flat(static))
+            g = prep["graph"][gkey] = (graph, static, out, sig)
         graph, static, out, _ = g
-        for dst, src in zip(static, (feats, ids_all, masks_all, ingr_flat)):
-            dst.copy_(src)
+        for dst, s_ in zip(static, src):
+            dst.copy_(s_)
         graph.replay()
         return out.clone()

@@ -166,6 +166,11 @@ def test_config5_at_64_videos_equals_eight_decodes_of_eight(precision):
         b64 = _to_dev(batch)
         full, _ = tr.translate_batch(syn.translate_inputs(b64))
         full2, _ = tr.translate_batch(syn.translate_inputs(b64))          # the replayed graph
+        tr.two_streams = True                                             # … and the two halves as two graphs on two streams (an option)
+        full3, _ = tr.translate_batch(syn.translate_inputs(b64))
+        full3, _ = tr.translate_batch(syn.translate_inputs(b64))
+        tr.two_streams = False
+        assert all(torch.equal(a, b) for a, b in zip(full, full3)), "the two-stream decode of the halves differs from the one-graph decode"
         chunks = []
         for c in range(8):
             d, _ = tr.translate_batch(syn.translate_inputs(_to_dev(_slice_batch(batch, 8 * c, 8 * c + 8))))
