@@ -144,8 +144,9 @@ def parse_args(argv=None):
                     help="after the timed region: this many EAGER steps over batches of the structure the reference's loop feeds (S_b ~ U{3..16}, "
                          "E_b ~ U{1..31}, X_b in {0,1,2}), a different structure every step; printed as the `ragged` field (0 = skip)")
     ap.add_argument("--bucket-timeline", action="store_true",
-                    help="N > 1: record per-bucket issue / completion events of the gradient exchange (exchange.bucket_timeline_ms); off by "
-                         "default — the events are created inside the timed region")
+                    help="record per-bucket issue / completion events of the gradient exchange (exchange.bucket_timeline_ms); ON by default "
+                         "when more than one rank runs, so that the first multi-GPU record is diagnosable without a second run")
+    ap.add_argument("--no-bucket-timeline", action="store_true", help="N > 1: do not record the per-bucket timeline")
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="run the data-parallel code path (process group, three graphs, bucketed all-reduce) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -537,7 +538,7 @@ def run_train(args, precision, device, world, rank, dist, steps, warmup, instrum
             if state["reducer"] is None:
                 # graph mode: the exchange runs between captured graphs (no hooks); eager mode: overlapped with backward
                 state["reducer"] = GradReducer(arena, overlap=args.no_graph, force=args.rehearse_dp, wire_dtype=args.exchange_dtype,
-                                               timeline=args.bucket_timeline)
+                                               timeline=(args.bucket_timeline or (world > 1 and not args.no_bucket_timeline)))
                 state["reducer"].mark_all_unlaunched()   # first step: hooks were not installed during this backward
             state["reducer"].finish()
         opt.step()
@@ -944,7 +945,7 @@ def _train_main(args, device, world, rank, dist, joined):
     if dist is not None:
         out["rccl_ranks"] = joined
         out["distinct_devices"] = min(joined, torch.cuda.device_count())      # < n_gpus only in a gloo rehearsal that shares cards
-        out["exchange"] = {"backend": args.backend, "allreduce_bytes_per_step": r["allreduce_bytes"], "buckets": r["n_buckets"],
+        out["exchange"] = {"backend": args.backend, "ranks_joined": joined, "allreduce_bytes_per_step": r["allreduce_bytes"], "buckets": r["n_buckets"],
                            "wire_dtype": args.exchange_dtype,
                            "op": "SUM over the fp32 gradient arena, before the global clip (src/train.py:140-143)",
                            # last step of the run: when each bucket's all-reduce was issued and when the compute stream could pass
