@@ -30,15 +30,20 @@ NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")          # src/train.p
 # summation order — reaches 9e-3 by step 16 after staying below 1e-6 for eight steps.  The headline mode (three-term forward, bf16
 # BACKWARD: gradient norms within 0.3 %, cosines ≥ 0.9999 per step) starts at the forward's 3e-7 and sits ≈ 7× above the fp32 run
 # from step 8 on; both descend to within 4 % of the oracle's final loss.  `early` bounds steps 0-6, `all` every step.
-# Round 5: bounds at 1.3× what THIS build measures (profiles/trajectory_parity.json: fp32 worst 9.5e-3 / drift 0.018;
-# bf16x3 worst 1.8e-2 / final 5.4e-3 / drift 0.075) — a backward that got 1.3× worse now fails.  What the bound cannot do is stay put across
-# kernel changes: the trajectory is chaotic (Adam's m/√v turns rounding into full-size steps), so a mere RE-DRAW of the rounding pattern
-# moves it by 2× — round 4's kernels gave worst 6.3e-2 / drift 0.155 with the same arithmetic; tests/tools/bwd_ablation.py
-# (profiles/r05_bwd_ablation.json) shows the same on two seeds and two shapes: no single family of the bf16 backward carries the drift
-# (exact text-side GEMMs, exact attention, fp32 stream storage each leave it where it was; only ALL of them together — a 4× slower
-# step — bring the config-1 run to the fp32 run's 0.001–0.017, and at the headline shape even that nearly exact backward, step-0 gradient
-# cosine 1.000000, drifts 0.17–0.24 from the fp32 mode in 20 steps).  Re-measure and re-state these numbers when the arithmetic changes.
-BOUND = {"fp32": dict(early=2e-6, all=1.25e-2, final=7.7e-3, drift=2.4e-2), "bf16x3": dict(early=6.6e-4, all=2.3e-2, final=7.1e-3, drift=9.8e-2)}
+# Round 5.  The FREE-RUNNING curve is chaotic: Adam's m/√v turns rounding into full-size steps, so a mere RE-DRAW of
+# the rounding pattern moves it by 2× — three builds of this round with the SAME arithmetic (only kernels fused differently) measured
+# worst loss deviation 1.8e-2 / 5.6e-2 / 6.3e-2 and drift / travel 0.075 / 0.133 / 0.155 in bf16x3; tests/tools/bwd_ablation.py
+# (profiles/r05_bwd_ablation.json) shows on two seeds and two shapes that no single family of the bf16 backward carries the drift and that
+# at the headline shape even a nearly exact backward (step-0 gradient cosine 1.000000) drifts 0.17–0.24 from the fp32 mode in 20 steps.
+# A bound at 1.3× one build's draw therefore fails on the next benign change (tried: it did, within three commits).  So the curve keeps
+# bounds that hold over the observed re-draws, and the REGRESSION gate of the backward is the teacher-forced test below
+# (test_backward_along_the_oracle_trajectory): the product's gradient at the ORACLE's parameters of every step against the oracle's
+# gradient there — no amplification, errors average over millions of elements, bounds at 1.3× measured.
+BOUND = {"fp32": dict(early=2e-6, all=2e-2, final=1.5e-2, drift=4e-2), "bf16x3": dict(early=1e-3, all=1.3e-1, final=8e-2, drift=3.2e-1)}
+# 1 − cosine and relative norm error of the WHOLE gradient (all tensors, flattened) at each of the 20 oracle states; measured on the MI355X
+# (profiles/trajectory_parity.json "teacher_forced"): fp32 5.2e-12 / 8.3e-7, bf16x3 1.33e-5 / 6.8e-4 → bounds at 1.3× (fp32: a floor an
+# fp32 summation re-order stays under)
+TF_BOUND = {"fp32": dict(one_minus_cos=1e-10, norm=2e-6), "bf16x3": dict(one_minus_cos=1.75e-5, norm=8.9e-4)}
 
 _ORACLE = {}
 
@@ -52,6 +57,7 @@ def _oracle_curve(golden_dir):
     names = [n for n, _ in model.named_parameters()]
     wd = {n: (0.0 if any(t in n for t in NO_DECAY) else WD) for n in names}
     state, losses = {}, []
+    _ORACLE["states"] = []            # (parameters, gradients) of every step: the teacher-forced test replays the product at these points
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     for k in range(STEPS):
         for n in names:
@@ -60,6 +66,7 @@ def _oracle_curve(golden_dir):
         total = orc.forward(P, cfg, *syn.forward_args(batch), gumbel_noise=noise)[0]
         total.backward()
         grads = {n: P[n].grad for n in names if P[n].grad is not None}
+        _ORACLE["states"].append(({n: P[n].detach().clone() for n in names}, {n: g.detach().clone() for n, g in grads.items()}))
         losses.append(float(total))
         with torch.no_grad():
             for n in names:
@@ -126,3 +133,51 @@ def test_twenty_captured_steps_follow_the_oracle(golden_dir, precision):
     assert rel[-1] <= b["final"], (precision, rel)
     assert rec[precision]["param_drift_over_travel"] <= b["drift"], (precision, rec[precision]["param_drift_over_travel"])
     assert losses[-1] < 0.25 * losses[0]                    # the product's own run descends as the oracle's does
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_backward_along_the_oracle_trajectory(golden_dir, precision):
+    """Teacher-forced: at the ORACLE's parameters of each of its 20 steps the product's whole gradient (every tensor, flattened) against the
+    oracle's gradient at that point — the backward's accuracy along a real descent, without the chaotic amplification of a free run."""
+    _oracle_curve(golden_dir)
+    states = _ORACLE["states"]
+    ops.set_precision(precision)
+    worst_c = worst_n = 0.0
+    per_step = []
+    try:
+        z, cfg, batch, model = build_model("c1", "vivt", golden_dir, DEV)
+        fargs = syn.forward_args(batch)
+        named = dict(model.named_parameters())
+        for k, (params, grads) in enumerate(states):
+            with torch.no_grad():
+                for n, p in named.items():
+                    p.copy_(params[n].to(DEV))
+                    p.grad = None
+            loss = model(*fargs)[0]
+            loss.backward()
+            ops.join_side()
+            torch.cuda.synchronize()
+            names = [n for n in grads if named[n].grad is not None]
+            assert len(names) == len(grads)
+            ga = torch.cat([named[n].grad.detach().double().cpu().reshape(-1) for n in names])
+            gb = torch.cat([grads[n].double().reshape(-1) for n in names])
+            omc = 1.0 - float(torch.dot(ga, gb) / (ga.norm() * gb.norm()))
+            nr = abs(float(ga.norm() / gb.norm()) - 1.0)
+            per_step.append((omc, nr))
+            worst_c, worst_n = max(worst_c, omc), max(worst_n, nr)
+    finally:
+        ops.set_precision("fp32")
+    rec_path = os.path.join(ROOT, "gpurun_out", "trajectory_parity.json")
+    try:
+        with open(rec_path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        rec = {}
+    rec.setdefault("teacher_forced", {})[precision] = dict(one_minus_cos_worst=worst_c, norm_rel_worst=worst_n, per_step=per_step, steps=len(states))
+    with open(rec_path, "w") as f:
+        json.dump(rec, f, indent=1)
+    print("%s teacher-forced: worst 1 - cos %.3e, worst |g| rel %.3e" % (precision, worst_c, worst_n))
+    b = TF_BOUND[precision]
+    assert worst_c <= b["one_minus_cos"], (precision, worst_c, per_step)
+    assert worst_n <= b["norm"], (precision, worst_n, per_step)
