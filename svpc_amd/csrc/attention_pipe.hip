@@ -372,6 +372,11 @@ __global__ __launch_bounds__(512) void attn_pipe_fwd_kernel(X3AttnArgs xa, int n
 constexpr int PB_NSTAGE = 2;
 constexpr int PB_TAB = 4 * 512;                   // per stage: mask terms (keys), LSE·log2e, δ, dropout row hashes (queries): 128 words each
 constexpr int PB_STAGE = 4 * PP_IMG + PB_TAB;     // Q, K, V, dO images + tables
+// column offset (bytes, multiple of 8, < 224) of a dS-image row, rotated by 16 bytes for rows whose index has bit 3 set
+__device__ __forceinline__ int pb_ds_rot(int off, int row) {
+    const int o = off + ((row & 8) ? 16 : 0);
+    return o >= 224 ? o - 224 : o;
+}
 constexpr int PB_DS_RS = 224;                     // dS image row: 112 queries bf16; 224 = 7·32 → the eight rows of a transposed read
 constexpr int PB_DS = 112 * PB_DS_RS;             // fall on eight different 32-byte bank groups
 
@@ -457,7 +462,11 @@ __global__ __launch_bounds__(512) void attn_pipe_bwd_kernel(MAttnArgs a, int n_p
     const int vq = l15 >> 2, vp = l15 & 3, vr = 4 * g + vq;
     const int vb = vr * PP_RB + (((vp >> 1) ^ pp_swz(vr)) << 4) + 8 * (vp & 1);
     const int vr3 = min(96 + vr, PP_ROWS - 1), vb3 = vr3 * PP_RB + (((vp >> 1) ^ pp_swz(vr3)) << 4) + 8 * (vp & 1);
-    const int dsb = vr * PB_DS_RS + 8 * vp + 2 * t0;                   // dSᵀ fragment of pass 2: rows 4·g + q, columns t0 + 4·p
+    // dSᵀ fragment of pass 2: rows 4·g + q, columns t0 + 4·p.  Rows with bit 3 set keep their columns rotated by 16 bytes (pb_ds_rot):
+    // with 224-byte rows the keys l and l + 8 of a pass-1 `ds_write_b64` met in the same banks (8·56 dwords = 7·64: SQ_LDS_BANK_CONFLICT 15 %
+    // of the LDS cycles in round 4); rotated, the 16 rows × 2 lane groups of a half-wave tile the 64 banks exactly, and the transposed
+    // reads (8 rows × 4 chunks per half-wave) stay conflict-free — rows 8..15 just sit 4 banks further on.
+    const int dsb = vr * PB_DS_RS + pb_ds_rot(8 * vp + 2 * t0, vr);
     const float cs = a.scale * LOG2E;
     const uint32_t kphi = (uint32_t)(t0 + l15) * SVPC_ATTN_PHI;
     // δ one pair ahead: this wave's 16 query rows, 16 head columns per lane group
@@ -519,7 +528,8 @@ __global__ __launch_bounds__(512) void attn_pipe_bwd_kernel(MAttnArgs a, int n_p
                 asm volatile("" : "+v"(i0), "+v"(i3));
                 ta[dt] = smem + i0; ta3[dt] = smem + i3;
             }
-            char* const dsw = ds_img + key * PB_DS_RS + 8 * g;          // dS image: row = key, four consecutive queries per 8-byte store
+            char* const dsw = ds_img + key * PB_DS_RS;                  // dS image: row = key, four consecutive queries per 8-byte store
+            const int dsw_b3 = key & 8;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 uint32_t pp_[4], dd_[4];                   // P̃ and dS of query tiles 2u, 2u+1 as one k-step's B fragment
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(512) void attn_pipe_bwd_kernel(MAttnArgs a, int n_p
                     }
                     pp_[2 * hf] = pp_cvt2(pt[0], pt[1]); pp_[2 * hf + 1] = pp_cvt2(pt[2], pt[3]);
                     dd_[2 * hf] = pp_cvt2(dsv[0], dsv[1]); dd_[2 * hf + 1] = pp_cvt2(dsv[2], dsv[3]);
-                    *reinterpret_cast<uint2*>(dsw + 32 * qt) = make_uint2(dd_[2 * hf], dd_[2 * hf + 1]);
+                    *reinterpret_cast<uint2*>(dsw + pb_ds_rot(8 * g + 32 * qt, dsw_b3)) = make_uint2(dd_[2 * hf], dd_[2 * hf + 1]);
                 }
                 const bf16x8 pf = pp_frag(pp_), df8 = pp_frag(dd_);
                 bf16x8 qtr[4], dtr[4];
