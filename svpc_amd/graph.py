@@ -25,6 +25,35 @@ import torch
 _STREAMS = {}
 
 
+class capturing:
+    """``with capturing(graph, **kw):`` = ``torch.cuda.graph(graph, **kw)`` with the Python garbage collector switched OFF for the
+    duration of the capture.  The collector runs whenever allocation counts say so — also in the middle of a capture — and a finaliser
+    that makes a HIP call which is not capturable (destroying another hipGraph whose last reference sat in a cycle: an evicted entry of
+    the per-clip-count caches; freeing an event) aborts the process ("Fatal Python error: Aborted … Garbage-collecting" inside
+    DecoderGraphs._capture, hit by this round's own GPU suite).  Collect first, capture, collect afterwards."""
+
+    def __init__(self, graph, **kw):
+        self.cm = torch.cuda.graph(graph, **kw)
+
+    def __enter__(self):
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+        try:
+            return self.cm.__enter__()
+        except BaseException:
+            if self.was:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        try:
+            return self.cm.__exit__(*exc)
+        finally:
+            if self.was:
+                gc.enable()
+
+
 def ops_stream(device=None):
     """The one warm-up / capture stream of this process per device (a fresh stream per captured object would pin a 256 MB
     kernel workspace each: svpc_amd.ops._ws is per (device, stream))."""
@@ -85,7 +114,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None
         if exchange is None:
-            with torch.cuda.graph(self.graph, stream=self.stream):
+            with capturing(self.graph, stream=self.stream):
                 optimizer.zero_grad()
                 self.loss = model(*forward_args)[0]
                 self.loss.backward()
@@ -94,18 +123,18 @@ class GraphedTrainStep:
             from . import ops
             model.split_backward = True
             # other threads (the collective library's watchdog) keep making driver calls: only this thread's are policed
-            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
+            with capturing(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                 optimizer.zero_grad()
                 self.loss = model(*forward_args)[0]
                 self.loss.backward()
                 ops.join_side()
             self.graph_clip = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_clip, pool=self.graph.pool(), stream=self.stream, capture_error_mode="thread_local"):
+            with capturing(self.graph_clip, pool=self.graph.pool(), stream=self.stream, capture_error_mode="thread_local"):
                 out, cut = model.split_boundary
                 out.backward(cut.grad)
                 ops.join_side()
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), stream=self.stream, capture_error_mode="thread_local"):
+            with capturing(self.graph_opt, pool=self.graph.pool(), stream=self.stream, capture_error_mode="thread_local"):
                 optimizer.launch()
         self._versions = optimizer.weights.versions()
 

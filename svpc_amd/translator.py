@@ -316,7 +316,8 @@ class Translator(object):
             cur.wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
+            from .graph import capturing
+            with capturing(graph, stream=side):
                 out = self._decode_core(model, prep, *flat(static))
             g = prep["graph"][gkey] = (graph, static, out, sig)
         graph, static, out, _ = g
