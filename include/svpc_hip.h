@@ -285,6 +285,16 @@ int svpc_sim_recur_bwd(const float* q, const float* c, const float* w4f, const f
                        const float* ebar, const float* eall, const float* de, const float* debar, const float* deall, float* dq,
                        float* dc, float* dw4f, float* dE0, svpc_stream_t stream);
 
+/* the simulator's two tiny heads in one launch each way: c = softmax(hh·W3^T + b3) (three choice weights per step, src/rtransformer/model.py:801)
+ * and w = fb·W4^T + b4 (one scalar per step, :804-805).  Backward: dhh (T, D) and dfb (T, Wd) fully written; the weight / bias gradients as
+ * per-workgroup partial sums part3 (groups, 3·D + 3) = [dW3 | db3], part4 (groups, Wd + 1) = [dW4 | db4], groups = svpc_sim_heads_groups(T),
+ * for svpc_multi_finalize.  dc / dw may be NULL (no gradient). */
+int svpc_sim_heads_groups(int T);
+int svpc_sim_heads_fwd(const float* hh, const float* fb, const float* W3, const float* b3, const float* W4, const float* b4, float* c, float* w,
+                       int T, int D, int Wd, svpc_stream_t stream);
+int svpc_sim_heads_bwd(const float* hh, const float* fb, const float* W3, const float* W4, const float* c, const float* dc, const float* dw,
+                       float* dhh, float* dfb, float* part3, float* part4, int T, int D, int Wd, svpc_stream_t stream);
+
 /* ---- decoder cross-attention over the <= 3 memory rows of a sentence + residual LayerNorm, one launch forward and one backward per
  * layer: src/rtransformer/model.py:657-658 (BertDecoderLayerNoMemoryUntied.forward), attention core :194-219, BertLayerNorm :143-156.
  *   y = LayerNorm(x1 + MHA(query rows q; keys / values = the sentence's nm memory rows))

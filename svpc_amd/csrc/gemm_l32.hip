@@ -552,10 +552,13 @@ __device__ __forceinline__ void skinny_partials(float (*part)[16][64], const flo
 }
 template <bool B_KC, int NW, bool X3 = false>
 __device__ __forceinline__ void skinny_tile(float (*part)[16][64], const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                            float* __restrict__ C, int ldc, int M, int N, int K, const Epi& epi, int tm, int tn) {
+                                            float* __restrict__ C, int ldc, int M, int N, int K, const Epi& epi, int tm, int tn,
+                                            int ts = 32) {
+    // ts: the tile's useful edge (32, or 24: M = 192 × N = 768 is 8 × 32 = 256 tiles of 24², one per CU, each pulling 147 KB instead of
+    // the 196 KB of 144 tiles of 32² — these launches are bound by what ONE CU pulls; lanes 24..31 re-read row 23)
     const int lane = threadIdx.x & 63;
-    const int m0 = tm * 32, n0 = tn * 32;
-    const int r = lane & 31, h = lane >> 5;
+    const int m0 = tm * ts, n0 = tn * ts;
+    const int r = min(lane & 31, ts - 1), h = lane >> 5;
     const float* __restrict__ arow = A + (size_t)min(m0 + r, M - 1) * lda + 8 * h;
     const int bcol = min(n0 + r, N - 1);
     const float* __restrict__ brow = B_KC ? B + (size_t)bcol * ldb + 8 * h : B + (size_t)(8 * h) * ldb + bcol;
@@ -573,17 +576,17 @@ __device__ __forceinline__ void skinny_tile(float (*part)[16][64], const float* 
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += part[w][e][l];        // wave order: deterministic
         vs[i] = v;
-        oks[i] = m0 + row < M && n0 + col < N;
+        oks[i] = row < ts && col < ts && m0 + row < M && n0 + col < N;
         rs[i] = min(m0 + row, M - 1); cs[i] = min(n0 + col, N - 1);
     }
     epilogue_store_n<NE>(vs, rs, cs, oks, C, ldc, epi, seed, inv_keep);      // every load of the epilogue in flight at once
 }
 template <bool B_KC, bool X3 = false>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                          float* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_n) {
+                                                          float* __restrict__ C, int ldc, int M, int N, int K, Epi epi, int tiles_n, int ts) {
     __shared__ float part[4][16][64];
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
-    skinny_tile<B_KC, 4, X3>(part, A, lda, B, ldb, C, ldc, M, N, K, epi, tm, tn);
+    skinny_tile<B_KC, 4, X3>(part, A, lda, B, ldb, C, ldc, M, N, K, epi, tm, tn, ts);
 }
 // grouped form (A k-contiguous; B k-contiguous, or — B_KC = false — k-strided [K][ldb]: the LSTM's recurrent dgrad reads W_hh (4D, D) in
 // place, no transposed copy per step), NW waves per 32×32 tile: 8 for the long reductions of the LSTM dgrad (K = 3072)
@@ -860,13 +863,18 @@ static int gemm_l32_x(const float* A, int lda, int a_kc, const float* B, int ldb
     static int skinny_m = -1;
     if (skinny_m < 0) { const char* e = getenv("SVPC_L32_SKINNY_M"); skinny_m = e ? atoi(e) : 256; }
     if (env_skinny && a_kc && M <= skinny_m && N >= 32 && (K & 15) == 0 && (lda & 3) == 0 && (!b_kc || (ldb & 3) == 0)) {
-        const int tn_ = ceil_div(N, 32);
-        dim3 grids(ceil_div(M, 32) * tn_);
+        static int env_ts = -1;
+        if (env_ts < 0) { const char* e = getenv("SVPC_L32_SKINNY_TS"); env_ts = e ? atoi(e) : 24; }
+        // 24² tiles when they put at most one tile on a CU where 32² tiles leave CUs idle (M = 192, N = 768: 256 tiles instead of 144)
+        const int t24 = ceil_div(M, 24) * ceil_div(N, 24), t32 = ceil_div(M, 32) * ceil_div(N, 32);
+        const int ts = (env_ts == 24 && t24 <= 256 && t32 < t24 && t32 > 64) ? 24 : 32;
+        const int tn_ = ceil_div(N, ts);
+        dim3 grids(ceil_div(M, ts) * tn_);
         if (x3) {
-            if (b_kc) hipLaunchKernelGGL((gemm_skinny_kernel<true, true>), grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_);
-            else hipLaunchKernelGGL((gemm_skinny_kernel<false, true>), grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_);
-        } else if (b_kc) hipLaunchKernelGGL((gemm_skinny_kernel<true, false>), grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_);
-        else hipLaunchKernelGGL((gemm_skinny_kernel<false, false>), grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_);
+            if (b_kc) hipLaunchKernelGGL((gemm_skinny_kernel<true, true>), grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_, ts);
+            else hipLaunchKernelGGL((gemm_skinny_kernel<false, true>), grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_, ts);
+        } else if (b_kc) hipLaunchKernelGGL((gemm_skinny_kernel<true, false>), grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_, ts);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<false, false>), grids, dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, epi, tn_, ts);
         return svpc_check_launch("gemm_skinny");
     }
     const int t128 = ceil_div(M, 128) * ceil_div(N, 128), t64 = ceil_div(M, 64) * ceil_div(N, 64);

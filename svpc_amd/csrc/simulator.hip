@@ -507,7 +507,162 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_lean_kernel(SimArgs a) {
 
 static int sim_set_lds(const void* fn, size_t bytes) { return svpc_raise_lds_once(fn, "sim_recur"); }   // once per kernel symbol, process-wide table (api.cpp)
 
+
+// ------------------------------------------------------------------------------------------------ the simulator's two tiny heads
+// c = softmax(ĥ·W3ᵀ + b3) (three choice weights per step, model.py:801) and w = f̄·W4ᵀ + b4 (one scalar per step, :804-805) — projections
+// onto 3 and 1 outputs.  As GEMM launches they fell on the generic kernel (N not a multiple of 4): 10-16 µs each forward, and backward a
+// dgrad + wgrad + column sum + finalize apiece plus the softmax backward: 9 launches (≈ 75 µs) per simulator for ≈ 1 MFLOP.  Here: one
+// launch forward, one backward (a wave per step row; the weight / bias gradients leave as per-workgroup partial sums for the table-driven
+// finalizer).  fp32 arithmetic.
+struct SimHeadArgs {
+    const float* hh; const float* fb; const float* W3; const float* b3; const float* W4; const float* b4;
+    float* c; float* w;            // (T, 3), (T)
+    int T, D, Wd;
+    // backward
+    const float* dc; const float* dw; float* dhh; float* dfb; float* part3; float* part4; int rows_per_wg;
+};
+constexpr int SH_NPL = 16;          // D <= 1024
+constexpr int SH_WPL = 8;           // word-vector width <= 512
+constexpr int SH_ROWS = 8;          // step rows per backward workgroup (two per wave): T = 192 → 24 workgroups; at 32 rows the six workgroups took 54 µs
+
+__global__ __launch_bounds__(256) void sim_heads_fwd_kernel(SimHeadArgs a) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.T) return;
+    const float* hr = a.hh + (size_t)r * a.D;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int d = lane; d < a.D; d += 64) {
+        const float h = hr[d];
+        s0 += h * a.W3[d]; s1 += h * a.W3[a.D + d]; s2 += h * a.W3[2 * a.D + d];
+    }
+    const float* fr = a.fb + (size_t)r * a.Wd;
+    for (int d = lane; d < a.Wd; d += 64) s3 += fr[d] * a.W4[d];
+    s0 = wave_sum(s0) + a.b3[0]; s1 = wave_sum(s1) + a.b3[1]; s2 = wave_sum(s2) + a.b3[2]; s3 = wave_sum(s3) + a.b4[0];
+    if (lane == 0) {
+        const float m = fmaxf(s0, fmaxf(s1, s2));
+        const float e0 = expf(s0 - m), e1 = expf(s1 - m), e2 = expf(s2 - m), inv = 1.0f / (e0 + e1 + e2);
+        a.c[(size_t)r * 3] = e0 * inv; a.c[(size_t)r * 3 + 1] = e1 * inv; a.c[(size_t)r * 3 + 2] = e2 * inv;
+        a.w[r] = s3;
+    }
+}
+
+// grid: ceil(T / rows_per_wg) workgroups of 256 threads; wave v takes rows r0 + v, r0 + v + 4, …;  partial sums of one workgroup:
+// part3[g][0 : 3D] = dW3, part3[g][3D : 3D + 3] = db3;  part4[g][0 : Wd] = dW4, part4[g][Wd] = db4
+__global__ __launch_bounds__(256) void sim_heads_bwd_kernel(SimHeadArgs a) {
+    __shared__ float red[4][3 * 64 * SH_NPL / 4];       // cross-wave sums, reused per chunk (3 × 64·NPL/4 floats per wave)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = blockIdx.x;
+    const int D = a.D, Wd = a.Wd;
+    const int r0 = g * a.rows_per_wg, r1 = min(a.T, r0 + a.rows_per_wg);
+    float aw3[3][SH_NPL], aw4[SH_WPL], ab[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < SH_NPL; ++i) { aw3[0][i] = aw3[1][i] = aw3[2][i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < SH_WPL; ++i) aw4[i] = 0.f;
+    float w3v[3][SH_NPL], w4v[SH_WPL];
+#pragma unroll
+    for (int i = 0; i < SH_NPL; ++i) {
+        const int d = lane + 64 * i;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) w3v[j][i] = d < D ? a.W3[(size_t)j * D + d] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < SH_WPL; ++i) { const int d = lane + 64 * i; w4v[i] = d < Wd ? a.W4[d] : 0.f; }
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const float c0 = a.c[(size_t)r * 3], c1 = a.c[(size_t)r * 3 + 1], c2 = a.c[(size_t)r * 3 + 2];
+        const float g0 = a.dc ? a.dc[(size_t)r * 3] : 0.f, g1 = a.dc ? a.dc[(size_t)r * 3 + 1] : 0.f, g2 = a.dc ? a.dc[(size_t)r * 3 + 2] : 0.f;
+        const float dot = c0 * g0 + c1 * g1 + c2 * g2;
+        const float d0 = c0 * (g0 - dot), d1 = c1 * (g1 - dot), d2 = c2 * (g2 - dot);      // softmax backward → gradient of the three logits
+        const float dwr = a.dw ? a.dw[r] : 0.f;
+        ab[0] += d0; ab[1] += d1; ab[2] += d2; ab[3] += dwr;
+        const float* hr = a.hh + (size_t)r * D;
+        float* dh = a.dhh + (size_t)r * D;
+#pragma unroll
+        for (int i = 0; i < SH_NPL; ++i) {
+            const int d = lane + 64 * i;
+            if (d < D) {
+                const float h = hr[d];
+                aw3[0][i] += d0 * h; aw3[1][i] += d1 * h; aw3[2][i] += d2 * h;
+                dh[d] = d0 * w3v[0][i] + d1 * w3v[1][i] + d2 * w3v[2][i];
+            }
+        }
+        const float* fr = a.fb + (size_t)r * Wd;
+        float* df = a.dfb + (size_t)r * Wd;
+#pragma unroll
+        for (int i = 0; i < SH_WPL; ++i) {
+            const int d = lane + 64 * i;
+            if (d < Wd) { aw4[i] += dwr * fr[d]; df[d] = dwr * w4v[i]; }
+        }
+    }
+    // the four waves' sums → one partial row per workgroup (wave order: deterministic), in chunks of four column groups through LDS
+    float* p3 = a.part3 + (size_t)g * (3 * D + 3);
+    float* p4 = a.part4 + (size_t)g * (Wd + 1);
+    for (int i0 = 0; i0 < SH_NPL; i0 += SH_NPL / 4) {
+        __syncthreads();
+#pragma unroll
+        for (int ii = 0; ii < SH_NPL / 4; ++ii)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) red[wave][(j * (SH_NPL / 4) + ii) * 64 + lane] = aw3[j][i0 + ii];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int ii = 0; ii < SH_NPL / 4; ++ii) {
+                const int d = lane + 64 * (i0 + ii);
+                if (d < D) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int o = (j * (SH_NPL / 4) + ii) * 64 + lane;
+                        p3[(size_t)j * D + d] = red[0][o] + red[1][o] + red[2][o] + red[3][o];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SH_WPL; ++i) red[wave][i * 64 + lane] = aw4[i];
+    {   // (ab is wave-uniform: every lane accumulated the same rows)
+        const float abv = lane == 0 ? ab[0] : (lane == 1 ? ab[1] : (lane == 2 ? ab[2] : ab[3]));
+        if (lane < 4) red[wave][SH_WPL * 64 + lane] = abv;
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < SH_WPL; ++i) {
+            const int d = lane + 64 * i;
+            if (d < Wd) { const int o = i * 64 + lane; p4[d] = red[0][o] + red[1][o] + red[2][o] + red[3][o]; }
+        }
+        if (lane < 4) {
+            const int o = SH_WPL * 64 + lane;
+            const float v = red[0][o] + red[1][o] + red[2][o] + red[3][o];
+            if (lane < 3) p3[3 * (size_t)D + lane] = v; else p4[Wd] = v;
+        }
+    }
+}
+
 extern "C" {
+
+// the simulator's choice softmax (D → 3) and verb scalar (W → 1) in one launch (model.py:801, :804-805); backward in one launch too: dhh / dfb
+// (T, D) / (T, Wd) fully written, part3 (groups, 3·D + 3) = per-workgroup [dW3 | db3], part4 (groups, Wd + 1) = [dW4 | db4] for the
+// finalizer; groups = svpc_sim_heads_groups(T)
+int svpc_sim_heads_groups(int T) { return T <= 0 ? 0 : ceil_div(T, SH_ROWS); }
+int svpc_sim_heads_fwd(const float* hh, const float* fb, const float* W3, const float* b3, const float* W4, const float* b4, float* c, float* w,
+                       int T, int D, int Wd, hipStream_t stream) {
+    if (T == 0) return 0;
+    SVPC_REQUIRE(D >= 1 && Wd >= 1, "sim_heads: empty rows");
+    SimHeadArgs a{};
+    a.hh = hh; a.fb = fb; a.W3 = W3; a.b3 = b3; a.W4 = W4; a.b4 = b4; a.c = c; a.w = w; a.T = T; a.D = D; a.Wd = Wd;
+    hipLaunchKernelGGL(sim_heads_fwd_kernel, dim3(ceil_div(T, 4)), dim3(256), 0, stream, a);
+    return svpc_check_launch("sim_heads_fwd");
+}
+int svpc_sim_heads_bwd(const float* hh, const float* fb, const float* W3, const float* W4, const float* c, const float* dc, const float* dw,
+                       float* dhh, float* dfb, float* part3, float* part4, int T, int D, int Wd, hipStream_t stream) {
+    if (T == 0) return 0;
+    SVPC_REQUIRE(D <= 64 * SH_NPL && Wd <= 64 * SH_WPL, "sim_heads: hidden size <= 1024, word-vector width <= 512");
+    SimHeadArgs a{};
+    a.hh = hh; a.fb = fb; a.W3 = W3; a.W4 = W4; a.c = const_cast<float*>(c); a.dc = dc; a.dw = dw; a.dhh = dhh; a.dfb = dfb; a.part3 = part3;
+    a.part4 = part4; a.T = T; a.D = D; a.Wd = Wd; a.rows_per_wg = SH_ROWS;
+    hipLaunchKernelGGL(sim_heads_bwd_kernel, dim3(svpc_sim_heads_groups(T)), dim3(256), 0, stream, a);
+    return svpc_check_launch("sim_heads_bwd");
+}
 
 int svpc_sim_recur_fwd(const float* q, const float* c, const float* w4f, const float* E0, const int* step_off, const int* step_len,
                        const int* ent_off, const int* ent_len, int n_videos, int e_max, int D, float* e_out, float* ebar,

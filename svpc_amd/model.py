@@ -555,8 +555,12 @@ class EntitiyReasoningNetwork(nn.Module):
         fbar = ops.linear(ops.row_normalize(a), self.verb_table(), None, trans_w=True)
         hat_h = ops.linear(g, self.W1[0].weight, self.W1[0].bias, act=ACT_RELU)
         q = ops.linear(torch.cat([hat_h, a], 1), self.W2.weight, self.W2.bias)
-        c = ops.softmax_rows(ops.linear(hat_h, self.W3.weight, self.W3.bias))
-        w4f = ops.linear(fbar, self.W4.weight, self.W4.bias).reshape(-1)
+        heads = ops.sim_heads(hat_h, fbar, self.W3.weight, self.W3.bias, self.W4.weight, self.W4.bias)
+        if heads is not None:          # the two tiny heads (D → 3 with its softmax, W → 1) in one launch, forward and backward
+            c, w4f = heads
+        else:
+            c = ops.softmax_rows(ops.linear(hat_h, self.W3.weight, self.W3.bias))
+            w4f = ops.linear(fbar, self.W4.weight, self.W4.bias).reshape(-1)
         e, ebar, eall = ops.sim_recur(q, c, w4f, ents, *plan_sim)
         return e, a, ebar, eall, fbar
 

@@ -1742,6 +1742,60 @@ def sim_recur(q, c, w4f, E0, step_off, step_len, ent_off, ent_len, e_max):
     return _SimRecur.apply(q, c, w4f, E0, as_idx(step_off), as_idx(step_len), as_idx(ent_off), as_idx(ent_len), int(e_max))
 
 
+class _SimHeads(Function):
+    """c = softmax(ĥ·W3ᵀ + b3), w = f̄·W4ᵀ + b4 (reference model.py:801, :804-805) in one launch; backward in one launch (svpc_sim_heads_*)."""
+
+    @staticmethod
+    def forward(ctx, hh, fb, W3, b3, W4, b4):
+        _need_gpu(hh)
+        hh, fb, W3, W4 = _c(hh), _c(fb), _c(W3), _c(W4)
+        T, D = hh.shape
+        Wd = fb.shape[1]
+        c = torch.empty(T, 3, dtype=torch.float32, device=hh.device)
+        w = torch.empty(T, dtype=torch.float32, device=hh.device)
+        _lib.call("sim_heads_fwd", _p(hh), _p(fb), _p(W3), _p(b3), _p(W4), _p(b4), _p(c), _p(w), T, D, Wd, _stream())
+        ctx.save_for_backward(hh, fb, W3, W4, c)
+        ctx.direct = (_direct(W3), _direct(b3), _direct(W4), _direct(b4))
+        ctx.set_materialize_grads(False)
+        return c, w
+
+    @staticmethod
+    def backward(ctx, dc, dw):
+        hh, fb, W3, W4, c = ctx.saved_tensors
+        T, D = hh.shape
+        Wd = fb.shape[1]
+        dev = hh.device
+        dc = _c(dc) if dc is not None else None
+        dw = _c(dw) if dw is not None else None
+        G = _lib.load().svpc_sim_heads_groups(T)
+        dhh, dfb = torch.empty_like(hh), torch.empty_like(fb)
+        p3 = torch.empty(G, 3 * D + 3, dtype=torch.float32, device=dev)
+        p4 = torch.empty(G, Wd + 1, dtype=torch.float32, device=dev)
+        _lib.call("sim_heads_bwd", _p(hh), _p(fb), _p(W3), _p(W4), _p(c), _p(dc), _p(dw), _p(dhh), _p(dfb), _p(p3), _p(p4), T, D, Wd, _stream())
+        w3d, b3d, w4d, b4d = ctx.direct
+        if all(t is not None for t in ctx.direct) and USE_MULTI_FINALIZE and not SIDE_WGRAD:
+            defer_finalize(p3, G, 3 * D + 3, w3d, b3d, 3 * D)
+            defer_finalize(p4, G, Wd + 1, w4d, b4d, Wd)
+            return dhh, dfb, None, None, None, None
+        s3, s4 = _colsum(p3).view(-1), _colsum(p4).view(-1)
+        outs = [s3[:3 * D].reshape(3, D), s3[3 * D:].clone(), s4[:Wd].reshape(1, Wd), s4[Wd:].clone()]
+        res = []
+        for tgt, val in zip(ctx.direct, outs):
+            if tgt is not None:
+                tgt.add_(val.view_as(tgt)); res.append(None)
+            else:
+                res.append(val)
+        return (dhh, dfb) + tuple(res)
+
+
+def sim_heads(hh, fb, W3, b3, W4, b4):
+    """(c (T, 3), w (T,)) — the simulator's choice softmax and verb scalar; None when the shape is not taken"""
+    if (not hh.is_cuda or hh.dtype != torch.float32 or fb.dtype != torch.float32 or tuple(W3.shape) != (3, hh.shape[1]) or
+            tuple(W4.shape) != (1, fb.shape[1]) or hh.shape[1] > 1024 or fb.shape[1] > 512 or b3 is None or b4 is None):
+        return None
+    return _SimHeads.apply(hh, fb, W3, b3, W4, b4)
+
+
 # ------------------------------------------------------------------------------------------------ pointer-generator
 class _PtrAttn(Function):
     @staticmethod

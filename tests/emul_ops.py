@@ -191,6 +191,11 @@ def ptr_attn(dec, proj, bank, step_ne, lt):
     return pi.reshape(T * lt, e_max), att.reshape(T * lt, D)
 
 
+def sim_heads(hh, fb, W3, b3, W4, b4):
+    """c = softmax(hh·W3ᵀ + b3), w = fb·W4ᵀ + b4 (model.py:801, :804-805)"""
+    return torch.softmax(hh @ W3.t() + b3, -1), (fb @ W4.t() + b4).reshape(-1)
+
+
 def take_rows_f32_alias(t, idx):
     return take_rows_f32(t, idx), t
 

@@ -246,6 +246,28 @@ def test_sim_recur(D, ent_len):
             [q, c, w4f, E0], rtol=5e-4, grad_rtol=2e-3, grad_atol=2e-4, name="sim_recur")
 
 
+@pytest.mark.parametrize("T,D,Wd", [(192, 768, 300), (7, 128, 300), (33, 32, 20), (1, 64, 12)])
+def test_sim_heads_forward_backward(T, D, Wd):
+    """the simulator's choice softmax (D → 3) and verb scalar (W → 1) in one launch each way (round 5) against linear → softmax / linear,
+    gradients through autograd and through arena-style direct targets (the table-driven finalizer)"""
+    hh, fb = rnd(T, D, seed=1), rnd(T, Wd, seed=2)
+    W3, b3, W4, b4 = rnd(3, D, seed=3, scale=0.2), rnd(3, seed=4), rnd(1, Wd, seed=5, scale=0.3), rnd(1, seed=6)
+    compare(lambda *a: O.sim_heads(*a), lambda *a: E.sim_heads(*a), [hh, fb, W3, b3, W4, b4], grad_rtol=1e-3, grad_atol=1e-5, name="sim_heads")
+    ps = [t.detach().clone().requires_grad_(True) for t in (W3, b3, W4, b4)]
+    for t in ps:
+        t.grad = torch.full_like(t, 0.25)
+        t._svpc_direct = True
+    c, w = O.sim_heads(hh.detach(), fb.detach(), *ps)
+    gc_, gw = torch.randn(c.shape, generator=torch.Generator().manual_seed(3)).to(DEV), torch.randn(w.shape, generator=torch.Generator().manual_seed(4)).to(DEV)
+    ((c * gc_).sum() + (w * gw).sum()).backward()
+    O.join_side()
+    rs = [t.detach().clone().requires_grad_(True) for t in (W3, b3, W4, b4)]
+    cr, wr = E.sim_heads(hh.detach(), fb.detach(), *rs)
+    ((cr * gc_).sum() + (wr * gw).sum()).backward()
+    for a_, b_ in zip(ps, rs):
+        assert float((a_.grad - 0.25 - b_.grad).abs().max()) <= 1e-5 + 1e-3 * float(b_.grad.abs().max())
+
+
 def test_ptr_attn_entity_chunks_and_full_width():
     """pointer attention at the production row width with more entities than one staged chunk (16) holds, and lt = 1
     (incremental decoding)"""
