@@ -73,6 +73,10 @@ int svpc_multi_colsum(const svpc_colsum_entry* entries, int n, svpc_stream_t str
 int svpc_multi_finalize_max(void);
 int svpc_multi_finalize(const svpc_finalize_entry* entries, int n, svpc_stream_t stream);
 int svpc_ln_bwd_groups(int R); /* workspace floats needed by svpc_ln_bwd = (groups + 1) * 2 * D */
+/* rows of `partial` that svpc_ln_bwd_rows_s writes when dh == dx == NULL (parameter gradients only: the first LayerNorm over the frame
+ * features, model.py:548) — fewer, longer workgroups than the rows pass; svpc_ln_param_grads_g sums a given number of partial rows */
+int svpc_ln_param_only_groups(int R);
+int svpc_ln_param_grads_g(const float* partial, int groups, int D, float* dgamma, float* dbeta, int accumulate, svpc_stream_t stream);
 int svpc_ln_bwd(const float* dy, const float* x, const int* src_rows, const float* res, const float* gamma,
                 const float* mean, const float* rstd, float* dh, float* dx, float* dgamma, float* dbeta, int accumulate,
                 float* workspace, int R, int D, float p_pre, unsigned site_pre, float p_post, unsigned site_post,

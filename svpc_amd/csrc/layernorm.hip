@@ -268,6 +268,88 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
     }
 }
 
+// ---- the first LayerNorm of the clip encoder (model.py:548: 3,072 frame features per row, fp32 in, stream format out): a pure stream of
+// 24 KB per row.  The general kernel above keeps a whole row in one wave (48 values per lane, 124 registers: four waves per SIMD, each
+// alternating between a load phase and a compute-and-store phase): 124–128 µs = 3.7 TB/s; this one: 115–121 µs).  Here TWO waves share a row (24 values per lane each, the two
+// half-row sums meet in LDS), a workgroup walks `rows_per_wg` rows two at a time with the NEXT row's loads issued before the current row is
+// normalised and stored (every wave always has 6 KB in flight), and gamma / beta are read from LDS (loaded once per workgroup).
+// Requires D == 3072 = 2 · 6 · 4 · 64, no residual, no pre-dropout, no added tables; statistics as above (two-pass, fp32).
+constexpr int LNW_NPL = 6;
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void ln_fwd_wide_kernel(LnArgs a, int rows_per_wg) {
+    __shared__ float gb[2][3072];
+    __shared__ float red[2][4];
+    const TX* __restrict__ xp = reinterpret_cast<const TX*>(a.x);
+    TY* __restrict__ yp = reinterpret_cast<TY*>(a.y);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave >> 1, half = wave & 1;
+    const int D = a.D;
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(a.R, r0 + rows_per_wg);
+    const int iters = (r1 - r0 + 1) >> 1;
+    const int cbase = (half * LNW_NPL * 64 + lane) * 4;             // this lane's columns: cbase + 256·i, i < 6
+    const u64 seed = a.p_post > 0.f ? a.seed[0] : 0ull;
+    const float ik_post = a.p_post > 0.f ? 1.0f / (1.0f - a.p_post) : 1.0f;
+    auto src = [&](int r) { return (size_t)(a.src_rows ? a.src_rows[r] : r) * a.ldx; };
+    float v[LNW_NPL * 4], nx[LNW_NPL * 4];
+    {
+        const size_t xrow = src(min(r0 + pair, r1 - 1));
+#pragma unroll
+        for (int i = 0; i < LNW_NPL; ++i) ln_load<4, TX>(xp + xrow + cbase + 256 * i, a.lox, &nx[i * 4]);
+    }
+    for (int c = threadIdx.x * 4; c < D; c += 1024) {
+        *reinterpret_cast<float4*>(&gb[0][c]) = *reinterpret_cast<const float4*>(a.gamma + c);
+        *reinterpret_cast<float4*>(&gb[1][c]) = *reinterpret_cast<const float4*>(a.beta + c);
+    }
+    for (int it = 0; it < iters; ++it) {
+        const int rr = r0 + 2 * it + pair;
+        const bool ok = rr < r1;
+        const int r = min(rr, r1 - 1);
+#pragma unroll
+        for (int k = 0; k < LNW_NPL * 4; ++k) v[k] = nx[k];
+        if (it + 1 < iters) {                                       // (uniform over the workgroup)
+            const size_t xrow = src(min(rr + 2, r1 - 1));
+#pragma unroll
+            for (int i = 0; i < LNW_NPL; ++i) ln_load<4, TX>(xp + xrow + cbase + 256 * i, a.lox, &nx[i * 4]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < LNW_NPL * 4; ++k) sum += v[k];
+        sum = wave_sum(sum);
+        if (lane == 0) red[0][wave] = sum;
+        __syncthreads();                                            // (also covers gamma / beta on the first trip)
+        const float mean = (red[0][pair * 2] + red[0][pair * 2 + 1]) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < LNW_NPL * 4; ++k) { const float d = v[k] - mean; sq += d * d; }
+        sq = wave_sum(sq);
+        if (lane == 0) red[1][wave] = sq;
+        __syncthreads();
+        const float var = (red[1][pair * 2] + red[1][pair * 2 + 1]) / (float)D;
+        const float rstd = 1.0f / sqrtf(var + a.eps);
+        if (ok && half == 0 && lane == 0) {
+            if (a.mean) a.mean[r] = mean;
+            if (a.rstd) a.rstd[r] = rstd;
+        }
+        if (ok) {
+            const size_t orow = (size_t)r * D, yrow = (size_t)r * a.ldy;
+#pragma unroll
+            for (int i = 0; i < LNW_NPL; ++i) {
+                const int col = cbase + 256 * i;
+                const float4 g = *reinterpret_cast<const float4*>(&gb[0][col]), b = *reinterpret_cast<const float4*>(&gb[1][col]);
+                const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = (v[i * 4 + j] - mean) * rstd * gg[j] + bb[j];
+                    if (a.p_post > 0.f) t *= drop_scale(seed, a.site_post, orow + col + j, a.p_post, ik_post);
+                    o[j] = t;
+                }
+                ln_store<4, TY>(yp + yrow + col, a.loy, o);
+            }
+        }
+    }
+}
+
 struct LnBwdArgs {
     const void* dy; const void* x; const int* src_rows; const void* res; const float* gamma;
     const float* mean; const float* rstd;
@@ -537,6 +619,21 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(LnBwdArgs a, int row
     };
     if (c0 < D) {
         int r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {          // four rows in flight per thread (96 bytes): the launch streams 354 MB and nothing else
+            float h4[4][4], d4[4][4], t4[4][4];
+            float m4[4], s4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rq = r + 4 * q;
+                VecIO<4, TX>::load(xp + (size_t)(a.src_rows ? a.src_rows[rq] : rq) * a.ldx + c0, h4[q]);
+                VecIO<4, TY>::load(dyp + (size_t)rq * D + c0, d4[q]);
+                if (a.res) VecIO<4, TY>::load(rp + (size_t)rq * a.ldr + c0, t4[q]);
+                else { t4[q][0] = t4[q][1] = t4[q][2] = t4[q][3] = 0.f; }
+                m4[q] = a.mean[rq]; s4[q] = a.rstd[rq];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) one(r + 4 * q, h4[q], d4[q], t4[q], m4[q], s4[q]);
+        }
         for (; r + 4 < r1; r += 8) {
             const int ra = r, rb = r + 4;
             float ha[4], hb[4], da[4], db[4], ta[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -768,6 +865,7 @@ static int launch_ln_bwd(const LnBwdArgs& a, int G, int x_dt, int y_dt, hipStrea
 }
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+extern "C" int svpc_ln_param_only_groups(int R);
 
 extern "C" {
 
@@ -797,6 +895,17 @@ int svpc_ln_fwd_s(const void* x, int x_dt, int ldx, int lox, const int* src_rows
         if (npl3 < 0) { const char* e = getenv("SVPC_LN_FWD_NPL3"); npl3 = e ? atoi(e) : 1; }
         if (D <= 768 && npl3) return launch_ln_fwd<3, 4>(a, x_dt, y_dt, stream);     // 12 values per lane: no dead quarter of registers
         if (D <= 1024) return launch_ln_fwd<4, 4>(a, x_dt, y_dt, stream);
+        static int wide = -1;
+        if (wide < 0) { const char* e = getenv("SVPC_LN_WIDE"); wide = e ? atoi(e) : 1; }
+        if (wide && D == 3072 && R >= 512 && x_dt == 0 && !res && p_pre <= 0.f && !add1 && !add2) {
+            int rpw = ceil_div(R, 1280);                 // five workgroups per CU, each walking its rows two at a time
+            rpw += rpw & 1;
+            const dim3 g(ceil_div(R, rpw)), b(256);
+            if (y_dt == 2) hipLaunchKernelGGL((ln_fwd_wide_kernel<float, split16>), g, b, 0, stream, a, rpw);
+            else if (y_dt == 1) hipLaunchKernelGGL((ln_fwd_wide_kernel<float, __bf16>), g, b, 0, stream, a, rpw);
+            else hipLaunchKernelGGL((ln_fwd_wide_kernel<float, float>), g, b, 0, stream, a, rpw);
+            return svpc_check_launch("ln_fwd_wide");
+        }
         if (D <= 3072) return launch_ln_fwd<12, 4>(a, x_dt, y_dt, stream);
         if (D <= 8192) return launch_ln_fwd<32, 4>(a, x_dt, y_dt, stream);
     } else {
@@ -832,7 +941,18 @@ int svpc_ln_bwd_groups(int R) {
     return g < 1 ? 1 : (g > cap ? cap : g);
 }
 
-// rows part only: dh / dx and the per-workgroup [dgamma ; dbeta] partials (svpc_ln_bwd_groups(R) × 2D floats)
+// partial rows written when neither dh nor dx is asked for (the first LayerNorm: its input is data).  That launch is a pure stream over
+// dy and x (354 MB at the headline shape).  Measured in the step, 12 column blocks × G groups: G = 112 (1,344 long workgroups) 98.5 µs,
+// 256: 82.4, 512: 80.2, 1,024 (the rows pass's count; 25 MB of partial sums): 83.8 — a plateau at ≈4.3 TB/s (device copy: 4.9–5.1)
+int svpc_ln_param_only_groups(int R) {
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("SVPC_LN_PARAM_GROUPS"); cap = e ? atoi(e) : 512; }
+    int g = ceil_div(R, 32);
+    return g < 1 ? 1 : (g > cap ? cap : g);
+}
+
+// rows part only: dh / dx and the per-workgroup [dgamma ; dbeta] partials (svpc_ln_bwd_groups(R) × 2D floats; svpc_ln_param_only_groups(R)
+// rows of it when dh == dx == null)
 // ldx / ldr: row strides (elements) of the saved x and residual (0 = dense): the hi planes of split rows are read in place
 int svpc_ln_bwd_rows_s(const void* dy, const void* x, int x_dt, int ldx, int y_dt, const int* src_rows, const void* res, int ldr,
                        const float* gamma, const float* mean, const float* rstd, void* dh, void* dx, float* partial, int R, int D,
@@ -851,7 +971,7 @@ int svpc_ln_bwd_rows_s(const void* dy, const void* x, int x_dt, int ldx, int y_d
     SVPC_REQUIRE(x_dt != 2 && y_dt != 2, "ln_bwd: split tensors are read through their hi plane (dtype 1 with the row's leading dimension)");
     if (ldx <= 0) ldx = D;
     if (ldr <= 0) ldr = D;
-    const int G = svpc_ln_bwd_groups(R);
+    const int G = (!dh && !dx) ? svpc_ln_param_only_groups(R) : svpc_ln_bwd_groups(R);
     LnBwdArgs a{dy, x, src_rows, res, gamma, mean, rstd, dh, dx, partial, R, D, p_pre, site_pre, p_post, site_post, seed, ldx, ldr};
     const bool vec = (D % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(gamma) && (!res || aligned16(res)) &&
                      (!dh || aligned16(dh)) && (!dx || aligned16(dx)) && ldx % 4 == 0 && ldr % 4 == 0;
@@ -881,11 +1001,14 @@ int svpc_ln_bwd_rows_s(const void* dy, const void* x, int x_dt, int ldx, int y_d
     return rc;
 }
 // parameter-gradient part: dgamma / dbeta (+)= column sums of the partials (may run on another stream than the rows part)
+int svpc_ln_param_grads_g(const float* partial, int groups, int D, float* dgamma, float* dbeta, int accumulate, hipStream_t stream) {
+    if (groups <= 0) return 0;
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(ceil_div(2 * D, 32)), dim3(1024), 0, stream, partial, groups, D, dgamma, dbeta, accumulate);
+    return svpc_check_launch("ln_param_grads");
+}
 int svpc_ln_param_grads(const float* partial, int R, int D, float* dgamma, float* dbeta, int accumulate, hipStream_t stream) {
     if (R == 0) return 0;
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3(ceil_div(2 * D, 32)), dim3(1024), 0, stream, partial, svpc_ln_bwd_groups(R), D, dgamma, dbeta,
-                       accumulate);
-    return svpc_check_launch("ln_param_grads");
+    return svpc_ln_param_grads_g(partial, svpc_ln_bwd_groups(R), D, dgamma, dbeta, accumulate, stream);
 }
 int svpc_ln_bwd_t(const void* dy, const void* x, int x_dt, int y_dt, const int* src_rows, const void* res, const float* gamma,
                   const float* mean, const float* rstd, void* dh, void* dx, float* dgamma, float* dbeta,
@@ -894,7 +1017,7 @@ int svpc_ln_bwd_t(const void* dy, const void* x, int x_dt, int y_dt, const int* 
     int rc = svpc_ln_bwd_rows_t(dy, x, x_dt, y_dt, src_rows, res, gamma, mean, rstd, dh, dx, workspace, R, D, p_pre, site_pre, p_post,
                                 site_post, seed, stream);
     if (rc) return rc;
-    return svpc_ln_param_grads(workspace, R, D, dgamma, dbeta, accumulate, stream);
+    return svpc_ln_param_grads_g(workspace, (!dh && !dx) ? svpc_ln_param_only_groups(R) : svpc_ln_bwd_groups(R), D, dgamma, dbeta, accumulate, stream);
 }
 int svpc_ln_bwd(const float* dy, const float* x, const int* src_rows, const float* res, const float* gamma,
                 const float* mean, const float* rstd, float* dh, float* dx, float* dgamma, float* dbeta,

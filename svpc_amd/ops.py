@@ -1099,17 +1099,18 @@ class _LayerNorm(Function):
         dgamma = g_dir if direct_gb else torch.empty(D, dtype=torch.float32, device=dev)
         dbeta = b_dir if direct_gb else torch.empty(D, dtype=torch.float32, device=dev)
         # rows part on this stream; the dgamma/dbeta tail only feeds the optimizer, so it is forked off (own partial buffer)
-        partial = torch.empty(_lib.load().svpc_ln_bwd_groups(R) * 2 * D, dtype=torch.float32, device=dev)
+        groups = (_lib.load().svpc_ln_param_only_groups(R) if dh is None and dx_rows is None else _lib.load().svpc_ln_bwd_groups(R))
+        partial = torch.empty(groups * 2 * D, dtype=torch.float32, device=dev)
         # (strided form: in bf16x3 mode the saved x / residual are the hi planes of split rows, read in place)
         _lib.call("ln_bwd_rows_s", _p(dy), _p(x), _dt(x), x.stride(0), _dt(dy), _p(src_rows), _p(residual),
                   residual.stride(0) if residual is not None else 0, _p(gamma), _p(mean), _p(rstd), _p(dh), _p(dx_rows), _p(partial), R, D,
                   p_pre, s_pre, p_post, s_post, _p(seed), _stream())
         if direct_gb and USE_MULTI_FINALIZE and not SIDE_WGRAD:
-            defer_finalize(partial, _lib.load().svpc_ln_bwd_groups(R), 2 * D, dgamma, dbeta, D)
+            defer_finalize(partial, groups, 2 * D, dgamma, dbeta, D)
             dgamma = dbeta = None
         else:
             with _side_of(g_dir if direct_gb else None, partial):
-                _lib.call("ln_param_grads", _p(partial), R, D, _p(dgamma), _p(dbeta), 1 if direct_gb else 0, _stream())
+                _lib.call("ln_param_grads_g", _p(partial), groups, D, _p(dgamma), _p(dbeta), 1 if direct_gb else 0, _stream())
             if direct_gb:
                 _ready(dgamma); _ready(dbeta)
                 dgamma = dbeta = None

@@ -124,7 +124,7 @@ def test_layernorm_fused_everything():
     compare(hip, ref, [table, res, g, b, tt], name="ln fused")
 
 
-@pytest.mark.parametrize("R,D,with_res", [(300, 3072, False), (77, 128, True), (4100, 768, False)])
+@pytest.mark.parametrize("R,D,with_res", [(300, 3072, False), (77, 128, True), (4100, 768, False), (1031, 3072, False), (5000, 3072, False)])
 def test_layernorm_parameter_gradients_only(R, D, with_res):
     """No input needs a gradient (the frame-feature LayerNorm): the backward is the streaming two-output column-sum kernel;
     gathered rows, post-LayerNorm dropout and an (ungraded) residual are honoured."""

@@ -153,9 +153,11 @@ def test_layernorm_split_vs_torch(R, D, with_res, drop):
     assert err <= 3e-5 * float(ref.abs().max()), err
 
 
-def test_layernorm_fp32_gather_to_split_and_backward():
-    """first LayerNorm of the video embedding: fp32 feature rows gathered → split rows; its backward reads the saved fp32 rows"""
-    R, D = 300, 3072
+@pytest.mark.parametrize("R", [300, 1037, 4100])
+def test_layernorm_fp32_gather_to_split_and_backward(R):
+    """first LayerNorm of the video embedding: fp32 feature rows gathered → split rows; its backward reads the saved fp32 rows
+    (R ≥ 512: the two-waves-per-row streaming forward and the long-workgroup parameter-gradient launch of round 5)"""
+    D = 3072
     table = _rand(500, D, seed=15)
     rows = torch.randint(0, 500, (R,), generator=torch.Generator().manual_seed(1)).to(torch.int32).to(DEV)
     gamma = (1.0 + 0.1 * _rand(D, seed=16)).requires_grad_(True)
