@@ -46,6 +46,33 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (__int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16))) +
            (__int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48)));
 }
+// Reduce-scatter butterfly: 32 per-lane addends in, ONE value out per lane pair — lane l ends with the 64-lane sum of value l >> 1.
+// v_permlane32_swap / v_permlane16_swap exchange register halves across lane^32 / lane^16, DPP row_ror:8, row_half_mirror and the quad
+// permutes finish inside a row: ≈70 instructions for 32 sums (32 separate wave_sum()s: ≈350).  Fixed order: deterministic.
+template <int CTRL> __device__ __forceinline__ float dpp_mov_(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_reduce_scatter32(const float (&v)[32], int lane) {
+    float w[16], x[8], y[4], z[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
+        w[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);      // lanes < 32: value i over both halves; lanes >= 32: value i + 16
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[i]), __float_as_uint(w[i + 8]), false, false);
+        x[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);      // even rows of 16 lanes: value i (+16); odd rows: value i + 8 (+16)
+    }
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = (b3 ? x[i + 4] : x[i]) + dpp_mov_<0x128>(b3 ? x[i] : x[i + 4]);          // lane ^ 8 (row_ror:8)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) z[i] = (b2 ? y[i + 2] : y[i]) + dpp_mov_<0x141>(b2 ? y[i] : y[i + 2]);          // lane ^ 7 (row_half_mirror)
+    float u = (b1 ? z[1] : z[0]) + dpp_mov_<0x4E>(b1 ? z[0] : z[1]);                                             // lane ^ 2
+    u += dpp_mov_<0xB1>(u);                                                                                       // lane ^ 1
+    return u;
+}
 template <int CTRL>
 __device__ __forceinline__ float dpp_max_(float v) {
     const int r = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false);

@@ -271,28 +271,8 @@ __global__ __launch_bounds__(64 * NPL) void xattn_ln_bwd_kernel(XaArgs a) {
 template <int CTRL> __device__ __forceinline__ float xa_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-// in: v[i] = this lane's addend of value i (i < 32); out: the sum over the 64 lanes of value (lane >> 1)
-__device__ __forceinline__ float xa_rs32(const float (&v)[32], int lane) {
-    float w[16], x[8], y[4], z[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
-        w[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);      // lanes < 32: value i over both halves; lanes >= 32: value i + 16
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[i]), __float_as_uint(w[i + 8]), false, false);
-        x[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);      // even rows of 16 lanes: value i (+16); odd rows: value i + 8 (+16)
-    }
-    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = (b3 ? x[i + 4] : x[i]) + xa_dpp<0x128>(b3 ? x[i] : x[i + 4]);          // lane ^ 8 (row_ror:8)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) z[i] = (b2 ? y[i + 2] : y[i]) + xa_dpp<0x141>(b2 ? y[i] : y[i + 2]);          // lane ^ 7 (row_half_mirror)
-    float u = (b1 ? z[1] : z[0]) + xa_dpp<0x4E>(b1 ? z[0] : z[1]);                                             // lane ^ 2
-    u += xa_dpp<0xB1>(u);                                                                                       // lane ^ 1
-    return u;
-}
+// in: v[i] = this lane's addend of value i (i < 32); out: the sum over the 64 lanes of value (lane >> 1)  (common.h)
+__device__ __forceinline__ float xa_rs32(const float (&v)[32], int lane) { return wave_reduce_scatter32(v, lane); }
 __device__ __forceinline__ float xa_bcast(float v, int src_lane) {       // wave-uniform copy of lane `src_lane`'s value (compile-time lane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }

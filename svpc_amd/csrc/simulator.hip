@@ -128,6 +128,12 @@ __device__ __forceinline__ void sim_dma(const float* __restrict__ src, float* __
         __builtin_amdgcn_global_load_lds((sim_gptr)(src + (size_t)i * 256 + lane * 4), (sim_lptr)(dst + (size_t)i * 256), 16, 0, 0);
 }
 
+// Barrier between two LDS phases of a step.  __syncthreads() is a workgroup fence + barrier, and with global_load_lds copies in flight the
+// fence waits for EVERY outstanding vector-memory operation (s_waitcnt vmcnt(0)): the next step's images and operands, requested at the
+// top of the step so that they land under its arithmetic, were waited for at the first barrier behind them — a memory round trip on
+// the chain of every step.  The phases inside a step exchange data through ordinary ds_write / ds_read only: lgkmcnt(0) is enough.
+__device__ __forceinline__ void sim_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // MODE 2: DMA double-buffered (4 images in LDS) · MODE 1: both images staged synchronously (2 images) · MODE 0: only the state is
 // staged, the upstream gradient is read from HBM inside the loops (1 image: up to 32 entities × 768) · MODE 3 (the 1-image case when
 // D % 256 == 0: 17-32 entities at D = 768, what the reference's batches with up to 31 ingredients need): the state image by DMA and the
@@ -150,14 +156,29 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
     float* sc = red + (2 * EM + 1) * NW;     // scalars: ds[32]
     float* dprev = sc + EM;                  // 32: gradient flowing into e_{t-1} through "prev"
     float* tot = dprev + EM;                 // 2·EM + 1 block totals of the wave partials in `red`
+    // the saved e rows and the upstream gradient of e, per step: e_t is needed at steps t (as e) and t+1 (as e_prev), so a ring of three
+    // rows holds them; thread e < EM requests row t-2 (and de of t-1) at the top of step t and stores it at the end of the step.  Read
+    // from global memory at the top of every step (3·E loads behind branches, then a wait for everything outstanding — the prefetched
+    // operands of the next step included) they put a memory round trip on the chain of every step.
+    float* eoR = tot + 2 * EM + 1;           // [3][EM]
+    float* deR = eoR + 3 * EM;               // [2][EM]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < EM && S > 0) {
+        const int e = threadIdx.x;
+        const bool ok = e < E;
+        const int ec = min(e, em - 1);
+        eoR[((S - 1) % 3) * EM + e] = ok ? a.e_out[(size_t)(s0 + S - 1) * em + ec] : 0.f;
+        eoR[((S + 1) % 3) * EM + e] = (ok && S > 1) ? a.e_out[(size_t)(s0 + max(S - 2, 0)) * em + ec] : 0.f;       // (S-2) mod 3
+        deR[((S - 1) & 1) * EM + e] = (ok && a.de) ? a.de[(size_t)(s0 + S - 1) * em + ec] : 0.f;
+    }
 
     float dE[EM][CPT];
 #pragma unroll
     for (int e = 0; e < EM; ++e)
 #pragma unroll
         for (int u = 0; u < CPT; ++u) dE[e][u] = 0.f;
-    if (threadIdx.x < EM) dprev[threadIdx.x] = 0.f;
+    float my_dprev = 0.f;                    // wave 0, lane e: gradient flowing into e_{t-1}[e] through "prev"
+    (void)dprev; (void)tot;
     if (!ONE && !a.deall)
         for (int i = threadIdx.x; i < (DMA ? 2 : 1) * img; i += NT) Ubuf[i] = 0.f;
 
@@ -190,6 +211,24 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
     for (int e = 0; e < (MODE == 3 ? EM : 1); ++e)
 #pragma unroll
         for (int u = 0; u < CPT; ++u) upv[e][u] = 0.f;
+    // the results of a step (dq row, dc, dw) leave at the START of the next step: a store issued at the end of a step is still on its way
+    // when the next step's top waits for its images (vmcnt counts stores too) — held back one step, everything the wait sees is a step old
+    float held_dq[CPT], held_dc0 = 0.f, held_dc1 = 0.f, held_dw = 0.f;
+    int held_j = -1;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) held_dq[u] = 0.f;
+    auto flush_held = [&]() {
+        if (held_j < 0) return;
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int d = threadIdx.x + NT * u;
+            if (d < D) a.dq[(size_t)held_j * D + d] = held_dq[u];
+        }
+        if (threadIdx.x == 0) {
+            a.dc[(size_t)held_j * 3] = held_dc0; a.dc[(size_t)held_j * 3 + 1] = held_dc1; a.dc[(size_t)held_j * 3 + 2] = 0.f;
+            a.dw4f[held_j] = held_dw;
+        }
+    };
     for (int t = S - 1; t >= 0; --t) {
         const int j = s0 + t;
         const int cur = DMA ? ((S - 1 - t) & 1) : 0;
@@ -198,6 +237,7 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
         if (DMA) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of step t have landed
             __syncthreads();                                       // everyone's have; everyone is done with the other buffers
+            flush_held();
             if (t > 0) {
                 sim_dma<NT>(state_before(t - 1), Ebuf + (cur ^ 1) * img, E * D, wave, lane);
                 if (a.deall) sim_dma<NT>(a.deall + (size_t)(j - 1) * em * D, Ubuf + (cur ^ 1) * img, E * D, wave, lane);
@@ -224,15 +264,23 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
             __syncthreads();
         }
         const float c0 = n_c0, c1 = n_c1, w = n_w;
-        float al[EM], evv[EM], pv[EM], dev[EM], ebv[CPT], debv[CPT], qv[CPT];
+        float al[EM], ebv[CPT], debv[CPT], qv[CPT];
         float Z = 0.f;
+        const float* er = eoR + (t % 3) * EM;
+        const float* pr = eoR + ((t + 2) % 3) * EM;        // (t-1) mod 3
+        const float* dr = deR + (t & 1) * EM;
+        const float pmul = t > 0 ? 1.f : 0.f;
 #pragma unroll
         for (int e = 0; e < EM; ++e) {
-            evv[e] = e < E ? a.e_out[(size_t)j * em + e] : 0.f;
-            pv[e] = (e < E && t > 0) ? a.e_out[(size_t)(j - 1) * em + e] : 0.f;
-            dev[e] = (e < E && a.de) ? a.de[(size_t)j * em + e] : 0.f;
-            al[e] = e < E ? c0 * evv[e] + c1 * pv[e] : 0.f;
+            al[e] = e < E ? c0 * er[e] + c1 * pmul * pr[e] : 0.f;
             Z += al[e];
+        }
+        // rows for the next steps (thread e < EM; clamped addresses, no branch around the loads): e of step t-2, de of step t-1
+        float nx_e = 0.f, nx_de = 0.f;
+        if (threadIdx.x < EM) {
+            const int ec = min((int)threadIdx.x, em - 1);
+            nx_e = a.e_out[(size_t)(s0 + max(t - 2, 0)) * em + ec];
+            nx_de = a.de ? a.de[(size_t)(s0 + max(t - 1, 0)) * em + ec] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < CPT; ++u) { ebv[u] = n_eb[u]; debv[u] = n_deb[u]; qv[u] = n_q[u]; }
@@ -278,59 +326,53 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
                 kq[u] = qv[u];
             }
         }
-        // block reduction of 2E+1 scalars
+        // block reduction of 2·EM + 1 scalars: one reduce-scatter butterfly over the wave for 32 of them at a time (lane l ends with value
+        // l >> 1), the wave partials to LDS
+        if constexpr (EM == 16) {
+            float v32[32];
 #pragma unroll
-        for (int e = 0; e < EM; ++e) {
-            if (e < E) {
-                const float ra = wave_sum(pA[e]), rb = wave_sum(pB[e]);
-                if (lane == 0) { red[e * NW + wave] = ra; red[(EM + e) * NW + wave] = rb; }
-            }
+            for (int e = 0; e < 16; ++e) { v32[e] = pA[e]; v32[16 + e] = pB[e]; }
+            const float u_ = wave_reduce_scatter32(v32, lane);
+            if ((lane & 1) == 0) red[(lane >> 1) * NW + wave] = u_;            // rows 0..15: A1[e], rows 16..31: dab[e]
+        } else {
+            const float ua = wave_reduce_scatter32(pA, lane), ub = wave_reduce_scatter32(pB, lane);
+            if ((lane & 1) == 0) { red[(lane >> 1) * NW + wave] = ua; red[(EM + (lane >> 1)) * NW + wave] = ub; }
         }
         pw = wave_sum(pw);
         if (lane == 0) red[(2 * EM) * NW + wave] = pw;
-        __syncthreads();
-        // 2·EM + 1 threads add the NW wave partials of one scalar each (wave order: deterministic) — every thread then reads 2E + 1
-        // totals instead of (2E + 1)·NW partials: with 12 waves that was 252 LDS reads per thread and step, the longest piece of a step
-        if (threadIdx.x < 2 * EM + 1) {
-            const float* rp = red + threadIdx.x * NW;
-            float t_ = rp[0];
+        sim_lds_barrier();
+        // wave 0 finishes the scalar algebra, lane e for entity e (every thread used to do all of it redundantly: ≈200 vector instructions
+        // per wave and step on a kernel that is bound by instruction issue — 12 waves on 4 SIMDs): the NW wave partials of A1[e] and dab[e]
+        // in wave order, the three sums over the entities as wave reductions, ds[e] to LDS for everyone
+        float dc0 = 0.f, dc1 = 0.f, dw = 0.f;
+        if (wave == 0) {
+            const int e = lane;
+            const bool on = e < E;                       // (E <= EM <= 32 < 64)
+            const int ec = min(e, EM - 1);
+            float A1 = 0.f, dabv = 0.f, dwv = 0.f;
 #pragma unroll
-            for (int w_ = 1; w_ < NW; ++w_) t_ += rp[w_];
-            tot[threadIdx.x] = t_;
-        }
-        __syncthreads();
-        // every thread finishes the scalar algebra redundantly (E <= 32)
-        float dab[EM], dal[EM];
-        float mix = 0.f;
-#pragma unroll
-        for (int e = 0; e < EM; ++e) {
-            dab[e] = 0.f; dal[e] = 0.f;
-            if (e < E) {
-                dab[e] = tot[EM + e];
-                mix += dab[e] * al[e] * invZ;
+            for (int w_ = 0; w_ < NW; ++w_) {
+                A1 += red[ec * NW + w_];
+                dabv += red[(EM + ec) * NW + w_];
+                dwv += red[(2 * EM) * NW + w_];
             }
+            const float ev_e = er[ec], pv_e = pmul * pr[ec];
+            const float al_e = on ? c0 * ev_e + c1 * pv_e : 0.f;
+            const float mix = wave_sum(on ? dabv * al_e * invZ : 0.f);
+            const float dal_e = on ? A1 + (dabv - mix) * invZ : 0.f;
+            dc0 = wave_sum(dal_e * ev_e);
+            dc1 = wave_sum(dal_e * pv_e);
+            dw = dwv;
+            const float de_tot = c0 * dal_e + dr[ec] + my_dprev;
+            if (e < EM) sc[e] = on ? de_tot * ev_e * (1.f - ev_e) : 0.f;
+            my_dprev = on ? c1 * dal_e : 0.f;            // gradient flowing into e_{t-1} through "prev": this lane's own entity
         }
-        float dc0 = 0.f, dc1 = 0.f;
+        sim_lds_barrier();
         float dsv[EM];
 #pragma unroll
-        for (int e = 0; e < EM; ++e) {
-            dsv[e] = 0.f;
-            if (e < E) {
-                const float A1 = tot[e];
-                dal[e] = A1 + (dab[e] - mix) * invZ;
-                dc0 += dal[e] * evv[e];
-                dc1 += dal[e] * pv[e];
-                const float de_tot = c0 * dal[e] + dev[e] + dprev[e];
-                dsv[e] = de_tot * evv[e] * (1.f - evv[e]);
-            }
-        }
-        const float dw = tot[2 * EM];
-        __syncthreads();   // all threads have read dprev / tot before they are overwritten
-        if (threadIdx.x < EM) dprev[threadIdx.x] = threadIdx.x < E ? c1 * dal[threadIdx.x] : 0.f;
-        if (threadIdx.x == 0) {
-            a.dc[(size_t)j * 3] = dc0; a.dc[(size_t)j * 3 + 1] = dc1; a.dc[(size_t)j * 3 + 2] = 0.f;
-            a.dw4f[j] = dw;
-        }
+        for (int e = 0; e < EM; ++e) dsv[e] = sc[e];
+        if (!DMA) flush_held();            // (the other modes stage synchronously: nothing to hide the stores from)
+        held_dc0 = dc0; held_dc1 = dc1; held_dw = dw; held_j = j;
         // dq and the last piece of dE
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
@@ -344,10 +386,16 @@ __global__ __launch_bounds__(NT) void sim_recur_bwd_kernel(SimArgs a) {
                         dE[e][u] += dsv[e] * kq[u];
                     }
                 }
-                a.dq[(size_t)j * D + d] = dqv;
+                held_dq[u] = dqv;
             }
         }
+        if (threadIdx.x < EM) {             // (the slots written here were last read at step t+1; the barrier at the top of step t-1 publishes them)
+            const bool ok = (int)threadIdx.x < E;
+            eoR[((t + 1) % 3) * EM + threadIdx.x] = (ok && t >= 2) ? nx_e : 0.f;          // (t-2) mod 3
+            deR[((t + 1) & 1) * EM + threadIdx.x] = (ok && t >= 1) ? nx_de : 0.f;         // (t-1) & 1
+        }
     }
+    flush_held();
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
         const int d = threadIdx.x + NT * u;
@@ -691,7 +739,7 @@ int svpc_sim_recur_bwd(const float* q, const float* c, const float* w4f, const f
     const int nt = D > 768 ? 1024 : (D > 512 ? 768 : (D > 256 ? 512 : 256));      // one column per thread up to D = 1024
     const size_t img = (((size_t)e_max * D + 255) / 256) * 256;
     const int EMv = e_max <= 16 ? 16 : 32;
-    const size_t tail = ((2 * EMv + 1) * (nt / 64) + 2 * EMv + (2 * EMv + 1)) * sizeof(float);
+    const size_t tail = ((2 * EMv + 1) * (nt / 64) + 2 * EMv + (2 * EMv + 1) + 5 * EMv) * sizeof(float);
     const size_t budget = 150 * 1024;
     const bool aligned = ((((uintptr_t)E0) | ((uintptr_t)eall) | ((uintptr_t)deall)) & 15) == 0;
     int mode = 0;

@@ -1064,8 +1064,9 @@ class StateAwareRecursiveTransformer(nn.Module):
         gx, whh = [], []
         for sfx in ("", "_reverse"):
             w_ih, w_hh = getattr(rnn, "weight_ih_l0" + sfx), getattr(rnn, "weight_hh_l0" + sfx)
-            bias = getattr(rnn, "bias_ih_l0" + sfx) + getattr(rnn, "bias_hh_l0" + sfx)
-            gx.append(ops.linear(x, w_ih, bias))                                             # (T, 4D)
+            b_ih, b_hh = getattr(rnn, "bias_ih_l0" + sfx), getattr(rnn, "bias_hh_l0" + sfx)
+            # (both biases receive the column sum of the gate gradients in place: no separate column-sum launches, no autograd adds)
+            gx.append(ops.linear(x, w_ih, b_ih + b_hh, bgrad=ops.direct_grads(b_ih, b_hh)))          # (T, 4D)
             whh.append(w_hh)
         out_f, out_b = ops.bilstm_sequences(gx[0], gx[1], whh[0], whh[1], plan.lstm_fwd_rows, plan.lstm_bwd_rows, plan.lstm_active,
                                             plan.lstm_pick[""], plan.lstm_pick["_reverse"])

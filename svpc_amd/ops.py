@@ -751,6 +751,13 @@ def _direct(p):
     return g if (g is not None and getattr(p, "_svpc_direct", False)) else None
 
 
+def direct_grads(*params):
+    """the arena gradients of ``params`` when every one of them is written in place (else None) — for ``linear(..., bgrad=(…))`` with a
+    bias that is a sum of parameters"""
+    gs = tuple(_direct(p) for p in params)
+    return gs if all(g is not None for g in gs) else None
+
+
 HOOKS_PAUSED = [0]         # > 0: gradient-ready notifications (pointer reports here, the reducer's post-accumulate hooks) are ignored
 
 
@@ -892,6 +899,19 @@ class _Linear(Function):
         else:
             dz = dy
         dx = dw = db = None
+        wgrad, bgrad = ctx.direct
+        if isinstance(bgrad, tuple):
+            # the bias is the sum of several parameters (the LSTM's b_ih + b_hh, model.py:1022): each of them receives Σ_rows dz in place —
+            # the first the usual way below, the others through one more entry of the grouped column sum
+            for e in bgrad[1:]:
+                V = 8 if dz.dtype == torch.bfloat16 else 4
+                if USE_MULTI_FINALIZE and not SIDE_WGRAD and N % V == 0 and dz.stride(0) % V == 0 and dz.data_ptr() % 16 == 0 and M > 0:
+                    defer_colsum(dz, e)
+                else:
+                    with _side_of(e, dz):
+                        _colsum(dz, out=e.view(1, -1), accumulate=1)
+                    _ready(e, "b")
+            bgrad = bgrad[0]
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=x.dtype, device=dy.device)
             parked = _RES_SINK.pop(x.data_ptr(), None) if _RES_SINK else None
@@ -903,7 +923,6 @@ class _Linear(Function):
             G = (tin["aux"], tin["act"]) if (tin is not None and tin.get("aux") is not None and parked is None) else None
             if _gemm(dz, N, 1, w, w.stride(0), 1 if trans_w else 0, dx, M, K, N, R=parked, G=G):
                 tin["done"] = (dx.data_ptr(), tuple(dx.shape))
-        wgrad, bgrad = ctx.direct
         w_done = False
         if wgrad is not None and not trans_w and (not has_b or bgrad is not None):
             if dz.dtype == torch.bfloat16:
