@@ -43,18 +43,42 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i0 = blockIdx.y * QROWS;
     if (i0 >= q_len) return;
-    for (int e = threadIdx.x; e < k_len * dh; e += 256) {
-        const int j = e / dh, d = e - j * dh;
-        Ks[j * ldr + d] = a.K[(size_t)(k_off + j) * a.ldk + h * dh + d];
-        Vs[j * ldr + d] = a.V[(size_t)(k_off + j) * a.ldv + h * dh + d];
+    // this wave's query rows, requested with the K / V images (read inside the loop, every group of four rows began with a memory round
+    // trip of its own); the loop ends with the sequence (a 12-row sequence ran 8 rounds of three barriers, 5 of them over nothing)
+    float qreg[QROWS / 4];
+#pragma unroll
+    for (int it = 0; it < QROWS / 4; ++it)
+        qreg[it] = a.Q[(size_t)(q_off + min(i0 + it * 4 + wave, q_len - 1)) * a.ldq + h * dh + min(lane, dh - 1)];
+    float mterm[MAXKPL];              // the key-pad term of this lane's keys: once per workgroup, not one conditional load per query row
+#pragma unroll
+    for (int u = 0; u < MAXKPL; ++u) mterm[u] = 0.f;
+    if (a.key_mask) {
+#pragma unroll
+        for (int u = 0; u < MAXKPL; ++u) mterm[u] = (1.0f - a.key_mask[k_off + min(lane + 64 * u, k_len - 1)]) * -10000.0f;
+    }
+    for (int e0 = 0; e0 < k_len * dh; e0 += 4 * 256) {          // four pieces of each image in flight per thread (clamped, unconditional)
+        float kq[4], vq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = min(e0 + u * 256 + (int)threadIdx.x, k_len * dh - 1), j = e / dh, d = e - j * dh;
+            kq[u] = a.K[(size_t)(k_off + j) * a.ldk + h * dh + d];
+            vq[u] = a.V[(size_t)(k_off + j) * a.ldv + h * dh + d];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256 + (int)threadIdx.x, j = e / dh, d = e - j * dh;
+            if (e < k_len * dh) { Ks[j * ldr + d] = kq[u]; Vs[j * ldr + d] = vq[u]; }
+        }
     }
     const u64 seed = a.p_drop > 0.f ? a.seed[0] : 0ull;
     const float ik = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+#pragma unroll
     for (int it = 0; it < QROWS / 4; ++it) {
+        if (i0 + it * 4 >= q_len) break;               // (uniform over the workgroup)
         const int i = i0 + it * 4 + wave;
         const bool valid = i < q_len;
         __syncthreads();
-        if (valid && lane < dh) qb[wave * dh + lane] = a.Q[(size_t)(q_off + i) * a.ldq + h * dh + lane] * a.scale;
+        if (valid && lane < dh) qb[wave * dh + lane] = qreg[it] * a.scale;
         __syncthreads();
         float sc[MAXKPL];
         float mx = -INFINITY;
@@ -67,7 +91,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 const float* kr = Ks + j * ldr;
                 const float* qr = qb + wave * dh;
                 for (int d = 0; d < dh; ++d) acc += qr[d] * kr[d];
-                acc += mask_term(a, k_off, i, j);
+                acc += (a.causal && j > i) ? -10000.0f : mterm[u];
                 sc[u] = acc;
                 mx = fmaxf(mx, acc);
             }

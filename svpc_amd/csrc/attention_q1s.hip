@@ -232,6 +232,229 @@ __global__ __launch_bounds__(256) void attn_q1s_bwd_kernel(Q1sArgs a) {
     }
 }
 
+// ---- head dim 64, rows read as whole lines (round 5).  The kernels above give every lane a key ROW: a 16-byte load instruction then
+// touches 64 different 128-byte lines and eight instructions are needed to use each of them — the CU's address path, not HBM, bounds the
+// launch (forward 40 µs, backward 80 µs for 59 MB read / 118 MB moved at the headline shape).  Here a row is read by EIGHT lanes
+// (lane = 8·g + c8: row group g, 16-byte piece c8), one instruction covers 8 consecutive keys as 8 whole lines, 13 instructions the 100
+// keys; a key's dot product is finished over its 8 lanes with three DPP adds, sums over the keys over the 8 row groups (lane ^ 8, 16, 32).
+// dK / dV rows leave the same way (whole lines).  Same arithmetic as above (fp32 on the values read), same dropout draws.
+template <bool SPLIT>
+__device__ __forceinline__ void q1r_row(const __bf16* p, int lo, float (&v)[8]) {
+    const bf16x8 h = *reinterpret_cast<const bf16x8*>(p);
+    if (SPLIT) {
+        const bf16x8 l = *reinterpret_cast<const bf16x8*>(p + lo);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)h[j] + (float)l[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+    }
+}
+__device__ __forceinline__ float q1r_sum8(float v) {          // over the 8 lanes of a row
+    v = dpp_add_<0xB1>(v); v = dpp_add_<0x4E>(v); v = dpp_add_<0x141>(v);
+    return v;
+}
+__device__ __forceinline__ float q1r_sum_groups(float v) {    // over the 8 row groups (lanes with equal lane & 7)
+    v += dpp_mov_<0x128>(v);                                   // lane ^ 8 (row_ror:8)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float q1r_max_groups(float v) {
+    v = fmaxf(v, dpp_mov_<0x128>(v));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+constexpr int Q1R_NI = 16;          // 16 instructions × 8 keys = 128 keys
+
+// probabilities of this lane's keys (key 8·i + g in slot i; 0 past k_len), every lane of a row holds the same values; returns the LSE
+template <bool SPLIT>
+__device__ __forceinline__ float q1r_probs(const Q1sArgs& a, const float (&q)[8], const __bf16* Kp, int k_off, int k_len, int g,
+                                           float (&p)[Q1R_NI]) {
+    float mk[Q1R_NI];
+#pragma unroll
+    for (int i = 0; i < Q1R_NI; ++i) mk[i] = 0.f;
+    if (a.key_mask) {
+#pragma unroll
+        for (int i = 0; i < Q1R_NI; ++i) mk[i] = (1.0f - a.key_mask[k_off + min(8 * i + g, k_len - 1)]) * -10000.0f;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (b == 0 || k_len > 64) {
+            float kv[8][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q1r_row<SPLIT>(Kp + (size_t)min(8 * (8 * b + u) + g, k_len - 1) * a.ldk, a.k_lo, kv[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dot = fmaf(q[j], kv[u][j], dot);
+                dot = q1r_sum8(dot);
+                p[8 * b + u] = (8 * (8 * b + u) + g) < k_len ? dot * a.scale + mk[8 * b + u] : -INFINITY;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[8 * b + u] = -INFINITY;
+        }
+    }
+    float mx = p[0];
+#pragma unroll
+    for (int i = 1; i < Q1R_NI; ++i) mx = fmaxf(mx, p[i]);
+    mx = q1r_max_groups(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < Q1R_NI; ++i) { p[i] = p[i] > -INFINITY ? expf(p[i] - mx) : 0.f; sum += p[i]; }
+    sum = q1r_sum_groups(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < Q1R_NI; ++i) p[i] *= inv;
+    return mx + logf(sum);
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void attn_q1r_fwd_kernel(Q1sArgs a) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sh = (int)blockIdx.x * 4 + wave;
+    if (sh >= a.n_seq * a.H) return;
+    const int s = sh / a.H, h = sh - s * a.H;
+    const int q_off = a.seq[s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
+    const int g = lane >> 3, c8 = lane & 7;
+    const u64 seed = a.p_drop > 0.f ? a.seed[0] : 0ull;
+    float q[8];
+    {
+        const float* qp = a.Q + (size_t)q_off * a.ldq + h * 64 + 8 * c8;
+        const float4 t0 = *reinterpret_cast<const float4*>(qp), t1 = *reinterpret_cast<const float4*>(qp + 4);
+        q[0] = t0.x; q[1] = t0.y; q[2] = t0.z; q[3] = t0.w; q[4] = t1.x; q[5] = t1.y; q[6] = t1.z; q[7] = t1.w;
+    }
+    const __bf16* Kp = a.K + (size_t)k_off * a.ldk + h * 64 + 8 * c8;
+    const __bf16* Vp = a.V + (size_t)k_off * a.ldv + h * 64 + 8 * c8;
+    float p[Q1R_NI];
+    const float lse = q1r_probs<SPLIT>(a, q, Kp, k_off, k_len, g, p);
+    if (lane == 0 && a.LSE) a.LSE[((size_t)s * a.H + h) * a.max_q] = lse;
+    const u64 row_base = (u64)(s * a.H + h) * a.max_q;
+#pragma unroll
+    for (int i = 0; i < Q1R_NI; ++i) p[i] *= q1s_drop(a, seed, row_base, 8 * i + g);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (b == 0 || k_len > 64) {
+            float vv[8][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q1r_row<SPLIT>(Vp + (size_t)min(8 * (8 * b + u) + g, k_len - 1) * a.ldv, a.v_lo, vv[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(p[8 * b + u], vv[u][j], acc[j]);          // (p is 0 past k_len)
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = q1r_sum_groups(acc[j]);
+    if (g == 0) {
+        float* op = a.O + (size_t)q_off * a.ldo + h * 64 + 8 * c8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) op[j] = acc[j];
+    }
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void attn_q1r_bwd_kernel(Q1sArgs a) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sh = (int)blockIdx.x * 4 + wave;
+    if (sh >= a.n_seq * a.H) return;
+    const int s = sh / a.H, h = sh - s * a.H;
+    const int q_off = a.seq[s], k_off = a.seq[2 * a.n_seq + s], k_len = a.seq[3 * a.n_seq + s];
+    const int g = lane >> 3, c8 = lane & 7;
+    const u64 seed = a.p_drop > 0.f ? a.seed[0] : 0ull;
+    float q[8], go[8];
+    {
+        const float* qp = a.Q + (size_t)q_off * a.ldq + h * 64 + 8 * c8;
+        const float* gp = a.dO + (size_t)q_off * a.lddo + h * 64 + 8 * c8;
+        const float4 t0 = *reinterpret_cast<const float4*>(qp), t1 = *reinterpret_cast<const float4*>(qp + 4);
+        const float4 u0 = *reinterpret_cast<const float4*>(gp), u1 = *reinterpret_cast<const float4*>(gp + 4);
+        q[0] = t0.x; q[1] = t0.y; q[2] = t0.z; q[3] = t0.w; q[4] = t1.x; q[5] = t1.y; q[6] = t1.z; q[7] = t1.w;
+        go[0] = u0.x; go[1] = u0.y; go[2] = u0.z; go[3] = u0.w; go[4] = u1.x; go[5] = u1.y; go[6] = u1.z; go[7] = u1.w;
+    }
+    const __bf16* Kp = a.K + (size_t)k_off * a.ldk + h * 64 + 8 * c8;
+    const __bf16* Vp = a.V + (size_t)k_off * a.ldv + h * 64 + 8 * c8;
+    float p[Q1R_NI];
+    q1r_probs<SPLIT>(a, q, Kp, k_off, k_len, g, p);
+    const u64 row_base = (u64)(s * a.H + h) * a.max_q;
+    // dP̃[k] = m[k]·(dO·V[k]);  dV[k] = p[k]·m[k]·dO (whole rows)
+    float dpt[Q1R_NI];
+    float part = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (b == 0 || k_len > 64) {
+            float vv[8][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q1r_row<SPLIT>(Vp + (size_t)min(8 * (8 * b + u) + g, k_len - 1) * a.ldv, a.v_lo, vv[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = 8 * b + u, k = 8 * i + g;
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dot = fmaf(go[j], vv[u][j], dot);
+                dot = q1r_sum8(dot);
+                const float m = q1s_drop(a, seed, row_base, k);
+                dpt[i] = m * dot;
+                part = fmaf(p[i], dpt[i], part);                          // (p is 0 past k_len)
+                if (k < k_len) {
+                    const float w = p[i] * m;
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (__bf16)(w * go[j]);
+                    *reinterpret_cast<bf16x8*>(a.dV + (size_t)(k_off + k) * a.lddv + h * 64 + 8 * c8) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dpt[8 * b + u] = 0.f;
+        }
+    }
+    const float delta = q1r_sum_groups(part);            // every lane of a row holds the row's term: the sum runs over the row groups only
+    // dS[k] = p[k]·(dP̃[k] − δ)·scale;  dK[k] = dS[k]·q (whole rows);  dQ = Σ_k dS[k]·K[k]
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (b == 0 || k_len > 64) {
+            float kv[8][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q1r_row<SPLIT>(Kp + (size_t)min(8 * (8 * b + u) + g, k_len - 1) * a.ldk, a.k_lo, kv[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = 8 * b + u, k = 8 * i + g;
+                const float ds = p[i] * (dpt[i] - delta) * a.scale;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(ds, kv[u][j], acc[j]);
+                if (k < k_len) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (__bf16)(ds * q[j]);
+                    *reinterpret_cast<bf16x8*>(a.dK + (size_t)(k_off + k) * a.lddk + h * 64 + 8 * c8) = o;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = q1r_sum_groups(acc[j]);
+    if (g == 0) {
+        float* dq = a.dQ + (size_t)q_off * a.lddq + h * 64 + 8 * c8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dq[j] = acc[j];
+    }
+}
+
+static bool q1r_on() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SVPC_Q1R"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
+
 static bool q1s_ok(int dh, int max_k, int ldq, int ldk, int ldv, int k_lo, int v_lo, const void* Q, const void* K, const void* V) {
     return (dh == 64 || dh == 32) && max_k >= 1 && max_k <= 128 && ldq % 4 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && k_lo % 8 == 0 && v_lo % 8 == 0 &&
            ((((uintptr_t)Q) | ((uintptr_t)K) | ((uintptr_t)V)) & 15) == 0;
@@ -259,7 +482,9 @@ int svpc_attn_q1s_fwd(const float* Q, int ldq, const void* K, int ldk, int k_lo,
     a.scale = scale; a.p_drop = p_drop; a.site = site; a.seed = seed;
     const dim3 grid(ceil_div(n_seq * H, 4)), block(256);
     const bool split = k_lo != 0;
-    if (dh == 64) { if (split) hipLaunchKernelGGL((attn_q1s_fwd_kernel<64, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((attn_q1s_fwd_kernel<64, false>), grid, block, 0, stream, a); }
+    if (dh == 64 && q1r_on() && ldq % 4 == 0 && ldo % 4 == 0 && (((uintptr_t)O) & 15) == 0) {
+        if (split) hipLaunchKernelGGL((attn_q1r_fwd_kernel<true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((attn_q1r_fwd_kernel<false>), grid, block, 0, stream, a);
+    } else if (dh == 64) { if (split) hipLaunchKernelGGL((attn_q1s_fwd_kernel<64, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((attn_q1s_fwd_kernel<64, false>), grid, block, 0, stream, a); }
     else { if (split) hipLaunchKernelGGL((attn_q1s_fwd_kernel<32, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((attn_q1s_fwd_kernel<32, false>), grid, block, 0, stream, a); }
     return svpc_check_launch("attn_q1s_fwd");
 }
@@ -281,7 +506,9 @@ int svpc_attn_q1s_bwd(const float* Q, int ldq, const void* K, int ldk, int k_lo,
     a.dV = (__bf16*)dV; a.lddv = lddv;
     const dim3 grid(ceil_div(n_seq * H, 4)), block(256);
     const bool split = k_lo != 0;
-    if (dh == 64) { if (split) hipLaunchKernelGGL((attn_q1s_bwd_kernel<64, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((attn_q1s_bwd_kernel<64, false>), grid, block, 0, stream, a); }
+    if (dh == 64 && q1r_on() && lddq % 4 == 0 && (((uintptr_t)dQ) & 15) == 0) {
+        if (split) hipLaunchKernelGGL((attn_q1r_bwd_kernel<true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((attn_q1r_bwd_kernel<false>), grid, block, 0, stream, a);
+    } else if (dh == 64) { if (split) hipLaunchKernelGGL((attn_q1s_bwd_kernel<64, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((attn_q1s_bwd_kernel<64, false>), grid, block, 0, stream, a); }
     else { if (split) hipLaunchKernelGGL((attn_q1s_bwd_kernel<32, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((attn_q1s_bwd_kernel<32, false>), grid, block, 0, stream, a); }
     return svpc_check_launch("attn_q1s_bwd");
 }

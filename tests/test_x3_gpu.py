@@ -347,7 +347,9 @@ def test_attention_short_sequences_split_vs_torch(n, Lq, Lk, H, dh, causal, drop
 
 
 @pytest.mark.parametrize("n,Lk,H,dh,drop,split", [(9, 100, 12, 64, 0.0, True), (9, 100, 12, 64, 0.1, True), (9, 100, 12, 64, 0.1, False),
-                                                   (5, 128, 4, 32, 0.0, True), (3, 37, 4, 32, 0.0, False), (4, 1, 12, 64, 0.0, True)])
+                                                   (5, 128, 4, 32, 0.0, True), (3, 37, 4, 32, 0.0, False), (4, 1, 12, 64, 0.0, True),
+                                                   (5, 128, 4, 64, 0.1, True), (3, 37, 4, 64, 0.0, False), (6, 64, 2, 64, 0.0, True),
+                                                   (7, 65, 3, 64, 0.1, False)])
 def test_one_query_attention_over_stream_rows(n, Lk, H, dh, drop, split):
     """the [CLS]-only clip-encoder layer: ONE fp32 query per clip against the stream's K | V rows in place — split rows (bf16x3 mode) or
     bf16 rows (bf16 mode); exact fp32 arithmetic on the stored values, forward and backward (attention_q1s.hip)"""
