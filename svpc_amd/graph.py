@@ -30,13 +30,14 @@ class capturing:
     duration of the capture.  The collector runs whenever allocation counts say so — also in the middle of a capture — and a finaliser
     that makes a HIP call which is not capturable (destroying another hipGraph whose last reference sat in a cycle: an evicted entry of
     the per-clip-count caches; freeing an event) aborts the process ("Fatal Python error: Aborted … Garbage-collecting" inside
-    DecoderGraphs._capture, hit by this round's own GPU suite).  Collect first, capture, collect afterwards."""
+    DecoderGraphs._capture, hit by this round's own GPU suite).  No collection of our own here: a full ``gc.collect()`` per capture cost
+    ≈ 50 ms each on the bench's heap — 44 of them took the cold ragged leg (22 captures of two graphs in 100 steps) from 74 to 28 steps/s;
+    whatever garbage exists is collected by the next automatic run after the capture."""
 
     def __init__(self, graph, **kw):
         self.cm = torch.cuda.graph(graph, **kw)
 
     def __enter__(self):
-        gc.collect()
         self.was = gc.isenabled()
         gc.disable()
         try:
