@@ -150,6 +150,8 @@ def parse_args(argv=None):
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="run the data-parallel code path (process group, three graphs, bucketed all-reduce) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pack-text", action="store_true",
+                    help="run the sentence side over all T x Lt padded rows (default: over the valid tokens only — model.pack_text_rows)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the decode / parity-mode / ceilings legs (N=1 only legs)")
     ap.add_argument("--cpu-videos", type=int, default=16, help="videos per CPU-baseline step (16 = the stated configuration)")
     ap.add_argument("--cpu-warmup", type=int, default=3)     # >= 3 warm-up + >= 5 timed steps, median
@@ -271,9 +273,13 @@ def device_batch(cfg, args, device, seed, n_videos=None):
     b = make_batch(cfg, n_videos=n_videos or args.batch, max_steps=args.clips, n_ingr=10, n_oov=0, seed=seed, full_clips=True)
     # one (S, N, ...) buffer per per-step list (what svpc_amd.input_pipeline builds on the device): the model consumes them in place
     stacked = ("video_features_list", "input_ids_list", "input_masks_list", "input_labels_list", "token_type_ids_list")
+    from svpc_amd import keep_host_copy
     for k in stacked:
-        buf = torch.stack(b[k]).to(device)
+        host = b[k]
+        buf = torch.stack(host).to(device)
         b[k] = [buf[s] for s in range(buf.shape[0])]
+        if k == "input_masks_list":          # the loader's host copy of the masks: the sentence lengths without a read-back (TextPack)
+            b[k] = [keep_host_copy(t, h) for t, h in zip(b[k], host)]
     for k, v in list(b.items()):
         if k in stacked:
             continue
@@ -521,6 +527,7 @@ def run_train(args, precision, device, world, rank, dist, steps, warmup, instrum
     ops.set_precision(precision)
     cfg, model = build(args, device)
     model.train()
+    model.pack_text_rows = not args.no_pack_text
     batch = device_batch(cfg, args, device, seed=2019 + rank)
     fargs = syn.forward_args(batch)
     opt = FusedBertAdam(list(model.named_parameters()), lr=1e-4, warmup=0.1, t_total=100000, grad_clip=1.0, ema_decay=-1.0)
@@ -748,7 +755,10 @@ def run_train(args, precision, device, world, rank, dist, steps, warmup, instrum
     launch = ("hipGraph replay" if not exchange_on else
               "hipGraph replay (fwd + text-side bwd | clip-encoder bwd beside the text-side all-reduce | remaining all-reduce | optimizer)") \
         if graph is not None else ("eager (capture failed: see config.degraded)" if degraded else "eager")
-    res = dict(cfg=cfg, model=model, ms=ms, elapsed=elapsed, final_loss=final_loss, host_enqueue_ms=host_enqueue_ms, launch=launch,
+    pk = next(iter(model._pack_cache.values()), None) if getattr(model, "_pack_cache", None) else None
+    text_rows = ("valid tokens only: %d of %d sentence rows (embedding stack + decoder; the head sees the padded layout)"
+                 % (pk.R, len(pk.lens) * cfg.max_t_len)) if pk is not None else "padded: T x Lt sentence rows"
+    res = dict(cfg=cfg, model=model, ms=ms, elapsed=elapsed, final_loss=final_loss, host_enqueue_ms=host_enqueue_ms, launch=launch, text_rows=text_rows,
                degraded=degraded, gsum=gsum, asum=(asum if instrument else None), glds=glds, bf16_stream=bf16_stream, rows_enc=rows_enc,
                no_exchange_ms=no_exchange_ms, ragged=ragged_res,
                allreduce_bytes=(reducer.bytes_per_step() if reducer is not None else 0),
@@ -921,6 +931,7 @@ def _train_main(args, device, world, rank, dist, joined):
                    "mode": precision, "arithmetic": arithmetic, "parity": recorded_parity(precision),
                    "global_batch": args.batch * joined, "parallelism": "dp%d" % joined, "final_loss": r["final_loss"],
                    "host_enqueue_ms_per_step": r["host_enqueue_ms"], "launch": r["launch"], "degraded": r["degraded"],
+                   "text_rows": r["text_rows"],
                    "gpus_requested": args.gpus},
         "roofline": {"bound": "mfma", "kernel": "%s — every forward projection of the clip-encoder activation stream (M=%d rows: "
                                "Q/K/V, attention-out, FFN, video embedding)" % (kname, r["rows_enc"]),

@@ -316,6 +316,18 @@ int svpc_cross_attn_ln_bwd(const void* q, int q_dt, int ldq, int loq, const void
                            const void* dy, int dy_dt, int lddy, void* dq, void* dres, int dg_dt, int lddg, void* dk, void* dv, int dkv_dt,
                            int ld_dkv, float* part_ln, int T, int lt, int nm, int D, int H, float scale, float p_drop, unsigned site,
                            const svpc_u64* seed, svpc_stream_t stream);
+/* the same over RAGGED sentences — the decoder run over the valid tokens only (nothing a pad token computes reaches the loss: model.py:630-640
+ * masks pad keys, the caption loss ignores pad labels): sentence s owns the rows [row_off[s], row_off[s] + row_len[s]) of q, x1, y, probs, mean,
+ * rstd, dy, dq, dres; row_len[s] <= lt, the padded length (register bound of the kernels, stride of the dropout rows); NULL, NULL = uniform */
+int svpc_cross_attn_ln_fwd_r(const void* q, int q_dt, int ldq, int loq, const void* x1, int x_dt, int ldx, int lox, const void* k, const void* v,
+                             int kv_dt, int ld_kv, int lokv, const float* gamma, const float* beta, float eps, void* y, int y_dt, int ldy, int loy,
+                             float* probs, float* mean, float* rstd, int T, int lt, int nm, int D, int H, float scale, float p_drop, unsigned site,
+                             const svpc_u64* seed, const int* row_off, const int* row_len, svpc_stream_t stream);
+int svpc_cross_attn_ln_bwd_r(const void* q, int q_dt, int ldq, int loq, const void* x1, int x_dt, int ldx, int lox, const void* k, const void* v,
+                             int kv_dt, int ld_kv, int lokv, const float* gamma, const float* probs, const float* mean, const float* rstd,
+                             const void* dy, int dy_dt, int lddy, void* dq, void* dres, int dg_dt, int lddg, void* dk, void* dv, int dkv_dt,
+                             int ld_dkv, float* part_ln, int T, int lt, int nm, int D, int H, float scale, float p_drop, unsigned site,
+                             const svpc_u64* seed, const int* row_off, const int* row_len, svpc_stream_t stream);
 
 /* ---- pointer-generator + caption loss: model.py:896-923, :37-55 */
 int svpc_ptr_attn_fwd(const float* dec, const float* proj, const float* bank, const int* step_ne, float* pi, float* att, int T,

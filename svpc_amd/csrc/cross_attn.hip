@@ -27,6 +27,8 @@ struct XaArgs {
     void* y; int y_dt, ldy, loy;
     float* probs;                                // (T·lt, H, 4) normalised probabilities BEFORE dropout (saved for backward)
     float* mean; float* rstd;                    // (T·lt)
+    const int* row_off; const int* row_len;      // ragged sentences (both or neither): sentence s owns rows [row_off[s], row_off[s] + row_len[s]),
+                                                 // row_len[s] <= lt; null: sentence s owns rows [s·lt, (s+1)·lt)
     int lt, nm, D, H;
     float scale, p_drop; uint32_t site; const u64* seed;
     // backward
@@ -85,14 +87,16 @@ __global__ __launch_bounds__(64 * NPL) void xattn_ln_fwd_kernel(XaArgs a) {
     constexpr int NW = NPL;
     __shared__ float red[NW][LTM][2];
     __shared__ float tot[LTM][2];
-    const int D = a.D, H = a.H, lt = a.lt, nm = a.nm;
+    const int D = a.D, H = a.H, ltu = a.lt, nm = a.nm;          // ltu: the uniform (maximum) sentence length — stride of the dropout rows
     const int s = blockIdx.x, d = threadIdx.x;
+    const int roff = a.row_off ? a.row_off[s] : s * ltu;         // this sentence's first row and its length (ragged: valid tokens only)
+    const int lt = a.row_len ? a.row_len[s] : ltu;
     const int lane = d & 63, wave = d >> 6, h = d / DH;
     // every load of the thread's column up front (Lt query values, Lt residual values, nm keys and values): one memory round trip
     float qv[LTM], xv[LTM], kk[XA_NM], vv[XA_NM];
 #pragma unroll
     for (int t = 0; t < LTM; ++t) {
-        const size_t row = (size_t)(s * lt + min(t, lt - 1));
+        const size_t row = (size_t)(roff + min(t, lt - 1));
         qv[t] = xa_load<KIND>(a.q, row * a.ldq + d, a.loq);
         xv[t] = xa_load<KIND>(a.x1, row * a.ldx + d, a.lox);
     }
@@ -112,9 +116,9 @@ __global__ __launch_bounds__(64 * NPL) void xattn_ln_fwd_kernel(XaArgs a) {
             float sc[XA_NM], p[XA_NM], pt[XA_NM];
 #pragma unroll
             for (int j = 0; j < XA_NM; ++j) sc[j] = seg_sum<DH>(qv[t] * kk[j]);
-            xa_softmax(sc, nm, a.scale, a.p_drop, seed, a.site, (u64)(s * H + h) * lt + t, inv_keep, p, pt);
+            xa_softmax(sc, nm, a.scale, a.p_drop, seed, a.site, (u64)(s * H + h) * ltu + t, inv_keep, p, pt);
             if ((d & (DH - 1)) == 0) {
-                float* pr = a.probs + ((size_t)(s * lt + t) * H + h) * 4;
+                float* pr = a.probs + ((size_t)(roff + t) * H + h) * 4;
                 pr[0] = p[0]; pr[1] = p[1]; pr[2] = p[2]; pr[3] = 0.f;
             }
             xv[t] += pt[0] * vv[0] + pt[1] * vv[1] + pt[2] * vv[2];
@@ -145,13 +149,13 @@ __global__ __launch_bounds__(64 * NPL) void xattn_ln_fwd_kernel(XaArgs a) {
         for (int w = 0; w < NW; ++w) q2 += red[w][d][1];
         const float rstd = 1.0f / sqrtf(q2 / (float)D + a.eps);
         tot[d][1] = rstd;
-        a.mean[(size_t)s * lt + d] = tot[d][0];
-        a.rstd[(size_t)s * lt + d] = rstd;
+        a.mean[(size_t)roff + d] = tot[d][0];
+        a.rstd[(size_t)roff + d] = rstd;
     }
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < LTM; ++t)
-        if (t < lt) xa_store<KIND>(a.y, (size_t)(s * lt + t) * a.ldy + d, a.loy, (xv[t] - tot[t][0]) * tot[t][1] * gam + bet);
+        if (t < lt) xa_store<KIND>(a.y, (size_t)(roff + t) * a.ldy + d, a.loy, (xv[t] - tot[t][0]) * tot[t][1] * gam + bet);
 }
 
 template <int DH, int NPL, int LTM, int KIND>
@@ -161,13 +165,15 @@ __global__ __launch_bounds__(64 * NPL) void xattn_ln_bwd_kernel(XaArgs a) {
     __shared__ float tot[LTM][2];
     __shared__ float stat[LTM][2];
     __shared__ __attribute__((aligned(16))) float pps[LTM][16][4];
-    const int D = a.D, H = a.H, lt = a.lt, nm = a.nm;
+    const int D = a.D, H = a.H, ltu = a.lt, nm = a.nm;          // ltu: the uniform (maximum) sentence length — stride of the dropout rows
     const int s = blockIdx.x, d = threadIdx.x;
+    const int roff = a.row_off ? a.row_off[s] : s * ltu;         // this sentence's first row and its length (ragged: valid tokens only)
+    const int lt = a.row_len ? a.row_len[s] : ltu;
     const int lane = d & 63, wave = d >> 6, h = d / DH;
     float qv[LTM], xh[LTM], g[LTM], kk[XA_NM], vv[XA_NM];
 #pragma unroll
     for (int t = 0; t < LTM; ++t) {
-        const size_t row = (size_t)(s * lt + min(t, lt - 1));
+        const size_t row = (size_t)(roff + min(t, lt - 1));
         qv[t] = xa_load<KIND>(a.q, row * a.ldq + d, a.loq);
         xh[t] = xa_load<KIND>(a.x1, row * a.ldx + d, a.lox);
         g[t] = xa_load<(KIND == 0 ? 0 : 1)>(a.dy, row * a.lddy + d, 0);
@@ -178,11 +184,11 @@ __global__ __launch_bounds__(64 * NPL) void xattn_ln_bwd_kernel(XaArgs a) {
         kk[j] = xa_load<KIND>(a.k, row * a.ld_kv + d, a.lokv);
         vv[j] = xa_load<KIND>(a.v, row * a.ld_kv + d, a.lokv);
     }
-    if (d < lt) { stat[d][0] = a.mean[(size_t)s * lt + d]; stat[d][1] = a.rstd[(size_t)s * lt + d]; }
+    if (d < lt) { stat[d][0] = a.mean[(size_t)roff + d]; stat[d][1] = a.rstd[(size_t)roff + d]; }
     // (the saved probabilities of the sentence through LDS, one coalesced round trip: a load inside the per-row blocks below would be a
     // memory round trip per row on the one chain of Lt rows this workgroup is)
     for (int i = d; i < lt * H; i += 64 * NPL)
-        *reinterpret_cast<float4*>(&pps[i / H][i % H][0]) = *reinterpret_cast<const float4*>(a.probs + ((size_t)s * lt * H + i) * 4);
+        *reinterpret_cast<float4*>(&pps[i / H][i % H][0]) = *reinterpret_cast<const float4*>(a.probs + ((size_t)roff * H + i) * 4);
     const float gam = a.gamma[d];
     const u64 seed = a.p_drop > 0.f ? a.seed[0] : 0ull;
     const float inv_keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(64 * NPL) void xattn_ln_bwd_kernel(XaArgs a) {
 #pragma unroll
             for (int j = 0; j < XA_NM; ++j) {
                 float mult = 1.0f;
-                if (a.p_drop > 0.f && j < nm) mult = attn_drop_scale(seed, a.site, (u64)(s * H + h) * lt + t, (uint32_t)j, a.p_drop, inv_keep);
+                if (a.p_drop > 0.f && j < nm) mult = attn_drop_scale(seed, a.site, (u64)(s * H + h) * ltu + t, (uint32_t)j, a.p_drop, inv_keep);
                 pt[j] = j < nm ? pr[j] * mult : 0.f;
             }
             const float yv = xh[t] + pt[0] * vv[0] + pt[1] * vv[1] + pt[2] * vv[2];
@@ -227,14 +233,14 @@ __global__ __launch_bounds__(64 * NPL) void xattn_ln_bwd_kernel(XaArgs a) {
     for (int t = 0; t < LTM; ++t) {
         if (t < lt) {
             const float dp = stat[t][1] * (g[t] - tot[t][0] - xh[t] * tot[t][1]);
-            const size_t row = (size_t)(s * lt + t);
+            const size_t row = (size_t)(roff + t);
             xa_store<(KIND == 0 ? 0 : 1)>(a.dres, row * a.lddg + d, 0, dp);
             const float* pr = &pps[t][h][0];
             float p[XA_NM], dpt[XA_NM], dot = 0.f;
 #pragma unroll
             for (int j = 0; j < XA_NM; ++j) {
                 float mult = 1.0f;
-                if (a.p_drop > 0.f && j < nm) mult = attn_drop_scale(seed, a.site, (u64)(s * H + h) * lt + t, (uint32_t)j, a.p_drop, inv_keep);
+                if (a.p_drop > 0.f && j < nm) mult = attn_drop_scale(seed, a.site, (u64)(s * H + h) * ltu + t, (uint32_t)j, a.p_drop, inv_keep);
                 p[j] = j < nm ? pr[j] : 0.f;
                 dvv[j] += p[j] * mult * dp;                            // dV[j] += p̃[t, j]·d o[t]
                 dpt[j] = j < nm ? seg_sum<DH>(dp * vv[j]) * mult : 0.f;  // d p[t, j] = <d o[t], v[j]>_head · dropout multiplier
@@ -284,14 +290,16 @@ __global__ __launch_bounds__(64 * NPL) void xattn64_fwd_kernel(XaArgs a) {
     constexpr int NW = NPL, LTM = XA_LT;
     __shared__ float red[NW][32];
     __shared__ float tot[2][32];
-    const int D = a.D, H = a.H, lt = a.lt, nm = a.nm;
+    const int D = a.D, H = a.H, ltu = a.lt, nm = a.nm;          // ltu: the uniform (maximum) sentence length — stride of the dropout rows
     const int s = blockIdx.x, d = threadIdx.x;
+    const int roff = a.row_off ? a.row_off[s] : s * ltu;         // this sentence's first row and its length (ragged: valid tokens only)
+    const int lt = a.row_len ? a.row_len[s] : ltu;
     const int lane = d & 63, wave = d >> 6, h = wave;
     const int r = lane >> 1;                    // the row this lane pair evaluates the softmax of
     float qv[LTM], xv[LTM], kk[XA_NM], vv[XA_NM];
 #pragma unroll
     for (int t = 0; t < LTM; ++t) {
-        const size_t row = (size_t)(s * lt + min(t, lt - 1));
+        const size_t row = (size_t)(roff + min(t, lt - 1));
         qv[t] = xa_load<KIND>(a.q, row * a.ldq + d, a.loq);
         xv[t] = xa_load<KIND>(a.x1, row * a.ldx + d, a.lox);
     }
@@ -313,9 +321,9 @@ __global__ __launch_bounds__(64 * NPL) void xattn64_fwd_kernel(XaArgs a) {
         for (int t = 0; t < 32; ++t) pr[t] = t < LTM ? qv[t] * kk[j] : 0.f;
         sc[j] = xa_rs32(pr, lane);
     }
-    xa_softmax(sc, nm, a.scale, a.p_drop, seed, a.site, (u64)(s * H + h) * lt + min(r, lt - 1), inv_keep, p, pt);
+    xa_softmax(sc, nm, a.scale, a.p_drop, seed, a.site, (u64)(s * H + h) * ltu + min(r, lt - 1), inv_keep, p, pt);
     if ((lane & 1) == 0 && r < lt) {
-        float* po = a.probs + ((size_t)(s * lt + r) * H + h) * 4;
+        float* po = a.probs + ((size_t)(roff + r) * H + h) * 4;
         *reinterpret_cast<float4*>(po) = make_float4(p[0], p[1], p[2], 0.f);
     }
     // attended vector + residual per column: the row's three dropped-out probabilities as wave-uniform scalars
@@ -356,12 +364,12 @@ __global__ __launch_bounds__(64 * NPL) void xattn64_fwd_kernel(XaArgs a) {
         for (int w = 0; w < NW; ++w) q2 += red[w][d];
         const float rstd = 1.0f / sqrtf(q2 / (float)D + a.eps);
         tot[1][d] = rstd;
-        if (d < lt) { a.mean[(size_t)s * lt + d] = tot[0][d]; a.rstd[(size_t)s * lt + d] = rstd; }
+        if (d < lt) { a.mean[(size_t)roff + d] = tot[0][d]; a.rstd[(size_t)roff + d] = rstd; }
     }
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < LTM; ++t)
-        if (t < lt) xa_store<KIND>(a.y, (size_t)(s * lt + t) * a.ldy + d, a.loy, xv[t] * tot[1][t] * gam + bet);
+        if (t < lt) xa_store<KIND>(a.y, (size_t)(roff + t) * a.ldy + d, a.loy, xv[t] * tot[1][t] * gam + bet);
 }
 
 template <int NPL, int KIND>
@@ -371,14 +379,16 @@ __global__ __launch_bounds__(64 * NPL) void xattn64_bwd_kernel(XaArgs a) {
     __shared__ float tot[2][32];
     __shared__ float stat[2][32];
     __shared__ __attribute__((aligned(16))) float pps[32][16][4];
-    const int D = a.D, H = a.H, lt = a.lt, nm = a.nm;
+    const int D = a.D, H = a.H, ltu = a.lt, nm = a.nm;          // ltu: the uniform (maximum) sentence length — stride of the dropout rows
     const int s = blockIdx.x, d = threadIdx.x;
+    const int roff = a.row_off ? a.row_off[s] : s * ltu;         // this sentence's first row and its length (ragged: valid tokens only)
+    const int lt = a.row_len ? a.row_len[s] : ltu;
     const int lane = d & 63, wave = d >> 6, h = wave;
     const int r = lane >> 1, rc = min(r, lt - 1);
     float xh[LTM], g[LTM], kk[XA_NM], vv[XA_NM];
 #pragma unroll
     for (int t = 0; t < LTM; ++t) {
-        const size_t row = (size_t)(s * lt + min(t, lt - 1));
+        const size_t row = (size_t)(roff + min(t, lt - 1));
         xh[t] = xa_load<KIND>(a.x1, row * a.ldx + d, a.lox);
         g[t] = xa_load<GK>(a.dy, row * a.lddy + d, 0);
     }
@@ -388,9 +398,9 @@ __global__ __launch_bounds__(64 * NPL) void xattn64_bwd_kernel(XaArgs a) {
         kk[j] = j < nm ? xa_load<KIND>(a.k, row * a.ld_kv + d, a.lokv) : 0.f;
         vv[j] = j < nm ? xa_load<KIND>(a.v, row * a.ld_kv + d, a.lokv) : 0.f;
     }
-    if (d < 32) { const int t = min(d, lt - 1); stat[0][d] = a.mean[(size_t)s * lt + t]; stat[1][d] = a.rstd[(size_t)s * lt + t]; }
+    if (d < 32) { const int t = min(d, lt - 1); stat[0][d] = a.mean[(size_t)roff + t]; stat[1][d] = a.rstd[(size_t)roff + t]; }
     for (int i = d; i < lt * H; i += 64 * NPL)
-        *reinterpret_cast<float4*>(&pps[i / H][i % H][0]) = *reinterpret_cast<const float4*>(a.probs + ((size_t)s * lt * H + i) * 4);
+        *reinterpret_cast<float4*>(&pps[i / H][i % H][0]) = *reinterpret_cast<const float4*>(a.probs + ((size_t)roff * H + i) * 4);
     const float gam = a.gamma[d];
     const u64 seed = a.p_drop > 0.f ? a.seed[0] : 0ull;
     const float inv_keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(64 * NPL) void xattn64_bwd_kernel(XaArgs a) {
 #pragma unroll
         for (int j = 0; j < XA_NM; ++j) {
             mult[j] = 1.0f;
-            if (a.p_drop > 0.f && j < nm) mult[j] = attn_drop_scale(seed, a.site, (u64)(s * H + h) * lt + rc, (uint32_t)j, a.p_drop, inv_keep);
+            if (a.p_drop > 0.f && j < nm) mult[j] = attn_drop_scale(seed, a.site, (u64)(s * H + h) * ltu + rc, (uint32_t)j, a.p_drop, inv_keep);
             if (j >= nm) p[j] = 0.f;
             pt[j] = p[j] * mult[j];
         }
@@ -442,13 +452,13 @@ __global__ __launch_bounds__(64 * NPL) void xattn64_bwd_kernel(XaArgs a) {
     // from the top of the kernel)
     float qv[LTM];
 #pragma unroll
-    for (int t = 0; t < LTM; ++t) qv[t] = xa_load<KIND>(a.q, (size_t)(s * lt + min(t, lt - 1)) * a.ldq + d, a.loq);
+    for (int t = 0; t < LTM; ++t) qv[t] = xa_load<KIND>(a.q, (size_t)(roff + min(t, lt - 1)) * a.ldq + d, a.loq);
     // (2) pre-LayerNorm gradient; d p̃ by three butterflies; dV column sums
     float dpt[XA_NM], dvv[XA_NM] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < LTM; ++t) {
         g[t] = stat[1][t] * (g[t] - tot[0][t] - xh[t] * tot[1][t]);          // g[] now holds d(x1 + o)
-        if (t < lt) xa_store<GK>(a.dres, (size_t)(s * lt + t) * a.lddg + d, 0, g[t]);
+        if (t < lt) xa_store<GK>(a.dres, (size_t)(roff + t) * a.lddg + d, 0, g[t]);
 #pragma unroll
         for (int j = 0; j < XA_NM; ++j) dvv[j] += xa_bcast(pt[j], 2 * t) * (t < lt ? g[t] : 0.f);
     }
@@ -471,7 +481,7 @@ __global__ __launch_bounds__(64 * NPL) void xattn64_bwd_kernel(XaArgs a) {
 #pragma unroll
     for (int t = 0; t < LTM; ++t) {
         const float g0 = xa_bcast(gs[0], 2 * t), g1 = xa_bcast(gs[1], 2 * t), g2 = xa_bcast(gs[2], 2 * t);
-        if (t < lt) xa_store<GK>(a.dq, (size_t)(s * lt + t) * a.lddg + d, 0, g0 * kk[0] + g1 * kk[1] + g2 * kk[2]);
+        if (t < lt) xa_store<GK>(a.dq, (size_t)(roff + t) * a.lddg + d, 0, g0 * kk[0] + g1 * kk[1] + g2 * kk[2]);
         dkk[0] += g0 * qv[t]; dkk[1] += g1 * qv[t]; dkk[2] += g2 * qv[t];
     }
 #pragma unroll
@@ -536,6 +546,16 @@ int xa_dispatch(const XaArgs& a, int T, bool bwd, hipStream_t s) {
 
 extern "C" {
 
+int svpc_cross_attn_ln_fwd_r(const void* q, int q_dt, int ldq, int loq, const void* x1, int x_dt, int ldx, int lox, const void* k, const void* v,
+                             int kv_dt, int ld_kv, int lokv, const float* gamma, const float* beta, float eps, void* y, int y_dt, int ldy, int loy,
+                             float* probs, float* mean, float* rstd, int T, int lt, int nm, int D, int H, float scale, float p_drop, unsigned site,
+                             const u64* seed, const int* row_off, const int* row_len, hipStream_t stream);
+int svpc_cross_attn_ln_bwd_r(const void* q, int q_dt, int ldq, int loq, const void* x1, int x_dt, int ldx, int lox, const void* k, const void* v,
+                             int kv_dt, int ld_kv, int lokv, const float* gamma, const float* probs, const float* mean, const float* rstd,
+                             const void* dy, int dy_dt, int lddy, void* dq, void* dres, int dg_dt, int lddg, void* dk, void* dv, int dkv_dt,
+                             int ld_dkv, float* part_ln, int T, int lt, int nm, int D, int H, float scale, float p_drop, unsigned site,
+                             const u64* seed, const int* row_off, const int* row_len, hipStream_t stream);
+
 // 1 if the fused cross-attention + LayerNorm kernels take this shape: D ∈ {256, 512, 768} with 64-wide heads or D ∈ {128, 256} with
 // 32-wide heads, ≤ 24 sentence rows, ≤ 3 memory rows
 int svpc_cross_attn_ln_supported(int D, int H, int lt, int nm) {
@@ -551,10 +571,21 @@ int svpc_cross_attn_ln_fwd(const void* q, int q_dt, int ldq, int loq, const void
                            int kv_dt, int ld_kv, int lokv, const float* gamma, const float* beta, float eps, void* y, int y_dt, int ldy, int loy,
                            float* probs, float* mean, float* rstd, int T, int lt, int nm, int D, int H, float scale, float p_drop, unsigned site,
                            const u64* seed, hipStream_t stream) {
+    return svpc_cross_attn_ln_fwd_r(q, q_dt, ldq, loq, x1, x_dt, ldx, lox, k, v, kv_dt, ld_kv, lokv, gamma, beta, eps, y, y_dt, ldy, loy, probs, mean,
+                                    rstd, T, lt, nm, D, H, scale, p_drop, site, seed, nullptr, nullptr, stream);
+}
+// the same over RAGGED sentences (valid tokens only): sentence s owns the rows [row_off[s], row_off[s] + row_len[s]) of q, x1, y, probs,
+// mean, rstd, row_len[s] <= lt (lt: the padded sentence length — bounds the kernel's registers and is the stride of the dropout rows)
+int svpc_cross_attn_ln_fwd_r(const void* q, int q_dt, int ldq, int loq, const void* x1, int x_dt, int ldx, int lox, const void* k, const void* v,
+                             int kv_dt, int ld_kv, int lokv, const float* gamma, const float* beta, float eps, void* y, int y_dt, int ldy, int loy,
+                             float* probs, float* mean, float* rstd, int T, int lt, int nm, int D, int H, float scale, float p_drop, unsigned site,
+                             const u64* seed, const int* row_off, const int* row_len, hipStream_t stream) {
     if (T == 0) return 0;
     SVPC_REQUIRE(svpc_cross_attn_ln_supported(D, H, lt, nm) == 1, "cross_attn_ln: unsupported shape");
     SVPC_REQUIRE(q_dt == x_dt && q_dt == kv_dt && q_dt == y_dt && q_dt >= 0 && q_dt <= 2, "cross_attn_ln: one storage kind for q, x1, k / v and y");
+    SVPC_REQUIRE((row_off == nullptr) == (row_len == nullptr), "cross_attn_ln: row_off and row_len come together");
     XaArgs a{};
+    a.row_off = row_off; a.row_len = row_len;
     a.q = q; a.q_dt = q_dt; a.ldq = ldq; a.loq = loq; a.x1 = x1; a.x_dt = x_dt; a.ldx = ldx; a.lox = lox; a.k = k; a.v = v; a.kv_dt = kv_dt;
     a.ld_kv = ld_kv; a.lokv = lokv; a.gamma = gamma; a.beta = beta; a.eps = eps; a.y = y; a.y_dt = y_dt; a.ldy = ldy; a.loy = loy;
     a.probs = probs; a.mean = mean; a.rstd = rstd; a.lt = lt; a.nm = nm; a.D = D; a.H = H; a.scale = scale; a.p_drop = p_drop; a.site = site;
@@ -569,8 +600,18 @@ int svpc_cross_attn_ln_bwd(const void* q, int q_dt, int ldq, int loq, const void
                            const void* dy, int dy_dt, int lddy, void* dq, void* dres, int dg_dt, int lddg, void* dk, void* dv, int dkv_dt,
                            int ld_dkv, float* part_ln, int T, int lt, int nm, int D, int H, float scale, float p_drop, unsigned site,
                            const u64* seed, hipStream_t stream) {
+    return svpc_cross_attn_ln_bwd_r(q, q_dt, ldq, loq, x1, x_dt, ldx, lox, k, v, kv_dt, ld_kv, lokv, gamma, probs, mean, rstd, dy, dy_dt, lddy, dq,
+                                    dres, dg_dt, lddg, dk, dv, dkv_dt, ld_dkv, part_ln, T, lt, nm, D, H, scale, p_drop, site, seed, nullptr, nullptr,
+                                    stream);
+}
+int svpc_cross_attn_ln_bwd_r(const void* q, int q_dt, int ldq, int loq, const void* x1, int x_dt, int ldx, int lox, const void* k, const void* v,
+                             int kv_dt, int ld_kv, int lokv, const float* gamma, const float* probs, const float* mean, const float* rstd,
+                             const void* dy, int dy_dt, int lddy, void* dq, void* dres, int dg_dt, int lddg, void* dk, void* dv, int dkv_dt,
+                             int ld_dkv, float* part_ln, int T, int lt, int nm, int D, int H, float scale, float p_drop, unsigned site,
+                             const u64* seed, const int* row_off, const int* row_len, hipStream_t stream) {
     if (T == 0) return 0;
     SVPC_REQUIRE(svpc_cross_attn_ln_supported(D, H, lt, nm) == 1, "cross_attn_ln: unsupported shape");
+    SVPC_REQUIRE((row_off == nullptr) == (row_len == nullptr), "cross_attn_ln: row_off and row_len come together");
     const int gdt = q_dt == 0 ? 0 : 1;
     SVPC_REQUIRE(q_dt == x_dt && q_dt == kv_dt && q_dt >= 0 && q_dt <= 2, "cross_attn_ln: one storage kind for q, x1 and k / v");
     SVPC_REQUIRE(dg_dt == gdt && dkv_dt == gdt && dy_dt == gdt, "cross_attn_ln: gradients are dense rows, fp32 for fp32 storage, bf16 otherwise");
@@ -579,7 +620,7 @@ int svpc_cross_attn_ln_bwd(const void* q, int q_dt, int ldq, int loq, const void
     a.ld_kv = ld_kv; a.lokv = lokv; a.gamma = gamma; a.probs = const_cast<float*>(probs); a.mean = const_cast<float*>(mean);
     a.rstd = const_cast<float*>(rstd); a.lt = lt; a.nm = nm; a.D = D; a.H = H; a.scale = scale; a.p_drop = p_drop; a.site = site; a.seed = seed;
     a.dy = dy; a.dy_dt = dy_dt; a.lddy = lddy; a.dq = dq; a.dres = dres; a.dg_dt = dg_dt; a.lddg = lddg; a.dk = dk; a.dv = dv;
-    a.dkv_dt = dkv_dt; a.ld_dkv = ld_dkv; a.part_ln = part_ln;
+    a.dkv_dt = dkv_dt; a.ld_dkv = ld_dkv; a.part_ln = part_ln; a.row_off = row_off; a.row_len = row_len;
     return xa_dispatch(a, T, true, stream);
 }
 

@@ -297,14 +297,17 @@ class BertDecoderLayerNoMemoryUntied(nn.Module):
         if kvc.dtype != qc.dtype:          # (memory rows handed over in another storage type than the sentence stream)
             kvc = kvc.to(qc.dtype)
         n_seq = seq_cross.n
-        lt = x1.shape[0] // max(n_seq, 1)
-        if (n_seq > 0 and x1.shape[0] == n_seq * seq_cross.max_q and kvc.shape[0] == n_seq * seq_cross.max_k and x1.is_cuda
+        uniform = n_seq > 0 and x1.shape[0] == n_seq * seq_cross.max_q
+        ragged = n_seq > 0 and not uniform and x1.shape[0] == seq_cross.n_q_rows and getattr(seq_cross, "packed_rows", False)
+        lt = seq_cross.max_q
+        if ((uniform or ragged) and kvc.shape[0] == n_seq * seq_cross.max_k and x1.is_cuda
                 and (ops.lo_off(qc) is None) == (ops.lo_off(kvc) is None) and (ops.lo_off(qc) is None) == (ops.lo_off(x1) is None)
                 and qc.dtype == x1.dtype and ops.cross_attn_ln_usable(D, cx.H, lt, seq_cross.max_k, mem_mask)):
-            # uniform sentences over ≤ 3 memory rows each: attention + residual + LayerNorm in one launch, forward and backward
-            # (svpc_amd/csrc/cross_attn.hip)
+            # sentences (uniform, or ragged: the valid tokens only) over ≤ 3 memory rows each: attention + residual + LayerNorm in one
+            # launch, forward and backward (svpc_amd/csrc/cross_attn.hip)
+            rows = (seq_cross.table[0], seq_cross.table[1]) if ragged else None
             x2 = ops.cross_attn_ln(qc, x1, kvc, self.norm2.weight, self.norm2.bias, cx.eps, cx.H, lt, seq_cross.max_k,
-                                   drop=cx.drop(cx.p_a), sink=True)
+                                   drop=cx.drop(cx.p_a), sink=True, rows=rows)
         else:
             ca = ops.attention(qc, kvc, (0, 0, D), D, cx.H, seq_cross, key_mask=mem_mask, causal=False, drop=cx.drop(cx.p_a))
             x2 = ops.layernorm(ca, self.norm2.weight, self.norm2.bias, cx.eps, residual=x1, sink=True)
@@ -438,10 +441,14 @@ class BertEmbeddingsTextUntied(nn.Module):
         self.word_embeddings = nn.Embedding.from_pretrained(pretrained_embedding, freeze=freeze,
                                                             padding_idx=self.word_embeddings.padding_idx)
 
-    def run(self, ids_flat, lt, cx, out_bf16=False):
+    def run(self, ids_flat, lt, cx, out_bf16=False, pos_idx=None):
+        """``pos_idx``: the position of every row inside its sentence (packed rows: svpc_amd.model.TextPack); default row % lt"""
+        pe = self.position_embeddings_text.pe[:lt].contiguous()
+        if pos_idx is not None:
+            return self.word_fc.run(self.word_embeddings.weight, cx.eps, src_rows=ids_flat, pad_row=PAD_ROW, drop=cx.drop(cx.p_h),
+                                    add2=pe, add2_idx=pos_idx, final_bf16=out_bf16)
         return self.word_fc.run(self.word_embeddings.weight, cx.eps, src_rows=ids_flat, pad_row=PAD_ROW,
-                                drop=cx.drop(cx.p_h), add1=self.position_embeddings_text.pe[:lt].contiguous(),
-                                add1_mod=lt, final_bf16=out_bf16)
+                                drop=cx.drop(cx.p_h), add1=pe, add1_mod=lt, final_bf16=out_bf16)
 
     def run_at(self, ids, pos, cx):
         """One token per sentence, all at sentence position ``pos`` (incremental decoding)."""
@@ -690,6 +697,42 @@ class BatchPlan:
         return sq
 
 
+class TextPack:
+    """Row maps for running the sentence side on the VALID tokens only (``model.pack_text_rows``).  A sentence of n ≤ Lt tokens is
+    padded to Lt by the loader (recursive_caption_dataset.py:528-576); nothing a pad row computes reaches the loss (its label is -1,
+    pad keys are masked in the causal self-attention, ``reconstruct`` weights it 0 — model.py:630-640, :1017-1025), so the decoder
+    stack runs over Σ n rows instead of T·Lt: sentence j owns rows [off_j, off_j + n_j).  Built per (batch plan, sentence lengths) on the
+    host from the loader's copy of the masks; every table in one upload."""
+
+    def __init__(self, plan, lens, N, Lv, Lt, L, n_mem, device):
+        self.lens = list(lens)
+        T = plan.T
+        off, acc = [], 0
+        for n in self.lens:
+            off.append(acc)
+            acc += n
+        self.R = acc
+        clip_b, clip_s = plan.step_vid.host, plan.step_idx.host
+        rows, pos, full = [], [], []
+        for j in range(T):
+            base = (clip_s[j] * N + clip_b[j]) * L + Lv
+            n = self.lens[j]
+            rows.extend(range(base, base + n))
+            pos.extend(range(n))
+            full.extend(range(j * Lt, j * Lt + n))
+        self.seq_self = ops.SeqInfo(off, self.lens, off, self.lens, None)
+        self.seq_cross = ops.SeqInfo(off, self.lens, [j * n_mem for j in range(T)], [n_mem] * T, None)
+        self.seq_cross.packed_rows = True        # (consecutive sentences, consecutive memory blocks: what the fused cross-attention assumes)
+        up = BulkUpload(device)
+        up.add(rows, sink=lambda t: setattr(self, "src_rows", t))          # rows of the flattened (S·N·L) id / label arrays
+        up.add(pos, sink=lambda t: setattr(self, "pos", t))                # position of each packed row inside its sentence
+        up.add(full, sink=lambda t: setattr(self, "full_rows", t))         # its row in the padded (T·Lt) layout
+        up.add_seq(self.seq_self)
+        up.add_seq(self.seq_cross)
+        up.flush()
+        self.full_rows64 = self.full_rows.long()
+
+
 class StateAwareRecursiveTransformer(nn.Module):
     """reference: src/rtransformer/model.py:826-1189."""
 
@@ -726,6 +769,7 @@ class StateAwareRecursiveTransformer(nn.Module):
         self._plans = {}
         self._ptr_plans = {}
         self._span_cache = {}
+        self._pack_cache = {}
         self._rng = None
         self.gumbel_noise = None  # test hook: list of (S_b, Lt, V+X_b) tensors, one per video
 
@@ -763,6 +807,35 @@ class StateAwareRecursiveTransformer(nn.Module):
                           self._n_mem(), device)
             self._plans[key] = p
         return p
+
+    def _text_pack(self, plan, input_masks_list, N, L, device):
+        """the valid-token row maps of this batch, or None: packing is opt-in (``model.pack_text_rows = True``: the caller does not read
+        the pad positions of the returned probabilities — they come back as zeros), needs gradients to be wanted and the loader's host
+        copy of every step's mask (``svpc_amd.keep_host_copy``; nothing is read back from the device for it), prefix-shaped masks."""
+        if not getattr(self, "pack_text_rows", False) or not torch.is_grad_enabled():
+            return None
+        hosts = [getattr(m, "_svpc_host", None) for m in input_masks_list]
+        if any(h is None or tuple(h.shape) != tuple(m.shape) for h, m in zip(hosts, input_masks_list)):
+            return None
+        cfg = self.config
+        Lv, Lt = cfg.max_v_len, cfg.max_t_len
+        key = (plan.key, tuple(id(h) for h in hosts), tuple(int(h._version) for h in hosts), str(device))
+        hit = self._pack_cache.get(key)
+        if hit is not None:
+            return hit
+        lens = []
+        for b, s_ in zip(plan.step_vid.host, plan.step_idx.host):
+            row = hosts[s_][b, Lv:Lv + Lt]
+            n = int(row.sum())
+            if n < 1 or not bool((row[:n] != 0).all()):
+                return None                  # not a prefix mask (or an empty sentence): the padded layout
+            lens.append(n)
+        if len(self._pack_cache) >= 8:
+            self._pack_cache.clear()
+        pk = TextPack(plan, lens, N, Lv, Lt, L, self._n_mem(), device)
+        pk.hosts = hosts                     # (keeps the ids of the key alive)
+        self._pack_cache[key] = pk
+        return pk
 
     def _spans_for(self, ingr_sep_masks):
         """[SEP]-span table of the batch.  The mask lives on the device; reading it is the one host sync of a step, so the result
@@ -930,10 +1003,14 @@ class StateAwareRecursiveTransformer(nn.Module):
         # (zero-copy when the per-step tensors are consecutive slices of one buffer: the input pipeline and bench.py hand them so)
         # token staging in one launch: the clip rows' ids / masks, the sentence rows' ids / masks / labels, the ingredient ids
         ids_src, masks_src, labels_src = (self._stacked(l).reshape(-1) for l in (input_ids_list, input_masks_list, input_labels_list))
-        ids_v, mask_v, text_ids, text_mask, labels, ingr_ids = ops.gather_cast_multi([
+        dg = getattr(self, "decoder_graphs", None)
+        pack = self._text_pack(plan, input_masks_list, N, L, dev) if dg is None else None
+        staged = ops.gather_cast_multi([
             (ids_src, plan.video_rows, torch.int32), (masks_src, plan.video_rows, torch.float32),
             (ids_src, plan.text_rows, torch.int32), (masks_src, plan.text_rows, torch.float32),
-            (labels_src, plan.text_rows, torch.int32), (ingr_input_ids, None, torch.int32)])
+            (labels_src, plan.text_rows, torch.int32), (ingr_input_ids, None, torch.int32)] +
+            ([(ids_src, pack.src_rows, torch.int32)] if pack is not None else []))
+        ids_v, mask_v, text_ids, text_mask, labels, ingr_ids = staged[:6]
 
         # (1) entity initial states, compact (ΣE, D)
         ents = self.ingredient_embeddings.run(ingr_ids, spans, cx)
@@ -979,12 +1056,18 @@ class StateAwareRecursiveTransformer(nn.Module):
             bank = None
 
         # (5) decoder over all T sentences at once (reference: per video, :1086/:925-1015)
-        xt = self.text_embeddings.run(text_ids, Lt, cx, out_bf16=self.decoder.streams_bf16(T * Lt, D))
-        dg = getattr(self, "decoder_graphs", None)
-        if dg is not None and dg.usable(xt, mem):         # (structure enters the decoder only through T: svpc_amd/clip_graphs.py)
-            dec = dg.run(xt, text_mask, mem, T, cx)
+        if pack is not None:
+            # valid tokens only (TextPack): the embedding stack and the six decoder layers over Σ n_j rows, ragged segments; the rows
+            # return to the padded layout (zeros at the pad positions) for the head
+            xt = self.text_embeddings.run(staged[6], Lt, cx, out_bf16=self.decoder.streams_bf16(pack.R, D), pos_idx=pack.pos)
+            dec_p = self.decoder.run(xt, None, mem, pack.seq_self, pack.seq_cross, None, cx)
+            dec = ops.scatter_rows(dec_p, pack.full_rows64, T * Lt)
         else:
-            dec = self.decoder.run(xt, text_mask, mem, plan.seq_dec_self, plan.seq_dec_cross, None, cx)
+            xt = self.text_embeddings.run(text_ids, Lt, cx, out_bf16=self.decoder.streams_bf16(T * Lt, D))
+            if dg is not None and dg.usable(xt, mem):     # (structure enters the decoder only through T: svpc_amd/clip_graphs.py)
+                dec = dg.run(xt, text_mask, mem, T, cx)
+            else:
+                dec = self.decoder.run(xt, text_mask, mem, plan.seq_dec_self, plan.seq_dec_cross, None, cx)
 
         # (6) head + pointer-generator + label-smoothed KL
         c_list = [V + (extra_zeros[b] if mode != "video" else 0) for b in range(N)]

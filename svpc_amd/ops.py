@@ -559,6 +559,27 @@ def to_f32(t):
     return _ToF32.apply(t, lo_off(t))
 
 
+class _ScatterRows(Function):
+    """out (n_rows, W) = zeros with out[idx[r]] = src[r] (idx int64, distinct rows); backward gathers the rows back"""
+
+    @staticmethod
+    def forward(ctx, src, idx, n_rows):
+        ctx.save_for_backward(idx)
+        out = torch.zeros(n_rows, src.shape[1], dtype=src.dtype, device=src.device)
+        out.index_copy_(0, idx, src)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return torch.index_select(g, 0, idx), None, None
+
+
+def scatter_rows(src, idx, n_rows):
+    """rows of a packed tensor back into a padded layout (zeros elsewhere); data movement"""
+    return _ScatterRows.apply(src, idx, int(n_rows))
+
+
 def take_rows_f32(t, idx):
     """fp32 rows ``idx`` of a (possibly split / bf16) 2-D tensor."""
     lo = lo_off(t)
@@ -1497,11 +1518,12 @@ def _kind(t):
 
 class _CrossAttnLn(Function):
     @staticmethod
-    def forward(ctx, q, x1, kv, gamma, beta, eps, H, lt, nm, drop, sink):
+    def forward(ctx, q, x1, kv, gamma, beta, eps, H, lt, nm, drop, sink, rows=None):
         _need_gpu(q)
         D = gamma.shape[0]
         R = q.shape[0]
-        T = R // lt
+        T = R // lt if rows is None else rows[0].numel()       # rows = (row_off, row_len) int32 device tensors: ragged sentences
+        ro, rl = rows if rows is not None else (None, None)
         dev = q.device
         out_kind = _kind(x1)
         if out_kind == 2:
@@ -1516,10 +1538,11 @@ class _CrossAttnLn(Function):
         p, site, seed = _drop_args(drop)
         scale = 1.0 / math.sqrt(D // H)
         es = kv.element_size()
-        _lib.call("cross_attn_ln_fwd", _p(q), _kind(q), q.stride(0), lo_off(q) or 0, _p(x1), out_kind, x1.stride(0), lo_off(x1) or 0,
+        _lib.call("cross_attn_ln_fwd_r", _p(q), _kind(q), q.stride(0), lo_off(q) or 0, _p(x1), out_kind, x1.stride(0), lo_off(x1) or 0,
                   kv.data_ptr(), kv.data_ptr() + D * es, _kind(kv), kv.stride(0), lo_off(kv) or 0, _p(gamma), _p(beta), float(eps),
-                  _p(y), out_kind, y.stride(0), loy, _p(probs), _p(mean), _p(rstd), T, lt, nm, D, H, scale, p, site, _p(seed), _stream())
-        ctx.save_for_backward(q, x1, kv, gamma, probs, mean, rstd, seed)
+                  _p(y), out_kind, y.stride(0), loy, _p(probs), _p(mean), _p(rstd), T, lt, nm, D, H, scale, p, site, _p(seed), _p(ro), _p(rl),
+                  _stream())
+        ctx.save_for_backward(q, x1, kv, gamma, probs, mean, rstd, seed, ro, rl)
         ctx.cfg = (T, lt, nm, D, H, scale, p, site, _kind(q), lo_off(q) or 0, out_kind, lo_off(x1) or 0, _kind(kv), lo_off(kv) or 0)
         ctx.kv_into = getattr(kv, "_svpc_grad_into", None)
         ctx.direct = (_direct(gamma), _direct(beta))
@@ -1528,11 +1551,11 @@ class _CrossAttnLn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        q, x1, kv, gamma, probs, mean, rstd, seed = ctx.saved_tensors
+        q, x1, kv, gamma, probs, mean, rstd, seed, ro, rl = ctx.saved_tensors
         T, lt, nm, D, H, scale, p, site, q_dt, q_lo, x_dt, x_lo, kv_dt, kv_lo = ctx.cfg
         dev = dy.device
         dy = _c(dy)
-        R = T * lt
+        R = q.shape[0]
         dq = torch.empty(R, D, dtype=dy.dtype, device=dev)
         dres = torch.empty(R, D, dtype=dy.dtype, device=dev)
         into = ctx.kv_into
@@ -1542,10 +1565,10 @@ class _CrossAttnLn(Function):
             dkv = torch.empty(kv.shape, dtype=kv.dtype, device=dev)
         part_ln = torch.empty(T, 2 * D, dtype=torch.float32, device=dev)
         es = dkv.element_size()
-        _lib.call("cross_attn_ln_bwd", _p(q), q_dt, q.stride(0), q_lo, _p(x1), x_dt, x1.stride(0), x_lo, kv.data_ptr(),
+        _lib.call("cross_attn_ln_bwd_r", _p(q), q_dt, q.stride(0), q_lo, _p(x1), x_dt, x1.stride(0), x_lo, kv.data_ptr(),
                   kv.data_ptr() + D * kv.element_size(), kv_dt, kv.stride(0), kv_lo, _p(gamma), _p(probs), _p(mean), _p(rstd), _p(dy), _dt(dy),
                   dy.stride(0), _p(dq), _p(dres), _dt(dq), dq.stride(0), dkv.data_ptr(), dkv.data_ptr() + D * es, _dt(dkv), dkv.stride(0),
-                  _p(part_ln), T, lt, nm, D, H, scale, p, site, _p(seed), _stream())
+                  _p(part_ln), T, lt, nm, D, H, scale, p, site, _p(seed), _p(ro), _p(rl), _stream())
         g_d, b_d = ctx.direct
         dgamma = dbeta = None
         if g_d is not None and b_d is not None and USE_MULTI_FINALIZE and not SIDE_WGRAD:
@@ -1562,17 +1585,18 @@ class _CrossAttnLn(Function):
             SINK_STATS[0] += 1
             _queue_end_of_backward_join()
             dres = None
-        return dq, dres, dkv, dgamma, dbeta, None, None, None, None, None, None
+        return dq, dres, dkv, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def cross_attn_ln(q, x1, kv, gamma, beta, eps, n_heads, lt, nm, drop=None, sink=False):
+def cross_attn_ln(q, x1, kv, gamma, beta, eps, n_heads, lt, nm, drop=None, sink=False, rows=None):
     """LayerNorm(x1 + CrossAttention(q; the sentence's nm memory rows)) in one launch — q, x1 (T·lt, D) fp32 / bf16 / split; kv (T·nm, 2D)
     [K | V] rows of the same storage family (may be a column block of the stacked memory projection).  Output in x1's storage kind.
+    rows = (row_off, row_len): ragged sentences (valid tokens only) — sentence s owns rows [row_off[s], row_off[s] + row_len[s]), ≤ lt each.
     sink=True: x1's only other consumer is the ops.linear that produced q — its dgrad absorbs the residual-path gradient (_RES_SINK)."""
     require_split_tag(q, "cross_attn_ln (queries)")
     require_split_tag(x1, "cross_attn_ln (residual)")
     require_split_tag(kv, "cross_attn_ln (memory rows)")
-    y = _CrossAttnLn.apply(q, x1, kv, gamma, beta, float(eps), int(n_heads), int(lt), int(nm), drop, sink)
+    y = _CrossAttnLn.apply(q, x1, kv, gamma, beta, float(eps), int(n_heads), int(lt), int(nm), drop, sink, rows)
     if lo_off(x1) is not None:
         y._svpc_lo = y.shape[1]
     return y

@@ -200,6 +200,11 @@ def sim_heads(hh, fb, W3, b3, W4, b4):
     return torch.softmax(hh @ W3.t() + b3, -1), (fb @ W4.t() + b4).reshape(-1)
 
 
+def scatter_rows(src, idx, n_rows):
+    out = torch.zeros(n_rows, src.shape[1], dtype=src.dtype, device=src.device)
+    return out.index_copy(0, idx, src)
+
+
 def take_rows_f32_alias(t, idx):
     return take_rows_f32(t, idx), t
 

@@ -695,3 +695,53 @@ def test_translator_built_after_the_optimizer_does_not_orphan_training(golden_di
         d2, _ = fresh.translate_batch(syn.translate_inputs(batch))
         torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(d1, d2))
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("mt", ["vivt", "v"])
+def test_packed_text_rows_equal_the_padded_layout(golden_dir, mt, mode):
+    """``model.pack_text_rows`` (svpc_amd.model.TextPack): the embedding stack and the decoder over the valid tokens only.  The loss is
+    the reference golden's and the padded path's, the probabilities agree at every valid position, every gradient agrees with the
+    padded path (config-1 shape: sentences of 7..22 of 22 tokens; eval mode, recorded Gumbel noise)."""
+    from svpc_amd import keep_host_copy, ops
+    z, cfg, batch, model = build_model("c1", mt, golden_dir, DEV)
+    args = syn.forward_args(batch)
+    host_masks = [m.cpu() for m in args[2]]
+    ops.set_precision(mode)
+    try:
+        loss0, probs0, _, _ = model(*args)
+        loss0.backward()
+        ops.join_side()
+        g0 = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        model.zero_grad()
+        for m, h in zip(args[2], host_masks):
+            keep_host_copy(m, h)
+        model.pack_text_rows = True
+        loss1, probs1, _, _ = model(*args)
+        assert model._pack_cache, "the packed path was not taken"
+        pk = next(iter(model._pack_cache.values()))
+        assert pk.R < len(pk.lens) * cfg.max_t_len
+        loss1.backward()
+        ops.join_side()
+    finally:
+        ops.set_precision("fp32")
+        model.pack_text_rows = False
+    ref = float(z["loss"])
+    tol = 2e-5 if mode == "fp32" else 1e-4
+    assert abs(loss1.item() - ref) <= tol * abs(ref), (loss1.item(), ref)
+    assert abs(loss1.item() - loss0.item()) <= 2e-6 * abs(ref), (loss1.item(), loss0.item())
+    Lv, Lt = cfg.max_v_len, cfg.max_t_len
+    for b, (p0, p1) in enumerate(zip(probs0, probs1)):
+        for s_ in range(p0.shape[0]):
+            n = int(host_masks[s_][b, Lv:Lv + Lt].sum())
+            d = float((p0[s_, :n] - p1[s_, :n]).abs().max())
+            assert d <= (1e-6 if mode == "fp32" else 1e-4), (b, s_, d)
+    biggest = max(float(g.abs().max()) for g in g0.values())
+    for n, p in model.named_parameters():
+        if n not in g0:
+            continue
+        d = float((p.grad - g0[n]).abs().max())
+        m = float(g0[n].abs().max())
+        # (analytically zero gradients — key biases: softmax shift invariance — hold rounding noise: bounded against the real ones)
+        # (bf16x3: the backward is one-term bf16 and its weight gradients sum over a different number of rows in a different tiling)
+        assert d <= ((2e-5 * m + 1e-6 * biggest) if mode == "fp32" else (3e-2 * m + 1e-3 * biggest)), (n, d, m)

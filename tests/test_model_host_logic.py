@@ -64,6 +64,45 @@ def test_batched_forward_backward_matches_reference(golden_dir, case, mt):
     assert n > 20
 
 
+@pytest.mark.parametrize("mt", ["vivt", "v"])
+def test_packed_text_rows_match_reference(golden_dir, mt):
+    """``model.pack_text_rows``: the sentence side over the valid tokens only (svpc_amd.model.TextPack) — the loss and the gradients are
+    the reference's (config-1 shape: sentences of 7..22 of 22 tokens); the returned probabilities are the reference's at the valid
+    positions (the pad positions hold what the head makes of a zero row)."""
+    from svpc_amd import keep_host_copy
+    z, cfg, batch, model = build("c1", mt, golden_dir)
+    args = syn.forward_args(batch)
+    for m in args[2]:
+        keep_host_copy(m, m)
+    model.pack_text_rows = True
+    loss, probs, ents, acts = model(*args)
+    assert model._pack_cache, "the packed path was not taken"
+    pk = next(iter(model._pack_cache.values()))
+    assert pk.R < sum(p.shape[0] * p.shape[1] for p in probs), "the fixture has no pad tokens"
+    assert abs(loss.item() - float(z["loss"])) <= 5e-5 * abs(float(z["loss"]))
+    Lv, Lt = cfg.max_v_len, cfg.max_t_len
+    for b, p in enumerate(probs):
+        ref = z["probs_slice/%d" % b]
+        for s_ in range(p.shape[0]):
+            n = int(args[2][s_][b, Lv:Lv + Lt].sum())
+            np.testing.assert_allclose(p[s_, :n, ::37].detach().numpy(), ref[s_, :n], rtol=2e-4, atol=1e-7)
+            assert bool(torch.isfinite(p[s_].detach()).all())         # (pad positions: defined, not the reference's values)
+    loss.backward()
+    n_checked = 0
+    for name, p in model.named_parameters():
+        k = "gradnorm/" + name
+        if k not in z.files:
+            continue
+        ref = float(z[k])
+        assert abs(float(p.grad.double().norm()) - ref) <= 1e-3 * ref + 1e-6, name
+        g = p.grad.reshape(-1)
+        sl = g[:: max(1, g.numel() // 64)][:64].numpy()
+        rs = z["gradslice/" + name]
+        assert float(np.abs(sl - rs).max()) <= 1e-3 * max(1e-6, float(np.abs(rs).max())) + 1e-6, name
+        n_checked += 1
+    assert n_checked > 20
+
+
 def test_c1_vivt_loss(golden_dir):
     z, cfg, batch, model = build("c1", "vivt", golden_dir)
     with torch.no_grad():

@@ -330,6 +330,49 @@ def test_cross_attn_ln_fused_vs_attention_then_layernorm(T, lt, nm, D, H, kind, 
         assert err <= gtol * float(w.abs().max()) + 1e-6, (name, err, float(w.abs().max()))
 
 
+@pytest.mark.parametrize("kind,D,H,p", [("x3", 768, 12, 0.1), ("f32", 768, 12, 0.0), ("bf16", 128, 4, 0.1)])
+def test_cross_attn_ln_ragged_rows_equal_the_padded_call(kind, D, H, p):
+    """the fused decoder cross-attention over RAGGED sentences (the valid tokens only: rows = (row_off, row_len), round 5) gives, at every
+    valid row, what the uniform call over the padded layout gives — outputs and the gradients of q, x1, [K | V], gamma, beta (the pad rows
+    of the padded call receive a zero output gradient, as the loss gives them)"""
+    T, lt, nm = 7, 22, 3
+    lens = [22, 7, 13, 1, 22, 9, 16]
+    off, acc = [], 0
+    for n in lens:
+        off.append(acc); acc += n
+    R, Rp = T * lt, acc
+    valid = torch.tensor([j * lt + t for j, n in enumerate(lens) for t in range(n)], dtype=torch.long, device=DEV)
+    q, x1 = rnd(R, D, seed=1, scale=0.5, grad=False), rnd(R, D, seed=7, grad=False)
+    kv0 = rnd(T * nm, 2 * D, seed=2, scale=0.7, grad=False)
+    g0, b0 = (1.0 + 0.1 * rnd(D, seed=5, grad=False)), rnd(D, seed=6, scale=0.1, grad=False)
+    rng = O.make_rng(DEV)
+    drop = (p, rng, 7) if p > 0 else None
+    gout = torch.randn(R, D, generator=torch.Generator().manual_seed(9)).to(DEV)
+    gmask = torch.zeros(R, 1, device=DEV)
+    gmask[valid] = 1.0
+    conv = {"x3": O.to_split, "bf16": lambda t: t.to(torch.bfloat16), "f32": lambda t: t}[kind]
+    O.set_precision("bf16" if kind == "bf16" else ("bf16x3" if kind == "x3" else "fp32"))
+    res = []
+    try:
+        for ragged in (False, True):
+            qq = (q[valid] if ragged else q).clone().requires_grad_(True)
+            xx = (x1[valid] if ragged else x1).clone().requires_grad_(True)
+            kv, ga, be = kv0.clone().requires_grad_(True), g0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            rows = (torch.tensor(off, dtype=torch.int32, device=DEV), torch.tensor(lens, dtype=torch.int32, device=DEV)) if ragged else None
+            y = O.to_f32(O.cross_attn_ln(conv(qq), conv(xx), conv(kv), ga, be, 1e-12, H, lt, nm, drop=drop, rows=rows))
+            go = gout[valid] if ragged else gout * gmask
+            (y * go).sum().backward()
+            O.join_side()
+            pick = (lambda t: t) if ragged else (lambda t: t[valid])
+            res.append([pick(y.detach()), pick(qq.grad), pick(xx.grad), kv.grad, ga.grad, be.grad])
+    finally:
+        O.set_precision("fp32")
+    tol = 1e-6 if kind == "f32" else 2e-2
+    for name, a_, b_ in zip(("y", "dq", "dx1", "dkv", "dgamma", "dbeta"), res[0], res[1]):
+        err = float((a_.float() - b_.float()).abs().max())
+        assert err <= tol * float(a_.float().abs().max()) + 1e-6, (name, err)
+
+
 @pytest.mark.parametrize("T,lt,em,D,ne", [(3, 22, 20, 768, [20, 17, 3]), (5, 6, 4, 64, [3, 3, 4, 2, 2]), (4, 1, 5, 128, [5, 1, 4, 2]),
                                           (2, 22, 31, 768, [31, 1]), (3, 7, 6, 200, [6, 2, 5])])
 def test_ptr_attn_gate_forward_backward(T, lt, em, D, ne):
