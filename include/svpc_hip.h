@@ -347,6 +347,14 @@ int svpc_ptr_attn_gate_fwd(const float* dec, const float* proj, const float* ban
 int svpc_ptr_attn_gate_bwd(const float* dec, const float* proj, const float* bank, const int* step_ne, const float* pi, const float* dpi,
                            const float* pgen, const float* dpgen, const float* pgen_w, float* ddec, float* dproj, float* dbank,
                            float* wpart, int T, int lt, int e_max, int D, svpc_stream_t stream);
+/* the same two over RAGGED sentences — the head run over the valid tokens only (model.pack_text_rows): sentence j owns the rows
+ * [row_off[j], row_off[j] + row_len[j]) of dec, pi, pgen (and of ddec, dpi, dpgen), row_len[j] <= lt (the padded length); NULL, NULL = uniform */
+int svpc_ptr_attn_gate_fwd_r(const float* dec, const float* proj, const float* bank, const int* step_ne, float* pi, const float* pgen_w,
+                             const float* pgen_b, float* pgen, int T, int lt, int e_max, int D, const int* row_off, const int* row_len,
+                             svpc_stream_t stream);
+int svpc_ptr_attn_gate_bwd_r(const float* dec, const float* proj, const float* bank, const int* step_ne, const float* pi, const float* dpi,
+                             const float* pgen, const float* dpgen, const float* pgen_w, float* ddec, float* dproj, float* dbank,
+                             float* wpart, int T, int lt, int e_max, int D, const int* row_off, const int* row_len, svpc_stream_t stream);
 int svpc_ptr_mix_loss_fwd(const float* logits, const float* g, const float* pi, const int* labels, const int* row_c,
                           const int* row_vid, const int* csr_off, const int* csr_ent, const int* csr_id, const float* csr_w, float* P,
                           float* loss_rows, int R, int V, int c_max, int e_max, float smoothing, svpc_stream_t stream);

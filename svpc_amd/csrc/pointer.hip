@@ -228,27 +228,32 @@ __global__ __launch_bounds__(768) void ptr_attn_gate_fwd_kernel(const float* __r
                                                                 const float* __restrict__ bank, const int* __restrict__ step_ne,
                                                                 float* __restrict__ pi, int lt, int em, int D,
                                                                 const float* __restrict__ pgen_w, const float* __restrict__ pgen_b,
-                                                                float* __restrict__ pgen) {
+                                                                float* __restrict__ pgen, const int* __restrict__ row_off,
+                                                                const int* __restrict__ row_len) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
     float* rows = psm;                         // lt × D
     float* ent = rows + (size_t)lt * D;        // PTR_EC × D
     float* sc = ent + (size_t)PTR_EC * D;      // lt × PTR_EMAX
     float* gred = sc + lt * PTR_EMAX;          // (waves) × PTR_LTMAX partial gate sums
     const int j = blockIdx.x, E = step_ne[j];
+    // ragged sentences (the valid tokens only): sentence j owns rows [row_off[j], row_off[j] + row_len[j]); `lt` stays the padded length
+    // (the LDS carve above); null tables: rows [j·lt, (j+1)·lt)
+    const int roff = row_off ? row_off[j] : j * lt;
+    const int ltj = row_len ? row_len[j] : lt;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
     const float* pj = proj + (size_t)j * em * D;
     const float* bj = bank + (size_t)j * em * D;
-    ptr_stage(rows, dec + (size_t)j * lt * D, lt * D);
+    ptr_stage(rows, dec + (size_t)roff * D, ltj * D);
     for (int i = threadIdx.x; i < NW * PTR_LTMAX; i += blockDim.x) gred[i] = 0.f;
     for (int e0 = 0; e0 < E; e0 += PTR_EC) {
         const int ec = min(PTR_EC, E - e0);
         __syncthreads();
         ptr_stage(ent, pj + (size_t)e0 * D, ec * D);
         __syncthreads();
-        ptr_dots(rows, ent, sc, lt, ec, e0, D);
+        ptr_dots(rows, ent, sc, ltj, ec, e0, D);
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < lt; t += blockDim.x) {
+    for (int t = threadIdx.x; t < ltj; t += blockDim.x) {
         float m = -INFINITY;
         for (int e = 0; e < E; ++e) m = fmaxf(m, sc[t * PTR_EMAX + e]);
         float s = 0.f;
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(768) void ptr_attn_gate_fwd_kernel(const float* __r
         for (int e = 0; e < em; ++e) {
             const float v = e < E ? sc[t * PTR_EMAX + e] * inv : 0.f;
             if (e < E) sc[t * PTR_EMAX + e] = v;
-            pi[((size_t)j * lt + t) * em + e] = v;
+            pi[((size_t)roff + t) * em + e] = v;
         }
         for (int e = E; e < ((E + 3) & ~3); ++e) sc[t * PTR_EMAX + e] = 0.f;
     }
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(768) void ptr_attn_gate_fwd_kernel(const float* __r
 #pragma unroll
         for (int e = 0; e < PTR_EMAX; ++e) bv[e] = (e < E && on) ? bj[(size_t)e * D + dc] : 0.f;
         const float w1 = on ? pgen_w[dc] : 0.f, w2 = on ? pgen_w[D + dc] : 0.f;
-        for (int t = 0; t < lt; ++t) {
+        for (int t = 0; t < ltj; ++t) {
             float acc = 0.f;
 #pragma unroll
             for (int q4 = 0; q4 < PTR_EMAX / 4; ++q4) {
@@ -285,10 +290,10 @@ __global__ __launch_bounds__(768) void ptr_attn_gate_fwd_kernel(const float* __r
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < lt; t += blockDim.x) {
+    for (int t = threadIdx.x; t < ltj; t += blockDim.x) {
         float tot = pgen_b[0];
         for (int w = 0; w < NW; ++w) tot += gred[w * PTR_LTMAX + t];
-        pgen[(size_t)j * lt + t] = 1.0f / (1.0f + expf(-tot));
+        pgen[(size_t)roff + t] = 1.0f / (1.0f + expf(-tot));
     }
 }
 
@@ -299,7 +304,8 @@ __global__ __launch_bounds__(768) void ptr_attn_gate_bwd_kernel(const float* __r
                                                                 const float* __restrict__ pgen, const float* __restrict__ dpgen,
                                                                 const float* __restrict__ pgen_w, float* __restrict__ ddec,
                                                                 float* __restrict__ dproj, float* __restrict__ dbank,
-                                                                float* __restrict__ wpart, int lt, int em, int D) {
+                                                                float* __restrict__ wpart, int lt, int em, int D,
+                                                                const int* __restrict__ row_off, const int* __restrict__ row_len) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
     float* w2row = psm;                        // D: w[D:]
     float* ent = w2row + D;                    // PTR_EC × D
@@ -311,13 +317,15 @@ __global__ __launch_bounds__(768) void ptr_attn_gate_bwd_kernel(const float* __r
     float* dzs = ue + PTR_EMAX;                // PTR_LTMAX: dz_t
     float* ces = dzs + PTR_LTMAX;              // PTR_EMAX: c_e
     const int j = blockIdx.x, E = step_ne[j];
+    const int roff = row_off ? row_off[j] : j * lt;          // (ragged sentences: see the forward; `lt` stays the padded length of the carve)
+    const int ltj = row_len ? row_len[j] : lt;
     const float* pj = proj + (size_t)j * em * D;
     const float* bj = bank + (size_t)j * em * D;
-    const float* dj = dec + (size_t)j * lt * D;
+    const float* dj = dec + (size_t)roff * D;
     ptr_stage(w2row, pgen_w + D, D);
     for (int t = threadIdx.x; t < PTR_LTMAX; t += blockDim.x) {
         float dz = 0.f;
-        if (t < lt) { const float g = pgen[(size_t)j * lt + t]; dz = (dpgen ? dpgen[(size_t)j * lt + t] : 0.f) * g * (1.0f - g); }
+        if (t < ltj) { const float g = pgen[(size_t)roff + t]; dz = (dpgen ? dpgen[(size_t)roff + t] : 0.f) * g * (1.0f - g); }
         dzs[t] = dz;
     }
     for (int e0 = 0; e0 < E; e0 += PTR_EC) {
@@ -328,14 +336,14 @@ __global__ __launch_bounds__(768) void ptr_attn_gate_bwd_kernel(const float* __r
         ptr_dots(w2row, ent, ue, 1, ec, e0, D);          // u_e = <w2, bank_e>
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < lt * E; i += blockDim.x) {
+    for (int i = threadIdx.x; i < ltj * E; i += blockDim.x) {
         const int t = i / E, e = i - t * E;
-        const size_t o = ((size_t)j * lt + t) * em + e;
+        const size_t o = ((size_t)roff + t) * em + e;
         dsc[t * PTR_EMAX + e] = dzs[t] * ue[e] + (dpi ? dpi[o] : 0.f);
         pis[t * PTR_EMAX + e] = pi[o];
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < lt; t += blockDim.x) {
+    for (int t = threadIdx.x; t < ltj; t += blockDim.x) {
         float mix = 0.f;
         for (int e = 0; e < E; ++e) mix += pis[t * PTR_EMAX + e] * dsc[t * PTR_EMAX + e];
         for (int e = 0; e < E; ++e) {
@@ -347,18 +355,18 @@ __global__ __launch_bounds__(768) void ptr_attn_gate_bwd_kernel(const float* __r
     }
     for (int i = threadIdx.x; i < E * PTR_LTMAX; i += blockDim.x) {
         const int e = i / PTR_LTMAX, t = i - e * PTR_LTMAX;
-        if (t >= lt) dscT[e * PTR_LTMAX + t] = 0.f;
+        if (t >= ltj) dscT[e * PTR_LTMAX + t] = 0.f;
     }
     for (int e = threadIdx.x; e < PTR_EMAX; e += blockDim.x) {        // c_e = Σ_t dz_t·pi[t,e]
         float c = 0.f;
-        if (e < E) for (int t = 0; t < lt; ++t) c += dzs[t] * pis[t * PTR_EMAX + e];
+        if (e < E) for (int t = 0; t < ltj; ++t) c += dzs[t] * pis[t * PTR_EMAX + e];
         ces[e] = c;
     }
     __syncthreads();
     float* wp = wpart + (size_t)j * (2 * D + 1);
     if (threadIdx.x == 0) {
         float sb = 0.f;
-        for (int t = 0; t < lt; ++t) sb += dzs[t];
+        for (int t = 0; t < ltj; ++t) sb += dzs[t];
         wp[2 * D] = sb;
     }
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
@@ -367,10 +375,10 @@ __global__ __launch_bounds__(768) void ptr_attn_gate_bwd_kernel(const float* __r
         for (int e = 0; e < PTR_EMAX; ++e) pv[e] = e < E ? pj[(size_t)e * D + d] : 0.f;
         float dv[PTR_LTMAX];
 #pragma unroll
-        for (int t = 0; t < PTR_LTMAX; ++t) dv[t] = t < lt ? dj[(size_t)t * D + d] : 0.f;
+        for (int t = 0; t < PTR_LTMAX; ++t) dv[t] = t < ltj ? dj[(size_t)t * D + d] : 0.f;
         const float w1 = pgen_w[d], w2 = w2row[d];
         // ddec[t][d] = Σ_e dsc[t][e]·proj[e][d] + dz_t·w1[d]
-        for (int t = 0; t < lt; ++t) {
+        for (int t = 0; t < ltj; ++t) {
             float acc = dzs[t] * w1;
 #pragma unroll
             for (int q4 = 0; q4 < PTR_EMAX / 4; ++q4) {
@@ -379,13 +387,13 @@ __global__ __launch_bounds__(768) void ptr_attn_gate_bwd_kernel(const float* __r
                     acc += p4.x * pv[4 * q4] + p4.y * pv[4 * q4 + 1] + p4.z * pv[4 * q4 + 2] + p4.w * pv[4 * q4 + 3];
                 }
             }
-            ddec[((size_t)j * lt + t) * D + d] = acc;
+            ddec[((size_t)roff + t) * D + d] = acc;
         }
         // dw1[d] partial = Σ_t dz_t·dec[t][d]
         float s1 = 0.f;
 #pragma unroll
         for (int q4 = 0; q4 < PTR_LTMAX / 4; ++q4) {
-            if (4 * q4 < lt) {
+            if (4 * q4 < ltj) {
                 const float4 z4 = *reinterpret_cast<const float4*>(dzs + 4 * q4);
                 s1 += z4.x * dv[4 * q4] + z4.y * dv[4 * q4 + 1] + z4.z * dv[4 * q4 + 2] + z4.w * dv[4 * q4 + 3];
             }
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(768) void ptr_attn_gate_bwd_kernel(const float* __r
             if (e < E) {
 #pragma unroll
                 for (int q4 = 0; q4 < PTR_LTMAX / 4; ++q4) {
-                    if (4 * q4 < lt) {
+                    if (4 * q4 < ltj) {
                         const float4 d4 = *reinterpret_cast<const float4*>(dscT + e * PTR_LTMAX + 4 * q4);
                         ap += d4.x * dv[4 * q4] + d4.y * dv[4 * q4 + 1] + d4.z * dv[4 * q4 + 2] + d4.w * dv[4 * q4 + 3];
                     }
@@ -767,11 +775,25 @@ int svpc_ptr_attn_bwd(const float* dec, const float* proj, const float* bank, co
     return svpc_check_launch("ptr_attn_bwd");
 }
 
+int svpc_ptr_attn_gate_fwd_r(const float* dec, const float* proj, const float* bank, const int* step_ne, float* pi, const float* pgen_w,
+                             const float* pgen_b, float* pgen, int T, int lt, int e_max, int D, const int* row_off, const int* row_len,
+                             hipStream_t s);
+int svpc_ptr_attn_gate_bwd_r(const float* dec, const float* proj, const float* bank, const int* step_ne, const float* pi, const float* dpi,
+                             const float* pgen, const float* dpgen, const float* pgen_w, float* ddec, float* dproj, float* dbank,
+                             float* wpart, int T, int lt, int e_max, int D, const int* row_off, const int* row_len, hipStream_t s);
 // pointer attention + generation gate of every row, training form (see ptr_attn_gate_*_kernel): forward → pi (T·lt, e_max), pgen (T·lt);
 // backward ← dpi, dpgen → ddec, dproj, dbank and the per-step partial sums wpart (T, 2D+1) of [d pgen_w | d pgen_b]
 int svpc_ptr_attn_gate_fwd(const float* dec, const float* proj, const float* bank, const int* step_ne, float* pi, const float* pgen_w,
                            const float* pgen_b, float* pgen, int T, int lt, int e_max, int D, hipStream_t s) {
+    return svpc_ptr_attn_gate_fwd_r(dec, proj, bank, step_ne, pi, pgen_w, pgen_b, pgen, T, lt, e_max, D, nullptr, nullptr, s);
+}
+// the same over RAGGED sentences (valid tokens only): sentence j owns the rows [row_off[j], row_off[j] + row_len[j]) of dec, pi, pgen
+// (row_len[j] <= lt, the padded length)
+int svpc_ptr_attn_gate_fwd_r(const float* dec, const float* proj, const float* bank, const int* step_ne, float* pi, const float* pgen_w,
+                             const float* pgen_b, float* pgen, int T, int lt, int e_max, int D, const int* row_off, const int* row_len,
+                             hipStream_t s) {
     if (T == 0) return 0;
+    SVPC_REQUIRE((row_off == nullptr) == (row_len == nullptr), "ptr_attn_gate: row_off and row_len come together");
     SVPC_REQUIRE(e_max <= PTR_EMAX, "ptr_attn: at most 32 entities");
     SVPC_REQUIRE(lt <= PTR_LTMAX, "ptr_attn: at most 32 tokens per sentence");
     SVPC_REQUIRE(pgen_w && pgen_b && pgen, "ptr_attn_gate: gate weights missing");
@@ -781,13 +803,21 @@ int svpc_ptr_attn_gate_fwd(const float* dec, const float* proj, const float* ban
     SVPC_REQUIRE(lds <= 150 * 1024, "ptr_attn: sentence rows do not fit LDS");
     int rc = ptr_set_lds((const void*)ptr_attn_gate_fwd_kernel);
     if (rc) return rc;
-    hipLaunchKernelGGL(ptr_attn_gate_fwd_kernel, dim3(T), dim3(nt), lds, s, dec, proj, bank, step_ne, pi, lt, e_max, D, pgen_w, pgen_b, pgen);
+    hipLaunchKernelGGL(ptr_attn_gate_fwd_kernel, dim3(T), dim3(nt), lds, s, dec, proj, bank, step_ne, pi, lt, e_max, D, pgen_w, pgen_b, pgen,
+                       row_off, row_len);
     return svpc_check_launch("ptr_attn_gate_fwd");
 }
 int svpc_ptr_attn_gate_bwd(const float* dec, const float* proj, const float* bank, const int* step_ne, const float* pi, const float* dpi,
                            const float* pgen, const float* dpgen, const float* pgen_w, float* ddec, float* dproj, float* dbank,
                            float* wpart, int T, int lt, int e_max, int D, hipStream_t s) {
+    return svpc_ptr_attn_gate_bwd_r(dec, proj, bank, step_ne, pi, dpi, pgen, dpgen, pgen_w, ddec, dproj, dbank, wpart, T, lt, e_max, D, nullptr,
+                                    nullptr, s);
+}
+int svpc_ptr_attn_gate_bwd_r(const float* dec, const float* proj, const float* bank, const int* step_ne, const float* pi, const float* dpi,
+                             const float* pgen, const float* dpgen, const float* pgen_w, float* ddec, float* dproj, float* dbank,
+                             float* wpart, int T, int lt, int e_max, int D, const int* row_off, const int* row_len, hipStream_t s) {
     if (T == 0) return 0;
+    SVPC_REQUIRE((row_off == nullptr) == (row_len == nullptr), "ptr_attn_gate: row_off and row_len come together");
     SVPC_REQUIRE(e_max <= PTR_EMAX, "ptr_attn: at most 32 entities");
     SVPC_REQUIRE(lt <= PTR_LTMAX, "ptr_attn: at most 32 tokens per sentence");
     SVPC_REQUIRE(D % 4 == 0 && ((((uintptr_t)pgen_w) | ((uintptr_t)proj) | ((uintptr_t)bank)) & 15) == 0, "ptr_attn: rows must be 16-byte aligned");
@@ -798,7 +828,7 @@ int svpc_ptr_attn_gate_bwd(const float* dec, const float* proj, const float* ban
     if (rc) return rc;
     const int nt = D >= 768 ? 768 : (D >= 512 ? 512 : 256);
     hipLaunchKernelGGL(ptr_attn_gate_bwd_kernel, dim3(T), dim3(nt), lds, s, dec, proj, bank, step_ne, pi, dpi, pgen, dpgen, pgen_w, ddec, dproj,
-                       dbank, wpart, lt, e_max, D);
+                       dbank, wpart, lt, e_max, D, row_off, row_len);
     return svpc_check_launch("ptr_attn_gate_bwd");
 }
 int svpc_ptr_mix_loss_fwd(const float* logits, const float* g, const float* pi, const int* labels, const int* row_c,

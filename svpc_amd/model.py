@@ -727,6 +727,10 @@ class TextPack:
         up.add(rows, sink=lambda t: setattr(self, "src_rows", t))          # rows of the flattened (S·N·L) id / label arrays
         up.add(pos, sink=lambda t: setattr(self, "pos", t))                # position of each packed row inside its sentence
         up.add(full, sink=lambda t: setattr(self, "full_rows", t))         # its row in the padded (T·Lt) layout
+        self.row_vid = Idx([clip_b[j] for j in range(T) for _ in range(self.lens[j])])      # the video of each packed row
+        self.off_idx, self.len_idx = Idx(off), Idx(self.lens)
+        for ix in (self.row_vid, self.off_idx, self.len_idx):
+            up.add_idx(ix)
         up.add_seq(self.seq_self)
         up.add_seq(self.seq_cross)
         up.flush()
@@ -913,8 +917,9 @@ class StateAwareRecursiveTransformer(nn.Module):
             return self.encoder.run(h, seq, key_mask_v, cx, last_rows=cls_only[0], last_seq=cls_only[1])
         return ops.to_f32(self.encoder.run(h, seq, key_mask_v, cx))
 
-    def _lm_probs(self, dec, bank, plan_like, cx, labels=None, proj=None):
-        """Head + pointer-generator (+ caption loss rows).  plan_like carries step_ne, row_vid, csr, row_c, c_max."""
+    def _lm_probs(self, dec, bank, plan_like, cx, labels=None, proj=None, pack=None):
+        """Head + pointer-generator (+ caption loss rows).  plan_like carries step_ne, row_vid, csr, row_c, c_max.  ``pack``: ``dec`` holds
+        the valid tokens only (TextPack): sentence j owns rows [off_j, off_j + n_j)."""
         cfg = self.config
         lt = plan_like["lt"]
         logits = self.decoder_classifier.run(dec, cx.eps)
@@ -931,9 +936,16 @@ class StateAwareRecursiveTransformer(nn.Module):
         fused = ops.ptr_attn_pgen(dec, proj, bank, plan_like["step_ne"], self.pgen_linear[0].weight, self.pgen_linear[0].bias) \
             if (lt == 1 and not torch.is_grad_enabled()) else None
         if fused is None:               # training / full-sentence form of the same fusion (differentiable)
-            fused = ops.ptr_attn_gate(dec, proj, bank, plan_like["step_ne"], lt, self.pgen_linear[0].weight, self.pgen_linear[0].bias)
+            rows = (pack.seq_self.table[0], pack.seq_self.table[1]) if pack is not None else None
+            fused = ops.ptr_attn_gate(dec, proj, bank, plan_like["step_ne"], lt, self.pgen_linear[0].weight, self.pgen_linear[0].bias,
+                                      rows=rows)
         if fused is not None:           # pointer attention and generation gate in one launch
             pi, g = fused
+        elif pack is not None:          # (shapes the fused kernels do not take: the unfused form over the padded layout, rows gathered back)
+            dpad = ops.scatter_rows(dec, pack.full_rows64, T * lt)
+            pi, att = ops.ptr_attn(dpad, proj, bank, plan_like["step_ne"], lt)
+            g = ops.linear(torch.cat([dpad, att], 1), self.pgen_linear[0].weight, self.pgen_linear[0].bias, act=ACT_SIGMOID)
+            pi, g = torch.index_select(pi, 0, pack.full_rows64), torch.index_select(g, 0, pack.full_rows64)
         else:
             pi, att = ops.ptr_attn(dec, proj, bank, plan_like["step_ne"], lt)
             g = ops.linear(torch.cat([dec, att], 1), self.pgen_linear[0].weight, self.pgen_linear[0].bias, act=ACT_SIGMOID)
@@ -1009,7 +1021,7 @@ class StateAwareRecursiveTransformer(nn.Module):
             (ids_src, plan.video_rows, torch.int32), (masks_src, plan.video_rows, torch.float32),
             (ids_src, plan.text_rows, torch.int32), (masks_src, plan.text_rows, torch.float32),
             (labels_src, plan.text_rows, torch.int32), (ingr_input_ids, None, torch.int32)] +
-            ([(ids_src, pack.src_rows, torch.int32)] if pack is not None else []))
+            ([(ids_src, pack.src_rows, torch.int32), (labels_src, pack.src_rows, torch.int32)] if pack is not None else []))
         ids_v, mask_v, text_ids, text_mask, labels, ingr_ids = staged[:6]
 
         # (1) entity initial states, compact (ΣE, D)
@@ -1057,11 +1069,11 @@ class StateAwareRecursiveTransformer(nn.Module):
 
         # (5) decoder over all T sentences at once (reference: per video, :1086/:925-1015)
         if pack is not None:
-            # valid tokens only (TextPack): the embedding stack and the six decoder layers over Σ n_j rows, ragged segments; the rows
-            # return to the padded layout (zeros at the pad positions) for the head
+            # valid tokens only (TextPack): the embedding stack, the decoder layers, the head, the pointer mixture, the caption loss and
+            # the Gumbel bag of words over Σ n_j rows, ragged segments; only the returned probabilities go back to the padded layout
             xt = self.text_embeddings.run(staged[6], Lt, cx, out_bf16=self.decoder.streams_bf16(pack.R, D), pos_idx=pack.pos)
-            dec_p = self.decoder.run(xt, None, mem, pack.seq_self, pack.seq_cross, None, cx)
-            dec = ops.scatter_rows(dec_p, pack.full_rows64, T * Lt)
+            dec = self.decoder.run(xt, None, mem, pack.seq_self, pack.seq_cross, None, cx)
+            labels = staged[7]
         else:
             xt = self.text_embeddings.run(text_ids, Lt, cx, out_bf16=self.decoder.streams_bf16(T * Lt, D))
             if dg is not None and dg.usable(xt, mem):     # (structure enters the decoder only through T: svpc_amd/clip_graphs.py)
@@ -1074,9 +1086,10 @@ class StateAwareRecursiveTransformer(nn.Module):
         c_max = max(c_list)
         if mode == "video":
             labels = ops.clamp_labels(labels, V, cfg.unk_id)          # labels ≥ V → UNK (model.py:1013)
-        pl = self._ptr_plan(ingr_id_dict if mode != "video" else [{}] * N, c_list, Lt, plan.step_ne, plan.row_vid, device=dev)
+        pl = self._ptr_plan(ingr_id_dict if mode != "video" else [{}] * N, c_list, Lt, plan.step_ne,
+                            plan.row_vid if pack is None else pack.row_vid, device=dev)
         row_c = pl["row_c"]
-        P, cap_rows = self._lm_probs(dec, bank, pl, cx, labels=labels)
+        P, cap_rows = self._lm_probs(dec, bank, pl, cx, labels=labels, pack=pack)
         # (7) simulator losses, the textual re-simulator, and the sum of all terms (one launch: ops.loss_tail)
         ent_list, act_list, mem_list = [], [], []
         if sim_out is None:
@@ -1089,15 +1102,22 @@ class StateAwareRecursiveTransformer(nn.Module):
                 noise = None
                 if self.gumbel_noise is not None:
                     noise = self._pad_cat([n.reshape(-1, n.shape[-1]) for n in self.gumbel_noise], c_max)
+                    if pack is not None:
+                        noise = torch.index_select(noise, 0, pack.full_rows64)
                 bow = ops.gumbel_bow(P, row_c, self.text_embeddings.word_embeddings.weight, cfg.temperature,
                                      noise=noise, rng=cx.rng, site=cx.rng.site())
-                pooled = ops.span_mean(bow, plan.text_starts, plan.text_lens, weights=text_mask)
+                if pack is not None:        # (every packed row is a valid token: the mask weights of the padded layout are all ones here)
+                    pooled = ops.span_mean(bow, pack.off_idx, pack.len_idx)
+                else:
+                    pooled = ops.span_mean(bow, plan.text_starts, plan.text_lens, weights=text_mask)
                 seq_vec = self._bilstm(pooled, plan)
                 r_e, r_a, _, r_all, _ = self.recipe_reasoner.run(seq_vec, ents, plan.sim, cx)
             # caption + entity BCE + action ASL (rows with a detected action) + lambda·(the same two for the re-simulation)
             total = ops.loss_tail(cap_rows, e_p, a_p, r_e, r_a, align, act_t, plan.step_ne, cfg.lambda_ if mode == "full" else 0.0)
 
         # (8) per-video views for the reference's return contract
+        if pack is not None:                # (pad positions: zeros — the caller asked for the packed run and does not read them)
+            P = ops.scatter_rows(P, pack.full_rows64, T * Lt)
         prediction_scores_list = []
         for b in range(N):
             o, n = plan.h_step_off[b], plan.h_step_len[b]

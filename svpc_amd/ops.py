@@ -1883,16 +1883,19 @@ class _PtrAttnGate(Function):
     projection (with its dgrad / wgrad / bias-sum launches) exist."""
 
     @staticmethod
-    def forward(ctx, dec, proj, bank, w, b, step_ne, lt):
+    def forward(ctx, dec, proj, bank, w, b, step_ne, lt, rows=None):
         _need_gpu(dec)
         dec, proj, bank, w = _c(dec), _c(proj), _c(bank), _c(w)
         T, e_max, D = bank.shape
         dev = dec.device
         ne = step_ne.dev(dev)
-        pi = torch.empty(T * lt, e_max, dtype=torch.float32, device=dev)
-        g = torch.empty(T * lt, 1, dtype=torch.float32, device=dev)
-        _lib.call("ptr_attn_gate_fwd", _p(dec), _p(proj), _p(bank), _p(ne), _p(pi), _p(w), _p(b), _p(g), T, lt, e_max, D, _stream())
-        ctx.save_for_backward(dec, proj, bank, w, ne, pi, g)
+        ro, rl = rows if rows is not None else (None, None)      # ragged sentences: (row_off, row_len) int32 device tensors
+        R = dec.shape[0]
+        pi = torch.empty(R, e_max, dtype=torch.float32, device=dev)
+        g = torch.empty(R, 1, dtype=torch.float32, device=dev)
+        _lib.call("ptr_attn_gate_fwd_r", _p(dec), _p(proj), _p(bank), _p(ne), _p(pi), _p(w), _p(b), _p(g), T, lt, e_max, D, _p(ro), _p(rl),
+                  _stream())
+        ctx.save_for_backward(dec, proj, bank, w, ne, pi, g, ro, rl)
         ctx.cfg = (T, lt, e_max, D)
         ctx.direct = (_direct(w), _direct(b))
         ctx.set_materialize_grads(False)
@@ -1900,15 +1903,15 @@ class _PtrAttnGate(Function):
 
     @staticmethod
     def backward(ctx, dpi, dg):
-        dec, proj, bank, w, ne, pi, g = ctx.saved_tensors
+        dec, proj, bank, w, ne, pi, g, ro, rl = ctx.saved_tensors
         T, lt, e_max, D = ctx.cfg
         dev = dec.device
         dpi = _c(dpi) if dpi is not None else None
         dg = _c(dg) if dg is not None else None
         ddec, dproj, dbank = torch.empty_like(dec), torch.empty_like(proj), torch.empty_like(bank)
         wpart = torch.empty(T, 2 * D + 1, dtype=torch.float32, device=dev)
-        _lib.call("ptr_attn_gate_bwd", _p(dec), _p(proj), _p(bank), _p(ne), _p(pi), _p(dpi), _p(g), _p(dg), _p(w), _p(ddec), _p(dproj),
-                  _p(dbank), _p(wpart), T, lt, e_max, D, _stream())
+        _lib.call("ptr_attn_gate_bwd_r", _p(dec), _p(proj), _p(bank), _p(ne), _p(pi), _p(dpi), _p(g), _p(dg), _p(w), _p(ddec), _p(dproj),
+                  _p(dbank), _p(wpart), T, lt, e_max, D, _p(ro), _p(rl), _stream())
         wg, bg = ctx.direct
         dw = db = None
         if wg is not None and bg is not None and USE_MULTI_FINALIZE and not SIDE_WGRAD:
@@ -1920,17 +1923,19 @@ class _PtrAttnGate(Function):
                 wg.add_(dw); dw = None
             if bg is not None:
                 bg.add_(db); db = None
-        return ddec, dproj, dbank, dw, db, None, None
+        return ddec, dproj, dbank, dw, db, None, None, None
 
 
-def ptr_attn_gate(dec, proj, bank, step_ne, lt, w, b):
+def ptr_attn_gate(dec, proj, bank, step_ne, lt, w, b, rows=None):
     """(pi (T·lt, e_max), p_gen (T·lt, 1)) with p_gen = sigmoid([dec ; att]·wᵀ + b), att = Σ_e pi·bank — training form (differentiable
-    in dec, proj, bank, w, b); None when the shape is not taken (the caller then uses ptr_attn + linear)."""
+    in dec, proj, bank, w, b); None when the shape is not taken (the caller then uses ptr_attn + linear).  rows = (row_off, row_len): ragged
+    sentences (valid tokens only) — sentence j owns the dec rows [row_off[j], row_off[j] + row_len[j]), ≤ lt each."""
     T, e_max, D = bank.shape
     if (not dec.is_cuda or dec.dtype != torch.float32 or D % 4 or tuple(w.shape) != (1, 2 * D) or b is None or b.numel() != 1
-            or lt > 32 or e_max > 32 or dec.shape != (T * lt, D) or w.dtype != torch.float32 or (w.data_ptr() % 16) or lo_off(dec) is not None):
+            or lt > 32 or e_max > 32 or (rows is None and dec.shape != (T * lt, D)) or dec.shape[1] != D or w.dtype != torch.float32
+            or (w.data_ptr() % 16) or lo_off(dec) is not None):
         return None
-    return _PtrAttnGate.apply(dec, proj, bank, w, b, as_idx(step_ne), int(lt))
+    return _PtrAttnGate.apply(dec, proj, bank, w, b, as_idx(step_ne), int(lt), rows)
 
 
 def ptr_attn_pgen(dec, proj, bank, step_ne, w, b):

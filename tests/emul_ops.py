@@ -213,8 +213,14 @@ def cross_attn_ln_usable(*a, **k):
     return False          # (the fused decoder cross-attention is a GPU kernel pair: the emulated model takes the unfused path)
 
 
-def ptr_attn_gate(dec, proj, bank, step_ne, lt, w, b):
+def ptr_attn_gate(dec, proj, bank, step_ne, lt, w, b, rows=None):
     """pointer attention + generation gate (model.py:899-908): (pi, sigmoid([dec ; att]·wᵀ + b))"""
+    if rows is not None:                     # ragged sentences: through the padded layout
+        off, ln = rows[0].tolist(), rows[1].tolist()
+        idx = torch.tensor([j * lt + t for j, n in enumerate(ln) for t in range(n)], dtype=torch.long, device=dec.device)
+        dpad = torch.zeros(len(ln) * lt, dec.shape[1], dtype=dec.dtype, device=dec.device).index_copy(0, idx, dec)
+        pi, g = ptr_attn_gate(dpad, proj, bank, step_ne, lt, w, b)
+        return pi[idx], g[idx]
     pi, att = ptr_attn(dec, proj, bank, step_ne, lt)
     return pi, torch.sigmoid(torch.cat([dec, att], 1) @ w.t() + b)
 

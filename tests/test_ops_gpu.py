@@ -383,6 +383,18 @@ def test_ptr_attn_gate_forward_backward(T, lt, em, D, ne):
     w, b = rnd(1, 2 * D, seed=4, scale=0.1), rnd(1, seed=5)
     compare(lambda d, p, bk, w_, b_: O.ptr_attn_gate(d, p, bk, step_ne, lt, w_, b_), lambda d, p, bk, w_, b_: E.ptr_attn_gate(d, p, bk, step_ne, lt, w_, b_),
             [dec, proj, bank, w, b], grad_rtol=1e-3, grad_atol=1e-4, name="ptr_attn_gate")
+    # ragged sentences (the valid tokens only, round 5): the same rows through (row_off, row_len) as through the padded layout
+    lens = [max(1, (lt * (j + 1)) // (T + 1) + (j % 2)) if lt > 1 else 1 for j in range(T)]
+    lens = [min(lt, n) for n in lens]
+    off, acc = [], 0
+    for n in lens:
+        off.append(acc); acc += n
+    rows = (torch.tensor(off, dtype=torch.int32, device=DEV), torch.tensor(lens, dtype=torch.int32, device=DEV))
+    valid = torch.tensor([j * lt + t for j, n in enumerate(lens) for t in range(n)], dtype=torch.long, device=DEV)
+    dec_p = dec.detach()[valid].clone().requires_grad_(True)
+    compare(lambda d, p, bk, w_, b_: O.ptr_attn_gate(d, p, bk, step_ne, lt, w_, b_, rows=rows),
+            lambda d, p, bk, w_, b_: E.ptr_attn_gate(d, p, bk, step_ne, lt, w_, b_, rows=rows),
+            [dec_p, proj, bank, w, b], grad_rtol=1e-3, grad_atol=1e-4, name="ptr_attn_gate ragged")
     # direct (arena-style) gate gradients through the deferred finalizer: accumulate onto what is already there
     wl, bl = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
     wl.grad, bl.grad = torch.full_like(wl, 0.5), torch.full_like(bl, -0.25)
