@@ -886,6 +886,19 @@ def _train_main(args, device, world, rank, dist, joined):
             except Exception as e:  # noqa: BLE001
                 extras[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         ops.set_precision(args.precision)
+        if not args.no_pack_text:
+            # the same step over the PADDED sentence layout (every one of the T x Lt rows, as the reference computes them): what the
+            # valid-tokens-only run of the headline is worth, measured on this box
+            try:
+                import copy
+                a2 = copy.copy(args)
+                a2.no_pack_text = True
+                p = run_train(a2, args.precision, device, 1, 0, None, args.parity_steps, 2, instrument=False)
+                extras["padded_text_rows"] = {"text_rows": p["text_rows"], "ms_per_step": p["ms"], "steps_per_s": 1000.0 / p["ms"],
+                                              "steps": args.parity_steps, "launch": p["launch"], "final_loss": p["final_loss"]}
+                del p
+            except Exception as e:  # noqa: BLE001
+                extras["padded_text_rows"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import ceilings

@@ -372,7 +372,9 @@ class BertDecoderNoMemoryUntied(nn.Module):
         """whether ``run`` keeps the sentence activations of (rows, width) in bf16"""
         return ops.bf16_stream_ok(rows, width, self.config.intermediate_size)
 
-    def run(self, x, text_mask, mem, seq_self, seq_cross, mem_mask, cx):
+    def run(self, x, text_mask, mem, seq_self, seq_cross, mem_mask, cx, keep_stream=False):
+        """keep_stream: return the rows as the activation stream holds them (bf16 / split) — the caller feeds a projection that reads the
+        stream and takes the fp32 copy itself where it needs one."""
         # interior-only row counts in bf16 precision: the sentence activations (and their gradients) stream through HBM as bf16
         stream_bf16 = self.streams_bf16(x.shape[0], x.shape[1])
         x3 = ops.is_x3()
@@ -395,7 +397,7 @@ class BertDecoderNoMemoryUntied(nn.Module):
             kvs = ops.split_cols(ops.linear(mem, w, b, wgrad=wg, bgrad=bg, w16=w16), len(self.layer))
         for layer, kvc in zip(self.layer, kvs):
             x = layer.run(x, text_mask, mem, seq_self, seq_cross, mem_mask, cx, kvc=kvc)
-        return ops.to_f32(x) if stream_bf16 else x
+        return ops.to_f32(x) if (stream_bf16 and not keep_stream) else x
 
     def forward(self, dec_hidden_states, dec_mask, enc_outputs, enc_mask, diagonal_mask=True,
                 output_all_encoded_layers=False):
@@ -917,12 +919,12 @@ class StateAwareRecursiveTransformer(nn.Module):
             return self.encoder.run(h, seq, key_mask_v, cx, last_rows=cls_only[0], last_seq=cls_only[1])
         return ops.to_f32(self.encoder.run(h, seq, key_mask_v, cx))
 
-    def _lm_probs(self, dec, bank, plan_like, cx, labels=None, proj=None, pack=None):
+    def _lm_probs(self, dec, bank, plan_like, cx, labels=None, proj=None, pack=None, dec_stream=None):
         """Head + pointer-generator (+ caption loss rows).  plan_like carries step_ne, row_vid, csr, row_c, c_max.  ``pack``: ``dec`` holds
         the valid tokens only (TextPack): sentence j owns rows [off_j, off_j + n_j)."""
         cfg = self.config
         lt = plan_like["lt"]
-        logits = self.decoder_classifier.run(dec, cx.eps)
+        logits = self.decoder_classifier.run(dec_stream if dec_stream is not None else dec, cx.eps)
         R = dec.shape[0]
         if labels is None:
             labels = torch.full((R,), -1, dtype=torch.int32, device=dec.device)
@@ -1068,18 +1070,21 @@ class StateAwareRecursiveTransformer(nn.Module):
             bank = None
 
         # (5) decoder over all T sentences at once (reference: per video, :1086/:925-1015)
+        dec_s = None
         if pack is not None:
             # valid tokens only (TextPack): the embedding stack, the decoder layers, the head, the pointer mixture, the caption loss and
             # the Gumbel bag of words over Σ n_j rows, ragged segments; only the returned probabilities go back to the padded layout
             xt = self.text_embeddings.run(staged[6], Lt, cx, out_bf16=self.decoder.streams_bf16(pack.R, D), pos_idx=pack.pos)
-            dec = self.decoder.run(xt, None, mem, pack.seq_self, pack.seq_cross, None, cx)
+            dec_s = self.decoder.run(xt, None, mem, pack.seq_self, pack.seq_cross, None, cx, keep_stream=True)
+            dec = ops.to_f32(dec_s)
             labels = staged[7]
         else:
             xt = self.text_embeddings.run(text_ids, Lt, cx, out_bf16=self.decoder.streams_bf16(T * Lt, D))
             if dg is not None and dg.usable(xt, mem):     # (structure enters the decoder only through T: svpc_amd/clip_graphs.py)
                 dec = dg.run(xt, text_mask, mem, T, cx)
             else:
-                dec = self.decoder.run(xt, text_mask, mem, plan.seq_dec_self, plan.seq_dec_cross, None, cx)
+                dec_s = self.decoder.run(xt, text_mask, mem, plan.seq_dec_self, plan.seq_dec_cross, None, cx, keep_stream=True)
+                dec = ops.to_f32(dec_s)
 
         # (6) head + pointer-generator + label-smoothed KL
         c_list = [V + (extra_zeros[b] if mode != "video" else 0) for b in range(N)]
@@ -1089,7 +1094,8 @@ class StateAwareRecursiveTransformer(nn.Module):
         pl = self._ptr_plan(ingr_id_dict if mode != "video" else [{}] * N, c_list, Lt, plan.step_ne,
                             plan.row_vid if pack is None else pack.row_vid, device=dev)
         row_c = pl["row_c"]
-        P, cap_rows = self._lm_probs(dec, bank, pl, cx, labels=labels, pack=pack)
+        # (the head's first projection reads the decoder's rows as the stream holds them; the pointer takes the fp32 copy)
+        P, cap_rows = self._lm_probs(dec, bank, pl, cx, labels=labels, pack=pack, dec_stream=dec_s)
         # (7) simulator losses, the textual re-simulator, and the sum of all terms (one launch: ops.loss_tail)
         ent_list, act_list, mem_list = [], [], []
         if sim_out is None:
