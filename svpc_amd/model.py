@@ -1082,9 +1082,8 @@ class StateAwareRecursiveTransformer(nn.Module):
             xt = self.text_embeddings.run(text_ids, Lt, cx, out_bf16=self.decoder.streams_bf16(T * Lt, D))
             if dg is not None and dg.usable(xt, mem):     # (structure enters the decoder only through T: svpc_amd/clip_graphs.py)
                 dec = dg.run(xt, text_mask, mem, T, cx)
-            else:
-                dec_s = self.decoder.run(xt, text_mask, mem, plan.seq_dec_self, plan.seq_dec_cross, None, cx, keep_stream=True)
-                dec = ops.to_f32(dec_s)
+            else:       # (the head reads the fp32 rows here, as it does behind a replayed decoder graph: the two paths stay bit-identical)
+                dec = self.decoder.run(xt, text_mask, mem, plan.seq_dec_self, plan.seq_dec_cross, None, cx)
 
         # (6) head + pointer-generator + label-smoothed KL
         c_list = [V + (extra_zeros[b] if mode != "video" else 0) for b in range(N)]
