@@ -756,7 +756,7 @@ def run_train(args, precision, device, world, rank, dist, steps, warmup, instrum
               "hipGraph replay (fwd + text-side bwd | clip-encoder bwd beside the text-side all-reduce | remaining all-reduce | optimizer)") \
         if graph is not None else ("eager (capture failed: see config.degraded)" if degraded else "eager")
     pk = next(iter(model._pack_cache.values()), None) if getattr(model, "_pack_cache", None) else None
-    text_rows = ("valid tokens only: %d of %d sentence rows (embedding stack + decoder; the head sees the padded layout)"
+    text_rows = ("valid tokens only: %d of %d sentence rows (text embeddings, decoder, head, pointer mixture, caption loss, Gumbel bag of words)"
                  % (pk.R, len(pk.lens) * cfg.max_t_len)) if pk is not None else "padded: T x Lt sentence rows"
     res = dict(cfg=cfg, model=model, ms=ms, elapsed=elapsed, final_loss=final_loss, host_enqueue_ms=host_enqueue_ms, launch=launch, text_rows=text_rows,
                degraded=degraded, gsum=gsum, asum=(asum if instrument else None), glds=glds, bf16_stream=bf16_stream, rows_enc=rows_enc,
