@@ -180,12 +180,12 @@ class ClipEncoderGraphs:
                 cx.rng._site = site0
                 self._warmed.add(wkey)
             e.g_fwd, e.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with capturing(e.g_fwd, pool=self.pool, stream=stream, capture_error_mode="thread_local"):
+            with capturing(e.g_fwd, pool=self.pool, stream=stream, capture_error_mode="thread_local", light=True):
                 cls = model._encode_clips(e.feats, None, e.ids, e.mask, e.seq, cx, cls_only=(e.cls_rows, e.seq_cls))
             e.cls = cls
             e.n_sites = cx.rng._site - site0
             cx.rng._site = site0                        # (the replay that follows advances the counter)
-            with capturing(e.g_bwd, pool=self.pool, stream=stream, capture_error_mode="thread_local"):
+            with capturing(e.g_bwd, pool=self.pool, stream=stream, capture_error_mode="thread_local", light=True):
                 cls.backward(e.gout)
                 ops.join_side()
         e.cls = cls.detach()
@@ -318,12 +318,12 @@ class DecoderGraphs:
                 e.xt_leaf.grad = e.mem_leaf.grad = None
                 cx.rng._site = site0
                 self._warmed.add(wkey)
-            with capturing(e.g_fwd, pool=self.pool, stream=stream, capture_error_mode="thread_local"):
+            with capturing(e.g_fwd, pool=self.pool, stream=stream, capture_error_mode="thread_local", light=True):
                 out = model.decoder.run(e.xt_leaf, e.mask, e.mem_leaf, e.seq_self, e.seq_cross, None, cx)
             assert out.shape == e.gout.shape and out.dtype == e.gout.dtype
             e.n_sites = cx.rng._site - site0
             cx.rng._site = site0
-            with capturing(e.g_bwd, pool=self.pool, stream=stream, capture_error_mode="thread_local"):
+            with capturing(e.g_bwd, pool=self.pool, stream=stream, capture_error_mode="thread_local", light=True):
                 out.backward(e.gout)
                 ops.join_side()
         e.out = out.detach()

@@ -34,14 +34,32 @@ class capturing:
     ≈ 50 ms each on the bench's heap — 44 of them took the cold ragged leg (22 captures of two graphs in 100 steps) from 74 to 28 steps/s;
     whatever garbage exists is collected by the next automatic run after the capture."""
 
-    def __init__(self, graph, **kw):
-        self.cm = torch.cuda.graph(graph, **kw)
+    def __init__(self, graph, light=False, **kw):
+        """light=True (the per-clip-count captures of svpc_amd/clip_graphs.py, tens per epoch): begin / end the capture directly —
+        ``torch.cuda.graph.__enter__`` synchronises the device and EMPTIES the caching allocator first (to give a one-off whole-step
+        capture as much memory as possible), which makes every allocation after it a fresh hipMalloc."""
+        self.light = bool(light)
+        if self.light:
+            self.graph = graph
+            self.pool = kw.get("pool")
+            self.stream = kw.get("stream") or torch.cuda.current_stream()
+            self.mode = kw.get("capture_error_mode", "global")
+            self.stream_ctx = torch.cuda.stream(self.stream)
+        else:
+            self.cm = torch.cuda.graph(graph, **kw)
 
     def __enter__(self):
         self.was = gc.isenabled()
         gc.disable()
         try:
-            return self.cm.__enter__()
+            if not self.light:
+                return self.cm.__enter__()
+            self.stream_ctx.__enter__()
+            if self.pool is not None:
+                self.graph.capture_begin(self.pool, capture_error_mode=self.mode)
+            else:
+                self.graph.capture_begin(capture_error_mode=self.mode)
+            return None
         except BaseException:
             if self.was:
                 gc.enable()
@@ -49,7 +67,11 @@ class capturing:
 
     def __exit__(self, *exc):
         try:
-            return self.cm.__exit__(*exc)
+            if not self.light:
+                return self.cm.__exit__(*exc)
+            self.graph.capture_end()
+            self.stream_ctx.__exit__(*exc)
+            return None
         finally:
             if self.was:
                 gc.enable()
