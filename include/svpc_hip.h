@@ -481,6 +481,9 @@ int svpc_rows_move(const void* src, int src_kind, int ld_src, int lo_src, const 
 /* table[idx[r]] += rows[r], fp32 rows into a dense bf16 table (distinct idx): the gradient of gathered stream rows joins the stream's
  * gradient in place */
 int svpc_scatter_add_rows_bf16(const float* rows, const int* idx, void* table, int ld_table, int R, int W, svpc_stream_t stream);
+/* rows of two (R', W) fp32 tables through two index lists in one launch — the two directions of the BiLSTM (model.py:1022-1024):
+ * mode 0: out[r] = a[ia[r]] + b[ib[r]];  mode 1: a[ia[r]] = b[ib[r]] = out[r];  mode 2: out[r] = a[ia[r]], out2[r] = b[ib[r]] */
+int svpc_pair_rows(float* a, const int* ia, float* b, const int* ib, float* out, float* out2, int R, int W, int mode, svpc_stream_t stream);
 int svpc_add(const float* a, const float* b, float* c, size_t n, svpc_stream_t stream);
 int svpc_sum_all(const float* x, size_t n, float* out, float scale, svpc_stream_t stream);
 int svpc_fill_from(float* x, size_t n, const float* v, svpc_stream_t stream);

@@ -785,7 +785,45 @@ __global__ __launch_bounds__(256) void scatter_add_rows_bf16_kernel(const float*
     for (int c = threadIdx.x; c < W; c += 256) table[to + c] = (__bf16)((float)table[to + c] + rows[(size_t)r * W + c]);
 }
 
+// ---- rows of two (R', W) fp32 tables through two index lists in one launch (the BiLSTM's two directions, model.py:1022-1024: outputs are
+// picked from the time-major states of both directions and summed; backward scatters the one output gradient into both and gathers both
+// gate gradients).  MODE 0: out[r] = a[ia[r]] + b[ib[r]];  MODE 1: a[ia[r]] = b[ib[r]] = out[r] (distinct indices);  MODE 2: oa[r] = a[ia[r]],
+// ob[r] = b[ib[r]] (out = oa, out2 = ob)
+template <int MODE>
+__global__ __launch_bounds__(256) void pair_rows_kernel(float* __restrict__ a, const int* __restrict__ ia, float* __restrict__ b,
+                                                        const int* __restrict__ ib, float* __restrict__ out, float* __restrict__ out2, int W) {
+    const int r = blockIdx.x;
+    float* ar = a + (size_t)ia[r] * W;
+    float* br = b + (size_t)ib[r] * W;
+    float* o = out + (size_t)r * W;
+    for (int c = threadIdx.x * 4; c < W; c += 1024) {
+        if (MODE == 0) {
+            const float4 x = *reinterpret_cast<const float4*>(ar + c), y = *reinterpret_cast<const float4*>(br + c);
+            *reinterpret_cast<float4*>(o + c) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        } else if (MODE == 1) {
+            const float4 v = *reinterpret_cast<const float4*>(o + c);
+            *reinterpret_cast<float4*>(ar + c) = v;
+            *reinterpret_cast<float4*>(br + c) = v;
+        } else {
+            *reinterpret_cast<float4*>(o + c) = *reinterpret_cast<const float4*>(ar + c);
+            *reinterpret_cast<float4*>(out2 + (size_t)r * W + c) = *reinterpret_cast<const float4*>(br + c);
+        }
+    }
+}
+
 extern "C" {
+
+// mode 0 gather + add, 1 scatter to both, 2 gather both (see pair_rows_kernel); W % 4 == 0, 16-byte aligned rows
+int svpc_pair_rows(float* a, const int* ia, float* b, const int* ib, float* out, float* out2, int R, int W, int mode, hipStream_t s) {
+    if (R == 0) return 0;
+    SVPC_REQUIRE(W % 4 == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)out) | ((uintptr_t)out2)) & 15) == 0 && mode >= 0 && mode <= 2 &&
+                     (mode != 2 || out2 != nullptr),
+                 "pair_rows: rows of W % 4 == 0 floats, 16-byte aligned; mode 0..2 (2 needs a second output)");
+    if (mode == 0) hipLaunchKernelGGL(pair_rows_kernel<0>, dim3(R), dim3(256), 0, s, a, ia, b, ib, out, out2, W);
+    else if (mode == 1) hipLaunchKernelGGL(pair_rows_kernel<1>, dim3(R), dim3(256), 0, s, a, ia, b, ib, out, out2, W);
+    else hipLaunchKernelGGL(pair_rows_kernel<2>, dim3(R), dim3(256), 0, s, a, ia, b, ib, out, out2, W);
+    return svpc_check_launch("pair_rows");
+}
 
 int svpc_act_bwd_t(const void* dy, const void* aux, void* dz, int dt, size_t n, int act, float p, unsigned site, const u64* seed,
                    hipStream_t s) {

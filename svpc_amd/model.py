@@ -1176,9 +1176,8 @@ class StateAwareRecursiveTransformer(nn.Module):
             # (both biases receive the column sum of the gate gradients in place: no separate column-sum launches, no autograd adds)
             gx.append(ops.linear(x, w_ih, b_ih + b_hh, bgrad=ops.direct_grads(b_ih, b_hh)))          # (T, 4D)
             whh.append(w_hh)
-        out_f, out_b = ops.bilstm_sequences(gx[0], gx[1], whh[0], whh[1], plan.lstm_fwd_rows, plan.lstm_bwd_rows, plan.lstm_active,
-                                            plan.lstm_pick[""], plan.lstm_pick["_reverse"])
-        return ops.add(out_f, out_b)
+        return ops.bilstm_sequences(gx[0], gx[1], whh[0], whh[1], plan.lstm_fwd_rows, plan.lstm_bwd_rows, plan.lstm_active,
+                                    plan.lstm_pick[""], plan.lstm_pick["_reverse"], summed=True)
 
     def reconstruct(self, prediction_scores, text_mask, ga_ingr_vectors):
         """reference-shaped wrapper (model.py:1017-1025) for one video."""

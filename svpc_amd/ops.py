@@ -2177,8 +2177,9 @@ class _BiLstmSeq(Function):
     half the launches of two independent direction nodes (see _LstmSeq for the per-direction scheme).  bf16-MFMA precision only."""
 
     @staticmethod
-    def forward(ctx, gx_f, gx_b, w_f, w_b, rows_f, rows_b, active_t, pick_f, pick_b, wgrad_f, wgrad_b):
+    def forward(ctx, gx_f, gx_b, w_f, w_b, rows_f, rows_b, active_t, pick_f, pick_b, wgrad_f, wgrad_b, summed=False):
         _need_gpu(gx_f)
+        ctx.summed = bool(summed)
         gx = [_c(gx_f), _c(gx_b)]
         w = [_c(w_f), _c(w_b)]
         rows = [rows_f, rows_b]
@@ -2207,15 +2208,25 @@ class _BiLstmSeq(Function):
             _gemm_pair([h_all[0][t], h_all[1][t]], w, gh, N, 4 * D, D, x3=is_x3())
             _lib.call("lstm_pair_fwd", args[0][0], args[1][0], args[2][0], args[3][0], args[4][0], _p(active_t[t]), args[6][0],
                       args[7][0], args[8][0], N, D, st)
-        outs = [torch.index_select(h_all[z][1:].reshape(S * N, D), 0, pk) for z, pk in enumerate((pick_f, pick_b))]
         ctx.save_for_backward(gates[0], gates[1], c_all[0], c_all[1], h_all[0], h_all[1], w[0], w[1], pick_f, pick_b)
         ctx.lists = active_t
         ctx.direct = (wgrad_f, wgrad_b)
         ctx.cfg = (S, N, D)
+        pair_ok = (D % 4 == 0 and pick_f.dtype == torch.int32 and pick_b.dtype == torch.int32 and pick_f.numel() == pick_b.numel())
+        ctx.pair_ok = pair_ok
+        if summed and pair_ok:      # the two directions' outputs picked from the time-major states and summed in one launch
+            out = mk(pick_f.numel(), D)
+            _lib.call("pair_rows", _p(h_all[0][1:]), _p(pick_f), _p(h_all[1][1:]), _p(pick_b), _p(out), None, pick_f.numel(), D, 0, st)
+            return out
+        outs = [torch.index_select(h_all[z][1:].reshape(S * N, D), 0, pk) for z, pk in enumerate((pick_f, pick_b))]
+        if summed:
+            return outs[0] + outs[1]
         return outs[0], outs[1]
 
     @staticmethod
-    def backward(ctx, dout_f, dout_b):
+    def backward(ctx, dout_f, dout_b=None):
+        if ctx.summed:
+            dout_b = dout_f
         g0, g1, c0, c1, h0, h1, w0, w1, pick_f, pick_b = ctx.saved_tensors
         gates, c_all, h_all, w, picks = [g0, g1], [c0, c1], [h0, h1], [w0, w1], [pick_f, pick_b]
         active_t = ctx.lists
@@ -2226,11 +2237,16 @@ class _BiLstmSeq(Function):
         # directions (2·S·N rows) and the four running state gradients (4·N rows)
         zeros = torch.zeros(2 * S * N + 4 * N, D, dtype=torch.float32, device=dev)
         dhs = []
-        for z, d in enumerate((dout_f, dout_b)):
-            t_ = zeros[z * S * N:(z + 1) * S * N]
-            if d is not None:
-                t_.index_copy_(0, picks[z].long(), _c(d))
-            dhs.append(t_.view(S, N, D))
+        if ctx.summed and ctx.pair_ok and dout_f is not None:      # the one output gradient into both directions' time-major rows: one launch
+            _lib.call("pair_rows", _p(zeros), _p(picks[0]), _p(zeros[S * N:]), _p(picks[1]), _p(_c(dout_f)), None, picks[0].numel(), D, 1,
+                      _stream())
+            dhs = [zeros[:S * N].view(S, N, D), zeros[S * N:2 * S * N].view(S, N, D)]
+        else:
+            for z, d in enumerate((dout_f, dout_b)):
+                t_ = zeros[z * S * N:(z + 1) * S * N]
+                if d is not None:
+                    t_.index_copy_(0, picks[z].long(), _c(d))
+                dhs.append(t_.view(S, N, D))
         dG = [mk(S, N, 4 * D) for _ in range(2)]
         tail = zeros[2 * S * N:].view(4, N, D)
         dh = [tail[0], tail[1]]
@@ -2279,16 +2295,22 @@ class _BiLstmSeq(Function):
                         _ready(wgrad, "w")
                     else:
                         dws[z] = dw
-            if ctx.needs_input_grad[z]:
+            if ctx.needs_input_grad[z] and not (ctx.pair_ok and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]):
                 dgx[z] = torch.index_select(dG2, 0, picks[z])
-        return dgx[0], dgx[1], dws[0], dws[1], None, None, None, None, None, None, None
+        if ctx.pair_ok and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:       # both gate gradients gathered in one launch
+            R_ = picks[0].numel()
+            dgx = [mk(R_, 4 * D), mk(R_, 4 * D)]
+            _lib.call("pair_rows", _p(dG[0]), _p(picks[0]), _p(dG[1]), _p(picks[1]), _p(dgx[0]), _p(dgx[1]), R_, 4 * D, 2, _stream())
+        return dgx[0], dgx[1], dws[0], dws[1], None, None, None, None, None, None, None, None
 
 
-def bilstm_sequences(gx_f, gx_b, w_f, w_b, rows_f, rows_b, active_t, pick_f, pick_b):
-    """Both LSTM directions (see lstm_sequence for the arguments) → (out_f, out_b), each (T, D)."""
+def bilstm_sequences(gx_f, gx_b, w_f, w_b, rows_f, rows_b, active_t, pick_f, pick_b, summed=False):
+    """Both LSTM directions (see lstm_sequence for the arguments) → (out_f, out_b), each (T, D); summed=True: their sum (what the model
+    uses, model.py:1024) — picked and added in one launch, the backward scatters / gathers both directions in one launch each."""
     if _fast() and gx_f.is_cuda and not BWD_EXACT:
-        return _BiLstmSeq.apply(gx_f, gx_b, w_f, w_b, rows_f, rows_b, active_t, pick_f, pick_b, _direct(w_f), _direct(w_b))
-    return lstm_sequence(gx_f, w_f, rows_f, active_t, pick_f), lstm_sequence(gx_b, w_b, rows_b, active_t, pick_b)
+        return _BiLstmSeq.apply(gx_f, gx_b, w_f, w_b, rows_f, rows_b, active_t, pick_f, pick_b, _direct(w_f), _direct(w_b), summed)
+    of, ob = lstm_sequence(gx_f, w_f, rows_f, active_t, pick_f), lstm_sequence(gx_b, w_b, rows_b, active_t, pick_b)
+    return add(of, ob) if summed else (of, ob)
 
 
 def lstm_sequence(gx_all, w_hh, rows_t, active_t, pick):

@@ -313,8 +313,9 @@ def lstm_sequence(gx_all, w_hh, rows_t, active_t, pick):
     return torch.stack(hs, 0).reshape(-1, D)[pick.long()]
 
 
-def bilstm_sequences(gx_f, gx_b, w_f, w_b, rows_f, rows_b, active_t, pick_f, pick_b):
-    return lstm_sequence(gx_f, w_f, rows_f, active_t, pick_f), lstm_sequence(gx_b, w_b, rows_b, active_t, pick_b)
+def bilstm_sequences(gx_f, gx_b, w_f, w_b, rows_f, rows_b, active_t, pick_f, pick_b, summed=False):
+    of, ob = lstm_sequence(gx_f, w_f, rows_f, active_t, pick_f), lstm_sequence(gx_b, w_b, rows_b, active_t, pick_b)
+    return of + ob if summed else (of, ob)
 
 
 def branch_stream(device):

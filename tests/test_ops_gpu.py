@@ -924,9 +924,19 @@ def test_bilstm_lockstep_matches_two_direction_nodes(bf16_mode, N, D, fused):
         ((of * wt_f).sum() + (ob * wt_b).sum()).backward()
         torch.cuda.synchronize()
         res.append([of.detach().clone(), ob.detach().clone()] + [l.grad.clone() for l in leaves])
+    # summed=True (what the model uses: the two directions picked and added in one launch, one scatter / gather launch each way back)
+    summed = []
+    for mod in (O, E):
+        for l in leaves:
+            l.grad = None
+        o_ = mod.bilstm_sequences(leaves[0], leaves[1], leaves[2], leaves[3], rows_f, rows_b, act_t, pick_f, pick_b, summed=True)
+        (o_ * wt_f).sum().backward()
+        torch.cuda.synchronize()
+        summed.append([o_.detach().clone()] + [l.grad.clone() for l in leaves])
     O.LSTM_FUSED_STEP = keep_fused
-    for a, b in zip(res[0], res[1]):
+    for a, b in list(zip(res[0], res[1])) + list(zip(summed[0], summed[1])):
         assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item()), (a - b).abs().max()
+    assert (summed[0][0] - (res[0][0] + res[0][1])).abs().max().item() == 0.0
 
 
 def test_grouped_weight_gradients_bf16(bf16_mode):
