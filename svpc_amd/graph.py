@@ -5,7 +5,8 @@ Everything on the step is capture-safe by construction: kernels launch on PyTorc
 synchronises inside the C-ABI, index maps are cached in HBM by ``BatchPlan``, dropout/Gumbel seeds live in HBM and are bumped
 by a kernel, and the optimizer's hyper-parameters are read from a device buffer refreshed before each replay.
 Inputs are static: refill the tensors handed to the constructor in place (``tensor.copy_``) to train on a new batch of the
-same shape (step counts / ingredient counts / copy tables are part of the captured plan).
+same shape (step counts / ingredient counts / copy tables are part of the captured plan — and, with ``model.pack_text_rows``, the
+sentence LENGTHS: the packed row maps are captured, so a refilled batch must have the same lengths or the step must be captured again).
 
 Data parallel (``exchange=`` a GradReducer): an eager step is host-bound (≈25 ms of Python/launch work for ≈17 ms of kernels), so
 the step is captured as THREE graphs with the RCCL exchange issued eagerly between their replays:
