@@ -100,6 +100,19 @@ def ops_stream_b(device=None):
     return st
 
 
+_ONES = {}
+
+
+def unit_grad(loss):
+    """a cached tensor of ones shaped like ``loss`` — ``loss.backward(unit_grad(loss))`` instead of ``loss.backward()``, whose implicit
+    ``ones_like`` is a fill launch per step"""
+    key = (str(loss.device), loss.dtype, tuple(loss.shape))
+    g = _ONES.get(key)
+    if g is None:
+        g = _ONES[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
+    return g
+
+
 def backward_all(model, loss, exchange=None):
     """``loss.backward()`` plus, when the model cut its autograd graph at the [CLS] rows (``model.split_backward``, or the clip encoder
     replayed from a per-clip-count hipGraph: svpc_amd/clip_graphs.py), the second phase through the clip encoder.  ``exchange``: the
@@ -107,7 +120,7 @@ def backward_all(model, loss, exchange=None):
     gradients, ≈74 % of the bytes, are final: those of eager parts were reported by their hooks during the backward, those of replayed
     parts — which fire no hook — are complete because their replay ran inside it), so they travel while the clip encoder's backward
     runs: the cut of the three-graph step.  The caller then calls ``exchange.finish()`` and the optimizer."""
-    loss.backward()
+    loss.backward(unit_grad(loss))
     cut = getattr(model, "split_boundary", None)
     if cut is not None:
         if exchange is not None:
@@ -135,13 +148,14 @@ class GraphedTrainStep:
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
         gc.collect()
+        unit_grad(torch.empty((), dtype=torch.float32, device=next(model.parameters()).device))     # (exists before the capture begins)
         self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None
         if exchange is None:
             with capturing(self.graph, stream=self.stream):
                 optimizer.zero_grad()
                 self.loss = model(*forward_args)[0]
-                self.loss.backward()
+                self.loss.backward(unit_grad(self.loss))
                 optimizer.launch()
         else:
             from . import ops
@@ -150,7 +164,7 @@ class GraphedTrainStep:
             with capturing(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                 optimizer.zero_grad()
                 self.loss = model(*forward_args)[0]
-                self.loss.backward()
+                self.loss.backward(unit_grad(self.loss))
                 ops.join_side()
             self.graph_clip = torch.cuda.CUDAGraph()
             with capturing(self.graph_clip, pool=self.graph.pool(), stream=self.stream, capture_error_mode="thread_local"):
