@@ -484,6 +484,9 @@ int svpc_scatter_add_rows_bf16(const float* rows, const int* idx, void* table, i
 /* rows of two (R', W) fp32 tables through two index lists in one launch — the two directions of the BiLSTM (model.py:1022-1024):
  * mode 0: out[r] = a[ia[r]] + b[ib[r]];  mode 1: a[ia[r]] = b[ib[r]] = out[r];  mode 2: out[r] = a[ia[r]], out2[r] = b[ib[r]] */
 int svpc_pair_rows(float* a, const int* ia, float* b, const int* ib, float* out, float* out2, int R, int W, int mode, svpc_stream_t stream);
+/* out = bf16(a + b), a bf16 (NULL: a plain cast), b fp32: the two gradients of a stream tensor that is also consumed as fp32 rows (the
+ * decoder's last rows: the LM head reads the stream, the pointer attention its fp32 copy — model.py:896-923) in one launch */
+int svpc_add_cast_bf16(const void* a, const float* b, void* out, size_t n, svpc_stream_t stream);
 int svpc_add(const float* a, const float* b, float* c, size_t n, svpc_stream_t stream);
 int svpc_sum_all(const float* x, size_t n, float* out, float scale, svpc_stream_t stream);
 int svpc_fill_from(float* x, size_t n, const float* v, svpc_stream_t stream);

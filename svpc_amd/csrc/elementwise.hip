@@ -811,7 +811,20 @@ __global__ __launch_bounds__(256) void pair_rows_kernel(float* __restrict__ a, c
     }
 }
 
+// out = bf16(a + b) for a bf16 (may be null: a plain cast) and b fp32: the two gradients of a stream tensor that is also read as fp32 rows
+__global__ __launch_bounds__(256) void add_cast_bf16_kernel(const __bf16* __restrict__ a, const float* __restrict__ b, __bf16* __restrict__ out,
+                                                            size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (__bf16)((a ? (float)a[i] : 0.f) + b[i]);
+}
+
 extern "C" {
+
+int svpc_add_cast_bf16(const void* a, const float* b, void* out, size_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(add_cast_bf16_kernel, dim3(grid1d(n)), dim3(256), 0, s, (const __bf16*)a, b, (__bf16*)out, n);
+    return svpc_check_launch("add_cast_bf16");
+}
 
 // mode 0 gather + add, 1 scatter to both, 2 gather both (see pair_rows_kernel); W % 4 == 0, 16-byte aligned rows
 int svpc_pair_rows(float* a, const int* ia, float* b, const int* ib, float* out, float* out2, int R, int W, int mode, hipStream_t s) {

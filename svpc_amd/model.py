@@ -1075,8 +1075,7 @@ class StateAwareRecursiveTransformer(nn.Module):
             # valid tokens only (TextPack): the embedding stack, the decoder layers, the head, the pointer mixture, the caption loss and
             # the Gumbel bag of words over Σ n_j rows, ragged segments; only the returned probabilities go back to the padded layout
             xt = self.text_embeddings.run(staged[6], Lt, cx, out_bf16=self.decoder.streams_bf16(pack.R, D), pos_idx=pack.pos)
-            dec_s = self.decoder.run(xt, None, mem, pack.seq_self, pack.seq_cross, None, cx, keep_stream=True)
-            dec = ops.to_f32(dec_s)
+            dec_s, dec = ops.stream_and_f32(self.decoder.run(xt, None, mem, pack.seq_self, pack.seq_cross, None, cx, keep_stream=True))
             labels = staged[7]
         else:
             xt = self.text_embeddings.run(text_ids, Lt, cx, out_bf16=self.decoder.streams_bf16(T * Lt, D))
@@ -1170,11 +1169,17 @@ class StateAwareRecursiveTransformer(nn.Module):
         autograd node (ops.bilstm_sequences: one grouped GEMM + one cell launch per time step for both directions)."""
         rnn = self.recipe_encoder
         gx, whh = [], []
-        for sfx in ("", "_reverse"):
+        pairs = [(getattr(rnn, "bias_ih_l0" + sfx), getattr(rnn, "bias_hh_l0" + sfx)) for sfx in ("", "_reverse")]
+        direct = [ops.direct_grads(bi, bh) for bi, bh in pairs]
+        if all(d is not None for d in direct) and x.is_cuda:
+            with torch.no_grad():       # (the sums need no autograd node: both biases of a direction receive their gradient in place)
+                sums = torch._foreach_add([p[0] for p in pairs], [p[1] for p in pairs])          # one launch for both directions
+        else:
+            sums = [bi + bh for bi, bh in pairs]
+        for z, sfx in enumerate(("", "_reverse")):
             w_ih, w_hh = getattr(rnn, "weight_ih_l0" + sfx), getattr(rnn, "weight_hh_l0" + sfx)
-            b_ih, b_hh = getattr(rnn, "bias_ih_l0" + sfx), getattr(rnn, "bias_hh_l0" + sfx)
             # (both biases receive the column sum of the gate gradients in place: no separate column-sum launches, no autograd adds)
-            gx.append(ops.linear(x, w_ih, b_ih + b_hh, bgrad=ops.direct_grads(b_ih, b_hh)))          # (T, 4D)
+            gx.append(ops.linear(x, w_ih, sums[z], bgrad=direct[z]))          # (T, 4D)
             whh.append(w_hh)
         return ops.bilstm_sequences(gx[0], gx[1], whh[0], whh[1], plan.lstm_fwd_rows, plan.lstm_bwd_rows, plan.lstm_active,
                                     plan.lstm_pick[""], plan.lstm_pick["_reverse"], summed=True)

@@ -552,6 +552,41 @@ class _ToF32(Function):
         return g.to(ctx.dt), None
 
 
+class _StreamAndF32(Function):
+    """(alias of the stream tensor, its fp32 copy) as ONE node: the backward adds the two gradients and casts in one launch (two separate
+    consumers cost a cast of the fp32 gradient, then autograd's add)."""
+
+    @staticmethod
+    def forward(ctx, t, lo):
+        out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+        _rows_move(t, lo, None, out, None, t.shape[0], t.shape[1])
+        ctx.set_materialize_grads(False)
+        return t.view_as(t), out
+
+    @staticmethod
+    def backward(ctx, g_stream, g32):
+        if g32 is None:
+            return g_stream, None
+        g32 = _c(g32)
+        a = _c(g_stream) if g_stream is not None else None
+        out = torch.empty(g32.shape, dtype=torch.bfloat16, device=g32.device)
+        _lib.call("add_cast_bf16", _p(a), _p(g32), _p(out), g32.numel(), _stream())
+        return out, None
+
+
+def stream_and_f32(t):
+    """(t, fp32 copy of t) for a bf16 / split 2-D stream tensor with two consumers (one per form); fp32 input: (t, t)"""
+    if t.dtype == torch.float32:
+        return t, t
+    lo = lo_off(t)
+    if not (t.dim() == 2 and t.is_cuda and t.stride(1) == 1):
+        return t, to_f32(t)
+    a, f = _StreamAndF32.apply(t, lo)
+    if lo is not None:
+        a._svpc_lo = lo
+    return a, f
+
+
 def to_f32(t):
     """fp32 copy of a bf16 / split tensor (hi + lo for a split one; data movement and one exact add)."""
     if t.dtype == torch.float32:
@@ -1616,6 +1651,7 @@ class _SpanMean(Function):
         _lib.call("span_mean_fwd", _p(x), _p(st), _p(ln), _p(weights), _p(add), _p(ai), _p(out), G, D, _stream())
         ctx.save_for_backward(st, ln, weights)
         ctx.cfg = (tuple(x.shape), G, D)
+        ctx.tiles = _spans_tile(starts, lens, x.shape[0])       # the spans cover every row exactly once: the backward writes all of dx
         return out
 
     @staticmethod
@@ -1623,9 +1659,31 @@ class _SpanMean(Function):
         st, ln, weights = ctx.saved_tensors
         shape, G, D = ctx.cfg
         dout = _c(dout)
-        dx = torch.zeros(shape, dtype=torch.float32, device=dout.device)
+        dx = (torch.empty if ctx.tiles else torch.zeros)(shape, dtype=torch.float32, device=dout.device)
         _lib.call("span_mean_bwd", _p(dout), _p(st), _p(ln), _p(weights), _p(dx), G, D, _stream())
         return dx, None, None, None, None, None
+
+
+_TILES = {}
+
+
+def _spans_tile(starts, lens, n_rows):
+    """whether the spans (host lists of two ``Idx``) are consecutive and cover rows 0..n_rows-1 exactly; cached per Idx pair"""
+    key = (id(starts), id(lens), n_rows)
+    hit = _TILES.get(key)
+    if hit is not None and hit[0] is starts and hit[1] is lens:
+        return hit[2]
+    pos, ok = 0, True
+    for s_, l_ in zip(starts.host, lens.host):
+        if s_ != pos or l_ < 1:
+            ok = False
+            break
+        pos += l_
+    ok = ok and pos == n_rows
+    if len(_TILES) > 256:
+        _TILES.clear()
+    _TILES[key] = (starts, lens, ok)
+    return ok
 
 
 def span_mean(x, starts, lens, weights=None, add=None, add_idx=None):

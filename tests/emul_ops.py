@@ -200,6 +200,10 @@ def sim_heads(hh, fb, W3, b3, W4, b4):
     return torch.softmax(hh @ W3.t() + b3, -1), (fb @ W4.t() + b4).reshape(-1)
 
 
+def stream_and_f32(t):
+    return t, t.float()
+
+
 def scatter_rows(src, idx, n_rows):
     out = torch.zeros(n_rows, src.shape[1], dtype=src.dtype, device=src.device)
     return out.index_copy(0, idx, src)

@@ -199,6 +199,12 @@ def test_span_mean_and_rownorm_softmax():
     aidx = Idx([3, 0, 8, 1, 1])
     compare(lambda x: O.span_mean(x, starts, lens, w, pe, aidx), lambda x: E.span_mean(x, starts, lens, w, pe, aidx), [x], name="span w")
     compare(lambda x: O.span_mean(x, starts, lens), lambda x: E.span_mean(x, starts, lens), [x], name="span")
+    # spans that tile the rows (the backward then writes every row itself: no zero fill), with and without weights
+    st2, ln2 = Idx([0, 5, 6, 16, 29]), Idx([5, 1, 10, 13, 11])
+    for s in st2.host:
+        w[s] = 1.0
+    compare(lambda x: O.span_mean(x, st2, ln2, w, pe, aidx), lambda x: E.span_mean(x, st2, ln2, w, pe, aidx), [x], name="span tiling w")
+    compare(lambda x: O.span_mean(x, st2, ln2), lambda x: E.span_mean(x, st2, ln2), [x], name="span tiling")
     a = torch.sigmoid(rnd(17, 384, seed=4)).detach().requires_grad_(True)
     compare(O.row_normalize, E.row_normalize, [a], name="row_normalize")
     compare(O.softmax_rows, E.softmax_rows, [rnd(50, 3, seed=5)], name="softmax3")
