@@ -487,6 +487,9 @@ int svpc_pair_rows(float* a, const int* ia, float* b, const int* ib, float* out,
 /* out = bf16(a + b), a bf16 (NULL: a plain cast), b fp32: the two gradients of a stream tensor that is also consumed as fp32 rows (the
  * decoder's last rows: the LM head reads the stream, the pointer attention its fp32 copy — model.py:896-923) in one launch */
 int svpc_add_cast_bf16(const void* a, const float* b, void* out, size_t n, svpc_stream_t stream);
+/* out[r] = inv[r] >= 0 ? src[inv[r]] : 0 for r < n_rows — the rows of a packed (valid tokens only) tensor back in the padded layout the
+ * reference's return values have (model.py:1105-1115), zeros at the pad positions; fp32 rows of W floats */
+int svpc_rows_expand(const float* src, const int* inv, float* out, int n_rows, int W, svpc_stream_t stream);
 int svpc_add(const float* a, const float* b, float* c, size_t n, svpc_stream_t stream);
 int svpc_sum_all(const float* x, size_t n, float* out, float scale, svpc_stream_t stream);
 int svpc_fill_from(float* x, size_t n, const float* v, svpc_stream_t stream);

@@ -811,6 +811,15 @@ __global__ __launch_bounds__(256) void pair_rows_kernel(float* __restrict__ a, c
     }
 }
 
+// out[r] = inv[r] >= 0 ? src[inv[r]] : 0 — packed rows back into a padded layout, zeros elsewhere, in one launch
+__global__ __launch_bounds__(256) void rows_expand_kernel(const float* __restrict__ src, const int* __restrict__ inv, float* __restrict__ out, int W) {
+    const int r = blockIdx.x, i = inv[r];
+    float* o = out + (size_t)r * W;
+    if (i < 0) { for (int c = threadIdx.x; c < W; c += 256) o[c] = 0.f; return; }
+    const float* q = src + (size_t)i * W;
+    for (int c = threadIdx.x; c < W; c += 256) o[c] = q[c];
+}
+
 // out = bf16(a + b) for a bf16 (may be null: a plain cast) and b fp32: the two gradients of a stream tensor that is also read as fp32 rows
 __global__ __launch_bounds__(256) void add_cast_bf16_kernel(const __bf16* __restrict__ a, const float* __restrict__ b, __bf16* __restrict__ out,
                                                             size_t n) {
@@ -820,6 +829,11 @@ __global__ __launch_bounds__(256) void add_cast_bf16_kernel(const __bf16* __rest
 
 extern "C" {
 
+int svpc_rows_expand(const float* src, const int* inv, float* out, int n_rows, int W, hipStream_t s) {
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(rows_expand_kernel, dim3(n_rows), dim3(256), 0, s, src, inv, out, W);
+    return svpc_check_launch("rows_expand");
+}
 int svpc_add_cast_bf16(const void* a, const float* b, void* out, size_t n, hipStream_t s) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(add_cast_bf16_kernel, dim3(grid1d(n)), dim3(256), 0, s, (const __bf16*)a, b, (__bf16*)out, n);

@@ -729,6 +729,10 @@ class TextPack:
         up.add(rows, sink=lambda t: setattr(self, "src_rows", t))          # rows of the flattened (S·N·L) id / label arrays
         up.add(pos, sink=lambda t: setattr(self, "pos", t))                # position of each packed row inside its sentence
         up.add(full, sink=lambda t: setattr(self, "full_rows", t))         # its row in the padded (T·Lt) layout
+        inv = [-1] * (T * Lt)
+        for i_, f_ in enumerate(full):
+            inv[f_] = i_
+        up.add(inv, sink=lambda t: setattr(self, "inv_rows", t))           # … and back: the packed row of a padded row, or -1
         self.row_vid = Idx([clip_b[j] for j in range(T) for _ in range(self.lens[j])])      # the video of each packed row
         self.off_idx, self.len_idx = Idx(off), Idx(self.lens)
         for ix in (self.row_vid, self.off_idx, self.len_idx):
@@ -1121,7 +1125,7 @@ class StateAwareRecursiveTransformer(nn.Module):
 
         # (8) per-video views for the reference's return contract
         if pack is not None:                # (pad positions: zeros — the caller asked for the packed run and does not read them)
-            P = ops.scatter_rows(P, pack.full_rows64, T * Lt)
+            P = ops.scatter_rows(P, pack.full_rows64, T * Lt, inv=pack.inv_rows)
         prediction_scores_list = []
         for b in range(N):
             o, n = plan.h_step_off[b], plan.h_step_len[b]

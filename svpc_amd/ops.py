@@ -598,8 +598,13 @@ class _ScatterRows(Function):
     """out (n_rows, W) = zeros with out[idx[r]] = src[r] (idx int64, distinct rows); backward gathers the rows back"""
 
     @staticmethod
-    def forward(ctx, src, idx, n_rows):
+    def forward(ctx, src, idx, n_rows, inv=None):
         ctx.save_for_backward(idx)
+        if inv is not None and src.is_cuda and src.dtype == torch.float32:       # inv: padded row → packed row or -1 (one launch)
+            src = _c(src)
+            out = torch.empty(n_rows, src.shape[1], dtype=torch.float32, device=src.device)
+            _lib.call("rows_expand", _p(src), _p(inv), _p(out), n_rows, src.shape[1], _stream())
+            return out
         out = torch.zeros(n_rows, src.shape[1], dtype=src.dtype, device=src.device)
         out.index_copy_(0, idx, src)
         return out
@@ -607,12 +612,13 @@ class _ScatterRows(Function):
     @staticmethod
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
-        return torch.index_select(g, 0, idx), None, None
+        return torch.index_select(g, 0, idx), None, None, None
 
 
-def scatter_rows(src, idx, n_rows):
-    """rows of a packed tensor back into a padded layout (zeros elsewhere); data movement"""
-    return _ScatterRows.apply(src, idx, int(n_rows))
+def scatter_rows(src, idx, n_rows, inv=None):
+    """rows of a packed tensor back into a padded layout (zeros elsewhere); data movement.  inv (int32, n_rows): the packed row of every
+    padded row or -1 — with it the expansion is one launch"""
+    return _ScatterRows.apply(src, idx, int(n_rows), inv)
 
 
 def take_rows_f32(t, idx):

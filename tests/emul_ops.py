@@ -204,7 +204,7 @@ def stream_and_f32(t):
     return t, t.float()
 
 
-def scatter_rows(src, idx, n_rows):
+def scatter_rows(src, idx, n_rows, inv=None):
     out = torch.zeros(n_rows, src.shape[1], dtype=src.dtype, device=src.device)
     return out.index_copy(0, idx, src)
 
