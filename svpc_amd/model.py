@@ -707,33 +707,30 @@ class TextPack:
     host from the loader's copy of the masks; every table in one upload."""
 
     def __init__(self, plan, lens, N, Lv, Lt, L, n_mem, device):
-        self.lens = list(lens)
+        self.lens = [int(n) for n in lens]
         T = plan.T
-        off, acc = [], 0
-        for n in self.lens:
-            off.append(acc)
-            acc += n
-        self.R = acc
-        clip_b, clip_s = plan.step_vid.host, plan.step_idx.host
-        rows, pos, full = [], [], []
-        for j in range(T):
-            base = (clip_s[j] * N + clip_b[j]) * L + Lv
-            n = self.lens[j]
-            rows.extend(range(base, base + n))
-            pos.extend(range(n))
-            full.extend(range(j * Lt, j * Lt + n))
+        ln = np.asarray(self.lens, dtype=np.int64)
+        off_a = np.concatenate([[0], np.cumsum(ln)[:-1]]) if T else np.zeros(0, np.int64)
+        self.R = int(ln.sum())
+        clip_b = np.asarray(plan.step_vid.host, dtype=np.int64)
+        clip_s = np.asarray(plan.step_idx.host, dtype=np.int64)
+        base = (clip_s * N + clip_b) * L + Lv
+        ar = np.arange(self.R, dtype=np.int64)
+        pos = ar - np.repeat(off_a, ln)                       # position of each packed row inside its sentence
+        rows = np.repeat(base, ln) + pos                      # rows of the flattened (S·N·L) id / label arrays
+        full = np.repeat(np.arange(T, dtype=np.int64) * Lt, ln) + pos       # its row in the padded (T·Lt) layout
+        inv = np.full(T * Lt, -1, dtype=np.int64)
+        inv[full] = ar                                        # … and back: the packed row of a padded row, or -1
+        off = off_a.tolist()
         self.seq_self = ops.SeqInfo(off, self.lens, off, self.lens, None)
         self.seq_cross = ops.SeqInfo(off, self.lens, [j * n_mem for j in range(T)], [n_mem] * T, None)
         self.seq_cross.packed_rows = True        # (consecutive sentences, consecutive memory blocks: what the fused cross-attention assumes)
         up = BulkUpload(device)
-        up.add(rows, sink=lambda t: setattr(self, "src_rows", t))          # rows of the flattened (S·N·L) id / label arrays
-        up.add(pos, sink=lambda t: setattr(self, "pos", t))                # position of each packed row inside its sentence
-        up.add(full, sink=lambda t: setattr(self, "full_rows", t))         # its row in the padded (T·Lt) layout
-        inv = [-1] * (T * Lt)
-        for i_, f_ in enumerate(full):
-            inv[f_] = i_
-        up.add(inv, sink=lambda t: setattr(self, "inv_rows", t))           # … and back: the packed row of a padded row, or -1
-        self.row_vid = Idx([clip_b[j] for j in range(T) for _ in range(self.lens[j])])      # the video of each packed row
+        up.add(rows, sink=lambda t: setattr(self, "src_rows", t))
+        up.add(pos, sink=lambda t: setattr(self, "pos", t))
+        up.add(full, sink=lambda t: setattr(self, "full_rows", t))
+        up.add(inv, sink=lambda t: setattr(self, "inv_rows", t))
+        self.row_vid = Idx(np.repeat(clip_b, ln).tolist())      # the video of each packed row
         self.off_idx, self.len_idx = Idx(off), Idx(self.lens)
         for ix in (self.row_vid, self.off_idx, self.len_idx):
             up.add_idx(ix)
