@@ -421,6 +421,8 @@ int svpc_row_any_eq1(const float* x, float* out, int R, int C, svpc_stream_t str
  * — the clip rows' and sentence rows' ids / masks / labels out of the loader's (step, video) tensors, reference train.py:91-112 +
  * model.py:1038-1042, 925-1015 (there: slicing inside a Python loop over steps and videos). */
 int svpc_gather_cast_multi(const void* segments, int n, svpc_stream_t stream);
+/* the same, advancing the step's dropout / Gumbel seed (the update of svpc_bump_seed) in the same launch when bump_seed != NULL */
+int svpc_gather_cast_multi_seed(const void* segments, int n, svpc_u64* bump_seed, svpc_stream_t stream);
 int svpc_clamp_labels(const int* in, int* out, int n, int vocab, int unk, svpc_stream_t stream); /* model.py:1013 */
 int svpc_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, const float* h_prev, const float* active, float* h,
                        float* c, float* gates_act, int N, int D, svpc_stream_t stream);

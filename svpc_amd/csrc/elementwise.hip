@@ -1008,8 +1008,11 @@ int svpc_row_any_eq1(const float* x, float* out, int R, int C, hipStream_t s) {
 // index_select launches otherwise.  dtype codes: 0 fp32, 1 int64, 2 int32.
 constexpr int GC_MAX = 8;
 struct GcSeg { const void* src; const int* idx; void* dst; int src_dt, dst_dt, n, block0; };
-struct GcArgs { int n; GcSeg s[GC_MAX]; };
+struct GcArgs { int n; GcSeg s[GC_MAX]; u64* bump; };
 __global__ __launch_bounds__(256) void gather_cast_multi_kernel(GcArgs a) {
+    // (the step's seed advances here when the staging is the first launch of the step: one launch fewer than a bump_seed of its own;
+    // nothing in this launch reads the seed)
+    if (a.bump && blockIdx.x == 0 && threadIdx.x == 0) a.bump[0] = a.bump[0] * 6364136223846793005ull + 1442695040888963407ull;
     int si = 0;
     while (si + 1 < a.n && (int)blockIdx.x >= a.s[si + 1].block0) ++si;
     const GcSeg& g = a.s[si];
@@ -1027,10 +1030,14 @@ __global__ __launch_bounds__(256) void gather_cast_multi_kernel(GcArgs a) {
     }
 }
 struct HostGcSeg { const void* src; const int* idx; void* dst; int src_dt, dst_dt, n; };
-int svpc_gather_cast_multi(const void* segments, int n, hipStream_t s) {
+int svpc_gather_cast_multi_seed(const void* segments, int n, u64* bump_seed, hipStream_t s);
+int svpc_gather_cast_multi(const void* segments, int n, hipStream_t s) { return svpc_gather_cast_multi_seed(segments, n, nullptr, s); }
+// the same, advancing the dropout / Gumbel seed of the step (svpc_bump_seed's update) in the same launch when bump_seed is not null
+int svpc_gather_cast_multi_seed(const void* segments, int n, u64* bump_seed, hipStream_t s) {
     SVPC_REQUIRE(n >= 0 && n <= GC_MAX, "gather_cast_multi: at most 8 segments per launch");
     const HostGcSeg* h = reinterpret_cast<const HostGcSeg*>(segments);
     GcArgs a{};
+    a.bump = bump_seed;
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
         SVPC_REQUIRE(h[i].src_dt >= 0 && h[i].src_dt <= 2 && (h[i].dst_dt == 0 || h[i].dst_dt == 2) && h[i].n >= 0,
@@ -1040,7 +1047,10 @@ int svpc_gather_cast_multi(const void* segments, int n, hipStream_t s) {
         g.src = h[i].src; g.idx = h[i].idx; g.dst = h[i].dst; g.src_dt = h[i].src_dt; g.dst_dt = h[i].dst_dt; g.n = h[i].n; g.block0 = blocks;
         blocks += ceil_div(h[i].n, 256);
     }
-    if (blocks == 0) return 0;
+    if (blocks == 0) {
+        if (bump_seed) return svpc_bump_seed(bump_seed, s);
+        return 0;
+    }
     hipLaunchKernelGGL(gather_cast_multi_kernel, dim3(blocks), dim3(256), 0, s, a);
     return svpc_check_launch("gather_cast_multi");
 }

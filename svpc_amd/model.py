@@ -1007,7 +1007,7 @@ class StateAwareRecursiveTransformer(nn.Module):
         S_pad = len(input_ids_list)
         Lv, Lt, D, V = cfg.max_v_len, cfg.max_t_len, cfg.hidden_size, cfg.vocab_size
         cx = self._cx(dev)
-        cx.rng.begin_step()
+        cx.rng.begin_step(defer=True)          # (the seed advances inside the token-staging launch below, the first of the step)
 
         spans = self._spans_for(ingr_sep_masks)
         ent_nums = spans[3]
@@ -1024,7 +1024,7 @@ class StateAwareRecursiveTransformer(nn.Module):
             (ids_src, plan.video_rows, torch.int32), (masks_src, plan.video_rows, torch.float32),
             (ids_src, plan.text_rows, torch.int32), (masks_src, plan.text_rows, torch.float32),
             (labels_src, plan.text_rows, torch.int32), (ingr_input_ids, None, torch.int32)] +
-            ([(ids_src, pack.src_rows, torch.int32), (labels_src, pack.src_rows, torch.int32)] if pack is not None else []))
+            ([(ids_src, pack.src_rows, torch.int32), (labels_src, pack.src_rows, torch.int32)] if pack is not None else []), rng=cx.rng)
         ids_v, mask_v, text_ids, text_mask, labels, ingr_ids = staged[:6]
 
         # (1) entity initial states, compact (ΣE, D)

@@ -378,9 +378,12 @@ class Rng:
         self.seed = torch.tensor([seed], dtype=torch.int64, device=device)
         self._site = 0
 
-    def begin_step(self):
+    def begin_step(self, defer=False):
+        """a new seed for the step's dropout / Gumbel draws; defer=True: the caller's first launch is ``gather_cast_multi(…, rng=self)``,
+        which advances the seed itself (one launch fewer)"""
         self._site = 0
-        _lib.call("bump_seed", _p(self.seed), _stream())
+        if not defer:
+            _lib.call("bump_seed", _p(self.seed), _stream())
 
     def site(self):
         self._site += 1
@@ -1775,9 +1778,10 @@ class _GcSeg(ctypes.Structure):
 _GC_CODE = {torch.float32: 0, torch.int64: 1, torch.int32: 2}
 
 
-def gather_cast_multi(items):
+def gather_cast_multi(items, rng=None):
     """items: [(src 1-D tensor, int32 row index or None, torch.float32 | torch.int32)] → [dst]; dst[i] = cast(src[idx[i]]) for all
-    items in ONE launch (data movement only, no gradient) — the token staging of the batched forward."""
+    items in ONE launch (data movement only, no gradient) — the token staging of the batched forward.  rng: advance its seed in the
+    same launch (``rng.begin_step(defer=True)`` was called)."""
     outs, segs = [], []
     for src, idx, dt in items:
         src = _c(src.reshape(-1))
@@ -1793,7 +1797,9 @@ def gather_cast_multi(items):
         for i, (src, idx, dst) in enumerate(part):
             arr[i] = _GcSeg(src.data_ptr(), idx.data_ptr() if idx is not None else None, dst.data_ptr(), _GC_CODE[src.dtype],
                             _GC_CODE[dst.dtype], dst.numel())
-        _lib.call("gather_cast_multi", ctypes.addressof(arr), len(part), _stream())
+        _lib.call("gather_cast_multi_seed", ctypes.addressof(arr), len(part), _p(rng.seed) if (rng is not None and k == 0) else None, _stream())
+    if rng is not None and not segs:
+        _lib.call("bump_seed", _p(rng.seed), _stream())
     return outs
 
 

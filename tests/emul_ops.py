@@ -375,7 +375,7 @@ def add(a, b):
     return a + b
 
 
-def gather_cast_multi(items):
+def gather_cast_multi(items, rng=None):
     return [(src.reshape(-1)[idx.long()] if idx is not None else src.reshape(-1)).to(dt) for src, idx, dt in items]
 
 
@@ -409,7 +409,7 @@ class EmulRng:
         self._site = 0
         self.device = torch.device(device)
 
-    def begin_step(self):
+    def begin_step(self, defer=False):
         self._site = 0
 
     def site(self):
