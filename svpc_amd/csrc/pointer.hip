@@ -297,6 +297,89 @@ __global__ __launch_bounds__(768) void ptr_attn_gate_fwd_kernel(const float* __r
     }
 }
 
+// ---- the same forward, rows in registers (round 5).  The kernel above stages the sentence's rows and an entity chunk in LDS, evaluates the
+// lt·E scores one WAVE per dot product (two LDS reads per multiply: 1.35 MB of LDS traffic per sentence) and then walks the rows a second
+// time per column for the gate.  The gate's argument needs no attended vector at all:
+//     [dec_t ; att_t]·w = dec_t·w1 + Σ_e pi[t,e]·<bank_e, w2>      (w = [w1 | w2])
+// — E dot products u_e = <bank_e, w2> per sentence and one more dot product per row.  So: the projected entity rows in LDS once, u_e by
+// one wave per entity, and every wave takes rows t = wave, wave + NW, …: the row straight from HBM into registers (KPL values per lane),
+// its E + 1 dot products (proj_e from LDS, w1 from registers) reduced by ONE reduce-scatter butterfly; a thread per row then does the
+// softmax over the E scores and the gate.  D = 64·KPL ≤ 768, E ≤ 31 (value slot 31 carries dec_t·w1); other shapes: the kernel above.
+template <int KPL>
+__global__ __launch_bounds__(64 * KPL) void ptr_attn_gate_fwd_rows_kernel(const float* __restrict__ dec, const float* __restrict__ proj,
+                                                                          const float* __restrict__ bank, const int* __restrict__ step_ne,
+                                                                          float* __restrict__ pi, int lt, int em, const float* __restrict__ pgen_w,
+                                                                          const float* __restrict__ pgen_b, float* __restrict__ pgen,
+                                                                          const int* __restrict__ row_off, const int* __restrict__ row_len) {
+    constexpr int D = 64 * KPL, NW = KPL;
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    float* ent = psm;                          // E × D projected entity rows
+    float* sc = ent + (size_t)em * D;          // PTR_LTMAX × 32: scores (slot 31: dec_t·w1)
+    float* ue = sc + PTR_LTMAX * 32;           // 32: <bank_e, w2>
+    const int j = blockIdx.x, E = step_ne[j];
+    const int roff = row_off ? row_off[j] : j * lt;
+    const int ltj = row_len ? row_len[j] : lt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* pj = proj + (size_t)j * em * D;
+    const float* bj = bank + (size_t)j * em * D;
+    // this wave's first row and the gate's two weight rows are requested first; the entity rows go to LDS
+    float w1[KPL], w2[KPL], row[KPL];
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) { w1[k] = pgen_w[lane + 64 * k]; w2[k] = pgen_w[D + lane + 64 * k]; }
+    {
+        const float* r0 = dec + (size_t)(roff + min(wave, ltj - 1)) * D;
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) row[k] = r0[lane + 64 * k];
+    }
+    ptr_stage(ent, pj, E * D);
+    for (int e = wave; e < E; e += NW) {       // u_e = <bank_e, w2>
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) dot = fmaf(bj[(size_t)e * D + lane + 64 * k], w2[k], dot);
+        dot = wave_sum(dot);
+        if (lane == 0) ue[e] = dot;
+    }
+    __syncthreads();
+    for (int t = wave; t < ltj; t += NW) {
+        float part[32];
+#pragma unroll
+        for (int e = 0; e < 31; ++e) {
+            float d_ = 0.f;
+            if (e < E) {
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) d_ = fmaf(row[k], ent[(size_t)e * D + lane + 64 * k], d_);
+            }
+            part[e] = d_;
+        }
+        float dw = 0.f;
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) dw = fmaf(row[k], w1[k], dw);
+        part[31] = dw;
+        if (t + NW < ltj) {                    // the wave's next row lands under the reduction
+            const float* rn = dec + (size_t)(roff + t + NW) * D;
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) row[k] = rn[lane + 64 * k];
+        }
+        const float v = wave_reduce_scatter32(part, lane);
+        if ((lane & 1) == 0) sc[t * 32 + (lane >> 1)] = v;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ltj; t += blockDim.x) {
+        float m = -INFINITY;
+        for (int e = 0; e < E; ++e) m = fmaxf(m, sc[t * 32 + e]);
+        float s_ = 0.f;
+        for (int e = 0; e < E; ++e) { const float v = expf(sc[t * 32 + e] - m); sc[t * 32 + e] = v; s_ += v; }
+        const float inv = 1.0f / s_;
+        float tot = pgen_b[0] + sc[t * 32 + 31];
+        for (int e = 0; e < em; ++e) {
+            const float v = e < E ? sc[t * 32 + e] * inv : 0.f;
+            pi[((size_t)roff + t) * em + e] = v;
+            if (e < E) tot = fmaf(v, ue[e], tot);
+        }
+        pgen[(size_t)roff + t] = 1.0f / (1.0f + expf(-tot));
+    }
+}
+
 // LDS: (1 + PTR_EC)·D floats (w2 row, entity chunk) + 2·lt·32 + 2·32·32 + 3·32 floats
 __global__ __launch_bounds__(768) void ptr_attn_gate_bwd_kernel(const float* __restrict__ dec, const float* __restrict__ proj,
                                                                 const float* __restrict__ bank, const int* __restrict__ step_ne,
@@ -798,6 +881,20 @@ int svpc_ptr_attn_gate_fwd_r(const float* dec, const float* proj, const float* b
     SVPC_REQUIRE(lt <= PTR_LTMAX, "ptr_attn: at most 32 tokens per sentence");
     SVPC_REQUIRE(pgen_w && pgen_b && pgen, "ptr_attn_gate: gate weights missing");
     SVPC_REQUIRE(D % 4 == 0 && ((((uintptr_t)dec) | ((uintptr_t)proj) | ((uintptr_t)bank)) & 15) == 0, "ptr_attn: rows must be 16-byte aligned");
+    static int rows_form = -1;
+    if (rows_form < 0) { const char* e = getenv("SVPC_PTR_GATE_ROWS"); rows_form = e ? atoi(e) : 1; }
+    const size_t lds_r = ((size_t)e_max * D + PTR_LTMAX * 32 + 32) * sizeof(float);
+    if (rows_form && (D == 768 || D == 512 || D == 256) && e_max <= 31 && lds_r <= 150 * 1024 && ((((uintptr_t)pgen_w)) & 3) == 0) {
+#define PTR_ROWS_GO(KPLV)                                                                                                          \
+        do {                                                                                                                       \
+            int rc_ = ptr_set_lds((const void*)ptr_attn_gate_fwd_rows_kernel<KPLV>); if (rc_) return rc_;                           \
+            hipLaunchKernelGGL((ptr_attn_gate_fwd_rows_kernel<KPLV>), dim3(T), dim3(64 * KPLV), lds_r, s, dec, proj, bank, step_ne, pi, lt, e_max, \
+                               pgen_w, pgen_b, pgen, row_off, row_len);                                                             \
+        } while (0)
+        if (D == 768) PTR_ROWS_GO(12); else if (D == 512) PTR_ROWS_GO(8); else PTR_ROWS_GO(4);
+#undef PTR_ROWS_GO
+        return svpc_check_launch("ptr_attn_gate_fwd");
+    }
     const int nt = D >= 768 ? 768 : (D >= 512 ? 512 : 256);
     const size_t lds = ((size_t)(lt + PTR_EC) * D + (size_t)lt * PTR_EMAX + (size_t)(nt / 64) * PTR_LTMAX) * sizeof(float);
     SVPC_REQUIRE(lds <= 150 * 1024, "ptr_attn: sentence rows do not fit LDS");
