@@ -48,6 +48,11 @@ def _worker(rank, world, port, golden_dir, overlap, out_q):
     for k in ("batch_step_num", "ingr_id_dict", "extra_zeros", "alignments", "actions"):
         shard[k] = batch[k][rank:rank + 1]
     model.gumbel_noise = [model.gumbel_noise[rank]]
+    if overlap == "pack":        # the sentence side over the valid tokens only (svpc_amd.model.TextPack) under the reducer's hooks
+        from svpc_amd import keep_host_copy
+        for m in shard["input_masks_list"]:
+            keep_host_copy(m, m)
+        model.pack_text_rows = True
     named = [(n, p) for n, p in model.named_parameters() if "memory_intermediate" not in n]
     if overlap == "split":
         # two-phase backward (svpc_amd/graph.py): cut at the [CLS] rows, exchange the text-side buckets before the clip encoder's
@@ -67,7 +72,7 @@ def _worker(rank, world, port, golden_dir, overlap, out_q):
         assert 0 < n_early < len(red.buckets)
         out.backward(cut.grad)
         red.finish()
-    elif overlap:
+    elif overlap is True or overlap == "pack":      # ("bf16" takes the branch below: the optional wire format)
         for _, p in named:
             p.grad = torch.zeros_like(p)
         arena = GradArena(named)
@@ -101,7 +106,7 @@ def arena_named(arena):
     return list(zip(arena.names, arena.params))
 
 
-@pytest.mark.parametrize("overlap", [False, True, "split", "bf16"])
+@pytest.mark.parametrize("overlap", [False, True, "split", "bf16", "pack"])
 def test_two_rank_sum_allreduce_equals_full_batch_gradient(golden_dir, overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
