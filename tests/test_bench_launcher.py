@@ -39,3 +39,25 @@ def test_parent_makes_no_gpu_call():
     assert "import torch" not in head.replace("import torch.distributed", "")
     body = src[src.index("def launch_ranks"):src.index("# ------------------------------------------------------------------------------------------------ worker")]
     assert "torch" not in body and "svpc_amd" not in body
+
+
+def test_committed_parity_records_are_readable_whether_fresh_or_stale(monkeypatch):
+    """bench.py quotes the committed parity records in its JSON line.  A record is either "stale" (recorded on other sources) or read —
+    and a FRESH record must not crash the reader: metadata keys ("_sources_sha16", "_attention_ab_vs_fp64") and the 64-video rows of the
+    config-5 record have no mode field (round 5: the first fresh record of the round crashed the bench line with an IndexError)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for fresh in (False, True):
+        if fresh:      # make every record count as recorded on the current sources
+            def load(path, _orig=bench._load_record):
+                with open(path) as f:
+                    rec = json.load(f)
+                rec.pop("_sources_sha16", None)
+                return rec, None
+            monkeypatch.setattr(bench, "_load_record", load)
+        for mode in ("bf16x3", "bf16", "fp32"):
+            a, b = bench.recorded_parity(mode), bench.recorded_config5(mode)
+            assert a is None or isinstance(a, dict)
+            assert b is None or isinstance(b, dict)
+            if fresh:
+                assert a and "loss_rel_vs_oracle_worst" in a and b and "token_agreement_vs_oracle" in b
