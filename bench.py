@@ -60,7 +60,7 @@ def measured_traffic(precision="bf16"):
     except (OSError, ValueError):
         return None, None
     if rec.get("kernel_sources_sha16") != dominant_kernel_sha(precision):
-        return None, "stale: %s was measured on other kernel sources" % os.path.basename(TRAFFIC_FILE)
+        return None, "stale: %s was measured on other kernel sources" % os.path.basename(TRAFFIC_FILE_X3 if precision == "bf16x3" else TRAFFIC_FILE)
     return rec.get("traffic_bytes_per_launch"), rec.get("source")
 
 
