@@ -994,6 +994,13 @@ def _train_main(args, device, world, rank, dist, joined):
             rg["vs_uniform_clips_per_s"] = rg["clips_per_s"] / (args.batch * args.clips * joined * args.steps / elapsed)
             if rg.get("cold"):
                 rg["cold"]["vs_uniform_steps_per_s"] = rg["cold"]["steps_per_s"] / (joined * args.steps / elapsed)
+            # the ragged legs run the PADDED sentence layout (the per-clip-count decoder graphs key on T only): like for like is the padded
+            # uniform step of this box, when it was measured (`padded_text_rows`)
+            pad = extras.get("padded_text_rows") or {}
+            if pad.get("steps_per_s"):
+                rg["vs_padded_uniform_steps_per_s"] = rg["steps_per_s"] / pad["steps_per_s"]
+                if rg.get("cold"):
+                    rg["cold"]["vs_padded_uniform_steps_per_s"] = rg["cold"]["steps_per_s"] / pad["steps_per_s"]
         out["ragged"] = rg
     out.update(extras)
     if world == 1 and not args.no_cpu_baseline and not args.rehearse_dp:
